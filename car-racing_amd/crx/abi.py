@@ -1,0 +1,212 @@
+"""ctypes mirror of include/crx.h (struct layouts + argument marshalling).
+
+Pure declarations: no library is loaded here.  `Binding` wraps any CDLL that exports the crx entry
+points under a given symbol prefix, so the same marshalling code drives libcrx (prefix "crx_") and,
+in tests only, the CPU oracle (prefix "crx_oracle_").
+"""
+import ctypes as C
+
+import numpy as np
+
+CRX_MAX_N = 24
+CRX_MAX_OBS = 3
+
+CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE = 0, 1, 2
+
+
+class IpmOpts(C.Structure):
+    _fields_ = [
+        ("tol", C.c_double),
+        ("max_iter", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("mu_init", C.c_double),
+        ("kappa_eps", C.c_double),
+        ("kappa_mu", C.c_double),
+        ("theta_mu", C.c_double),
+        ("tau_min", C.c_double),
+        ("slack_push", C.c_double),
+        ("grad_scale_max", C.c_double),
+    ]
+
+
+def default_opts():
+    """IPOPT defaults the reference inherits (control.py:593 passes print options only)."""
+    return IpmOpts(1e-8, 200, 0, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0)
+
+
+class PlannerDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("A", C.c_double * 36),
+        ("B", C.c_double * 12),
+        ("w_ref", C.c_double),
+        ("w_dey", C.c_double),
+        ("w_prog", C.c_double),
+        ("vx_max", C.c_double),
+        ("delta_max", C.c_double),
+        ("a_max", C.c_double),
+        ("dt_ref", C.c_double),
+        ("fallback_gain", C.c_double),
+        ("opts", IpmOpts),
+    ]
+
+
+class CbfDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("n_obs_max", C.c_int32),
+        ("per_stage_target", C.c_int32),
+        ("degree", C.c_int32),
+        ("A", C.c_double * 36),
+        ("B", C.c_double * 12),
+        ("Q", C.c_double * 6),
+        ("R", C.c_double * 2),
+        ("delta_max", C.c_double),
+        ("a_max", C.c_double),
+        ("v_min", C.c_double),
+        ("v_max", C.c_double),
+        ("ey_max", C.c_double),
+        ("alpha", C.c_double),
+        ("margin", C.c_double),
+        ("l_sum", C.c_double),
+        ("w_sum", C.c_double),
+        ("w_slack", C.c_double),
+        ("opts", IpmOpts),
+    ]
+
+
+class SelectDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("n_veh_max", C.c_int32),
+        ("veh_length", C.c_double),
+        ("veh_width", C.c_double),
+        ("lap_length", C.c_double),
+        ("w_prog", C.c_double),
+        ("w_coll", C.c_double),
+        ("w_switch", C.c_double),
+    ]
+
+
+def _arr(ctype, n, values):
+    return (ctype * n)(*[float(v) for v in np.asarray(values, dtype=float).reshape(-1)])
+
+
+def planner_desc(N, A, B, opts=None):
+    """Constants hard-coded in the reference's planner (overtake_traj_planner.py:276-334,367)."""
+    return PlannerDesc(
+        int(N), 0, _arr(C.c_double, 36, A), _arr(C.c_double, 12, B),
+        20.0, 30.0, 200.0, 5.0, 0.5, 1.5, 0.1, 1.1, opts or default_opts(),
+    )
+
+
+def cbf_desc(N, n_obs_max, A, B, Q=(10.0, 0.0, 0.0, 4.0, 0.0, 40.0), R=(0.1, 0.1), alpha=0.8,
+             margin=0.2, ey_max=1.0, per_stage_target=False, delta_max=0.5, a_max=1.0, v_min=0.0,
+             v_max=10.0, l_sum=0.4, w_sum=0.2, w_slack=1e4, degree=6, opts=None):
+    """Defaults = MPCCBFRacingParam / SystemParam / CarParam (utils/base.py:272-291,708-713,699-705)
+    and the literals in control.mpccbf (control.py:527-528,560)."""
+    return CbfDesc(
+        int(N), int(n_obs_max), int(bool(per_stage_target)), int(degree),
+        _arr(C.c_double, 36, A), _arr(C.c_double, 12, B), _arr(C.c_double, 6, Q),
+        _arr(C.c_double, 2, R), delta_max, a_max, v_min, v_max, ey_max, alpha, margin, l_sum,
+        w_sum, w_slack, opts or default_opts(),
+    )
+
+
+def select_desc(N, n_veh_max, lap_length, veh_length=0.4, veh_width=0.2):
+    """overtake_traj_planner.py:209,223,243 literals."""
+    return SelectDesc(int(N), int(n_veh_max), veh_length, veh_width, lap_length, 10.0, 100.0, 100.0)
+
+
+_D = np.float64
+_I = np.int32
+
+
+def _in(a, dtype, shape):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.shape != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Binding:
+    """Host-pointer entry points of a library exporting <prefix>planner_solve / cbf_solve / select."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        for name in ("planner_solve", "cbf_solve", "select"):
+            fn = getattr(lib, prefix + name)
+            fn.restype = C.c_int
+        self._check = None
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, self.prefix + name)(*args)
+        if rc != 0:
+            msg = ""
+            if hasattr(self.lib, self.prefix + "last_error"):
+                f = getattr(self.lib, self.prefix + "last_error")
+                f.restype = C.c_char_p
+                msg = (f() or b"").decode()
+            raise RuntimeError("%s%s failed: rc=%d %s" % (self.prefix, name, rc, msg))
+
+    def planner_solve(self, desc, x0, bez_s, bez_ey, ey_lb, ey_ub):
+        N = desc.N
+        x0 = np.ascontiguousarray(x0, dtype=_D)
+        Bn = x0.shape[0]
+        x0 = _in(x0, _D, (Bn, 6))
+        bez_s = _in(bez_s, _D, (Bn, N + 1))
+        bez_ey = _in(bez_ey, _D, (Bn, N + 1))
+        ey_lb = _in(ey_lb, _D, (Bn, N))
+        ey_ub = _in(ey_ub, _D, (Bn,))
+        out = dict(
+            X=np.zeros((Bn, N + 1, 6)), U=np.zeros((Bn, N, 2)), cost=np.zeros(Bn),
+            status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn), iters=np.zeros(Bn, dtype=_I),
+        )
+        self._call(
+            "planner_solve", C.byref(desc), C.c_int(Bn), _p(x0), _p(bez_s), _p(bez_ey), _p(ey_lb),
+            _p(ey_ub), _p(out["X"]), _p(out["U"]), _p(out["cost"]), _p(out["status"]),
+            _p(out["kkt"]), _p(out["iters"]),
+        )
+        return out
+
+    def cbf_solve(self, desc, x0, xt, obs_s, obs_ey, lap_off, n_obs):
+        N, V = desc.N, desc.n_obs_max
+        x0 = np.ascontiguousarray(x0, dtype=_D)
+        Bn = x0.shape[0]
+        x0 = _in(x0, _D, (Bn, 6))
+        xt = _in(xt, _D, (Bn, N + 1, 6) if desc.per_stage_target else (Bn, 6))
+        obs_s = _in(obs_s, _D, (Bn, V, N + 1))
+        obs_ey = _in(obs_ey, _D, (Bn, V, N + 1))
+        lap_off = _in(lap_off, _D, (Bn, V))
+        n_obs = _in(n_obs, _I, (Bn,))
+        out = dict(
+            X=np.zeros((Bn, N + 1, 6)), U=np.zeros((Bn, N, 2)), sigma=np.zeros((Bn, V, N + 1)),
+            cost=np.zeros(Bn), status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn),
+            iters=np.zeros(Bn, dtype=_I),
+        )
+        self._call(
+            "cbf_solve", C.byref(desc), C.c_int(Bn), _p(x0), _p(xt), _p(obs_s), _p(obs_ey),
+            _p(lap_off), _p(n_obs), _p(out["X"]), _p(out["U"]), _p(out["sigma"]), _p(out["cost"]),
+            _p(out["status"]), _p(out["kkt"]), _p(out["iters"]),
+        )
+        return out
+
+    def select(self, desc, n_veh, X, obs_s, obs_ey, old_flag):
+        N, V = desc.N, desc.n_veh_max
+        n_veh = np.ascontiguousarray(n_veh, dtype=_I)
+        S = n_veh.shape[0]
+        X = _in(X, _D, (S, V + 1, N + 1, 6))
+        obs_s = _in(obs_s, _D, (S, V, N + 1))
+        obs_ey = _in(obs_ey, _D, (S, V, N + 1))
+        old_flag = _in(old_flag, _I, (S,))
+        out = dict(flag=np.zeros(S, dtype=_I), sel_cost=np.zeros((S, V + 1)), best_X=np.zeros((S, N + 1, 6)))
+        self._call(
+            "select", C.byref(desc), C.c_int(S), _p(n_veh), _p(X), _p(obs_s), _p(obs_ey),
+            _p(old_flag), _p(out["flag"]), _p(out["sel_cost"]), _p(out["best_X"]),
+        )
+        return out

@@ -1,0 +1,219 @@
+/*
+ * crx.h -- C ABI of libcrx, the MI355X-native batched optimal-control solver behind
+ * HybridRobotics/car-racing's planner / MPC-CBF hot path.
+ *
+ * The reference has NO native boundary for this path: the boundary is three Python call sites
+ * that build a CasADi `Opti` problem and hand it to IPOPT.  Each entry point below replaces one
+ * of them (file:line into /root/reference/car_racing); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add at exactly those lines.
+ *
+ *   crx_planner_solve      <- planning/overtake_traj_planner.py:248-379  generate_traj_per_region
+ *                             (Opti build :263-334, opti.solve() :359-364, fallback :365-374),
+ *                             batched over what the reference forks one process per region for
+ *                             (:182-197)
+ *   crx_select             <- planning/overtake_traj_planner.py:205-246  region selection
+ *   crx_planner_plan       <- planning/overtake_traj_planner.py:162-246  solve_optimization_problem
+ *                             (= crx_planner_solve over all regions + crx_select, one launch chain)
+ *   crx_cbf_solve          <- control/control.py:476-607 mpccbf  and  control/control.py:251-473
+ *                             mpc_multi_agents  (same NLP family; the latter with a per-stage target)
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; all arrays C-contiguous, float64 / int32.
+ *   - `*_dev` variants take DEVICE pointers (e.g. torch tensor .data_ptr()) and a stream handle
+ *     (hipStream_t passed as void*, NULL = default stream); they enqueue work and return without
+ *     synchronising.  The non-`_dev` variants take HOST pointers, stage through library-owned
+ *     device buffers and block until the result is back.
+ *   - the caller owns every buffer; the library never keeps a pointer after a call returns.
+ *   - return value: 0 on success, negative crx_err on a CALL failure (bad argument, no device,
+ *     HIP error; text via crx_last_error()).  A problem that does not converge is NOT a call
+ *     failure: it is reported per problem in status[] (crx_status), with X/U holding the last
+ *     iterate (mpccbf / mpc_multi_agents consume the last iterate, control.py:600-603,458-469) or
+ *     the reference's synthetic fall-back trajectory (planner, overtake_traj_planner.py:365-374).
+ *   - not fork-safe (a HIP context does not survive fork()); callers must replace the reference's
+ *     Process fan-out (:182-197) with ONE batched call from the parent.
+ *
+ * State order  x = [vx, vy, wz, epsi, s, ey]   (utils/constants.py:1, control/lmpc_helper.py:133-138)
+ * Input order  u = [delta, a]                  (system/vehicle_dynamics.py:10-11)
+ */
+#ifndef CRX_H
+#define CRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRX_VERSION 100 /* 0.1.0 */
+#define CRX_NX 6
+#define CRX_NU 2
+#define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
+#define CRX_MAX_OBS 3      /* obstacles per NLP / vehicles of interest per scenario */
+#define CRX_MAX_REGIONS (CRX_MAX_OBS + 1)
+
+typedef enum crx_err {
+    CRX_OK = 0,
+    CRX_ERR_ARG = -1,      /* NULL pointer, N out of range, batch < 0, ... */
+    CRX_ERR_NO_DEVICE = -2,
+    CRX_ERR_HIP = -3,
+    CRX_ERR_NOT_INIT = -4
+} crx_err;
+
+typedef enum crx_status {
+    CRX_CONVERGED = 0,     /* KKT error <= tol */
+    CRX_MAX_ITER = 1,      /* iteration cap or line-search failure; last iterate returned */
+    CRX_INFEASIBLE = 2     /* constraints cannot be met (incl. a bound already violated by the fixed x0) */
+} crx_status;
+
+/* Interior-point options.  Defaults (crx_ipm_opts_default) restate IPOPT 3.x defaults that the
+ * reference inherits by passing only print options (control.py:593, overtake_traj_planner.py:335). */
+typedef struct crx_ipm_opts {
+    double tol;            /* 1e-8  convergence tolerance on the scaled KKT error */
+    int32_t max_iter;      /* 200   (IPOPT: 3000; capped, status CRX_MAX_ITER beyond) */
+    int32_t reserved0;
+    double mu_init;        /* 0.1   */
+    double kappa_eps;      /* 10    barrier sub-problem tolerance factor */
+    double kappa_mu;       /* 0.2   linear decrease factor */
+    double theta_mu;       /* 1.5   superlinear decrease power */
+    double tau_min;        /* 0.99  fraction-to-the-boundary */
+    double slack_push;     /* 1e-2  initial slack floor (bound_push) */
+    double grad_scale_max; /* 100   gradient-based row scaling target (nlp_scaling_max_gradient) */
+} crx_ipm_opts;
+
+/* ---- planner region QP (overtake_traj_planner.py:263-334) ------------------------------------ */
+typedef struct crx_planner_desc {
+    int32_t N;             /* num_horizon_planner (utils/base.py:391) */
+    int32_t reserved0;
+    double A[36];          /* row-major 6x6, racing_game_param.matrix_A (:272) */
+    double B[12];          /* row-major 6x2, racing_game_param.matrix_B (:273) */
+    double w_ref;          /* 20   weight on (ey-ey_bez)^2 and (s-s_ref)^2          (:333-334) */
+    double w_dey;          /* 30   weight on (ey_k-ey_{k-1})^2, k=2..N-1            (:325-327) */
+    double w_prog;         /* 200  weight on -(s_N - s_0)                           (:328) */
+    double vx_max;         /* 5.0  vx_{k+1} <= vx_max                               (:276) */
+    double delta_max;      /* 0.5                                                   (:280-281) */
+    double a_max;          /* 1.5                                                   (:283-284) */
+    double dt_ref;         /* 0.1  literal time step in s_ref and the window test   (:296,:330) */
+    double fallback_gain;  /* 1.1  speed factor of the fall-back trajectory         (:367-368) */
+    crx_ipm_opts opts;
+} crx_planner_desc;
+
+/* ---- MPC-CBF NLP (control.py:492-591 / :270-382) --------------------------------------------- */
+typedef struct crx_cbf_desc {
+    int32_t N;             /* num_horizon (utils/base.py:281) / num_horizon_ctrl (:390) */
+    int32_t n_obs_max;     /* leading dimension of the obstacle arrays, <= CRX_MAX_OBS */
+    int32_t per_stage_target; /* 0: xt is [batch][6] (mpccbf); 1: xt is [batch][N+1][6] (mpc_multi_agents :373-382) */
+    int32_t degree;        /* 6, must be even, (control.py:528 / :312) */
+    double A[36];
+    double B[12];
+    double Q[6];           /* diag(matrix_Q)  (utils/base.py:277 / :384) */
+    double R[2];           /* diag(matrix_R)  (utils/base.py:278 / :385) */
+    double delta_max;      /* system_param.delta_max (utils/base.py:709) */
+    double a_max;
+    double v_min;
+    double v_max;
+    double ey_max;         /* track.width (control.py:585-586) */
+    double alpha;          /* 0.8 mpc_cbf_param.alpha / 0.6 literal (control.py:285) */
+    double margin;         /* 0.2 (control.py:527) / 0.15 (:311) */
+    double l_sum;          /* l_agent + l_obs (control.py:532-535) = 0.4 */
+    double w_sum;          /* w_agent + w_obs = 0.2 */
+    double w_slack;        /* 1e4 (control.py:560,562) */
+    crx_ipm_opts opts;
+} crx_cbf_desc;
+
+/* ---- region selection (overtake_traj_planner.py:205-246) ------------------------------------- */
+typedef struct crx_select_desc {
+    int32_t N;
+    int32_t n_veh_max;     /* leading dimension V of the obstacle arrays; regions R = V + 1 */
+    double veh_length;     /* 0.4 */
+    double veh_width;      /* 0.2 */
+    double lap_length;     /* obstacle s is wrapped `while s > lap_length` (:216-217) */
+    double w_prog;         /* 10  (:209) */
+    double w_coll;         /* 100 (:223,:237) */
+    double w_switch;       /* 100 (:243) */
+} crx_select_desc;
+
+/* library management */
+int crx_version(void);
+/* device >= 0: HIP device ordinal.  There is no CPU back-end in this library: a missing device is
+ * an error (CRX_ERR_NO_DEVICE), never a silent fall-back. */
+int crx_init(int device);
+void crx_shutdown(void);
+const char* crx_last_error(void);
+int crx_device_count(void);
+
+void crx_ipm_opts_default(crx_ipm_opts* o);
+void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B);
+void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B);
+void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length);
+
+/*
+ * Planner region QPs.  One problem per (scenario, region).
+ *   x0      [batch][6]      ego.xcurv, raw (quirk Q5: the start-line-wrapped copy is only used by
+ *                           the host when it builds ey_lb)
+ *   bez_s   [batch][N+1]    Bezier reference polyline, s coordinates   (bezier_xcurvs[r,:,0])
+ *   bez_ey  [batch][N+1]    ... ey coordinates                         (bezier_xcurvs[r,:,1])
+ *   ey_lb   [batch][N]      effective lower bound on ey_k, k=0..N-1: max of -(ey_ub) and the
+ *                           neighbour constraints active at k (:286-324, quirk Q2)
+ *   ey_ub   [batch]         track.width - 0.5*veh_width (:277-278)
+ *   X       [batch][N+1][6] out: solution, or fall-back trajectory when status != 0
+ *   U       [batch][N][2]   out: inputs (zeros with the fall-back)
+ *   cost    [batch]         out: sol.value(cost) (:364); +inf with the fall-back (:374)
+ *   status  [batch]         out: crx_status
+ *   kkt     [batch]         out: final scaled KKT error
+ *   iters   [batch]         out: interior-point iterations
+ */
+int crx_planner_solve(const crx_planner_desc* d, int batch, const double* x0, const double* bez_s,
+                      const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X,
+                      double* U, double* cost, int32_t* status, double* kkt, int32_t* iters);
+int crx_planner_solve_dev(const crx_planner_desc* d, int batch, const double* x0,
+                          const double* bez_s, const double* bez_ey, const double* ey_lb,
+                          const double* ey_ub, double* X, double* U, double* cost, int32_t* status,
+                          double* kkt, int32_t* iters, void* stream);
+
+/*
+ * Region selection.  Scenario i has n_veh[i] <= V sorted vehicles and n_veh[i]+1 regions.
+ *   X        [n_scen][V+1][N+1][6]  per-region trajectories (solution_xvar, transposed)
+ *   obs_s    [n_scen][V][N+1]       predicted s of sorted vehicle v (obs_infos[name][4,:])
+ *   obs_ey   [n_scen][V][N+1]
+ *   old_flag [n_scen]               previous direction_flag, -1 for None (:238-243)
+ *   flag     [n_scen]               out: direction_flag (first arg-min, :244)
+ *   sel_cost [n_scen][V+1]          out: cost_selection (regions >= n_veh+1: +inf)
+ *   best_X   [n_scen][N+1][6]       out: traj_xcurv (:245)
+ */
+int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X,
+               const double* obs_s, const double* obs_ey, const int32_t* old_flag, int32_t* flag,
+               double* sel_cost, double* best_X);
+int crx_select_dev(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X,
+                   const double* obs_s, const double* obs_ey, const int32_t* old_flag,
+                   int32_t* flag, double* sel_cost, double* best_X, void* stream);
+
+/*
+ * MPC-CBF NLPs.
+ *   x0      [batch][6]
+ *   xt      [batch][6] or [batch][N+1][6]   tracking target(s) (d->per_stage_target)
+ *   obs_s   [batch][n_obs_max][N+1]         obstacle prediction rows 4 of obs_traj
+ *   obs_ey  [batch][n_obs_max][N+1]         rows 5
+ *   lap_off [batch][n_obs_max]              (num_cycle_ego - num_cycle_obs) * lap_length; applied
+ *                                           to h_i only, not to h_{i+1} (quirk Q1, control.py:539-542)
+ *   n_obs   [batch]                         obstacles inside the +-2*vx window (control.py:520-523)
+ *   X [batch][N+1][6], U [batch][N][2], sigma [batch][n_obs_max][N+1] (cbf_slack), cost, status,
+ *   kkt, iters as above.  No fall-back: the last iterate is returned (control.py:600-603).
+ */
+int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
+                  const double* obs_s, const double* obs_ey, const double* lap_off,
+                  const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
+                  int32_t* status, double* kkt, int32_t* iters);
+int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
+                      const double* obs_s, const double* obs_ey, const double* lap_off,
+                      const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
+                      int32_t* status, double* kkt, int32_t* iters, void* stream);
+
+/* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
+ * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this. */
+void crx_set_timing(int enable);
+double crx_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRX_H */

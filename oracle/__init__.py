@@ -1,0 +1,46 @@
+"""Loader for the CPU oracle (oracle/crx_oracle.c).
+
+TEST INFRASTRUCTURE: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg only.  The product package (car-racing_amd/) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "crx_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "crx.h")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return _LIB
+
+
+_binding = None
+
+
+def load():
+    """Return an abi.Binding over liboracle.so (building it with gcc if missing/stale)."""
+    global _binding
+    if _binding is None:
+        pkg = os.path.join(_HERE, "..", "car-racing_amd")
+        if pkg not in sys.path:
+            sys.path.insert(0, pkg)
+        from crx import abi
+
+        lib = ctypes.CDLL(build())
+        lib.crx_oracle_threads.restype = ctypes.c_int
+        _binding = abi.Binding(lib, "crx_oracle_")
+    return _binding
+
+
+def threads():
+    return load().lib.crx_oracle_threads()
+
+
+def set_threads(n):
+    load().lib.crx_oracle_set_threads(int(n))

@@ -1,0 +1,736 @@
+/*
+ * crx_oracle.c -- CPU restatement (plain C, double) of the car-racing planner / MPC-CBF hot path.
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load this; the product (libcrx, HIP) never links, imports or falls back to it.
+ *
+ * What is restated, and from where (paths into /root/reference/car_racing):
+ *   problem construction
+ *     planner region QP     planning/overtake_traj_planner.py:263-334  (cost :325-334, bounds :276-284,
+ *                           dynamics :270-274, reference points :329-332, fall-back :365-374)
+ *     MPC-CBF NLP           control/control.py:492-591 (mpccbf) and :270-382 (mpc_multi_agents):
+ *                           CBF rows :537-562, dynamics :566-570, input box :572-576,
+ *                           state box + tracking cost :580-591, input cost :578-579
+ *     region selection      planning/overtake_traj_planner.py:205-246
+ *     linear interpolation  scipy.interpolate.interp1d(kind="linear") as used at
+ *                           planning/overtake_traj_planner.py:112-117,332
+ *   solver
+ *     The reference delegates the arithmetic to casadi==3.5.5 -> IPOPT (requirements.txt:6;
+ *     call sites control.py:593-599, overtake_traj_planner.py:359-364), a third-party wheel that is
+ *     not in the reference tree and cannot be installed here.  What follows restates IPOPT's
+ *     published algorithm (Waechter & Biegler, Math. Prog. 106, 2006): slack form g(x)-t=0, t>=0
+ *     for every inequality (CasADi Opti passes all constraints as general g), monotone
+ *     Fiacco-McCormick barrier update (eq. 7), fraction-to-the-boundary rule (eq. 15), primal-dual
+ *     Newton step with inertia correction by W + delta_w*I (Alg. IC), multiplier safeguard (eq. 16),
+ *     gradient-based constraint scaling (sec. 3.8), error measure E_mu (eq. 5); IPOPT's filter is
+ *     replaced by an l1-merit backtracking line search and there is no restoration phase.
+ *     Because the dynamics are linear and x0 is fixed, states are eliminated (condensing) and the
+ *     reduced Newton system is factorised by a DENSE Cholesky -- on purpose a different linear-algebra
+ *     route from the HIP kernel's Riccati recursion, so that agreement between the two is evidence.
+ *
+ * PARITY PIN: the reference's own tests hold no golden vectors for this path.
+ * This oracle is pinned instead against tests/golden/ *.npz: problems recorded from the reference's
+ * own, unmodified code running against a recording CasADi stand-in, with independently certified
+ * KKT solutions (tests/golden/tools/make_golden.py).  IPOPT itself never ran: "parity vs IPOPT's
+ * iterates" is unpinned; "parity vs the reference's problem + a certified KKT point" is pinned.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/crx.h"
+
+#define MAXN CRX_MAX_N
+#define MAXO CRX_MAX_OBS
+#define NXS 6
+#define NUS 2
+#define MAXRED (MAXN * (NUS + MAXO) + MAXO)
+#define MAXM (MAXN * 4 + MAXN * 4 + MAXO * (MAXN + 1) + MAXO * MAXN)
+
+/* ------------------------------------------------------------------------------------------------
+ * canonical stage-structured problem shared by both front-ends
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int N, nobs;
+    double A[36], B[12];
+    double x0[6];
+    double wq[6];                 /* cost  sum_k sum_i wq_i (x_ki - xr_ki)^2           k = 0..N  */
+    double xr[MAXN + 1][6];
+    double lin[MAXN + 1][6];      /*     + sum_k lin_k . x_k + cconst                            */
+    double cconst;
+    double wr[2];                 /*     + sum_k sum_i wr_i u_ki^2                      k = 0..N-1 */
+    double wc[MAXN];              /*     + sum_k wc_k (ey_{k+1} - ey_k)^2               k = 0..N-1 */
+    double wsig;                  /*     + wsig * sum sigma                                      */
+    double ulo[2], uhi[2];
+    double vlo[MAXN + 1], vhi[MAXN + 1], elo[MAXN + 1], ehi[MAXN + 1]; /* +-HUGE_VAL = absent */
+    double obs_s[MAXO][MAXN + 1], obs_ey[MAXO][MAXN + 1], lap_off[MAXO];
+    double alpha, cm, Ls, Ws;
+    int degree;
+} ocp_t;
+
+enum { ROW_ULO, ROW_UHI, ROW_XLO, ROW_XHI, ROW_SIG, ROW_CBF };
+
+typedef struct {
+    int kind, k, i, o; /* stage, component (u index or state index), obstacle */
+} rowdef_t;
+
+typedef struct {
+    const ocp_t* p;
+    const crx_ipm_opts* o;
+    int nred, m, nsv; /* nsv = 2 + nobs inputs per stage */
+    rowdef_t row[MAXM];
+    double d[MAXM];                       /* row scaling */
+    double Sx[MAXN + 1][6][MAXRED];       /* state sensitivities dx_k/dv */
+    double Hf[MAXRED][MAXRED];            /* constant cost Hessian in v */
+    /* iterate */
+    double v[MAXRED], t[MAXM], nu[MAXM];
+    double x[MAXN + 1][6];
+    double u[MAXN][2];
+    double sig[MAXO][MAXN + 1];
+    /* work */
+    double f, g[MAXRED], c[MAXM], J[MAXM][MAXRED];
+    double H[MAXRED][MAXRED], rhs[MAXRED], dv[MAXRED], dt[MAXM], dnu[MAXM];
+} work_t;
+
+static inline int iu(const work_t* w, int k) { return (w->p->N - 1 - k) * w->nsv; }
+static inline int isig(const work_t* w, int k, int o) {
+    return k == 0 ? w->p->N * w->nsv + o : iu(w, k - 1) + 2 + o;
+}
+
+static inline double ipow(double a, int p) {
+    double r = 1.0;
+    for (int i = 0; i < p; i++) r *= a;
+    return r;
+}
+
+/* v -> (u, sigma, x) */
+static void unpack(work_t* w, const double* v) {
+    const ocp_t* p = w->p;
+    for (int k = 0; k < p->N; k++) {
+        w->u[k][0] = v[iu(w, k)];
+        w->u[k][1] = v[iu(w, k) + 1];
+    }
+    for (int o = 0; o < p->nobs; o++)
+        for (int k = 0; k <= p->N; k++) w->sig[o][k] = v[isig(w, k, o)];
+    memcpy(w->x[0], p->x0, sizeof(double) * 6);
+    for (int k = 0; k < p->N; k++)
+        for (int i = 0; i < 6; i++) {
+            double s = 0.0;
+            for (int j = 0; j < 6; j++) s += p->A[i * 6 + j] * w->x[k][j];
+            s += p->B[i * 2] * w->u[k][0] + p->B[i * 2 + 1] * w->u[k][1];
+            w->x[k + 1][i] = s;
+        }
+}
+
+static double cost_value(const work_t* w) {
+    const ocp_t* p = w->p;
+    double f = p->cconst;
+    for (int k = 0; k <= p->N; k++)
+        for (int i = 0; i < 6; i++) {
+            double e = w->x[k][i] - p->xr[k][i];
+            f += p->wq[i] * e * e + p->lin[k][i] * w->x[k][i];
+        }
+    for (int k = 0; k < p->N; k++) {
+        f += p->wr[0] * w->u[k][0] * w->u[k][0] + p->wr[1] * w->u[k][1] * w->u[k][1];
+        double de = w->x[k + 1][5] - w->x[k][5];
+        f += p->wc[k] * de * de;
+    }
+    for (int o = 0; o < p->nobs; o++)
+        for (int k = 0; k <= p->N; k++) f += p->wsig * w->sig[o][k];
+    return f;
+}
+
+/* CBF pieces for obstacle o between stages i and i+1 (control.py:537-558):
+ *   c = g_next(x_{i+1}) - sigma_{i+1} - (1-alpha) (g_cur(x_i) - sigma_i) - alpha*(1+margin)      */
+static inline void cbf_terms(const ocp_t* p, const double x[][6], int o, int i, double* dsc,
+                             double* dec, double* dsn, double* den) {
+    *dsc = (x[i][4] - p->obs_s[o][i] - p->lap_off[o]) / p->Ls;     /* lap-corrected (:539-540) */
+    *dec = (x[i][5] - p->obs_ey[o][i]) / p->Ws;
+    *dsn = (x[i + 1][4] - p->obs_s[o][i + 1]) / p->Ls;             /* NOT lap-corrected (:542) */
+    *den = (x[i + 1][5] - p->obs_ey[o][i + 1]) / p->Ws;
+}
+
+static double row_value(const work_t* w, int j) {
+    const ocp_t* p = w->p;
+    const rowdef_t* r = &w->row[j];
+    switch (r->kind) {
+        case ROW_ULO: return w->u[r->k][r->i] - p->ulo[r->i];
+        case ROW_UHI: return p->uhi[r->i] - w->u[r->k][r->i];
+        case ROW_XLO: return w->x[r->k][r->i] - (r->i == 0 ? p->vlo[r->k] : p->elo[r->k]);
+        case ROW_XHI: return (r->i == 0 ? p->vhi[r->k] : p->ehi[r->k]) - w->x[r->k][r->i];
+        case ROW_SIG: return w->sig[r->o][r->k];
+        default: {
+            double dsc, dec, dsn, den;
+            cbf_terms(p, w->x, r->o, r->k, &dsc, &dec, &dsn, &den);
+            int q = p->degree;
+            double gc = ipow(dsc, q) + ipow(dec, q), gn = ipow(dsn, q) + ipow(den, q);
+            return gn - w->sig[r->o][r->k + 1] - (1.0 - p->alpha) * (gc - w->sig[r->o][r->k]) -
+                   p->alpha * p->cm;
+        }
+    }
+}
+
+/* dense Jacobian row in v (unscaled) */
+static void row_jac(const work_t* w, int j, double* out) {
+    const ocp_t* p = w->p;
+    const rowdef_t* r = &w->row[j];
+    int n = w->nred;
+    memset(out, 0, sizeof(double) * n);
+    switch (r->kind) {
+        case ROW_ULO: out[iu(w, r->k) + r->i] = 1.0; break;
+        case ROW_UHI: out[iu(w, r->k) + r->i] = -1.0; break;
+        case ROW_XLO:
+            for (int a = 0; a < n; a++) out[a] = w->Sx[r->k][r->i][a];
+            break;
+        case ROW_XHI:
+            for (int a = 0; a < n; a++) out[a] = -w->Sx[r->k][r->i][a];
+            break;
+        case ROW_SIG: out[isig(w, r->k, r->o)] = 1.0; break;
+        default: {
+            double dsc, dec, dsn, den;
+            int i = r->k, q = p->degree;
+            cbf_terms(p, w->x, r->o, i, &dsc, &dec, &dsn, &den);
+            double gsn = q * ipow(dsn, q - 1) / p->Ls, gen = q * ipow(den, q - 1) / p->Ws;
+            double gsc = q * ipow(dsc, q - 1) / p->Ls, gec = q * ipow(dec, q - 1) / p->Ws;
+            double om = 1.0 - p->alpha;
+            for (int a = 0; a < n; a++)
+                out[a] = gsn * w->Sx[i + 1][4][a] + gen * w->Sx[i + 1][5][a] -
+                         om * (gsc * w->Sx[i][4][a] + gec * w->Sx[i][5][a]);
+            out[isig(w, i + 1, r->o)] -= 1.0;
+            out[isig(w, i, r->o)] += om;
+        }
+    }
+}
+
+/* full evaluation at w->v: x,u,sigma, f, g, c (scaled), J (scaled) */
+static void eval_full(work_t* w) {
+    const ocp_t* p = w->p;
+    int n = w->nred, N = p->N;
+    unpack(w, w->v);
+    w->f = cost_value(w);
+    /* gradient: adjoint sweep */
+    double lam[6] = {0, 0, 0, 0, 0, 0};
+    memset(w->g, 0, sizeof(double) * n);
+    for (int k = N; k >= 1; k--) {
+        double gx[6];
+        for (int i = 0; i < 6; i++)
+            gx[i] = 2.0 * p->wq[i] * (w->x[k][i] - p->xr[k][i]) + p->lin[k][i] + lam[i];
+        /* coupling terms touching ey_k: wc_{k-1}(ey_k - ey_{k-1})^2 and wc_k(ey_{k+1}-ey_k)^2 */
+        gx[5] += 2.0 * p->wc[k - 1] * (w->x[k][5] - w->x[k - 1][5]);
+        if (k < N) gx[5] -= 2.0 * p->wc[k] * (w->x[k + 1][5] - w->x[k][5]);
+        /* gx now = dL/dx_k including costate of later stages; push through x_k = A x_{k-1} + B u_{k-1} */
+        for (int c = 0; c < 2; c++) {
+            double s = 0.0;
+            for (int i = 0; i < 6; i++) s += p->B[i * 2 + c] * gx[i];
+            w->g[iu(w, k - 1) + c] = s + 2.0 * p->wr[c] * w->u[k - 1][c];
+        }
+        for (int j = 0; j < 6; j++) {
+            double s = 0.0;
+            for (int i = 0; i < 6; i++) s += p->A[i * 6 + j] * gx[i];
+            lam[j] = s;
+        }
+    }
+    for (int o = 0; o < p->nobs; o++)
+        for (int k = 0; k <= N; k++) w->g[isig(w, k, o)] = p->wsig;
+    for (int j = 0; j < w->m; j++) {
+        w->c[j] = w->d[j] * row_value(w, j);
+        if (w->row[j].kind == ROW_CBF || w->J[j][0] != w->J[j][0] /* first fill */) {
+            row_jac(w, j, w->J[j]);
+            for (int a = 0; a < n; a++) w->J[j][a] *= w->d[j];
+        }
+    }
+}
+
+/* cheap evaluation for the line search: f and c at a trial v */
+static void eval_fc(work_t* w, const double* v, double* f, double* c) {
+    unpack(w, v);
+    *f = cost_value(w);
+    for (int j = 0; j < w->m; j++) c[j] = w->d[j] * row_value(w, j);
+}
+
+static int chol(int n, double H[][MAXRED]) {
+    for (int j = 0; j < n; j++) {
+        double s = H[j][j];
+        for (int k = 0; k < j; k++) s -= H[j][k] * H[j][k];
+        if (!(s > 0.0)) return 0;
+        double l = sqrt(s);
+        H[j][j] = l;
+        for (int i = j + 1; i < n; i++) {
+            double t = H[i][j];
+            for (int k = 0; k < j; k++) t -= H[i][k] * H[j][k];
+            H[i][j] = t / l;
+        }
+    }
+    return 1;
+}
+
+static void chol_solve(int n, double L[][MAXRED], double* b) {
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i][k] * b[k];
+        b[i] = s / L[i][i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= L[k][i] * b[k];
+        b[i] = s / L[i][i];
+    }
+}
+
+static void setup(work_t* w, const ocp_t* p, const crx_ipm_opts* o) {
+    int N = p->N;
+    w->p = p;
+    w->o = o;
+    w->nsv = 2 + p->nobs;
+    w->nred = N * w->nsv + p->nobs;
+    int n = w->nred;
+    /* sensitivities */
+    memset(w->Sx, 0, sizeof(w->Sx));
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < 6; i++) {
+            for (int a = 0; a < n; a++) {
+                double s = 0.0;
+                for (int j = 0; j < 6; j++) s += p->A[i * 6 + j] * w->Sx[k][j][a];
+                w->Sx[k + 1][i][a] = s;
+            }
+            w->Sx[k + 1][i][iu(w, k)] += p->B[i * 2];
+            w->Sx[k + 1][i][iu(w, k) + 1] += p->B[i * 2 + 1];
+        }
+    /* constant cost Hessian */
+    for (int a = 0; a < n; a++) memset(w->Hf[a], 0, sizeof(double) * n);
+    for (int k = 1; k <= N; k++) {
+        for (int i = 0; i < 6; i++) {
+            double wt = 2.0 * p->wq[i];
+            if (wt == 0.0) continue;
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b <= a; b++) w->Hf[a][b] += wt * w->Sx[k][i][a] * w->Sx[k][i][b];
+        }
+    }
+    for (int k = 0; k < N; k++) {
+        if (p->wc[k] != 0.0) {
+            double wt = 2.0 * p->wc[k];
+            for (int a = 0; a < n; a++) {
+                double da = w->Sx[k + 1][5][a] - w->Sx[k][5][a];
+                for (int b = 0; b <= a; b++)
+                    w->Hf[a][b] += wt * da * (w->Sx[k + 1][5][b] - w->Sx[k][5][b]);
+            }
+        }
+        for (int c = 0; c < 2; c++) w->Hf[iu(w, k) + c][iu(w, k) + c] += 2.0 * p->wr[c];
+    }
+    /* inequality rows */
+    int m = 0;
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < 2; i++) {
+            w->row[m++] = (rowdef_t){ROW_ULO, k, i, 0};
+            w->row[m++] = (rowdef_t){ROW_UHI, k, i, 0};
+        }
+    for (int k = 1; k <= N; k++) {
+        if (p->vlo[k] > -HUGE_VAL) w->row[m++] = (rowdef_t){ROW_XLO, k, 0, 0};
+        if (p->vhi[k] < HUGE_VAL) w->row[m++] = (rowdef_t){ROW_XHI, k, 0, 0};
+        if (p->elo[k] > -HUGE_VAL) w->row[m++] = (rowdef_t){ROW_XLO, k, 5, 0};
+        if (p->ehi[k] < HUGE_VAL) w->row[m++] = (rowdef_t){ROW_XHI, k, 5, 0};
+    }
+    for (int o2 = 0; o2 < p->nobs; o2++)
+        for (int k = 0; k <= N; k++) w->row[m++] = (rowdef_t){ROW_SIG, k, 0, o2};
+    for (int o2 = 0; o2 < p->nobs; o2++)
+        for (int k = 0; k < N; k++) w->row[m++] = (rowdef_t){ROW_CBF, k, 0, o2};
+    w->m = m;
+    for (int j = 0; j < m; j++) {
+        w->d[j] = 1.0;
+        w->J[j][0] = NAN; /* marks "constant row not yet filled" */
+    }
+}
+
+/* gradient-based scaling of the CBF rows at the starting point, measured in the reference's own
+ * (full-space) variables like IPOPT does: d = min(1, gmax / ||grad c||_inf) */
+static void scale_rows(work_t* w) {
+    const ocp_t* p = w->p;
+    for (int j = 0; j < w->m; j++) {
+        if (w->row[j].kind != ROW_CBF) continue;
+        double dsc, dec, dsn, den;
+        int q = p->degree;
+        cbf_terms(p, w->x, w->row[j].o, w->row[j].k, &dsc, &dec, &dsn, &den);
+        double gm = 1.0; /* |d/d sigma_{i+1}| */
+        double v;
+        v = fabs(q * ipow(dsn, q - 1) / p->Ls); if (v > gm) gm = v;
+        v = fabs(q * ipow(den, q - 1) / p->Ws); if (v > gm) gm = v;
+        if (w->row[j].k > 0) { /* x_0 is not a variable */
+            v = fabs((1.0 - p->alpha) * q * ipow(dsc, q - 1) / p->Ls); if (v > gm) gm = v;
+            v = fabs((1.0 - p->alpha) * q * ipow(dec, q - 1) / p->Ws); if (v > gm) gm = v;
+        }
+        w->d[j] = fmin(1.0, w->o->grad_scale_max / gm);
+    }
+}
+
+typedef struct {
+    int status, iters;
+    double kkt, cost;
+} result_t;
+
+static void ipm_solve(work_t* w, result_t* res) {
+    const ocp_t* p = w->p;
+    const crx_ipm_opts* o = w->o;
+    const int n = w->nred, m = w->m;
+    const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
+    memset(w->v, 0, sizeof(double) * n);
+    unpack(w, w->v);
+    scale_rows(w);
+    eval_full(w);
+    for (int j = 0; j < m; j++) {
+        w->t[j] = fmax(w->c[j], o->slack_push);
+        w->nu[j] = 1.0;
+    }
+    double mu = o->mu_init, dw_last = 0.0, rho = 1.0, E0 = HUGE_VAL;
+    int status = CRX_MAX_ITER, it = 0;
+    static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
+    for (it = 0;; it++) {
+        /* residuals */
+        double nus = 0.0;
+        for (int j = 0; j < m; j++) nus += fabs(w->nu[j]);
+        double sd = fmax(smax, nus / (m > 0 ? m : 1)) / smax;
+        double e_d = 0.0, e_p = 0.0, e_c = 0.0;
+        for (int a = 0; a < n; a++) {
+            double s = w->g[a];
+            for (int j = 0; j < m; j++) s -= w->J[j][a] * w->nu[j];
+            rd[a] = s;
+            if (fabs(s) > e_d) e_d = fabs(s);
+        }
+        e_d /= sd;
+        for (int j = 0; j < m; j++) {
+            rp[j] = w->c[j] - w->t[j];
+            if (fabs(rp[j]) > e_p) e_p = fabs(rp[j]);
+            double cc = fabs(w->t[j] * w->nu[j]);
+            if (cc > e_c) e_c = cc;
+        }
+        e_c /= sd;
+        E0 = fmax(e_d, fmax(e_p, e_c));
+        if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
+        if (it >= o->max_iter) break;
+        /* barrier update */
+        for (;;) {
+            double e_cm = 0.0;
+            for (int j = 0; j < m; j++) {
+                double cc = fabs(w->t[j] * w->nu[j] - mu);
+                if (cc > e_cm) e_cm = cc;
+            }
+            e_cm /= sd;
+            double Emu = fmax(e_d, fmax(e_p, e_cm));
+            if (Emu <= o->kappa_eps * mu && mu > o->tol / 10.0) {
+                mu = fmax(o->tol / 10.0, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
+                rho = 1.0;
+            } else
+                break;
+        }
+        double tau = fmax(o->tau_min, 1.0 - mu);
+        /* H = Hf + curvature + J' Sigma J  (lower triangle) */
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b <= a; b++) w->H[a][b] = w->Hf[a][b];
+        for (int j = 0; j < m; j++) {
+            if (w->row[j].kind != ROW_CBF) continue;
+            int i = w->row[j].k, ob = w->row[j].o, q = p->degree;
+            double dsc, dec, dsn, den;
+            cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
+            double wn = w->nu[j] * w->d[j];
+            double hsn = q * (q - 1) * ipow(dsn, q - 2) / (p->Ls * p->Ls);
+            double hen = q * (q - 1) * ipow(den, q - 2) / (p->Ws * p->Ws);
+            double hsc = q * (q - 1) * ipow(dsc, q - 2) / (p->Ls * p->Ls);
+            double hec = q * (q - 1) * ipow(dec, q - 2) / (p->Ws * p->Ws);
+            double om = 1.0 - p->alpha;
+            /* W -= nu * hess c */
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b <= a; b++)
+                    w->H[a][b] += wn * (-hsn * w->Sx[i + 1][4][a] * w->Sx[i + 1][4][b] -
+                                        hen * w->Sx[i + 1][5][a] * w->Sx[i + 1][5][b] +
+                                        om * (hsc * w->Sx[i][4][a] * w->Sx[i][4][b] +
+                                              hec * w->Sx[i][5][a] * w->Sx[i][5][b]));
+        }
+        for (int j = 0; j < m; j++) {
+            double sg = w->nu[j] / w->t[j];
+            const double* Jr = w->J[j];
+            for (int a = 0; a < n; a++) {
+                if (Jr[a] == 0.0) continue;
+                double sa = sg * Jr[a];
+                for (int b = 0; b <= a; b++) w->H[a][b] += sa * Jr[b];
+            }
+        }
+        for (int a = 0; a < n; a++) {
+            double s = -w->g[a];
+            for (int j = 0; j < m; j++)
+                s += w->J[j][a] * (mu / w->t[j] - w->nu[j] / w->t[j] * rp[j]);
+            w->rhs[a] = s;
+        }
+        /* inertia correction */
+        static _Thread_local double Hs[MAXRED][MAXRED];
+        for (int a = 0; a < n; a++) memcpy(Hs[a], w->H[a], sizeof(double) * (a + 1));
+        double dw = 0.0;
+        int ok = chol(n, w->H);
+        if (!ok) {
+            dw = dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0);
+            for (;;) {
+                for (int a = 0; a < n; a++) {
+                    memcpy(w->H[a], Hs[a], sizeof(double) * (a + 1));
+                    w->H[a][a] += dw;
+                }
+                ok = chol(n, w->H);
+                if (ok) break;
+                dw *= dw_last == 0.0 ? 100.0 : 8.0;
+                if (dw > 1e40) break;
+            }
+            if (!ok) break;
+            dw_last = dw;
+        }
+        memcpy(w->dv, w->rhs, sizeof(double) * n);
+        chol_solve(n, w->H, w->dv);
+        double a_p = 1.0, a_d = 1.0, theta = 0.0, Dphi = 0.0, curv = 0.0;
+        for (int j = 0; j < m; j++) {
+            double s = rp[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * w->dv[a];
+            w->dt[j] = s;
+            w->dnu[j] = (mu - w->t[j] * w->nu[j] - w->nu[j] * s) / w->t[j];
+            if (s < 0.0) a_p = fmin(a_p, -tau * w->t[j] / s);
+            if (w->dnu[j] < 0.0) a_d = fmin(a_d, -tau * w->nu[j] / w->dnu[j]);
+            theta += fabs(rp[j]);
+            Dphi -= mu * s / w->t[j];
+        }
+        for (int a = 0; a < n; a++) Dphi += w->g[a] * w->dv[a];
+        /* dv' (H + dw I) dv  = dv' rhs  (H dv = rhs) */
+        for (int a = 0; a < n; a++) curv += w->dv[a] * w->rhs[a];
+        if (theta > 0.0) {
+            double rt = (Dphi + 0.5 * fmax(curv, 0.0)) / (0.9 * theta);
+            if (rho < rt) rho = rt + 1.0;
+        }
+        double DM = Dphi - rho * theta, M0 = w->f + rho * theta;
+        for (int j = 0; j < m; j++) M0 -= mu * log(w->t[j]);
+        double al = a_p;
+        int acc = 0;
+        for (int ls = 0; ls < 40; ls++) {
+            for (int a = 0; a < n; a++) vtrial[a] = w->v[a] + al * w->dv[a];
+            double fn;
+            eval_fc(w, vtrial, &fn, ctrial);
+            double Mn = fn;
+            for (int j = 0; j < m; j++) {
+                double tn = w->t[j] + al * w->dt[j];
+                if (ctrial[j] > tn) tn = ctrial[j]; /* slack reset */
+                ttrial[j] = tn;
+                Mn += -mu * log(tn) + rho * fabs(ctrial[j] - tn);
+            }
+            if (Mn <= M0 + eta * al * DM + 1e-13 * fabs(M0)) { acc = 1; break; }
+            al *= 0.5;
+        }
+        if (!acc) break;
+        memcpy(w->v, vtrial, sizeof(double) * n);
+        memcpy(w->t, ttrial, sizeof(double) * m);
+        eval_full(w);
+        double numax = 0.0, th = 0.0;
+        for (int j = 0; j < m; j++) {
+            double nn = w->nu[j] + a_d * w->dnu[j];
+            nn = fmin(fmax(nn, mu / (kappa_sigma * w->t[j])), kappa_sigma * mu / w->t[j]);
+            w->nu[j] = nn;
+            if (nn > numax) numax = nn;
+            th = fmax(th, fabs(w->c[j] - w->t[j]));
+        }
+        (void)tmp;
+        if (numax > 1e12 && th > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+    }
+    res->status = status;
+    res->iters = it;
+    res->kkt = E0;
+    res->cost = w->f;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * scipy.interpolate.interp1d(kind="linear") restated (scipy/interpolate/_interpolate.py
+ * _call_linear): searchsorted on x, clip index to [1, n-1], slope form.
+ * ---------------------------------------------------------------------------------------------- */
+static double interp_lin(const double* xs, const double* ys, int n, double x) {
+    int hi = 0;
+    while (hi < n && xs[hi] < x) hi++; /* searchsorted(xs, x, side="left") */
+    if (hi < 1) hi = 1;
+    if (hi > n - 1) hi = n - 1;
+    int lo = hi - 1;
+    double slope = (ys[hi] - ys[lo]) / (xs[hi] - xs[lo]);
+    return slope * (x - xs[lo]) + ys[lo];
+}
+
+static double clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
+    o->tol = 1e-8; o->max_iter = 200; o->reserved0 = 0; o->mu_init = 0.1; o->kappa_eps = 10.0;
+    o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2;
+    o->grad_scale_max = 100.0;
+}
+
+int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double* x0,
+                             const double* bez_s, const double* bez_ey, const double* ey_lb,
+                             const double* ey_ub, double* X, double* U, double* cost,
+                             int32_t* status, double* kkt, int32_t* iters) {
+    if (!d || d->N < 2 || d->N > MAXN || batch < 0) return CRX_ERR_ARG;
+    const int N = d->N;
+#pragma omp parallel
+    {
+    work_t* w = (work_t*)malloc(sizeof(work_t));
+    ocp_t* p = (ocp_t*)calloc(1, sizeof(ocp_t));
+#pragma omp for schedule(dynamic, 4)
+    for (int b = 0; b < batch; b++) {
+        const double* xb = x0 + 6 * b;
+        const double* bs = bez_s + (size_t)(N + 1) * b;
+        const double* be = bez_ey + (size_t)(N + 1) * b;
+        memset(p, 0, sizeof(*p));
+        p->N = N; p->nobs = 0;
+        memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
+        memcpy(p->x0, xb, sizeof(p->x0));
+        p->wq[4] = d->w_ref; p->wq[5] = d->w_ref;                     /* :333-334 */
+        for (int j = 0; j <= N; j++) {
+            double st = clip(xb[4] + 1.0 * j * xb[0] * d->dt_ref, bs[0], bs[N]);   /* :330-331 */
+            p->xr[j][4] = st;
+            p->xr[j][5] = interp_lin(bs, be, N + 1, st);                            /* :332 */
+        }
+        p->lin[N][4] = -d->w_prog; p->cconst = d->w_prog * xb[4];      /* :328 */
+        for (int k = 0; k < N; k++) p->wc[k] = (k >= 1 && k <= N - 2) ? d->w_dey : 0.0; /* :325-327 */
+        p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;            /* :280-281 */
+        p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                    /* :283-284 */
+        int infeas0 = 0;
+        for (int k = 0; k <= N; k++) {
+            p->vlo[k] = -HUGE_VAL; p->vhi[k] = (k >= 1) ? d->vx_max : HUGE_VAL;   /* :276 */
+            if (k < N) { p->elo[k] = ey_lb[(size_t)N * b + k]; p->ehi[k] = ey_ub[b]; } /* :277-324 */
+            else { p->elo[k] = -HUGE_VAL; p->ehi[k] = HUGE_VAL; }
+        }
+        /* rows on the fixed x0 are constants: feasible -> inert, violated -> IPOPT cannot succeed */
+        if (xb[5] < p->elo[0] - d->opts.tol || xb[5] > p->ehi[0] + d->opts.tol) infeas0 = 1;
+        result_t r;
+        setup(w, p, &d->opts);
+        ipm_solve(w, &r);
+        if (infeas0) r.status = CRX_INFEASIBLE;
+        double* Xb = X + (size_t)(N + 1) * 6 * b;
+        double* Ub = U + (size_t)N * 2 * b;
+        if (r.status == CRX_CONVERGED) {
+            unpack(w, w->v);
+            memcpy(Xb, w->x, sizeof(double) * 6 * (N + 1));
+            memcpy(Ub, w->u, sizeof(double) * 2 * N);
+            cost[b] = r.cost;
+        } else { /* :365-374 */
+            memset(Xb, 0, sizeof(double) * 6 * (N + 1));
+            memset(Ub, 0, sizeof(double) * 2 * N);
+            for (int j = 0; j <= N; j++) {
+                double st = xb[4] + d->fallback_gain * j * d->dt_ref * xb[0];
+                Xb[6 * j + 0] = d->fallback_gain * xb[0];
+                Xb[6 * j + 4] = st;
+                Xb[6 * j + 5] = interp_lin(bs, be, N + 1, clip(st, bs[0], bs[N]));
+            }
+            cost[b] = HUGE_VAL;
+        }
+        status[b] = r.status; kkt[b] = r.kkt; iters[b] = r.iters;
+    }
+    free(w); free(p);
+    }
+    return CRX_OK;
+}
+
+int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
+                         const double* obs_s, const double* obs_ey, const double* lap_off,
+                         const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
+                         int32_t* status, double* kkt, int32_t* iters) {
+    if (!d || d->N < 2 || d->N > MAXN || batch < 0 || d->n_obs_max < 0 || d->n_obs_max > MAXO ||
+        (d->degree & 1) || d->degree < 2)
+        return CRX_ERR_ARG;
+    const int N = d->N, V = d->n_obs_max;
+    if (n_obs)
+        for (int b = 0; b < batch; b++)
+            if (n_obs[b] < 0 || n_obs[b] > V) return CRX_ERR_ARG;
+#pragma omp parallel
+    {
+    work_t* w = (work_t*)malloc(sizeof(work_t));
+    ocp_t* p = (ocp_t*)calloc(1, sizeof(ocp_t));
+#pragma omp for schedule(dynamic, 4)
+    for (int b = 0; b < batch; b++) {
+        const double* xb = x0 + 6 * b;
+        memset(p, 0, sizeof(*p));
+        p->N = N; p->nobs = n_obs ? n_obs[b] : V;
+        memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
+        memcpy(p->x0, xb, sizeof(p->x0));
+        memcpy(p->wq, d->Q, sizeof(p->wq));                            /* :588-591 */
+        for (int k = 0; k <= N; k++)
+            memcpy(p->xr[k], d->per_stage_target ? xt + ((size_t)(N + 1) * b + k) * 6 : xt + 6 * b,
+                   sizeof(double) * 6);
+        p->wr[0] = d->R[0]; p->wr[1] = d->R[1];                        /* :578-579 */
+        p->wsig = d->w_slack;                                          /* :560,562 */
+        p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;           /* :572-573 */
+        p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                   /* :575-576 */
+        for (int k = 0; k <= N; k++) {                                 /* :582-586 */
+            p->vlo[k] = d->v_min; p->vhi[k] = d->v_max; p->elo[k] = -d->ey_max; p->ehi[k] = d->ey_max;
+        }
+        for (int o = 0; o < p->nobs; o++) {
+            memcpy(p->obs_s[o], obs_s + ((size_t)V * b + o) * (N + 1), sizeof(double) * (N + 1));
+            memcpy(p->obs_ey[o], obs_ey + ((size_t)V * b + o) * (N + 1), sizeof(double) * (N + 1));
+            p->lap_off[o] = lap_off[(size_t)V * b + o];
+        }
+        p->alpha = d->alpha; p->cm = 1.0 + d->margin; p->Ls = d->l_sum; p->Ws = d->w_sum;
+        p->degree = d->degree;
+        int infeas0 = (xb[0] < d->v_min - d->opts.tol || xb[0] > d->v_max + d->opts.tol ||
+                       xb[5] < -d->ey_max - d->opts.tol || xb[5] > d->ey_max + d->opts.tol); /* Q9 */
+        result_t r;
+        setup(w, p, &d->opts);
+        ipm_solve(w, &r);
+        if (infeas0) r.status = CRX_INFEASIBLE;
+        unpack(w, w->v);
+        memcpy(X + (size_t)(N + 1) * 6 * b, w->x, sizeof(double) * 6 * (N + 1));
+        memcpy(U + (size_t)N * 2 * b, w->u, sizeof(double) * 2 * N);
+        for (int o = 0; o < V; o++)
+            for (int k = 0; k <= N; k++)
+                sigma[((size_t)V * b + o) * (N + 1) + k] = o < p->nobs ? w->sig[o][k] : 0.0;
+        cost[b] = r.cost; status[b] = r.status; kkt[b] = r.kkt; iters[b] = r.iters;
+    }
+    free(w); free(p);
+    }
+    return CRX_OK;
+}
+
+#ifdef _OPENMP
+#include <omp.h>
+int crx_oracle_threads(void) { return omp_get_max_threads(); }
+void crx_oracle_set_threads(int n) { omp_set_num_threads(n); }
+#else
+int crx_oracle_threads(void) { return 1; }
+void crx_oracle_set_threads(int n) { (void)n; }
+#endif
+
+/* planning/overtake_traj_planner.py:205-246 */
+int crx_oracle_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X,
+                      const double* obs_s, const double* obs_ey, const int32_t* old_flag,
+                      int32_t* flag, double* sel_cost, double* best_X) {
+    if (!d || d->N < 1 || d->N > MAXN || d->n_veh_max < 0 || d->n_veh_max > MAXO) return CRX_ERR_ARG;
+    const int N = d->N, V = d->n_veh_max, R = V + 1;
+    const double r2 = d->veh_length * d->veh_length + d->veh_width * d->veh_width;
+    for (int s = 0; s < n_scen; s++) {
+        int nv = n_veh[s];
+        if (nv < 0 || nv > V) return CRX_ERR_ARG;
+        int best = 0;
+        double bestc = HUGE_VAL;
+        for (int r = 0; r < R; r++) {
+            double c = HUGE_VAL;
+            if (r <= nv) {
+                const double* Xr = X + (((size_t)s * R + r) * (N + 1)) * 6;
+                c = -d->w_prog * (Xr[6 * N + 4] - Xr[4]);                                /* :209 */
+                for (int side = 0; side < 2; side++) {
+                    int v = side == 0 ? r - 1 : r;                                       /* :213, :227 */
+                    if (v < 0 || v >= nv) continue;
+                    for (int j = 0; j <= N; j++) {
+                        double os = obs_s[((size_t)s * V + v) * (N + 1) + j];
+                        while (os > d->lap_length) os -= d->lap_length;                  /* :216-217 */
+                        double ds = Xr[6 * j + 4] - os;
+                        double de = Xr[6 * j + 5] - obs_ey[((size_t)s * V + v) * (N + 1) + j];
+                        if (!(ds * ds + de * de - r2 >= 0.0)) c += d->w_coll;            /* :220-223 */
+                    }
+                }
+                if (old_flag[s] >= 0 && old_flag[s] != r) c += d->w_switch;              /* :238-243 */
+                if (c < bestc) { bestc = c; best = r; }                                  /* first arg-min :244 */
+            }
+            sel_cost[(size_t)s * R + r] = c;
+        }
+        flag[s] = best;
+        memcpy(best_X + (size_t)s * (N + 1) * 6, X + (((size_t)s * R + best) * (N + 1)) * 6,
+               sizeof(double) * 6 * (N + 1));
+    }
+    return CRX_OK;
+}

@@ -1,0 +1,183 @@
+"""Independent solver + KKT certificate for problems recorded by the CasADi shim.
+
+TEST TOOLING ONLY (golden generation in the build container).  Stands in for IPOPT, which the
+reference calls at /root/reference/car_racing/control/control.py:593-599 and
+/root/reference/car_racing/planning/overtake_traj_planner.py:359-364 and which cannot be
+installed here.  Everything a fixture claims about a solution is backed by the explicit
+certificate computed in ``kkt_certificate`` (solver-agnostic), never by a solver's success flag
+(SciPy's SLSQP routinely reports ``success=False`` on these ill-conditioned problems although it
+has reached a KKT point).
+"""
+import numpy as np
+from scipy.optimize import linprog, minimize
+
+
+def _funcs(opti):
+    cache = {}
+
+    def ev(z):
+        k = z.tobytes()
+        if cache.get("k") != k:
+            cache["k"] = k
+            cache["v"] = opti.eval_all(np.asarray(z, dtype=float))
+        return cache["v"]
+
+    return ev
+
+
+def is_affine(opti, rng):
+    z1 = rng.normal(size=opti.nvar)
+    z2 = rng.normal(size=opti.nvar) * 3.0
+    a = opti.eval_all(z1)
+    b = opti.eval_all(z2)
+    return np.allclose(a[3], b[3], atol=1e-12, rtol=1e-12) and np.allclose(a[5], b[5], atol=1e-12, rtol=1e-12)
+
+
+def kkt_certificate(opti, z, nu=None, act_tol=1e-7):
+    """Explicit first-order certificate at z.
+
+    With ``nu`` (inequality multipliers supplied by whichever solver produced z) the equality
+    multipliers are fitted by least squares and the certificate is the residual of
+    grad f - Je' lam - Ji' nu together with feasibility, sign and complementarity of nu.  Without
+    ``nu`` the inequality multipliers are fitted too, on the rows active to ``act_tol``.
+    Convention: L = f - lam'ce - nu'ci, ci >= 0, nu >= 0.
+    """
+    f, gf, ce, Je, ci, Ji = opti.eval_all(z)
+    if nu is None:
+        act = np.where(ci <= act_tol)[0]
+        rows = np.vstack([Je, Ji[act]]) if len(act) else Je
+        nz = np.where(np.abs(rows).max(axis=1) > 0)[0]
+        lam_fit, *_ = np.linalg.lstsq(rows[nz].T, gf, rcond=None)
+        lam = np.zeros(rows.shape[0])
+        lam[nz] = lam_fit
+        stat = gf - rows.T @ lam
+        nu = np.zeros(len(ci))
+        if len(act):
+            nu[act] = lam[len(ce):]
+        lam_eq = lam[: len(ce)]
+    else:
+        nu = np.asarray(nu, dtype=float)
+        r = gf - Ji.T @ nu
+        lam_eq, *_ = np.linalg.lstsq(Je.T, r, rcond=None)
+        stat = r - Je.T @ lam_eq
+    return dict(
+        f=float(f),
+        stationarity=float(np.abs(stat).max()),
+        eq_violation=float(np.abs(ce).max()) if len(ce) else 0.0,
+        ineq_violation=float(max(0.0, -ci.min())) if len(ci) else 0.0,
+        min_multiplier=float(nu.min()) if len(ci) else 0.0,
+        complementarity=float(np.abs(nu * ci).max()) if len(ci) else 0.0,
+        n_active=int((ci <= act_tol).sum()),
+        lam_eq=lam_eq,
+        nu=nu,
+    )
+
+
+def _polish_qp(H, g, Ae, be, Ai, bi, z, iters=50):
+    """Primal active-set clean-up of an (almost converged) convex-QP solution: fix the active set
+    found by SLSQP, solve the equality-constrained KKT system exactly, repair sign/feasibility."""
+    n = len(z)
+    act = set(np.where(Ai @ z - bi <= 1e-6)[0].tolist())
+    for _ in range(iters):
+        idx = sorted(act)
+        C = np.vstack([Ae, Ai[idx]]) if idx else Ae
+        d = np.concatenate([be, bi[idx]]) if idx else be
+        m = C.shape[0]
+        K = np.block([[H, -C.T], [C, np.zeros((m, m))]])
+        rhs = np.concatenate([-g, d])
+        sol, *_ = np.linalg.lstsq(K, rhs, rcond=None)
+        znew, lam = sol[:n], sol[n:]
+        nu = lam[len(be):]
+        slack = Ai @ znew - bi
+        viol = np.where(slack < -1e-10)[0]
+        viol = [i for i in viol if i not in act]
+        if viol:
+            act.add(int(viol[np.argmin(slack[viol])]))
+            continue
+        if len(nu) and nu.min() < -1e-9:
+            act.remove(idx[int(np.argmin(nu))])
+            continue
+        return znew, True
+    return z, False
+
+
+def solve_recorded(opti, seed=0):
+    """Solve the recorded problem.  Returns (z, info).  info['success'] False <=> infeasible/not certified."""
+    rng = np.random.default_rng(seed)
+    n = opti.nvar
+    ev = _funcs(opti)
+    z0 = opti.z0()
+    affine = is_affine(opti, rng)
+    info = dict(affine=bool(affine), success=False, reason="")
+    f0, g0, ce0, Je0, ci0, Ji0 = opti.eval_all(np.zeros(n))
+    if affine:
+        # constant infeasible rows or LP infeasibility => the reference's IPOPT would fail
+        res = linprog(
+            np.zeros(n),
+            A_ub=-Ji0,
+            b_ub=ci0,
+            A_eq=Je0,
+            b_eq=-ce0,
+            bounds=[(None, None)] * n,
+            method="highs",
+        )
+        info["lp_status"] = int(res.status)
+        if res.status == 2:
+            info["reason"] = "infeasible (HiGHS certificate)"
+            return z0, info
+        zfeas = res.x if res.status == 0 else z0
+    else:
+        zfeas = z0
+
+    cons = [
+        dict(type="eq", fun=lambda z: ev(z)[2], jac=lambda z: ev(z)[3]),
+        dict(type="ineq", fun=lambda z: ev(z)[4], jac=lambda z: ev(z)[5]),
+    ]
+    best = None
+    starts = [z0] + ([zfeas] if affine else [])
+    for zs in starts:
+        r = minimize(
+            lambda z: ev(z)[0],
+            zs,
+            jac=lambda z: ev(z)[1],
+            constraints=cons,
+            method="SLSQP",
+            options=dict(maxiter=1000, ftol=1e-15),
+        )
+        z = r.x
+        if affine:
+            # exact Hessian of a quadratic from two gradient evaluations per column is overkill;
+            # use the identity grad(z) = H z + g
+            H = np.zeros((n, n))
+            for i in range(n):
+                e = np.zeros(n)
+                e[i] = 1.0
+                H[:, i] = opti.eval_all(e)[1] - g0
+            H = 0.5 * (H + H.T)
+            z, ok = _polish_qp(H, g0, Je0, -ce0, Ji0, -ci0, z)
+            info["polished"] = bool(ok)
+        cert = kkt_certificate(opti, z)
+        good = (
+            cert["stationarity"] <= 1e-6 * max(1.0, np.abs(opti.eval_all(z)[1]).max())
+            and cert["eq_violation"] <= 1e-8
+            and cert["ineq_violation"] <= 1e-8
+            and cert["min_multiplier"] >= -1e-6
+        )
+        cand = (z, cert, good, r)
+        if best is None or (good and not best[2]) or (good == best[2] and cert["f"] < best[1]["f"]):
+            best = cand
+        if good:
+            break
+    z, cert, good, r = best
+    info.update({k: v for k, v in cert.items()})
+    info["slsqp_status"] = int(r.status)
+    info["slsqp_nit"] = int(r.nit)
+    info["success"] = bool(good)
+    if not good:
+        info["reason"] = "not certified (stationarity %.2e, eq %.2e, ineq %.2e, minmult %.2e)" % (
+            cert["stationarity"],
+            cert["eq_violation"],
+            cert["ineq_violation"],
+            cert["min_multiplier"],
+        )
+    return z, info
