@@ -1,0 +1,344 @@
+"""Generate tests/golden/*.npz by running the reference's OWN, unmodified solver front-ends
+(/root/reference/car_racing) against the recording CasADi stand-in (shim/casadi.py).
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/tools/make_golden.py            # writes tests/golden/*.npz
+
+What a fixture holds (all data, no reference source):
+  * the raw scenario the reference was called with (ego state, vehicle states, obstacle predictions
+    as returned by the reference's vehicle models, Bezier polylines as computed by the reference's
+    planner_helper, parameters),
+  * what the reference returned (u, x_pred, direction_flag, trajectories, fall-back use),
+  * the solution of the recorded problem with an explicit, solver-agnostic KKT certificate
+    (stationarity / feasibility / multiplier sign / complementarity evaluated on the recorded
+    expression graphs).
+IPOPT never ran (not installable offline): the per-problem solver is tools/ipm_dense.py
+(+ exact active-set polish for the QPs, + a HiGHS feasibility verdict for the QPs).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.normpath(os.path.join(HERE, ".."))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+M = ref_harness.install()
+import sympy as sp  # noqa: E402
+from scipy.optimize import linprog  # noqa: E402
+
+import ipm_dense  # noqa: E402
+import nlp_solve  # noqa: E402
+
+base, offboard, racing_env = M["base"], M["offboard"], M["racing_env"]
+control, casadi, planner_mod = M["control"], M["casadi"], M["planner"]
+
+RECORDS = []
+
+
+def golden_solver(opti):
+    """Opti.solve() stand-in: certified solve of the recorded problem."""
+    n = opti.nvar
+    rng = np.random.default_rng(0)
+    affine = nlp_solve.is_affine(opti, rng)
+    info = dict(affine=bool(affine), success=False, reason="")
+    f0, g0, ce0, Je0, ci0, Ji0 = opti.eval_all(np.zeros(n))
+    if affine:
+        res = linprog(np.zeros(n), A_ub=-Ji0, b_ub=ci0, A_eq=Je0, b_eq=-ce0,
+                      bounds=[(None, None)] * n, method="highs")
+        info["lp_status"] = int(res.status)
+        if res.status == 2:
+            info["reason"] = "infeasible (HiGHS)"
+            RECORDS.append((opti, np.zeros(n), info))
+            return np.zeros(n), info
+    gopts = ipm_dense.Opts()
+    gopts.tol = 1e-11  # goldens are solved two orders tighter than the product default (1e-8)
+    r = ipm_dense.solve_recorded(opti, gopts)
+    z, nu = r["z"], r["nu_full"]
+    info["ipm_status"] = int(r["status"])
+    info["ipm_iters"] = int(r["iters"])
+    info["const_violation"] = float(r["const_violation"])
+    if affine and r["status"] == 0:
+        H = np.zeros((n, n))
+        for i in range(n):
+            e = np.zeros(n)
+            e[i] = 1.0
+            H[:, i] = opti.eval_all(e)[1] - g0
+        H = 0.5 * (H + H.T)
+        zp, ok = nlp_solve._polish_qp(H, g0, Je0, -ce0, Ji0, -ci0, z)
+        info["polished"] = bool(ok)
+        if ok:
+            z, nu = zp, None
+    cert = nlp_solve.kkt_certificate(opti, z, nu)
+    info.update(cert)
+    gscale = max(1.0, float(np.abs(opti.eval_all(z)[1]).max()))
+    info["success"] = bool(
+        r["status"] == 0
+        and r["const_violation"] <= 1e-8
+        and cert["stationarity"] <= 1e-7 * gscale
+        and cert["eq_violation"] <= 1e-9
+        and cert["ineq_violation"] <= 1e-8
+        and cert["min_multiplier"] >= -1e-7
+    )
+    if not info["success"]:
+        info["reason"] = "status %d const_violation %.2e stationarity %.2e" % (
+            r["status"], r["const_violation"], cert["stationarity"])
+    RECORDS.append((opti, z, info))
+    return z, info
+
+
+casadi.Opti.solver_fn = staticmethod(golden_solver)
+
+
+# in-process stand-ins for the fork fan-out (overtake_traj_planner.py:177-197) so that the
+# per-region records reach this process
+class _Proc:
+    def __init__(self, target, args):
+        self.target, self.args = target, args
+
+    def start(self):
+        self.target(*self.args)
+
+    def join(self):
+        pass
+
+
+class _Mgr:
+    def dict(self):
+        return {}
+
+
+planner_mod.Process = _Proc
+planner_mod.Manager = _Mgr
+
+TRACK_SPEC = np.genfromtxt("data/track_layout/l_shape.csv", delimiter=",")
+OPTI_XCURV = np.genfromtxt("data/optimal_traj/xcurv_l_shape.csv", delimiter=",")
+T = sp.symbols("t")
+
+
+def make_track(width=1.0):
+    return racing_env.ClosedTrack(TRACK_SPEC, track_width=width)
+
+
+def cert_fields(info):
+    keys = ("f", "stationarity", "eq_violation", "ineq_violation", "min_multiplier", "complementarity")
+    return np.array([info.get(k, np.nan) for k in keys], dtype=float)
+
+
+# -------------------------------------------------------------------------------------------------
+# mpccbf (control.py:476-607)
+# -------------------------------------------------------------------------------------------------
+def mpccbf_case(x0, cars, N=10, alpha=0.8, vt=0.8, width=1.0, time=0.0):
+    """cars: list of (s0, v, ey) for NoDynamicsModel obstacles s(t) = v t + s0, ey(t) = ey."""
+    track = make_track(width)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+    ego.set_zero_noise()
+    par = base.MPCCBFRacingParam(vt=vt, num_horizon=N, alpha=alpha)
+    ego.set_state_curvilinear(np.array(x0, float))
+    ego.set_state_global(np.zeros(6))
+    ego.set_ctrl_policy(offboard.MPCCBFRacing(par, ego.system_param))
+    ego.ctrl_policy.set_timestep(0.1)
+    ego.set_track(track)
+    ego.ctrl_policy.set_track(track)
+    sim = offboard.CarRacingSim()
+    sim.set_timestep(0.1)
+    sim.set_track(track)
+    sim.add_vehicle(ego)
+    ego.ctrl_policy.set_racing_sim(sim)
+    for i, (s0, v, ey) in enumerate(cars):
+        c = offboard.NoDynamicsModel(name="car%d" % (i + 1), param=base.CarParam())
+        c.set_track(track)
+        c.set_state_curvilinear_func(T, v * T + s0, ey + 0.0 * T)
+        sim.add_vehicle(c)
+        c.time = time
+    ego.ctrl_policy.time = time
+    del RECORDS[:]
+    ego.ctrl_policy.set_state(ego.xcurv, ego.xglob)
+    ego.ctrl_policy.calc_input()
+    opti, z, info = RECORDS[-1]
+    n_obs_rec = (opti.nvar - (8 * N + 6)) // (N + 1)
+    # obstacle predictions exactly as the reference's vehicle model returns them
+    preds = []
+    for i in range(len(cars)):
+        tr, _ = sim.vehicles["car%d" % (i + 1)].get_trajectory_nsteps(time, 0.1, N + 1)
+        preds.append(tr)
+    X = z[: 6 * (N + 1)].reshape(N + 1, 6)
+    U = z[6 * (N + 1): 6 * (N + 1) + 2 * N].reshape(N, 2)
+    S = z[6 * (N + 1) + 2 * N:].reshape(N + 1, n_obs_rec).T if n_obs_rec else np.zeros((0, N + 1))
+    return dict(
+        x0=np.array(x0, float), N=N, alpha=alpha, vt=vt, width=width, lap_length=track.lap_length,
+        cars=np.array(cars, float).reshape(-1, 3), obs_pred=np.array(preds).reshape(len(cars), 6, N + 1),
+        n_obs_in_problem=n_obs_rec, u_returned=np.array(ego.ctrl_policy.u, float),
+        X=X, U=U, sigma=S, success=info["success"], cert=cert_fields(info),
+        ipm_iters=info.get("ipm_iters", -1), const_violation=info.get("const_violation", 0.0),
+    )
+
+
+def gen_mpccbf():
+    cases = {
+        "free_road": dict(x0=[0.7, 0.01, 0.02, 0.03, 2.9, 0.05], cars=[(4.0, 0.2, 0.1)]),
+        "blocked_brake": dict(x0=[0.7, 0.01, 0.02, 0.03, 2.9, 0.05], cars=[(3.6, 0.2, 0.05)]),
+        "pass_left": dict(x0=[1.0, 0.0, 0.0, 0.0, 3.0, 0.35], cars=[(3.9, 0.3, -0.1)]),
+        "pass_right": dict(x0=[1.0, 0.0, 0.0, 0.0, 3.0, -0.4], cars=[(3.8, 0.3, 0.1)]),
+        "two_cars": dict(x0=[0.9, 0.0, 0.0, 0.0, 6.0, 0.0], cars=[(6.9, 0.4, 0.3), (7.4, 0.2, -0.35)]),
+        "out_of_window": dict(x0=[0.8, 0.0, 0.0, 0.0, 1.0, 0.0], cars=[(8.0, 0.2, 0.1)]),
+        "behind_ego": dict(x0=[0.8, 0.0, 0.0, 0.0, 5.0, 0.1], cars=[(4.3, 0.9, 0.15)]),
+        "n12_alpha06": dict(x0=[1.1, 0.02, -0.05, 0.04, 9.0, -0.2], cars=[(9.9, 0.5, 0.0)], N=12, alpha=0.6),
+        "lap_quirk_q1": dict(x0=[0.8, 0.0, 0.0, 0.0, 19.6, 0.0], cars=[(1.2, 0.2, 0.4)]),
+        "x0_off_track_q9": dict(x0=[0.8, 0.0, 0.0, 0.05, 3.0, 1.05], cars=[(4.0, 0.2, 0.1)]),
+        "late_time_q6": dict(x0=[0.9, 0.0, 0.0, 0.0, 4.6, -0.1], cars=[(4.0, 0.2, 0.1)], time=6.0),
+    }
+    out = {}
+    for name, kw in cases.items():
+        r = mpccbf_case(**kw)
+        print("mpccbf %-18s n_obs %d success %s f %.8f stat %.1e iters %d u %s" % (
+            name, r["n_obs_in_problem"], r["success"], r["cert"][0], r["cert"][1], r["ipm_iters"], r["u_returned"]))
+        for k, v in r.items():
+            out[name + "/" + k] = v
+    out["names"] = np.array(sorted(cases))
+    np.savez_compressed(os.path.join(OUT, "mpccbf.npz"), **out)
+
+
+# -------------------------------------------------------------------------------------------------
+# planner (overtake_traj_planner.py:44-379) and mpc_multi_agents (control.py:251-473)
+# -------------------------------------------------------------------------------------------------
+def planner_case(x0, cars, dyn_cars=(), N=10, old_flag=None, width=1.0, time=0.0, raw_s=None):
+    """cars: NoDynamics obstacles (s0, v, ey); dyn_cars: DynamicBicycleModel obstacles given by xcurv."""
+    track = make_track(width)
+    par = base.RacingGameParam(timestep=0.1, num_horizon_planner=N, num_horizon_ctrl=N)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+    xraw = np.array(x0, float)
+    if raw_s is not None:
+        xraw[4] = raw_s
+    ego.set_state_curvilinear(xraw)
+    ego.set_state_global(np.zeros(6))
+    ego.set_track(track)
+    ego.set_timestep(0.1)
+    vehicles = {"ego": ego}
+    for i, (s0, v, ey) in enumerate(cars):
+        c = offboard.NoDynamicsModel(name="car%d" % (i + 1), param=base.CarParam())
+        c.set_track(track)
+        c.set_timestep(0.1)
+        c.set_state_curvilinear_func(T, v * T + s0, ey + 0.0 * T)
+        c.time = time
+        c.xcurv, c.xglob = c.get_estimation(time)
+        vehicles[c.name] = c
+    for i, xc in enumerate(dyn_cars):
+        c = offboard.DynamicBicycleModel(name="dyn%d" % (i + 1), param=base.CarParam(), system_param=base.SystemParam())
+        c.set_track(track)
+        c.set_timestep(0.1)
+        c.set_state_curvilinear(np.array(xc, float))
+        X, Y = track.get_global_position(xc[4], xc[5])
+        psi = track.get_orientation(xc[4], xc[5])
+        c.set_state_global(np.array([xc[0], xc[1], xc[2], psi + xc[3], X, Y]))
+        vehicles[c.name] = c
+    pl = planner_mod.OvertakeTrajPlanner(par)
+    pl.vehicles, pl.agent_name, pl.track, pl.opti_traj_xcurv = vehicles, "ego", track, OPTI_XCURV
+    x = np.array(x0, float)  # start-line-wrapped copy handed to the planner (utils/base.py:460-462)
+    flag, interest = pl.get_overtake_flag(x)
+    res = dict(x_wrapped=x, x_raw=xraw, N=N, width=width, lap_length=track.lap_length,
+               overtake_flag=bool(flag), interest=np.array(sorted(interest)),
+               old_flag=-1 if old_flag is None else int(old_flag))
+    names = [n for n in vehicles if n != "ego"]
+    res["veh_names"] = np.array(names)
+    res["veh_xcurv"] = np.array([vehicles[n].xcurv for n in names]).reshape(len(names), 6)
+    res["veh_is_interest"] = np.array([n in interest for n in names])
+    if not flag:
+        return res
+    del RECORDS[:]
+    (traj, traj_glob, dflag, sorted_veh, bez_glob, solve_time, all_bez_glob, all_traj_glob) = pl.get_local_traj(
+        x, time, interest, None, None, None, None, old_flag)
+    V = len(sorted_veh)
+    recs = list(RECORDS)
+    assert len(recs) == V + 1
+    res.update(
+        sorted_vehicles=np.array(sorted_veh),
+        obs_pred=np.array([pl.obs_infos[n] for n in sorted_veh]).reshape(V, 6, N + 1),
+        bezier_xcurvs=pl.bezier_xcurvs.copy(),
+        direction_flag=int(dflag), traj_xcurv=np.array(traj), traj_xglob=np.array(traj_glob),
+        region_success=np.array([r[2]["success"] for r in recs]),
+        region_cert=np.array([cert_fields(r[2]) for r in recs]),
+        region_X=np.array([pl_sol for pl_sol in all_local_xcurv(pl, recs, N)]),
+        region_lp_status=np.array([r[2].get("lp_status", -1) for r in recs]),
+        all_traj_xglob=np.array(all_traj_glob), all_bezier_xglob=np.array(all_bez_glob),
+    )
+    # follow-up tracking controller (utils/base.py:558-572).  With a DynamicBicycleModel obstacle
+    # the reference itself raises TypeError (control.py:296 always uses the 3-argument form).
+    res["mma_present"] = not dyn_cars
+    if dyn_cars:
+        return res
+    del RECORDS[:]
+    u, x_pred = control.mpc_multi_agents(
+        x, par, track, None, None, None, base.SystemParam(), target_traj_xcurv=traj, vehicles=vehicles,
+        agent_name="ego", direction_flag=dflag, target_traj_xglob=traj_glob, sorted_vehicles=sorted_veh)
+    opti, z, info = RECORDS[-1]
+    n_obs_rec = (opti.nvar - (8 * N + 6)) // (N + 1)
+    res.update(
+        mma_u=np.array(u, float), mma_x_pred=np.array(x_pred, float), mma_success=info["success"],
+        mma_cert=cert_fields(info), mma_n_obs=n_obs_rec,
+        mma_X=z[: 6 * (N + 1)].reshape(N + 1, 6), mma_U=z[6 * (N + 1): 8 * N + 6].reshape(N, 2),
+        mma_sigma=z[8 * N + 6:].reshape(N + 1, n_obs_rec).T if n_obs_rec else np.zeros((0, N + 1)),
+        mma_obs_pred=np.array([vehicles[n].get_trajectory_nsteps(None, 0.1, N + 1)[0] if vehicles[n].no_dynamics
+                               else vehicles[n].get_trajectory_nsteps(N + 1)[0] for n in sorted_veh]).reshape(V, 6, N + 1),
+    )
+    return res
+
+
+def all_local_xcurv(pl, recs, N):
+    """Per-region trajectories as the reference stored them (solution or fall-back), (V+1, N+1, 6)."""
+    # solve_optimization_problem returns solution_xvar as 4th value; re-derive from the records the
+    # same way the reference does: success -> sol.value(opti_xvar); failure -> fall-back (:365-374)
+    out = []
+    for idx, (opti, z, info) in enumerate(recs):
+        if info["success"]:
+            out.append(z[: 6 * (N + 1)].reshape(N + 1, 6))
+        else:
+            xc = pl.xcurv_ego
+            sol = np.zeros((N + 1, 6))
+            for j in range(N + 1):
+                stmp = xc[4] + 1.1 * j * 0.1 * xc[0]
+                sol[j, 0] = 1.1 * xc[0]
+                sol[j, 4] = stmp
+                stmp = np.clip(stmp, pl.bezier_xcurvs[idx, 0, 0], pl.bezier_xcurvs[idx, -1, 0])
+                sol[j, 5] = pl.bezier_funcs[idx](stmp)
+            out.append(sol)
+    return out
+
+
+def gen_planner():
+    cases = {
+        "one_car_ahead": dict(x0=[1.2, 0.0, 0.0, 0.0, 5.0, 0.1], cars=[(6.0, 0.7, -0.1)]),
+        "one_car_left": dict(x0=[1.3, 0.0, 0.0, 0.02, 8.0, -0.2], cars=[(8.9, 0.6, 0.4)]),
+        "two_cars": dict(x0=[1.3, 0.0, 0.0, 0.0, 5.0, 0.0], cars=[(5.9, 0.7, -0.5), (6.4, 0.72, -0.2)]),
+        "three_cars": dict(x0=[1.4, 0.01, 0.0, 0.0, 10.0, 0.1], cars=[(10.7, 0.7, -0.5), (11.2, 0.72, 0.0), (11.6, 0.74, 0.5)]),
+        "three_cars_oldflag": dict(x0=[1.4, 0.01, 0.0, 0.0, 10.0, 0.1], cars=[(10.7, 0.7, -0.5), (11.2, 0.72, 0.0), (11.6, 0.74, 0.5)], old_flag=0),
+        "alongside": dict(x0=[1.0, 0.0, 0.0, 0.0, 12.0, 0.3], cars=[(12.2, 0.9, -0.2)]),
+        "n12": dict(x0=[1.2, 0.0, 0.0, 0.0, 3.0, 0.0], cars=[(4.2, 0.6, 0.2)], N=12),
+        "dyn_obstacle": dict(x0=[1.2, 0.0, 0.0, 0.0, 14.0, 0.0], cars=[], dyn_cars=[[0.6, 0.0, 0.0, 0.0, 15.0, 0.2]]),
+        "start_line_q5": dict(x0=[1.2, 0.0, 0.0, 0.0, 0.2, 0.0], cars=[(1.3, 0.6, 0.2)], raw_s=0.2 + 19.22957795362994),
+        "no_interest": dict(x0=[1.0, 0.0, 0.0, 0.0, 2.0, 0.0], cars=[(9.0, 0.7, 0.0)]),
+    }
+    out = {}
+    for name, kw in cases.items():
+        r = planner_case(**kw)
+        if r["overtake_flag"]:
+            print("planner %-18s V %d flag %d region_success %s lp %s mma_success %s n_obs %s u %s" % (
+                name, len(r["sorted_vehicles"]), r["direction_flag"], r["region_success"],
+                r["region_lp_status"], r.get("mma_success"), r.get("mma_n_obs"), r.get("mma_u")))
+        else:
+            print("planner %-18s no vehicle of interest" % name)
+        for k, v in r.items():
+            out[name + "/" + k] = v
+    out["names"] = np.array(sorted(cases))
+    np.savez_compressed(os.path.join(OUT, "planner.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["mpccbf", "planner"]
+    if "mpccbf" in which:
+        gen_mpccbf()
+    if "planner" in which:
+        gen_planner()

@@ -1,0 +1,45 @@
+"""Shared builders: turn a golden scenario into crx C-ABI inputs through the PRODUCT's host prep."""
+import numpy as np
+from crx import abi, hostprep
+
+
+def mpccbf_inputs(g, A, B, n_obs_max=None):
+    N = int(g["N"])
+    V = g["obs_pred"].shape[0]
+    obs_s = g["obs_pred"][None, :, 4, :]
+    obs_ey = g["obs_pred"][None, :, 5, :]
+    x0 = g["x0"][None, :]
+    keep, lap_off = hostprep.cbf_window(x0, obs_s[:, :, 0], float(g["lap_length"]))
+    nmax = max(1, int(keep.sum())) if n_obs_max is None else n_obs_max
+    ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s, obs_ey, lap_off, nmax)
+    d = abi.cbf_desc(N, nmax, A, B, alpha=float(g["alpha"]), margin=0.2, ey_max=float(g["width"]))
+    xt = np.array([[float(g["vt"]), 0, 0, 0, 0, 0.0]])
+    return d, (x0, xt, ps, pe, po, n)
+
+
+def planner_inputs(g, A, B):
+    N = int(g["N"])
+    V = g["obs_pred"].shape[0]
+    R = V + 1
+    obs_s = g["obs_pred"][None, :, 4, :]
+    obs_ey = g["obs_pred"][None, :, 5, :]
+    lb, ub = hostprep.planner_ey_bounds(g["x_wrapped"][None, :], obs_s, obs_ey, np.array([V]),
+                                        float(g["width"]), float(g["lap_length"]), N)
+    d = abi.planner_desc(N, A, B)
+    x0 = np.repeat(g["x_raw"][None, :], R, axis=0)
+    return d, (x0, g["bezier_xcurvs"][:, :, 0], g["bezier_xcurvs"][:, :, 1], lb[0], ub[0])
+
+
+def mma_inputs(g, A, B):
+    """mpc_multi_agents (control.py:251-473): Q/alpha/margin literals, per-stage target."""
+    N = int(g["N"])
+    obs_s = g["mma_obs_pred"][None, :, 4, :]
+    obs_ey = g["mma_obs_pred"][None, :, 5, :]
+    x = g["x_wrapped"][None, :]
+    keep, lap_off = hostprep.cbf_window(x, obs_s[:, :, 0], float(g["lap_length"]))
+    nmax = max(1, int(keep.sum()))
+    ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s, obs_ey, lap_off, nmax)
+    d = abi.cbf_desc(N, nmax, A, B, Q=(10.0, 0, 0, 5.0, 0, 50.0), alpha=0.6, margin=0.15,
+                     ey_max=float(g["width"]), per_stage_target=True)
+    xt = hostprep.tracking_targets(g["x_wrapped"], g["traj_xcurv"], N)[None]
+    return d, (x, xt, ps, pe, po, n)
