@@ -1,0 +1,149 @@
+"""Synthetic batched racing scenarios for the BASELINE.json configs.
+
+Deterministic: numpy Generator(PCG64(seed)), seed = config index.  Used by bench.py and by the
+parity tests; no reference code or data beyond the LTI model CSVs is involved.
+"""
+import os
+
+import numpy as np
+
+LAP_L_SHAPE = 19.22957795362994  # l_shape lap length (SURVEY.md section 8c probe)
+_ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+
+
+def load_AB():
+    A = np.genfromtxt(os.path.join(_ROOT, "data/sys/LTI/matrix_A.csv"), delimiter=",")
+    B = np.genfromtxt(os.path.join(_ROOT, "data/sys/LTI/matrix_B.csv"), delimiter=",")
+    return A, B
+
+
+def _ego(rng, n, vx_lo, vx_hi):
+    x = np.zeros((n, 6))
+    x[:, 0] = rng.uniform(vx_lo, vx_hi, n)
+    x[:, 1] = rng.normal(0.0, 0.02, n)
+    x[:, 2] = rng.normal(0.0, 0.02, n)
+    x[:, 3] = rng.uniform(-0.1, 0.1, n)
+    x[:, 4] = rng.uniform(0.0, 19.2, n)
+    x[:, 5] = rng.uniform(-0.6, 0.6, n)
+    return x
+
+
+def _safe_start(x0, obs_s, obs_ey, margin, l_sum=0.4, w_sum=0.2, degree=6):
+    """h_0 >= 0 for every obstacle: the CBF formulation presumes the current state is in the safe
+    set (two 0.4 x 0.2 m cars cannot overlap); control.py:544-550."""
+    ds = (x0[:, 4, None] - obs_s[:, :, 0]) / l_sum
+    de = (x0[:, 5, None] - obs_ey[:, :, 0]) / w_sum
+    return (ds ** degree + de ** degree - 1.0 - margin >= 0.05).all(axis=1)
+
+
+def _resample_unsafe(gen, batch, margin, max_rounds=64):
+    """Draw with `gen(n)` until `batch` scenarios with a safe start are collected (rejection)."""
+    parts = None
+    have = 0
+    for _ in range(max_rounds):
+        p = gen(2 * batch)
+        ok = _safe_start(p["x0"], p["obs_s"], p["obs_ey"], margin)
+        p = {k: v[ok] for k, v in p.items()}
+        parts = p if parts is None else {k: np.concatenate([parts[k], p[k]]) for k in p}
+        have = parts["x0"].shape[0]
+        if have >= batch:
+            break
+    return {k: v[:batch] for k, v in parts.items()}
+
+
+def _lanes(rng, shape):
+    return 0.7 - 0.1 * rng.integers(0, 15, size=shape)  # mirrors overtake_planner_test.py:81-82
+
+
+def cfg2_mpccbf(batch=256, N=12, seed=2, n_obs=1, safe_start=True):
+    """MPC-CBF NLP batch: one obstacle inside the +-2*vx window (control.py:520-522)."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    j = np.arange(N + 1)
+
+    def gen(n):
+        x0 = _ego(rng, n, 0.4, 1.2)
+        s_o = x0[:, 4, None] + rng.uniform(-1.5, 1.5, (n, n_obs)) * x0[:, 0, None]
+        v_o = rng.uniform(0.0, 1.0, (n, n_obs))
+        ey_o = _lanes(rng, (n, n_obs))
+        obs_s = s_o[:, :, None] + 0.1 * j[None, None, :] * v_o[:, :, None]
+        obs_ey = np.repeat(ey_o[:, :, None], N + 1, axis=2)
+        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey)
+
+    p = _resample_unsafe(gen, batch, 0.2) if safe_start else gen(batch)
+    xt = np.tile(np.array([0.8, 0, 0, 0, 0, 0.0]), (batch, 1))
+    p.update(xt=xt, lap_off=np.zeros((batch, n_obs)), n_obs=np.full(batch, n_obs, dtype=np.int32),
+             N=N, alpha=0.8, margin=0.2)
+    return p
+
+
+def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True):
+    """mpc_multi_agents-form NLP (control.py:251-473): per-stage ey target, alpha 0.6, margin 0.15,
+    three obstacles ahead in the planner's front window (planner_helper.py:231-236)."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    j = np.arange(N + 1)
+
+    def gen(n):
+        x0 = _ego(rng, n, 0.8, 1.5)
+        v_o = rng.uniform(0.5, 1.2, (n, n_obs))
+        dv = np.abs(x0[:, 0, None] - v_o)
+        s_o = x0[:, 4, None] + rng.uniform(0.0, 1.0, (n, n_obs)) * (4.5 * 0.4 + 0.5 * dv)
+        ey_o = _lanes(rng, (n, n_obs))
+        obs_s = s_o[:, :, None] + 0.1 * j[None, None, :] * v_o[:, :, None]
+        obs_ey = np.repeat(ey_o[:, :, None], N + 1, axis=2)
+        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey)
+
+    p = _resample_unsafe(gen, batch, 0.15) if safe_start else gen(batch)
+    x0 = p["x0"]
+    # target: smooth lateral move from the current ey to a random lane over the horizon
+    ey_goal = _lanes(rng, (batch,))
+    w = (j / N)[None, :]
+    blend = 3 * w ** 2 - 2 * w ** 3
+    xt = np.zeros((batch, N + 1, 6))
+    xt[:, :, 0] = x0[:, 0, None]
+    xt[:, :, 5] = x0[:, 5, None] * (1 - blend) + ey_goal[:, None] * blend
+    p.update(xt=xt, lap_off=np.zeros((batch, n_obs)), n_obs=np.full(batch, n_obs, dtype=np.int32),
+             N=N, alpha=0.6, margin=0.15)
+    return p
+
+
+def cfg3_planner(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_SHAPE):
+    """Overtake-planner scenarios: ego + V surrounding vehicles in the front interest window
+    (planner_helper.py:231-236), constant-speed predictions; all V+1 region QPs per scenario
+    (overtake_traj_planner.py:182-197) and the selection inputs (:205-246).
+
+    Returns the crx_planner_solve arrays with batch = n_scen*(V+1) (scenario-major, region minor)
+    plus the per-scenario selection arrays."""
+    from planning import planner_helper as ph
+
+    from . import hostprep
+
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    opt = np.genfromtxt(os.path.join(_ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
+    j = np.arange(N + 1)
+    R = V + 1
+    x = _ego(rng, n_scen, 0.8, 1.5)
+    x[:, 4] = rng.uniform(0.5, 13.0, n_scen)  # keep s + look-ahead inside one lap of the optimal-trajectory table
+    v_o = rng.uniform(0.5, 1.2, (n_scen, V))
+    dv = np.abs(x[:, 0, None] - v_o)
+    s_o = x[:, 4, None] + rng.uniform(0.0, 1.0, (n_scen, V)) * (4.5 * 0.4 + 0.5 * dv)
+    ey_o = _lanes(rng, (n_scen, V))
+    bez = np.zeros((n_scen, R, N + 1, 2))
+    obs_s = np.zeros((n_scen, V, N + 1))
+    obs_ey = np.zeros((n_scen, V, N + 1))
+    for i in range(n_scen):
+        order = ph.sort_by_ey(list(range(V)), lambda n: ey_o[i, n])
+        # veh_infos in ITERATION order (quirk Q4); predictions in SORTED order
+        vi = np.stack([s_o[i], ey_o[i], ey_o[i]], axis=1)
+        cp = ph.bezier_control_points(V, vi, dv[i].max(), 0.5, track_width, lap_length, 0.2, opt, x[i])
+        bez[i] = ph.bezier_polylines(cp, N)
+        for k, n in enumerate(order):
+            obs_s[i, k] = s_o[i, n] + 0.1 * j * v_o[i, n]
+            obs_ey[i, k] = ey_o[i, n]
+    n_veh = np.full(n_scen, V, dtype=np.int32)
+    lb, ub = hostprep.planner_ey_bounds(x, obs_s, obs_ey, n_veh, track_width, lap_length, N)
+    return dict(
+        x0=np.repeat(x, R, axis=0), bez_s=bez[..., 0].reshape(n_scen * R, N + 1),
+        bez_ey=bez[..., 1].reshape(n_scen * R, N + 1), ey_lb=lb.reshape(n_scen * R, N),
+        ey_ub=ub.reshape(n_scen * R), N=N, V=V, n_scen=n_scen, n_veh=n_veh, obs_s=obs_s, obs_ey=obs_ey,
+        old_flag=rng.integers(-1, R, n_scen).astype(np.int32), lap_length=lap_length,
+    )

@@ -368,20 +368,40 @@ typedef struct {
     double kkt, cost;
 } result_t;
 
+#include <stdio.h>
+static int g_verbose = 0;
+void crx_oracle_set_verbose(int v) { g_verbose = v; }
+
 static void ipm_solve(work_t* w, result_t* res) {
     const ocp_t* p = w->p;
     const crx_ipm_opts* o = w->o;
     const int n = w->nred, m = w->m;
     const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
+    (void)smax;
     memset(w->v, 0, sizeof(double) * n);
     unpack(w, w->v);
     scale_rows(w);
     eval_full(w);
     for (int j = 0; j < m; j++) {
-        w->t[j] = fmax(w->c[j], o->slack_push);
+        /* slack start: inside the bound by at least slack_push, and for a violated row as large
+         * as the violation so that the first fraction-to-the-boundary step is O(1/2), not O(push) */
+        w->t[j] = fmax(fabs(w->c[j]), o->slack_push);
         w->nu[j] = 1.0;
+        /* simple-bound rows: start the multiplier at the cost gradient that pushes against the
+         * bound (dual-feasible start for the 1e4-weighted CBF slacks; IPOPT starts all at 1) */
+        {
+            const rowdef_t* r = &w->row[j];
+            double gg = 0.0;
+            if (r->kind == ROW_SIG) gg = w->g[isig(w, r->k, r->o)];
+            else if (r->kind == ROW_ULO) gg = w->g[iu(w, r->k) + r->i];
+            else if (r->kind == ROW_UHI) gg = -w->g[iu(w, r->k) + r->i];
+            if (gg > 1.0) w->nu[j] = gg;
+        }
     }
-    double mu = o->mu_init, dw_last = 0.0, rho = 1.0, E0 = HUGE_VAL;
+    double mu = o->mu_init, dw_last = 0.0, E0 = HUGE_VAL, theta_min = 0.0, theta_max = HUGE_VAL;
+    enum { MAXF = 32 };
+    double Fth[MAXF], Fph[MAXF];
+    int nf = 0;
     int status = CRX_MAX_ITER, it = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     for (it = 0;; it++) {
@@ -405,6 +425,8 @@ static void ipm_solve(work_t* w, result_t* res) {
         }
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
+        if (g_verbose)
+            fprintf(stderr, "it %3d f %.8e ed %.2e ep %.2e ec %.2e mu %.1e dw %.1e nf %d\n", it, w->f, e_d, e_p, e_c, mu, dw_last, nf);
         if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
         /* barrier update */
@@ -418,7 +440,7 @@ static void ipm_solve(work_t* w, result_t* res) {
             double Emu = fmax(e_d, fmax(e_p, e_cm));
             if (Emu <= o->kappa_eps * mu && mu > o->tol / 10.0) {
                 mu = fmax(o->tol / 10.0, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
-                rho = 1.0;
+                nf = 0; /* new barrier problem: reset the filter */
             } else
                 break;
         }
@@ -494,29 +516,48 @@ static void ipm_solve(work_t* w, result_t* res) {
             Dphi -= mu * s / w->t[j];
         }
         for (int a = 0; a < n; a++) Dphi += w->g[a] * w->dv[a];
-        /* dv' (H + dw I) dv  = dv' rhs  (H dv = rhs) */
         for (int a = 0; a < n; a++) curv += w->dv[a] * w->rhs[a];
-        if (theta > 0.0) {
-            double rt = (Dphi + 0.5 * fmax(curv, 0.0)) / (0.9 * theta);
-            if (rho < rt) rho = rt + 1.0;
+        /* filter line search (Waechter & Biegler sec. 2.3; no second-order correction, no
+         * restoration phase): theta = ||c - t||_1, phi = barrier objective */
+        double phi0 = w->f;
+        for (int j = 0; j < m; j++) phi0 -= mu * log(w->t[j]);
+        if (it == 0) {
+            theta_min = 1e-4 * fmax(1.0, theta);
+            theta_max = 1e4 * fmax(1.0, theta);
         }
-        double DM = Dphi - rho * theta, M0 = w->f + rho * theta;
-        for (int j = 0; j < m; j++) M0 -= mu * log(w->t[j]);
         double al = a_p;
-        int acc = 0;
+        int acc = 0, ftype = 0;
         for (int ls = 0; ls < 40; ls++) {
             for (int a = 0; a < n; a++) vtrial[a] = w->v[a] + al * w->dv[a];
             double fn;
             eval_fc(w, vtrial, &fn, ctrial);
-            double Mn = fn;
+            double phin = fn, thn = 0.0;
             for (int j = 0; j < m; j++) {
                 double tn = w->t[j] + al * w->dt[j];
-                if (ctrial[j] > tn) tn = ctrial[j]; /* slack reset */
+                if (ctrial[j] > tn) tn = ctrial[j]; /* slack reset: lowers theta and phi */
                 ttrial[j] = tn;
-                Mn += -mu * log(tn) + rho * fabs(ctrial[j] - tn);
+                phin -= mu * log(tn);
+                thn += fabs(ctrial[j] - tn);
             }
-            if (Mn <= M0 + eta * al * DM + 1e-13 * fabs(M0)) { acc = 1; break; }
+            int okf = (thn <= theta_max) && (phin == phin);
+            for (int i = 0; i < nf && okf; i++)
+                if (!(thn < Fth[i] || phin < Fph[i])) okf = 0;
+            if (okf) {
+                int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                if (theta <= theta_min && sw) {
+                    if (phin <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
+                    acc = 1;
+                }
+            }
+            if (acc) break;
             al *= 0.5;
+        }
+        if (g_verbose) fprintf(stderr, "      a_p %.3e a_d %.3e alpha %.3e acc %d ftype %d theta %.2e Dphi %.2e curv %.2e dw %.1e\n", a_p, a_d, al, acc, ftype, theta, Dphi, curv, dw);
+        if (acc && !ftype && nf < MAXF) {
+            Fth[nf] = (1.0 - 1e-5) * theta;
+            Fph[nf] = phi0 - 1e-8 * theta;
+            nf++;
         }
         if (!acc) break;
         memcpy(w->v, vtrial, sizeof(double) * n);
