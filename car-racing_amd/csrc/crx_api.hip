@@ -1,0 +1,429 @@
+// crx_api.hip -- the C ABI of libcrx (include/crx.h) on top of the gfx950 kernels.
+//
+// Host-pointer entry points stage through library-owned, grow-only device buffers on one private
+// stream and block; *_dev entry points only enqueue on the caller's stream.  There is no CPU
+// path in this library: without a HIP device every solve entry point fails with CRX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "crx_kparams.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::mutex g_mu;
+int g_device = -1;
+bool g_init = false;
+hipStream_t g_stream = nullptr;
+bool g_timing = false;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+bool g_ev_valid = false;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(CRX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 2 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(CRX_ERR_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+DevBuf g_in, g_out;  // staging for the host-pointer entry points
+DevBuf g_trace;
+int g_trace_rows = 0, g_trace_problem = 0;
+
+int ensure_init() {
+    if (g_init) return 0;
+    return fail(CRX_ERR_NOT_INIT, "crx_init() has not been called (or failed)");
+}
+
+// bump allocator over a DevBuf
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* r = (T*)(base + off);
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+void timing_begin(hipStream_t st) {
+    if (!g_timing) return;
+    if (!g_ev0) {
+        (void)hipEventCreate(&g_ev0);
+        (void)hipEventCreate(&g_ev1);
+    }
+    (void)hipEventRecord(g_ev0, st);
+}
+void timing_end(hipStream_t st) {
+    if (!g_timing) return;
+    (void)hipEventRecord(g_ev1, st);
+    g_ev_valid = true;
+}
+
+int check_opts(const crx_ipm_opts& o) {
+    if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
+        !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0))
+        return fail(CRX_ERR_ARG, "invalid crx_ipm_opts");
+    return 0;
+}
+
+int fill_planner(crx_kparams& kp, const crx_planner_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 3 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [3,%d]", d->N, CRX_MAX_N);
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (int rc = check_opts(d->opts)) return rc;
+    memset(&kp, 0, sizeof(kp));
+    kp.N = d->N; kp.batch = batch; kp.mode = 0; kp.n_obs_max = 0; kp.degree = 6;
+    memcpy(kp.A, d->A, sizeof(kp.A)); memcpy(kp.B, d->B, sizeof(kp.B));
+    kp.wq[4] = d->w_ref; kp.wq[5] = d->w_ref;
+    kp.w_dey = d->w_dey; kp.w_prog = d->w_prog; kp.w_slack = 0.0;
+    kp.delta_max = d->delta_max; kp.a_max = d->a_max; kp.v_min = -INFINITY; kp.v_max = d->vx_max; kp.ey_max = INFINITY;
+    kp.alpha = 0.0; kp.margin = 0.0; kp.l_sum = 1.0; kp.w_sum = 1.0;
+    kp.dt_ref = d->dt_ref; kp.fallback_gain = d->fallback_gain; kp.opts = d->opts;
+    return 0;
+}
+
+int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 3 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [3,%d]", d->N, CRX_MAX_N);
+    if (d->n_obs_max < 0 || d->n_obs_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_obs_max=%d outside [0,%d]", d->n_obs_max, CRX_MAX_OBS);
+    if (d->degree < 2 || (d->degree & 1)) return fail(CRX_ERR_ARG, "degree must be even and >= 2");
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (!(d->alpha > 0.0 && d->alpha <= 1.0)) return fail(CRX_ERR_ARG, "alpha outside (0,1]");
+    if (int rc = check_opts(d->opts)) return rc;
+    memset(&kp, 0, sizeof(kp));
+    kp.N = d->N; kp.batch = batch; kp.mode = 1; kp.per_stage_target = d->per_stage_target ? 1 : 0;
+    kp.n_obs_max = d->n_obs_max; kp.degree = d->degree;
+    memcpy(kp.A, d->A, sizeof(kp.A)); memcpy(kp.B, d->B, sizeof(kp.B));
+    memcpy(kp.wq, d->Q, sizeof(kp.wq)); kp.wr[0] = d->R[0]; kp.wr[1] = d->R[1];
+    kp.w_dey = 0.0; kp.w_prog = 0.0; kp.w_slack = d->w_slack;
+    kp.delta_max = d->delta_max; kp.a_max = d->a_max; kp.v_min = d->v_min; kp.v_max = d->v_max; kp.ey_max = d->ey_max;
+    kp.alpha = d->alpha; kp.margin = d->margin; kp.l_sum = d->l_sum; kp.w_sum = d->w_sum;
+    kp.dt_ref = 0.1; kp.fallback_gain = 1.1; kp.opts = d->opts;
+    return 0;
+}
+
+int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
+    crx_kparams kq = kp;
+    if (g_trace_rows > 0) { kq.trace = (double*)g_trace.p; kq.trace_problem = g_trace_problem; kq.trace_rows = g_trace_rows; }
+    size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
+    if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
+    timing_begin(st);
+    hipError_t e = crx_launch_solve(kq, tmpl, st);
+    timing_end(st);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "solver launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crx_version(void) { return CRX_VERSION; }
+
+const char* crx_last_error(void) { return g_err; }
+
+int crx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int crx_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(CRX_ERR_NO_DEVICE, "no HIP device visible (%s); libcrx has no CPU back-end",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(CRX_ERR_ARG, "device %d outside [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    if (g_init && g_device == device) return CRX_OK;
+    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    g_in.release(); g_out.release();
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_init = true;
+    return CRX_OK;
+}
+
+void crx_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return;
+    (void)hipSetDevice(g_device);
+    g_in.release(); g_out.release();
+    if (g_stream) (void)hipStreamDestroy(g_stream);
+    if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); }
+    g_stream = nullptr; g_ev0 = g_ev1 = nullptr; g_ev_valid = false;
+    g_init = false; g_device = -1;
+}
+
+void crx_set_timing(int enable) { g_timing = enable != 0; }
+
+// diagnostics (not in crx.h): record e_d, e_p, e_c, mu, alpha, alpha_dual, delta_w, accept-type per
+// iteration of one problem of the following solves
+int crx_trace_enable(int problem, int rows) {
+    if (int rc = ensure_init()) return rc;
+    g_trace_rows = 0;
+    if (rows <= 0) return CRX_OK;
+    if (int rc = g_trace.ensure((size_t)rows * 8 * sizeof(double))) return rc;
+    HIP_TRY(hipMemset(g_trace.p, 0, (size_t)rows * 8 * sizeof(double)));
+    g_trace_rows = rows; g_trace_problem = problem;
+    return CRX_OK;
+}
+int crx_trace_read(double* host, int rows) {
+    if (rows > g_trace_rows) rows = g_trace_rows;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, g_trace.p, (size_t)rows * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return CRX_OK;
+}
+
+double crx_last_kernel_ms(void) {
+    if (!g_ev_valid) return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+void crx_ipm_opts_default(crx_ipm_opts* o) {
+    o->tol = 1e-8; o->max_iter = 200; o->reserved0 = 0; o->mu_init = 0.1; o->kappa_eps = 10.0;
+    o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2; o->grad_scale_max = 100.0;
+}
+
+void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B) {
+    memset(d, 0, sizeof(*d));
+    d->N = N;
+    memcpy(d->A, A, sizeof(d->A)); memcpy(d->B, B, sizeof(d->B));
+    d->w_ref = 20.0; d->w_dey = 30.0; d->w_prog = 200.0; d->vx_max = 5.0; d->delta_max = 0.5; d->a_max = 1.5;
+    d->dt_ref = 0.1; d->fallback_gain = 1.1;
+    crx_ipm_opts_default(&d->opts);
+}
+
+void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->n_obs_max = n_obs_max; d->per_stage_target = 0; d->degree = 6;
+    memcpy(d->A, A, sizeof(d->A)); memcpy(d->B, B, sizeof(d->B));
+    const double Q[6] = {10.0, 0.0, 0.0, 4.0, 0.0, 40.0};
+    memcpy(d->Q, Q, sizeof(Q)); d->R[0] = 0.1; d->R[1] = 0.1;
+    d->delta_max = 0.5; d->a_max = 1.0; d->v_min = 0.0; d->v_max = 10.0; d->ey_max = 1.0;
+    d->alpha = 0.8; d->margin = 0.2; d->l_sum = 0.4; d->w_sum = 0.2; d->w_slack = 1e4;
+    crx_ipm_opts_default(&d->opts);
+}
+
+void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length) {
+    d->N = N; d->n_veh_max = n_veh_max; d->veh_length = 0.4; d->veh_width = 0.2; d->lap_length = lap_length;
+    d->w_prog = 10.0; d->w_coll = 100.0; d->w_switch = 100.0;
+}
+
+// ---- planner --------------------------------------------------------------------------------------
+int crx_planner_solve_dev(const crx_planner_desc* d, int batch, const double* x0, const double* bez_s,
+                          const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X, double* U,
+                          double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    crx_kparams kp;
+    if (int rc = fill_planner(kp, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub || !X || !U || !cost || !status || !kkt || !iters)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    kp.x0 = x0; kp.bez_s = bez_s; kp.bez_ey = bez_ey; kp.ey_lb = ey_lb; kp.ey_ub = ey_ub;
+    kp.X = X; kp.U = U; kp.sigma = nullptr; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    return launch_solve(kp, 0, (hipStream_t)stream);
+}
+
+int crx_planner_solve(const crx_planner_desc* d, int batch, const double* x0, const double* bez_s,
+                      const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X, double* U,
+                      double* cost, int32_t* status, double* kkt, int32_t* iters) {
+    if (int rc = ensure_init()) return rc;
+    crx_kparams chk;
+    if (int rc = fill_planner(chk, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub || !X || !U || !cost || !status || !kkt || !iters)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t B = (size_t)batch, N = (size_t)d->N;
+    const size_t n_x0 = B * 6, n_bz = B * (N + 1), n_lb = B * N, n_ub = B;
+    const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2;
+    if (int rc = g_in.ensure((n_x0 + 2 * n_bz + n_lb + n_ub) * 8 + 8 * 256)) return rc;
+    if (int rc = g_out.ensure((n_X + n_U + 2 * B) * 8 + 2 * B * 4 + 8 * 256)) return rc;
+    Carver ci(g_in.p), co(g_out.p);
+    double* dx0 = ci.take<double>(n_x0); double* dbs = ci.take<double>(n_bz); double* dbe = ci.take<double>(n_bz);
+    double* dlb = ci.take<double>(n_lb); double* dub = ci.take<double>(n_ub);
+    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dc = co.take<double>(B);
+    double* dk = co.take<double>(B); int32_t* ds = co.take<int32_t>(B); int32_t* di = co.take<int32_t>(B);
+    HIP_TRY(hipMemcpyAsync(dx0, x0, n_x0 * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dbs, bez_s, n_bz * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dbe, bez_ey, n_bz * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dlb, ey_lb, n_lb * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dub, ey_ub, n_ub * 8, hipMemcpyHostToDevice, g_stream));
+    if (int rc = crx_planner_solve_dev(d, batch, dx0, dbs, dbe, dlb, dub, dX, dU, dc, ds, dk, di, g_stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(cost, dc, B * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(kkt, dk, B * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(status, ds, B * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(iters, di, B * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return CRX_OK;
+}
+
+// ---- MPC-CBF ---------------------------------------------------------------------------------------
+int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
+                      const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X, double* U,
+                      double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    crx_kparams kp;
+    if (int rc = fill_cbf(kp, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !xt || !X || !U || !cost || !status || !kkt || !iters) return fail(CRX_ERR_ARG, "NULL array argument");
+    if (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off || !n_obs || !sigma))
+        return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
+    kp.x0 = x0; kp.xt = xt; kp.obs_s = obs_s; kp.obs_ey = obs_ey; kp.lap_off = lap_off; kp.n_obs = n_obs;
+    kp.X = X; kp.U = U; kp.sigma = sigma; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    return launch_solve(kp, d->n_obs_max, (hipStream_t)stream);
+}
+
+int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
+                  const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X, double* U,
+                  double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters) {
+    if (int rc = ensure_init()) return rc;
+    crx_kparams chk;
+    if (int rc = fill_cbf(chk, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !xt || !X || !U || !cost || !status || !kkt || !iters) return fail(CRX_ERR_ARG, "NULL array argument");
+    const size_t B = (size_t)batch, N = (size_t)d->N, V = (size_t)d->n_obs_max;
+    if (V > 0) {
+        if (!obs_s || !obs_ey || !lap_off || !n_obs || !sigma) return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
+        for (size_t b = 0; b < B; b++)
+            if (n_obs[b] < 0 || n_obs[b] > (int)V) return fail(CRX_ERR_ARG, "n_obs[%zu]=%d outside [0,%zu]", b, n_obs[b], V);
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t n_x0 = B * 6, n_xt = d->per_stage_target ? B * (N + 1) * 6 : B * 6, n_ob = B * V * (N + 1), n_lo = B * V;
+    const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2;
+    if (int rc = g_in.ensure((n_x0 + n_xt + 2 * n_ob + n_lo) * 8 + B * 4 + 8 * 256)) return rc;
+    if (int rc = g_out.ensure((n_X + n_U + n_ob + 2 * B) * 8 + 2 * B * 4 + 8 * 256)) return rc;
+    Carver ci(g_in.p), co(g_out.p);
+    double* dx0 = ci.take<double>(n_x0); double* dxt = ci.take<double>(n_xt);
+    double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1); double* dlo = ci.take<double>(n_lo + 1);
+    int32_t* dno = ci.take<int32_t>(B);
+    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dsg = co.take<double>(n_ob + 1);
+    double* dc = co.take<double>(B); double* dk = co.take<double>(B); int32_t* ds = co.take<int32_t>(B); int32_t* di = co.take<int32_t>(B);
+    HIP_TRY(hipMemcpyAsync(dx0, x0, n_x0 * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dxt, xt, n_xt * 8, hipMemcpyHostToDevice, g_stream));
+    if (V > 0) {
+        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(dlo, lap_off, n_lo * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(dno, n_obs, B * 4, hipMemcpyHostToDevice, g_stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(dno, 0, B * 4, g_stream));
+    }
+    if (int rc = crx_cbf_solve_dev(d, batch, dx0, dxt, dos, doe, dlo, dno, dX, dU, dsg, dc, ds, dk, di, g_stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
+    if (V > 0) HIP_TRY(hipMemcpyAsync(sigma, dsg, n_ob * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(cost, dc, B * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(kkt, dk, B * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(status, ds, B * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(iters, di, B * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return CRX_OK;
+}
+
+// ---- selection -------------------------------------------------------------------------------------
+int crx_select_dev(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X, const double* obs_s,
+                   const double* obs_ey, const int32_t* old_flag, int32_t* flag, double* sel_cost, double* best_X,
+                   void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
+        return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (n_scen == 0) return CRX_OK;
+    if (!n_veh || !X || !old_flag || !flag || !sel_cost || !best_X || (d->n_veh_max > 0 && (!obs_s || !obs_ey)))
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_select_kparams sp;
+    sp.N = d->N; sp.V = d->n_veh_max; sp.n_scen = n_scen;
+    sp.veh_length = d->veh_length; sp.veh_width = d->veh_width; sp.lap_length = d->lap_length;
+    sp.w_prog = d->w_prog; sp.w_coll = d->w_coll; sp.w_switch = d->w_switch;
+    sp.n_veh = n_veh; sp.X = X; sp.obs_s = obs_s; sp.obs_ey = obs_ey; sp.old_flag = old_flag;
+    sp.flag = flag; sp.sel_cost = sel_cost; sp.best_X = best_X;
+    hipError_t e = crx_launch_select(sp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "selection launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X, const double* obs_s,
+               const double* obs_ey, const int32_t* old_flag, int32_t* flag, double* sel_cost, double* best_X) {
+    if (int rc = ensure_init()) return rc;
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
+        return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (n_scen == 0) return CRX_OK;
+    if (!n_veh || !X || !old_flag || !flag || !sel_cost || !best_X || (d->n_veh_max > 0 && (!obs_s || !obs_ey)))
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    const size_t S = (size_t)n_scen, N = (size_t)d->N, V = (size_t)d->n_veh_max, R = V + 1;
+    for (size_t s = 0; s < S; s++)
+        if (n_veh[s] < 0 || n_veh[s] > (int)V) return fail(CRX_ERR_ARG, "n_veh[%zu]=%d outside [0,%zu]", s, n_veh[s], V);
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t n_X = S * R * (N + 1) * 6, n_ob = S * V * (N + 1), n_bX = S * (N + 1) * 6;
+    if (int rc = g_in.ensure((n_X + 2 * n_ob) * 8 + 2 * S * 4 + 8 * 256)) return rc;
+    if (int rc = g_out.ensure((S * R + n_bX) * 8 + S * 4 + 8 * 256)) return rc;
+    Carver ci(g_in.p), co(g_out.p);
+    double* dX = ci.take<double>(n_X); double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1);
+    int32_t* dnv = ci.take<int32_t>(S); int32_t* dof = ci.take<int32_t>(S);
+    int32_t* dfl = co.take<int32_t>(S); double* dsc = co.take<double>(S * R); double* dbX = co.take<double>(n_bX);
+    HIP_TRY(hipMemcpyAsync(dX, X, n_X * 8, hipMemcpyHostToDevice, g_stream));
+    if (V > 0) {
+        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dnv, n_veh, S * 4, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dof, old_flag, S * 4, hipMemcpyHostToDevice, g_stream));
+    if (int rc = crx_select_dev(d, n_scen, dnv, dX, dos, doe, dof, dfl, dsc, dbX, g_stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(flag, dfl, S * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(sel_cost, dsc, S * R * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(best_X, dbX, n_bX * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return CRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// crx_kparams.h -- internal launch descriptors shared by crx_kernels.hip and crx_api.hip.
+// Not part of the public ABI (include/crx.h is).
+#ifndef CRX_KPARAMS_H
+#define CRX_KPARAMS_H
+#include <stdint.h>
+
+#include "../../include/crx.h"
+
+struct crx_kparams {
+    int N, batch, mode /* 0 planner QP, 1 CBF NLP */, per_stage_target, n_obs_max, degree;
+    double A[36], B[12];
+    double wq[6], wr[2];
+    double w_dey, w_prog, w_slack;
+    double delta_max, a_max, v_min, v_max, ey_max;
+    double alpha, margin, l_sum, w_sum;
+    double dt_ref, fallback_gain;
+    crx_ipm_opts opts;
+    // planner inputs (device pointers)
+    const double *x0, *bez_s, *bez_ey, *ey_lb, *ey_ub;
+    // cbf inputs
+    const double *xt, *obs_s, *obs_ey, *lap_off;
+    const int32_t* n_obs;
+    // outputs
+    double *X, *U, *sigma, *cost, *kkt;
+    int32_t *status, *iters;
+    // optional per-iteration trace of ONE problem (diagnostics): trace[it][8]
+    double* trace;
+    int trace_problem, trace_rows;
+};
+
+struct crx_select_kparams {
+    int N, V, n_scen;
+    double veh_length, veh_width, lap_length, w_prog, w_coll, w_switch;
+    const int32_t* n_veh;
+    const double *X, *obs_s, *obs_ey;
+    const int32_t* old_flag;
+    int32_t* flag;
+    double *sel_cost, *best_X;
+};
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
+hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
+size_t crx_solve_lds_bytes(int N, int nobs_template);
+#endif
+#endif
