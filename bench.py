@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: NLP solves/s (N=12, 6-state bicycle).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM.  Default workload = BASELINE.json configs[1]: MPC-CBF NLP (control/control.py:476-607 of
+the reference), 1 obstacle, batch 256, N = 12 -- per GPU (weak scaling: the batch shards by problem,
+no data-path collective).  `--workload cfg3` = 1024 planner scenarios x 4 region QPs + region
+selection per GPU, followed by ONE all-gather of the winning trajectories (the only exchange step
+the path has); cfg4 = 16384 tracking NLPs, N = 20, 3 obstacles.
+
+Rank 0 prints ONE JSON line.  `value` counts every problem handed to the solver per second of the
+timed region, whole job (all GPUs); converged fraction and KKT bound are reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "car-racing_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_GFLOPS = 78600.0  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (vector FP64, spec)
+
+
+def algorithmic_bytes(workload, N, n_obs):
+    """doubles in + doubles out per solve, times 8."""
+    if workload == "cfg3":
+        return (11 * N + 18) * 8                                   # a1: 1200 B at N = 12
+    tgt = (N + 1) if workload == "cfg4" else 0                      # per-stage ey target
+    d_in = 6 + 6 + 2 * n_obs * (N + 1) + n_obs + tgt
+    d_out = 6 * (N + 1) + 2 * N + n_obs * (N + 1) + 3
+    return (d_in + d_out) * 8                                       # a5: 1256 B (N=12, 1 obs); a6: 3152 B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus, file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import crx
+    from crx import abi, synth, torch_api
+
+    crx.init(local)
+    A, B = synth.load_AB()
+    wl = args.workload
+    seed_shift = 1000 * rank
+
+    def to_dev(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return t.to(dtype) if dtype is not None else t
+
+    if wl in ("cfg2", "cfg4"):
+        if wl == "cfg2":
+            batch = args.batch or 256
+            p = synth.cfg2_mpccbf(batch, N=12, seed=2 + seed_shift)
+            desc = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+        else:
+            batch = args.batch or 16384
+            p = synth.cfg4_tracking_cbf(batch, N=20, seed=4 + seed_shift)
+            desc = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+        N, n_obs = desc.N, desc.n_obs_max
+        t_in = [to_dev(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [to_dev(p["n_obs"], torch.int32)]
+        ws = torch_api.CbfWorkspace(desc, batch, dev)
+        units = batch
+
+        def step():
+            torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
+
+        name = ("MPC-CBF NLP (control.py:476-607), l_shape model, 1 obstacle, N=12, batch 256/GPU" if wl == "cfg2"
+                else "tracking NLP with CBF rows (control.py:251-473 form), 3 obstacles, N=20, batch %d/GPU" % batch)
+    else:
+        n_scen = args.batch or 1024
+        p = synth.cfg3_planner(n_scen, N=12, seed=3 + seed_shift)
+        N, n_obs, V = 12, 0, p["V"]
+        desc = abi.planner_desc(N, A, B)
+        sdesc = abi.select_desc(N, V, p["lap_length"])
+        t_in = [to_dev(p[k]) for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
+        t_sel = [to_dev(p["n_veh"], torch.int32), to_dev(p["obs_s"]), to_dev(p["obs_ey"]), to_dev(p["old_flag"], torch.int32)]
+        batch = n_scen * (V + 1)
+        ws = torch_api.PlannerWorkspace(desc, batch, dev)
+        sws = torch_api.SelectWorkspace(sdesc, n_scen, dev)
+        gathered = torch.empty((world, n_scen, N + 1, 6), dtype=torch.float64, device=dev) if world > 1 else None
+        units = batch
+
+        def step():
+            torch_api.planner_solve_dev(desc, *t_in, ws=ws)
+            torch_api.select_dev(sdesc, t_sel[0], ws.X.view(n_scen, V + 1, N + 1, 6), t_sel[1], t_sel[2], t_sel[3], ws=sws)
+            if world > 1:  # the path's only exchange: winners to every rank (RCCL all-gather over xGMI)
+                dist.all_gather_into_tensor(gathered, sws.best_X)
+
+        name = "overtake planner: %d scenarios x %d region QPs (overtake_traj_planner.py:248-379) + selection (:205-246), N=12, per GPU" % (n_scen, V + 1)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = units * world * args.steps / elapsed
+
+    # ---- per-launch kernel time, measured with HIP events on the launch stream -----------------------
+    L = crx.lib()
+    L.crx_set_timing(1)
+    kms = []
+    for _ in range(min(50, max(5, args.steps))):
+        if wl == "cfg3":
+            torch_api.planner_solve_dev(desc, *t_in, ws=ws)
+        else:
+            torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
+        kms.append(L.crx_last_kernel_ms())
+    L.crx_set_timing(0)
+    k_ms = float(np.mean(kms))
+    # latency of one synchronous control step (what a 10 Hz controller sees): p50 over blocking calls
+    lat = []
+    for _ in range(min(100, max(10, args.steps))):
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    st = ws.status.cpu().numpy()
+    it = ws.iters.cpu().numpy()
+    kkt = ws.kkt.cpu().numpy()
+    conv = st == 0
+    abytes = algorithmic_bytes(wl, N, n_obs)
+    achieved = abytes * batch / (k_ms * 1e-3) / 1e9
+    # analytic FP64 work: Riccati factor + solves per interior-point iteration
+    nx, nu = 6 + n_obs, 2 + n_obs
+    nz = nx + nu
+    flop_iter = N * (2 * nx * nx * nz + 2 * nx * nz * nz + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nu * nx * (nx + 1)) \
+        + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
+    gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3}[wl], "batch_per_gpu": int(batch),
+                   "horizon": int(N), "n_obs": int(n_obs), "tol": desc.opts.tol,
+                   "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
+                   "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
+                   "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
+                     "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
+                     "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, desc, p, batch)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl, desc, p, batch):
+    """The oracle (a C port of the same iteration, condensed dense Cholesky) on the host cores of this
+    box, on a bounded sample of the same workload.  The reference's own CasADi/IPOPT path is timed
+    only if `import casadi` works here (it does not in this image; nothing is substituted)."""
+    import oracle
+
+    orc = oracle.load()
+    cores = oracle.threads()
+    n = min(batch, 1024)
+    if wl == "cfg3":
+        a = (p["x0"][:n], p["bez_s"][:n], p["bez_ey"][:n], p["ey_lb"][:n], p["ey_ub"][:n])
+        fn = lambda: orc.planner_solve(desc, *a)  # noqa: E731
+    else:
+        a = (p["x0"][:n], p["xt"][:n], p["obs_s"][:n], p["obs_ey"][:n], p["lap_off"][:n], p["n_obs"][:n])
+        fn = lambda: orc.cbf_solve(desc, *a)  # noqa: E731
+    fn()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 3.0 or reps >= 200:
+            break
+    try:
+        import casadi  # noqa: F401
+        ref = "casadi importable: reference path NOT timed in this round"
+    except Exception:
+        ref = "casadi: unavailable (not installed; no network) -> reference CasADi/IPOPT path not timed"
+    return {"value": n * reps / el, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (reps, n, el),
+            "reference": ref}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Device-resident entry points: torch CUDA(HIP) tensors in, torch tensors out, no host staging.
+
+torch is used for device memory, streams and torch.distributed only; the solve itself is
+libcrx's `*_dev` C ABI called with raw device pointers on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import binding, lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, dtype, shape, name):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise ValueError("%s: expected contiguous cuda %s tensor of shape %s, got %s %s %s" % (
+            name, dtype, tuple(shape), t.device, t.dtype, tuple(t.shape)))
+    return t
+
+
+def _call(name, *args):
+    binding()
+    L = lib()
+    fn = getattr(L, name)
+    fn.restype = C.c_int
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed: rc=%d %s" % (name, rc, (L.crx_last_error() or b"").decode()))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class CbfWorkspace:
+    """Pre-allocated outputs for repeated cbf_solve_dev calls of one shape."""
+
+    def __init__(self, desc, batch, device):
+        N, V = desc.N, max(desc.n_obs_max, 1)
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.X = torch.empty((batch, N + 1, 6), **f64)
+        self.U = torch.empty((batch, N, 2), **f64)
+        self.sigma = torch.empty((batch, V, N + 1), **f64)
+        self.cost = torch.empty(batch, **f64)
+        self.kkt = torch.empty(batch, **f64)
+        self.status = torch.empty(batch, **i32)
+        self.iters = torch.empty(batch, **i32)
+
+
+def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None):
+    N, V, B = desc.N, desc.n_obs_max, x0.shape[0]
+    _chk(x0, torch.float64, (B, 6), "x0")
+    _chk(xt, torch.float64, (B, N + 1, 6) if desc.per_stage_target else (B, 6), "xt")
+    _chk(obs_s, torch.float64, (B, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (B, V, N + 1), "obs_ey")
+    _chk(lap_off, torch.float64, (B, V), "lap_off")
+    _chk(n_obs, torch.int32, (B,), "n_obs")
+    ws = ws or CbfWorkspace(desc, B, x0.device)
+    _call("crx_cbf_solve_dev", C.byref(desc), C.c_int(B), _ptr(x0), _ptr(xt), _ptr(obs_s), _ptr(obs_ey),
+          _ptr(lap_off), _ptr(n_obs), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost), _ptr(ws.status),
+          _ptr(ws.kkt), _ptr(ws.iters), _stream())
+    return ws
+
+
+class PlannerWorkspace:
+    def __init__(self, desc, batch, device):
+        N = desc.N
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.X = torch.empty((batch, N + 1, 6), **f64)
+        self.U = torch.empty((batch, N, 2), **f64)
+        self.cost = torch.empty(batch, **f64)
+        self.kkt = torch.empty(batch, **f64)
+        self.status = torch.empty(batch, **i32)
+        self.iters = torch.empty(batch, **i32)
+
+
+def planner_solve_dev(desc, x0, bez_s, bez_ey, ey_lb, ey_ub, ws=None):
+    N, B = desc.N, x0.shape[0]
+    _chk(x0, torch.float64, (B, 6), "x0")
+    _chk(bez_s, torch.float64, (B, N + 1), "bez_s")
+    _chk(bez_ey, torch.float64, (B, N + 1), "bez_ey")
+    _chk(ey_lb, torch.float64, (B, N), "ey_lb")
+    _chk(ey_ub, torch.float64, (B,), "ey_ub")
+    ws = ws or PlannerWorkspace(desc, B, x0.device)
+    _call("crx_planner_solve_dev", C.byref(desc), C.c_int(B), _ptr(x0), _ptr(bez_s), _ptr(bez_ey), _ptr(ey_lb),
+          _ptr(ey_ub), _ptr(ws.X), _ptr(ws.U), _ptr(ws.cost), _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters),
+          _stream())
+    return ws
+
+
+class SelectWorkspace:
+    def __init__(self, desc, n_scen, device):
+        N, R = desc.N, desc.n_veh_max + 1
+        self.flag = torch.empty(n_scen, dtype=torch.int32, device=device)
+        self.sel_cost = torch.empty((n_scen, R), dtype=torch.float64, device=device)
+        self.best_X = torch.empty((n_scen, N + 1, 6), dtype=torch.float64, device=device)
+
+
+def select_dev(desc, n_veh, X, obs_s, obs_ey, old_flag, ws=None):
+    N, V, S = desc.N, desc.n_veh_max, n_veh.shape[0]
+    _chk(n_veh, torch.int32, (S,), "n_veh")
+    _chk(X, torch.float64, (S, V + 1, N + 1, 6), "X")
+    _chk(obs_s, torch.float64, (S, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (S, V, N + 1), "obs_ey")
+    _chk(old_flag, torch.int32, (S,), "old_flag")
+    ws = ws or SelectWorkspace(desc, S, X.device)
+    _call("crx_select_dev", C.byref(desc), C.c_int(S), _ptr(n_veh), _ptr(X), _ptr(obs_s), _ptr(obs_ey),
+          _ptr(old_flag), _ptr(ws.flag), _ptr(ws.sel_cost), _ptr(ws.best_X), _stream())
+    return ws
