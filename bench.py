@@ -109,7 +109,7 @@ def main():
         batch = n_scen * (V + 1)
         ws = torch_api.PlannerWorkspace(desc, batch, dev)
         sws = torch_api.SelectWorkspace(sdesc, n_scen, dev)
-        gathered = torch.empty((world, n_scen, N + 1, 6), dtype=torch.float64, device=dev) if world > 1 else None
+        gathered = torch.empty((world * n_scen, N + 1, 6), dtype=torch.float64, device=dev) if world > 1 else None
         units = batch
 
         def step():

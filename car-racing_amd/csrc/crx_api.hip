@@ -202,15 +202,15 @@ int crx_trace_enable(int problem, int rows) {
     if (int rc = ensure_init()) return rc;
     g_trace_rows = 0;
     if (rows <= 0) return CRX_OK;
-    if (int rc = g_trace.ensure((size_t)rows * 8 * sizeof(double))) return rc;
-    HIP_TRY(hipMemset(g_trace.p, 0, (size_t)rows * 8 * sizeof(double)));
+    if (int rc = g_trace.ensure((size_t)rows * 16 * sizeof(double))) return rc;
+    HIP_TRY(hipMemset(g_trace.p, 0, (size_t)rows * 16 * sizeof(double)));
     g_trace_rows = rows; g_trace_problem = problem;
     return CRX_OK;
 }
 int crx_trace_read(double* host, int rows) {
     if (rows > g_trace_rows) rows = g_trace_rows;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host, g_trace.p, (size_t)rows * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, g_trace.p, (size_t)rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return CRX_OK;
 }
 

@@ -45,6 +45,31 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 
+// sum over the wave of log(v) for positive v (lanes with nothing to add pass 1.0): mantissas are
+// multiplied (a product of up to 6*64 values in [0.5,1) cannot underflow a double: 2^-384),
+// exponents are added, and ONE log is taken.
+struct LogAcc {
+    double m;
+    int e;
+    __device__ __forceinline__ LogAcc() : m(1.0), e(0) {}
+    __device__ __forceinline__ void mul(double v) {
+        int ex;
+        double mm = frexp(v, &ex);
+        m *= mm;
+        e += ex;
+    }
+    __device__ __forceinline__ double wave_total() {
+        double mm = m;
+        int ee = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mm *= __shfl_xor(mm, o);
+            ee += __shfl_xor(ee, o);
+        }
+        return log(mm) + 0.6931471805599453 * (double)ee;
+    }
+};
+
 __device__ __forceinline__ double ipow_d(double a, int p) {
     double r = 1.0;
     for (int i = 0; i < p; i++) r *= a;
@@ -539,8 +564,10 @@ __device__ __forceinline__ bool riccati_backward(Ctx<NOBS>& c, double dw) {
             c.s.hv[lane] = s;
         }
         SYNC();
-        // every lane factorises Huu = L L' itself (NU <= 5, broadcast LDS reads)
-        double L[NU][NU];
+        // every lane factorises Huu = L D L' itself (NU <= 5, broadcast LDS reads).  Unit-lower L,
+        // pivots D, reciprocal pivots rD: no square roots, and one division per pivot on the
+        // dependent chain (FP64 sqrt/div are ~20-instruction sequences on CDNA4).
+        double L[NU][NU], Dp[NU], rD[NU];
 #pragma unroll
         for (int a = 0; a < NU; a++)
 #pragma unroll
@@ -549,25 +576,25 @@ __device__ __forceinline__ bool riccati_backward(Ctx<NOBS>& c, double dw) {
         for (int j = 0; j < NU; j++) {
             double d = L[j][j];
 #pragma unroll
-            for (int q = 0; q < j; q++) d -= L[j][q] * L[j][q];
+            for (int q = 0; q < j; q++) d -= L[j][q] * L[j][q] * Dp[q];
             if (!(d > 0.0)) ok = false;
-            d = sqrt(d);
-            L[j][j] = d;
+            Dp[j] = d;
+            rD[j] = 1.0 / d;
 #pragma unroll
             for (int i = j + 1; i < NU; i++) {
                 double t = L[i][j];
 #pragma unroll
-                for (int q = 0; q < j; q++) t -= L[i][q] * L[j][q];
-                L[i][j] = t / d;
+                for (int q = 0; q < j; q++) t -= L[i][q] * L[j][q] * Dp[q];
+                L[i][j] = t * rD[j];
             }
         }
         if (!ok) break;  // uniform: every lane computed the same pivots
-        // Factorised (square-root) update, the block-Cholesky form of the recursion:
-        //   Y = L^{-1} Hux  (forward substitution),   P_new = Hxx - Y'Y,   K = -L^{-T} Y,
-        //   yg = L^{-1} gu,  p_new = gx - Y'yg,  kff = -L^{-T} yg.
-        // P_new is formed symmetrically from the SAME triangular factor for (i,j) and (j,i), which
-        // keeps it symmetric positive semi-definite under barrier weights Sigma up to ~1e13 (the
-        // K-form  Hxx + Hux'K  does not).  Column index NX stands for the gradient column.
+        // Factorised update, the block-Cholesky form of the recursion (Huu = L D L'):
+        //   Y = L^{-1} Hux  (unit forward substitution),  P_new = Hxx - Y' D^{-1} Y,  K = -L^{-T} D^{-1} Y,
+        //   yg = L^{-1} gu,  p_new = gx - Y' D^{-1} yg,   kff = -L^{-T} D^{-1} yg.
+        // P_new is formed symmetrically from the SAME factor for (i,j) and (j,i), which keeps it
+        // symmetric positive semi-definite under barrier weights Sigma up to ~1e13 (the K-form
+        // Hxx + Hux'K does not).  Column index NX stands for the gradient column.
         constexpr int PCNT = (NX * (NX + 1) + WAVE - 1) / WAVE;
         double Pn[PCNT];
 #pragma unroll
@@ -582,23 +609,20 @@ __device__ __forceinline__ bool riccati_backward(Ctx<NOBS>& c, double dw) {
                 yj[a] = (j < NX) ? c.s.H[(NX + a) * NZ + j] : c.s.hv[NX + a];
             }
 #pragma unroll
-            for (int a = 0; a < NU; a++) {
+            for (int a = 1; a < NU; a++) {
 #pragma unroll
                 for (int q = 0; q < a; q++) { yi[a] -= L[a][q] * yi[q]; yj[a] -= L[a][q] * yj[q]; }
-                yi[a] /= L[a][a];
-                yj[a] /= L[a][a];
             }
             double s = (j < NX) ? c.s.H[i * NZ + j] : c.s.hv[i];
 #pragma unroll
-            for (int a = 0; a < NU; a++) s -= yi[a] * yj[a];
+            for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; s -= yi[a] * yj[a]; }
             Pn[cnt] = s;
             if (i == 0) {
-                // feedback column j: K[:,j] = -L^{-T} yj
+                // feedback column j: K[:,j] = -L^{-T} (D^{-1} yj)
 #pragma unroll
-                for (int a = NU - 1; a >= 0; a--) {
+                for (int a = NU - 2; a >= 0; a--) {
 #pragma unroll
                     for (int q = a + 1; q < NU; q++) yj[a] -= L[q][a] * yj[q];
-                    yj[a] /= L[a][a];
                 }
 #pragma unroll
                 for (int a = 0; a < NU; a++) {
@@ -884,7 +908,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     mact = (int)wave_sum((double)mact);
     const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
 
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (it = 0;; it++) {
+        long long tc0 = clock64();
         // ---- KKT error ---------------------------------------------------------------------------
         double nus = 0.0, e_p = 0.0, e_c = 0.0;
         for (int j = lane; j < m; j += WAVE) {
@@ -896,7 +922,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         }
         nus = wave_sum(nus); e_p = wave_max(e_p); e_c = wave_max(e_c);
         double sd = fmax(smax, nus / (mact > 0 ? mact : 1)) / smax;
+        long long tc1 = clock64();
         double e_d = dual_infeasibility(c) / sd;
+        long long tc2 = clock64();
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (E0 <= o.tol) { status = 0; break; }
@@ -909,14 +937,16 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             e_cm = wave_max(e_cm) / sd;
             double Emu = fmax(e_d, fmax(e_p, e_cm));
             if (Emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-                mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, o.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, o.theta_mu)));
                 nf = 0;
             } else
                 break;
         }
         const double tau = fmax(o.tau_min, 1.0 - mu);
         // ---- Newton step -------------------------------------------------------------------------
+        long long tc3 = clock64();
         assemble_newton(c, mu);
+        long long tc4 = clock64();
         double dw = 0.0;
         bool ok = riccati_backward(c, 0.0);
         if (!ok) {
@@ -930,9 +960,12 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (!ok) break;
             dw_last = dw;
         }
+        long long tc5 = clock64();
         riccati_forward(c);
+        long long tc6 = clock64();
         // ---- row steps, step lengths, merit pieces -------------------------------------------------
         double a_p = 1.0, a_d = 1.0, theta = 0.0, Dphi = 0.0, phi0 = 0.0;
+        LogAcc lg0;
         for (int j = lane; j < m; j += WAVE) {
             if (!row_active(c, j)) { c.s.rdt[j] = 0.0; c.s.rdnu[j] = 0.0; continue; }
             double t = c.s.rt[j], nu = c.s.rnu[j], rp = c.s.rc[j] - t;
@@ -964,21 +997,26 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (dnu < 0.0) a_d = fmin(a_d, -tau * nu / dnu);
             theta += fabs(rp);
             Dphi -= mu * dt / t;
-            phi0 -= mu * log(t);
+            lg0.mul(t);
         }
         a_p = wave_min(a_p); a_d = wave_min(a_d); theta = wave_sum(theta);
         Dphi = wave_sum(Dphi) + cost_dir(c);
-        phi0 = wave_sum(phi0) + f;
+        phi0 = f - mu * lg0.wave_total();
         if (it == 0) {
             theta_min = 1e-4 * fmax(1.0, theta);
             theta_max = 1e4 * fmax(1.0, theta);
         }
+        long long tc7 = clock64();
         // ---- filter line search --------------------------------------------------------------------
         double al = a_p, fn = f;
         int acc = 0, ftype = 0;
+        // switching condition al * (-Dphi)^2.3 > theta^1.1 (only consulted when theta <= theta_min)
+        const bool sw_try = (theta <= theta_min) && (Dphi < 0.0);
+        const double sw_lhs = sw_try ? pow(-Dphi, 2.3) : 0.0, sw_rhs = sw_try ? pow(theta, 1.1) : 0.0;
         for (int ls = 0; ls < 40; ls++) {
             fn = cost_value(c, al);
             double phin = 0.0, thn = 0.0;
+            LogAcc lg;
             for (int j = lane; j < m; j += WAVE) {
                 if (!row_active(c, j)) continue;
                 bool cbf = NOBS && j < N * NR && (j % NR) >= 8 + NOBS;
@@ -987,10 +1025,10 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                 double tn = t + al * dt;
                 if (cn > tn) tn = cn;  // slack reset
                 c.s.rtt[j] = tn;
-                phin -= mu * log(tn);
+                lg.mul(tn);
                 thn += fabs(cn - tn);
             }
-            phin = wave_sum(phin) + fn; thn = wave_sum(thn);
+            phin = fn - mu * lg.wave_total(); thn = wave_sum(thn);
             int okf = (thn <= theta_max) && (phin == phin);
             {
                 int bad = 0;
@@ -999,8 +1037,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                 if (__any(bad)) okf = 0;
             }
             if (okf) {
-                int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
-                if (theta <= theta_min && sw) {
+                if (sw_try && al * sw_lhs > sw_rhs) {
                     if (phin <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
                 } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
                     acc = 1;
@@ -1009,8 +1046,11 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (acc) break;
             al *= 0.5;
         }
+        long long tc8 = clock64();
+        tph[0] = tc1 - tc0; tph[1] = tc2 - tc1; tph[2] = tc3 - tc2; tph[3] = tc4 - tc3; tph[4] = tc5 - tc4; tph[5] = tc6 - tc5; tph[6] = tc7 - tc6; tph[7] = tc8 - tc7;
         if (kp.trace && b == kp.trace_problem && it < kp.trace_rows && lane == 0) {
-            double* tr = kp.trace + (size_t)it * 8;
+            double* tr = kp.trace + (size_t)it * 16;
+            for (int q = 0; q < 8; q++) tr[8 + q] = (double)(tph[q]);
             tr[0] = e_d; tr[1] = e_p; tr[2] = e_c; tr[3] = mu; tr[4] = al; tr[5] = a_d; tr[6] = dw; tr[7] = acc ? (ftype ? 2.0 : 1.0) : 0.0;
         }
         if (acc && !ftype && nf < MAXF) {

@@ -1,0 +1,433 @@
+"""Controller / vehicle / simulator classes with the reference's surface (utils/base.py), so that
+the reference's drivers (tests/auto_mpccbf_test.py, car_racing/tests/mpccbf_test.py) run against
+this package unchanged.  Only what the accelerated hot path and its harness need is here; the
+LMPC learning controller, LQR and iLQR are out of scope and raise.
+
+Objects stay picklable: the GPU library handle lives in the `crx` module, never in instance state
+(the reference pickles its simulator, tests/auto_mpccbf_test.py:42-43).
+"""
+import copy
+import os
+
+import numpy as np
+
+from control import control
+from planning import overtake_traj_planner
+from system import vehicle_dynamics
+from utils import racing_env
+from utils.constants import U_DIM, X_DIM
+
+_REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+
+
+def _csv(rel):
+    """The reference reads its model CSVs relative to the CWD at import time (base.py:124-125);
+    fall back to this repository's copy of the same data files."""
+    path = rel if os.path.exists(rel) else os.path.join(_REPO, rel)
+    return np.genfromtxt(path, delimiter=",")
+
+
+_A_DEFAULT = _csv("data/sys/LTI/matrix_A.csv")
+_B_DEFAULT = _csv("data/sys/LTI/matrix_B.csv")
+
+
+class ControlBase:
+    def __init__(self):
+        self.agent_name = None
+        self.time = 0.0
+        self.timestep = None
+        self.x = None
+        self.xglob = None
+        self.u = None
+        self.realtime_flag = False
+        self.lap_times, self.lap_xcurvs, self.lap_xglobs, self.lap_inputs = [self.time], [], [], []
+        self.times, self.xglobs, self.xcurvs, self.inputs = [], [], [], []
+        self.laps = 0
+        self.track = None
+        self.opti_traj_xcurv = None
+        self.opti_traj_xglob = None
+
+    def set_track(self, track):
+        self.track = track
+        self.lap_length = track.lap_length
+        self.point_and_tangent = track.point_and_tangent
+        self.lap_width = track.width
+
+    def set_opti_traj(self, opti_traj_xcurv, opti_traj_xglob):
+        self.opti_traj_xcurv, self.opti_traj_xglob = opti_traj_xcurv, opti_traj_xglob
+
+    def set_racing_sim(self, racing_sim):
+        self.racing_sim = racing_sim
+
+    def set_timestep(self, timestep):
+        self.timestep = timestep
+
+    def set_target_speed(self, vt):
+        self.vt = vt
+
+    def set_target_deviation(self, eyt):
+        self.eyt = eyt
+
+    def set_state(self, xcurv, xglob):
+        self.x, self.xglob = xcurv, xglob
+
+    def calc_input(self):
+        pass
+
+    def get_input(self):
+        return self.u
+
+    def _ego_log_none(self, **kw):
+        """Per-step bookkeeping the reference appends to vehicles['ego'] (base.py:106-117,336-347)."""
+        if self.agent_name != "ego":
+            return
+        veh = (self.racing_sim.vehicles if self.realtime_flag is False else self.vehicles)["ego"]
+        for key in ("local_trajs", "vehicles_interest", "splines", "all_splines", "all_local_trajs",
+                    "lmpc_prediction", "mpc_cbf_prediction"):
+            getattr(veh, key).append(kw.get(key))
+
+
+class PIDTracking(ControlBase):
+    def __init__(self, vt=0.6, eyt=0.0):
+        ControlBase.__init__(self)
+        self.set_target_speed(vt)
+        self.set_target_deviation(eyt)
+
+    def calc_input(self):
+        xtarget = np.array([self.vt, 0, 0, 0, 0, self.eyt]).reshape(X_DIM, 1)
+        self.u = control.pid(self.x, xtarget)
+        self._ego_log_none()
+        self.time += self.timestep
+
+
+class MPCTrackingParam:
+    def __init__(self, matrix_A=_A_DEFAULT, matrix_B=_B_DEFAULT, matrix_Q=np.diag([10.0, 0.0, 0.0, 4.0, 0.0, 40.0]),
+                 matrix_R=np.diag([0.1, 0.1]), vt=0.6, eyt=0.0, num_horizon=10):
+        self.matrix_A, self.matrix_B, self.matrix_Q, self.matrix_R = matrix_A, matrix_B, matrix_Q, matrix_R
+        self.vt, self.eyt, self.num_horizon = vt, eyt, num_horizon
+
+
+class MPCTracking(ControlBase):
+    def __init__(self, mpc_lti_param, system_param):
+        ControlBase.__init__(self)
+        self.set_target_speed(mpc_lti_param.vt)
+        self.set_target_deviation(mpc_lti_param.eyt)
+        self.mpc_lti_param, self.system_param = mpc_lti_param, system_param
+
+    def calc_input(self):
+        xtarget = np.array([self.vt, 0, 0, 0, 0, self.eyt]).reshape(X_DIM, 1)
+        self.u = control.mpc_lti(self.x, xtarget, self.mpc_lti_param, self.system_param, self.track)
+        self._ego_log_none()
+        self.time += self.timestep
+
+
+class MPCCBFRacingParam:
+    def __init__(self, matrix_A=_A_DEFAULT, matrix_B=_B_DEFAULT, matrix_Q=np.diag([10.0, 0.0, 0.0, 4.0, 0.0, 40.0]),
+                 matrix_R=np.diag([0.1, 0.1]), vt=0.6, eyt=0.0, num_horizon=10, alpha=0.8):
+        self.matrix_A, self.matrix_B, self.matrix_Q, self.matrix_R = matrix_A, matrix_B, matrix_Q, matrix_R
+        self.vt, self.eyt, self.num_horizon, self.alpha = vt, eyt, num_horizon, alpha
+
+
+class MPCCBFRacing(ControlBase):
+    def __init__(self, mpc_cbf_param, system_param):
+        ControlBase.__init__(self)
+        self.set_target_speed(mpc_cbf_param.vt)
+        self.set_target_deviation(mpc_cbf_param.eyt)
+        self.realtime_flag = None
+        self.mpc_cbf_param, self.system_param = mpc_cbf_param, system_param
+
+    def calc_input(self):
+        xtarget = np.array([self.vt, 0, 0, 0, 0, self.eyt]).reshape(X_DIM, 1)
+        if self.realtime_flag is False:
+            vehicles, lap_length = self.racing_sim.vehicles, self.racing_sim.track.lap_length
+        elif self.realtime_flag is True:
+            vehicles, lap_length = self.vehicles, self.lap_length
+        else:
+            vehicles = None
+        if vehicles is not None:
+            self.u = control.mpccbf(self.x, xtarget, self.mpc_cbf_param, vehicles, self.agent_name, lap_length,
+                                    self.time, self.timestep, self.realtime_flag, self.track, self.system_param)
+        self._ego_log_none()
+        self.time += self.timestep
+
+
+class RacingGameParam:
+    def __init__(self, matrix_A=_A_DEFAULT, matrix_B=_B_DEFAULT, matrix_Q=np.diag([10.0, 0.0, 0.0, 5.0, 0.0, 50.0]),
+                 matrix_R=np.diag([0.1, 0.1]), matrix_R_planner=1 * np.diag([5, 0.10]),
+                 matrix_dR_planner=5 * np.diag([1.8, 0.0]), bezier_order=3, safety_factor=4.5, num_horizon_ctrl=10,
+                 num_horizon_planner=10, planning_prediction_factor=0.5, alpha=0.98, timestep=None):
+        self.matrix_A, self.matrix_B, self.matrix_Q, self.matrix_R = matrix_A, matrix_B, matrix_Q, matrix_R
+        self.matrix_R_planner, self.matrix_dR_planner = matrix_R_planner, matrix_dR_planner
+        self.num_horizon_ctrl, self.num_horizon_planner = num_horizon_ctrl, num_horizon_planner
+        self.planning_prediction_factor, self.alpha, self.timestep = planning_prediction_factor, alpha, timestep
+        self.bezier_order, self.safety_factor = bezier_order, safety_factor
+
+
+class LMPCRacingParam:
+    def __init__(self, matrix_Q=0 * np.diag([0.0] * 6), matrix_R=1 * np.diag([1.0, 0.25]),
+                 matrix_Qslack=5 * np.diag([10, 0, 0, 1, 10, 0]), matrix_dR=5 * np.diag([0.8, 0.0]),
+                 num_ss_points=32 + 12, num_ss_iter=2, num_horizon=12, shift=0, timestep=None, lap_number=None,
+                 time_lmpc=None):
+        self.matrix_Q, self.matrix_R, self.matrix_Qslack, self.matrix_dR = matrix_Q, matrix_R, matrix_Qslack, matrix_dR
+        self.num_ss_points, self.num_ss_iter, self.num_horizon, self.shift = num_ss_points, num_ss_iter, num_horizon, shift
+        self.timestep, self.lap_number, self.time_lmpc = timestep, lap_number, time_lmpc
+
+
+class LMPCRacingGame(ControlBase):
+    """Overtaking branch of the reference's racing-game controller (base.py:518-582): planner fan-out
+    + tracking NLP, both on the GPU.  The learning-MPC branch (no vehicle nearby, base.py:468-517)
+    needs control.lmpc and the safe-set regression, which are 'next' rows."""
+
+    def __init__(self, lmpc_param, racing_game_param=None, system_param=None):
+        ControlBase.__init__(self)
+        self.path_planner = False
+        self.lmpc_param, self.racing_game_param, self.system_param = lmpc_param, racing_game_param, system_param
+        self.overtake_planner = overtake_traj_planner.OvertakeTrajPlanner(racing_game_param)
+        self.x_pred = self.u_pred = None
+        self.old_ey = self.old_direction_flag = None
+
+    def set_vehicles_track(self):
+        if self.realtime_flag is False:
+            vehicles = self.racing_sim.vehicles
+            self.overtake_planner.track = self.track
+        else:
+            vehicles = self.vehicles
+        self.overtake_planner.vehicles = vehicles
+
+    def calc_input(self):
+        pl = self.overtake_planner
+        pl.agent_name, pl.opti_traj_xcurv = self.agent_name, self.opti_traj_xcurv
+        x = copy.deepcopy(self.x)
+        while x[4] > self.lap_length:
+            x[4] = x[4] - self.lap_length
+        overtake_flag, vehicles_interest = pl.get_overtake_flag(x)
+        ego = pl.vehicles["ego"]
+        if not overtake_flag:
+            raise NotImplementedError("LMPC branch (control.lmpc) is a 'next' row; only the overtaking branch is accelerated")
+        (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
+         all_traj_xglob) = pl.get_local_traj(x, self.time, vehicles_interest, None, None, None, self.old_ey,
+                                             self.old_direction_flag)
+        self.old_ey, self.old_direction_flag = traj_xcurv[-1, 5], direction_flag
+        ego.local_trajs.append(traj_xglob)
+        ego.vehicles_interest.append(vehicles_interest)
+        ego.splines.append(bezier_xglob)
+        ego.solver_time.append(solve_time)
+        ego.all_splines.append(all_bezier_xglob)
+        ego.all_local_trajs.append(all_traj_xglob)
+        self.u, x_pred = control.mpc_multi_agents(
+            x, self.racing_game_param, self.track, None, None, None, self.system_param, target_traj_xcurv=traj_xcurv,
+            vehicles=pl.vehicles, agent_name=self.agent_name, direction_flag=direction_flag,
+            target_traj_xglob=traj_xglob, sorted_vehicles=sorted_vehicles)
+        self.x_pred = x_pred
+        n = x_pred.shape[0]
+        pred_glob = np.zeros((n, X_DIM))
+        for j in range(n):
+            pred_glob[j, 0:3] = x_pred[j, 0:3]
+            pred_glob[j, 3] = self.track.get_orientation(x_pred[j, 4], x_pred[j, 5])
+            pred_glob[j, 4], pred_glob[j, 5] = self.track.get_global_position(x_pred[j, 4], x_pred[j, 5])
+        ego.lmpc_prediction.append(None)
+        ego.mpc_cbf_prediction.append(pred_glob)
+        self.time += self.timestep
+
+
+# ---------------------------------------------------------------------------------------------------
+# vehicle models
+# ---------------------------------------------------------------------------------------------------
+class BicycleDynamicsParam:
+    def __init__(self, m=1.98, lf=0.125, lr=0.125, Iz=0.024, Df=0.8 * 1.98 * 9.81 / 2.0, Cf=1.25, Bf=1.0,
+                 Dr=0.8 * 1.98 * 9.81 / 2.0, Cr=1.25, Br=1.0):
+        self.m, self.lf, self.lr, self.Iz = m, lf, lr, Iz
+        self.Df, self.Cf, self.Bf, self.Dr, self.Cr, self.Br = Df, Cf, Bf, Dr, Cr, Br
+
+    def get_params(self):
+        return (self.m, self.lf, self.lr, self.Iz, self.Df, self.Cf, self.Bf, self.Dr, self.Cr, self.Br)
+
+
+class CarParam:
+    def __init__(self, length=0.4, width=0.2, facecolor="None", edgecolor="black"):
+        self.length, self.width, self.facecolor, self.edgecolor = length, width, facecolor, edgecolor
+        self.dynamics_param = BicycleDynamicsParam()
+
+
+class SystemParam:
+    def __init__(self, delta_max=0.5, a_max=1.0, v_max=10, v_min=0):
+        self.delta_max, self.a_max, self.v_max, self.v_min = delta_max, a_max, v_max, v_min
+
+
+class ModelBase:
+    def __init__(self, name=None, param=None, no_dynamics=False, system_param=None):
+        self.name, self.param, self.system_param = name, param, system_param
+        self.no_dynamics = False
+        self.time = 0.0
+        self.timestep = None
+        self.xcurv = self.xglob = self.u = None
+        self.zero_noise_flag = False
+        self.lap_times = [self.time]
+        self.lap_xcurvs, self.lap_xglobs, self.lap_inputs = [], [], []
+        self.times, self.xglobs, self.xcurvs, self.inputs = [], [], [], []
+        self.laps = 0
+        self.realtime_flag = False
+        self.xglob_log, self.xcurv_log = [], []
+        self.local_trajs, self.vehicles_interest, self.splines, self.solver_time = [], [], [], []
+        self.all_splines, self.all_local_trajs, self.lmpc_prediction, self.mpc_cbf_prediction = [], [], [], []
+
+    def set_zero_noise(self):
+        self.zero_noise_flag = True
+
+    def set_timestep(self, dt):
+        self.timestep = dt
+
+    def set_state_curvilinear(self, xcurv):
+        self.xcurv = xcurv
+
+    def set_state_global(self, xglob):
+        self.xglob = xglob
+
+    def start_logging(self):
+        self.lap_xcurvs, self.lap_xglobs, self.lap_inputs = [self.xcurv], [self.xglob], []
+
+    def set_track(self, track):
+        self.track = track
+        self.lap_length = track.lap_length
+        self.point_and_tangent = track.point_and_tangent
+        self.lap_width = track.width
+
+    def set_ctrl_policy(self, ctrl_policy):
+        self.ctrl_policy = ctrl_policy
+        self.ctrl_policy.agent_name = self.name
+
+    def calc_ctrl_input(self):
+        self.ctrl_policy.set_state(self.xcurv, self.xglob)
+        self.ctrl_policy.calc_input()
+        self.u = self.ctrl_policy.get_input()
+
+    def forward_dynamics(self):
+        pass
+
+    def forward_one_step(self, realtime_flag):
+        if self.no_dynamics:
+            self.forward_dynamics()
+            self.update_memory()
+        elif realtime_flag is False:
+            self.calc_ctrl_input()
+            self.forward_dynamics(realtime_flag)
+            self.ctrl_policy.set_state(self.xcurv, self.xglob)
+            self.update_memory()
+        elif realtime_flag is True:
+            self.forward_dynamics(realtime_flag)
+
+    def update_memory(self):
+        """Lap bookkeeping (reference base.py:795-819): when s passes the lap length the lap's logs are
+        archived and s is wrapped IN PLACE."""
+        crossed = self.xcurv[4] > self.lap_length
+        self.xglob_log.append(self.xglob)
+        self.xcurv_log.append(self.xcurv)
+        self.lap_xglobs.append(self.xglob)
+        self.lap_times.append(self.time)
+        self.lap_xcurvs.append(copy.deepcopy(self.xcurv) if crossed else self.xcurv)
+        if crossed:
+            self.lap_inputs.append(self.u)
+            self.xglobs.append(self.lap_xglobs)
+            self.times.append(self.lap_times)
+            self.xcurvs.append(self.lap_xcurvs)
+            self.inputs.append(self.lap_inputs)
+            self.xcurv[4] = self.xcurv[4] - self.lap_length
+            self.laps += 1
+            self.lap_xglobs, self.lap_xcurvs, self.lap_inputs, self.lap_times = [self.xglob], [self.xcurv], [], [self.time]
+        else:
+            self.lap_inputs.append(self.u)
+
+
+_MOTION_CACHE = {}
+
+
+def _compiled_motion(t_symbol, s_func, ey_func):
+    """s(t), ey(t) and their derivatives as plain callables.  The reference substitutes into the
+    sympy expressions on every call (base.py:860-868); compiling once gives the same numbers.  The
+    cache is module-level so that vehicle objects stay picklable."""
+    import sympy as sp
+
+    key = (str(t_symbol), sp.srepr(sp.sympify(s_func)), sp.srepr(sp.sympify(ey_func)))
+    if key not in _MOTION_CACHE:
+        def mk(e):
+            f = sp.lambdify(t_symbol, sp.sympify(e), "math")
+            return lambda t, f=f: float(f(t))
+        _MOTION_CACHE[key] = (mk(s_func), mk(ey_func), mk(sp.diff(s_func, t_symbol)), mk(sp.diff(ey_func, t_symbol)))
+    return _MOTION_CACHE[key]
+
+
+class NoDynamicsModel(ModelBase):
+    """Scripted vehicle: s(t), ey(t) given as sympy expressions of `t_symbol` (base.py:847-890)."""
+
+    def __init__(self, name=None, param=None, xcurv=None, xglob=None):
+        ModelBase.__init__(self, name=name, param=param)
+        self.no_dynamics = True
+
+    def set_state_curvilinear_func(self, t_symbol, s_func, ey_func):
+        self.t_symbol, self.s_func, self.ey_func = t_symbol, s_func, ey_func
+        self.xcurv, self.xglob = self.get_estimation(0)
+
+    def get_estimation(self, t0):
+        fs, fe, fds, fde = _compiled_motion(self.t_symbol, self.s_func, self.ey_func)
+        xc = np.zeros((X_DIM,))
+        xc[0], xc[1] = fds(t0), fde(t0)
+        xc[4], xc[5] = fs(t0), fe(t0)
+        xg = np.zeros((X_DIM,))
+        xg[0:3] = xc[0:3]
+        xg[3] = self.track.get_orientation(xc[4], xc[5])
+        xg[4], xg[5] = self.track.get_global_position(xc[4], xc[5])
+        return xc, xg
+
+    def get_trajectory_nsteps(self, t0, delta_t, n):
+        """n-step prediction from the vehicle's OWN clock; t0 is ignored, as in the reference
+        (base.py:879-883, quirk Q6)."""
+        xc, xg = np.zeros((X_DIM, n)), np.zeros((X_DIM, n))
+        for j in range(n):
+            xc[:, j], xg[:, j] = self.get_estimation(self.time + j * delta_t)
+        return xc, xg
+
+    def forward_dynamics(self):
+        self.time += self.timestep
+        self.xcurv, self.xglob = self.get_estimation(self.time)
+
+
+class DynamicBicycleModel(ModelBase):
+    def __init__(self, name=None, param=None, xcurv=None, xglob=None, system_param=None):
+        ModelBase.__init__(self, name=name, param=param, system_param=system_param)
+
+    def forward_dynamics(self, realtime_flag):
+        """100 explicit Euler sub-steps of 1 ms per 0.1 s control step, then bounded process noise
+        on (vx, vy, wz) unless zero-noise (reference base.py:897-942)."""
+        delta_t = 0.001
+        xg, xc = self.xglob, self.xcurv
+        dyn = CarParam().dynamics_param
+        i = 0
+        while (i + 1) * delta_t <= self.timestep:
+            if self.u is not None:
+                curv = (self.track.get_curvature(xc[4]) if realtime_flag is False
+                        else racing_env.get_curvature(self.lap_length, self.point_and_tangent, xc[4]))
+                xg, xc = vehicle_dynamics.vehicle_dynamics(dyn, curv, xg, xc, delta_t, self.u)
+            i += 1
+        noise = (np.clip(np.random.randn() * 0.01, -0.05, 0.05), np.clip(np.random.randn() * 0.01, -0.1, 0.1),
+                 np.clip(np.random.randn() * 0.005, -0.05, 0.05))
+        if not (((realtime_flag is True) and (self.u is None)) or self.zero_noise_flag):
+            for c in range(3):
+                xc[c] = xc[c] + 0.5 * noise[c]
+        self.xcurv, self.xglob = xc, xg
+        self.time += self.timestep
+
+
+class CarRacingSim:
+    def __init__(self):
+        self.track = None
+        self.vehicles = {}
+        self.opti_traj_xglob = None
+
+    def set_timestep(self, dt):
+        self.timestep = dt
+
+    def set_track(self, track):
+        self.track = track
+
+    def set_opti_traj(self, opti_traj_xglob):
+        self.opti_traj_xglob = opti_traj_xglob

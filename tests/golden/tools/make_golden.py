@@ -336,8 +336,104 @@ def gen_planner():
     np.savez_compressed(os.path.join(OUT, "planner.npz"), **out)
 
 
+def gen_harness():
+    """Solver-free host code: track geometry, plant step, vehicle predictions, PID closed loop."""
+    from system import vehicle_dynamics as vd
+
+    out = {}
+    rng = np.random.default_rng(7)
+    for tname in ("l_shape", "m_shape", "goggle", "ellipse"):
+        spec = np.genfromtxt("data/track_layout/%s.csv" % tname, delimiter=",")
+        tr = racing_env.ClosedTrack(spec, track_width=1.0)
+        s = np.concatenate([rng.uniform(0, tr.lap_length, 60), tr.point_and_tangent[:, 3] + 1e-9,
+                            [0.0, tr.lap_length - 1e-6, tr.lap_length + 0.5, -0.3]])
+        ey = rng.uniform(-0.8, 0.8, len(s))
+        out[tname + "/lap_length"] = tr.lap_length
+        out[tname + "/table"] = tr.point_and_tangent
+        out[tname + "/s"] = s
+        out[tname + "/ey"] = ey
+        out[tname + "/xy"] = np.array([tr.get_global_position(a, b) for a, b in zip(s, ey)])
+        out[tname + "/psi"] = np.array([tr.get_orientation(a, b) for a, b in zip(s, ey)])
+        sc = rng.uniform(0, tr.lap_length, 60)  # interior points only: the reference raises at joints
+        out[tname + "/s_curv"] = sc
+        out[tname + "/curv"] = np.array([tr.get_curvature(a) for a in sc])
+    # plant: 40 random single Euler steps
+    dyn = base.CarParam().dynamics_param
+    xg = rng.normal(size=(40, 6)); xc = rng.normal(size=(40, 6)) * 0.3
+    xc[:, 0] = rng.uniform(0.3, 1.5, 40); xg[:, 0:3] = xc[:, 0:3]
+    u = np.stack([rng.uniform(-0.5, 0.5, 40), rng.uniform(-1, 1, 40)], axis=1)
+    curv = rng.uniform(-0.7, 0.7, 40)
+    res = [vd.vehicle_dynamics(dyn, curv[i], xg[i], xc[i], 0.001, u[i]) for i in range(40)]
+    out.update({"plant/xglob": xg, "plant/xcurv": xc, "plant/u": u, "plant/curv": curv,
+                "plant/xglob_next": np.array([r[0] for r in res]), "plant/xcurv_next": np.array([r[1] for r in res])})
+    # PID closed loop, zero noise, 30 steps on l_shape (ModelBase + plant + lap bookkeeping)
+    track = make_track(0.8)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+    ego.set_zero_noise()
+    ego.set_state_curvilinear(np.zeros(6)); ego.set_state_global(np.zeros(6)); ego.start_logging()
+    ego.set_ctrl_policy(offboard.PIDTracking(vt=0.8)); ego.ctrl_policy.set_timestep(0.1)
+    ego.set_track(track); ego.ctrl_policy.set_track(track)
+    sim = offboard.CarRacingSim(); sim.set_timestep(0.1); sim.set_track(track); sim.add_vehicle(ego)
+    ego.ctrl_policy.set_racing_sim(sim)
+    sim.sim(sim_time=3.0)
+    out["pid/xcurv_log"] = np.array(ego.xcurv_log)
+    out["pid/xglob_log"] = np.array(ego.xglob_log)
+    # predictions of both vehicle kinds
+    car = offboard.NoDynamicsModel(name="car1", param=base.CarParam()); car.set_track(track); car.set_timestep(0.1)
+    car.set_state_curvilinear_func(T, 0.2 * T + 4.0, 0.1 + 0.0 * T); car.time = 1.3
+    out["pred/nodyn"] = car.get_trajectory_nsteps(0.0, 0.1, 11)[0]
+    dynv = offboard.DynamicBicycleModel(name="d", param=base.CarParam(), system_param=base.SystemParam())
+    dynv.set_track(track); dynv.set_timestep(0.1)
+    dynv.set_state_curvilinear(np.array([0.9, 0.02, 0.1, 0.05, 18.9, 0.2])); dynv.set_state_global(np.array([0.9, 0.02, 0.1, 0.3, 1.0, 0.5]))
+    out["pred/dyn"] = dynv.get_trajectory_nsteps(11)[0]
+    # interest test grid (planner_helper.check_ego_agent_distance)
+    par = base.RacingGameParam(timestep=0.1)
+    class V:  # noqa: E306
+        def __init__(self, xc): self.xcurv, self.param = np.array(xc, float), base.CarParam()
+    cases = []
+    for se in (0.5, 5.0, 18.9, 19.5):
+        for sa in (0.2, 1.0, 5.3, 6.5, 7.5, 18.8, 19.1, 20.0):
+            for dv in (0.0, 0.6):
+                e, a = V([1.0, 0, 0, 0, se, 0]), V([1.0 - dv, 0, 0, 0, sa, 0])
+                cases.append((se, sa, dv, float(M["planner_helper"].check_ego_agent_distance(e, a, par, track.lap_length))))
+    out["interest/cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "harness.npz"), **out)
+    print("harness fixture written:", len(out), "arrays")
+
+
+def gen_closed_loop(steps=150):
+    """The scenario of the reference's tests/auto_mpccbf_test.py:9-46 (zero noise), first `steps`
+    control steps, every NLP solved by the certified golden solver."""
+    track = make_track(1.0)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
+    ego.set_zero_noise()
+    ego.set_state_curvilinear(np.zeros((6,))); ego.set_state_global(np.zeros((6,))); ego.start_logging()
+    ego.set_ctrl_policy(offboard.MPCCBFRacing(base.MPCCBFRacingParam(vt=0.8), ego.system_param))
+    ego.ctrl_policy.set_timestep(0.1); ego.set_track(track); ego.ctrl_policy.set_track(track)
+    car1 = offboard.NoDynamicsModel(name="car1", param=base.CarParam()); car1.set_track(track)
+    car1.set_state_curvilinear_func(T, 0.2 * T + 4.0, 0.1 + 0.0 * T); car1.start_logging()
+    car2 = offboard.NoDynamicsModel(name="car2", param=base.CarParam()); car2.set_track(track)
+    car2.set_state_curvilinear_func(T, 0.2 * T + 10.0, -0.1 + 0.0 * T); car2.start_logging()
+    sim = offboard.CarRacingSim(); sim.set_timestep(0.1); sim.set_track(track)
+    sim.add_vehicle(ego); ego.ctrl_policy.set_racing_sim(sim); sim.add_vehicle(car1); sim.add_vehicle(car2)
+    del RECORDS[:]
+    sim.sim(sim_time=steps * 0.1)
+    ok = np.array([r[2]["success"] for r in RECORDS])
+    nobs = np.array([(r[0].nvar - 86) // 11 for r in RECORDS])
+    np.savez_compressed(os.path.join(OUT, "closed_loop_mpccbf.npz"), steps=steps,
+                        ego_xcurv=np.array(ego.xcurv_log), ego_xglob=np.array(ego.xglob_log),
+                        ego_u=np.array([r[1][66:68] for r in RECORDS]), solve_success=ok, n_obs=nobs,
+                        car1_xcurv=np.array(car1.xcurv_log), car2_xcurv=np.array(car2.xcurv_log))
+    print("closed loop: %d steps, %d certified solves, obstacles per step max %d, final ego s %.3f" % (
+        steps, ok.sum(), nobs.max(), ego.xcurv[4]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mpccbf", "planner"]
+    which = sys.argv[1:] or ["mpccbf", "planner", "harness"]
+    if "closed_loop" in which:
+        gen_closed_loop()
+    if "harness" in which:
+        gen_harness()
     if "mpccbf" in which:
         gen_mpccbf()
     if "planner" in which:
