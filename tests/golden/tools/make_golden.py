@@ -401,7 +401,7 @@ def gen_harness():
     print("harness fixture written:", len(out), "arrays")
 
 
-def gen_closed_loop(steps=150):
+def gen_closed_loop(steps=int(os.environ.get("CRX_GOLDEN_STEPS", "150"))):
     """The scenario of the reference's tests/auto_mpccbf_test.py:9-46 (zero noise), first `steps`
     control steps, every NLP solved by the certified golden solver."""
     track = make_track(1.0)
