@@ -141,7 +141,7 @@ int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
 
 int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
     crx_kparams kq = kp;
-    if (g_trace_rows > 0) { kq.trace = (double*)g_trace.p; kq.trace_problem = g_trace_problem; kq.trace_rows = g_trace_rows; }
+    if (g_trace_rows != 0) { kq.trace = (double*)g_trace.p; kq.trace_problem = g_trace_problem; kq.trace_rows = g_trace_rows; }
     size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
     if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
     timing_begin(st);
@@ -201,14 +201,16 @@ void crx_set_timing(int enable) { g_timing = enable != 0; }
 int crx_trace_enable(int problem, int rows) {
     if (int rc = ensure_init()) return rc;
     g_trace_rows = 0;
-    if (rows <= 0) return CRX_OK;
+    const bool sub = rows < 0;   // negative: report Riccati sub-phase cycles in slots 8..11
+    if (rows < 0) rows = -rows;
+    if (rows == 0) return CRX_OK;
     if (int rc = g_trace.ensure((size_t)rows * 16 * sizeof(double))) return rc;
     HIP_TRY(hipMemset(g_trace.p, 0, (size_t)rows * 16 * sizeof(double)));
-    g_trace_rows = rows; g_trace_problem = problem;
+    g_trace_rows = sub ? -rows : rows; g_trace_problem = problem;
     return CRX_OK;
 }
 int crx_trace_read(double* host, int rows) {
-    if (rows > g_trace_rows) rows = g_trace_rows;
+    { int cap = g_trace_rows < 0 ? -g_trace_rows : g_trace_rows; if (rows > cap) rows = cap; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(host, g_trace.p, (size_t)rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return CRX_OK;

@@ -9,7 +9,7 @@ A, B = synth.load_AB()
 p = synth.cfg2_mpccbf(256); d = abi.cbf_desc(12, 1, A, B)
 args = (p['x0'], p['xt'], p['obs_s'], p['obs_ey'], p['lap_off'], p['n_obs'])
 R = 20
-L.crx_trace_enable(3, R)
+L.crx_trace_enable(3, -R if len(sys.argv) > 1 else R)
 rg = gpu.cbf_solve(d, *args)
 tr = np.zeros((R, 16)); L.crx_trace_read(tr.ctypes.data_as(ctypes.c_void_p), R)
 print("status", rg['status'][3], "iters", rg['iters'][3])
