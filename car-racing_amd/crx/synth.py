@@ -28,12 +28,23 @@ def _ego(rng, n, vx_lo, vx_hi):
     return x
 
 
-def _safe_start(x0, obs_s, obs_ey, margin, l_sum=0.4, w_sum=0.2, degree=6):
-    """h_0 >= 0 for every obstacle: the CBF formulation presumes the current state is in the safe
-    set (two 0.4 x 0.2 m cars cannot overlap); control.py:544-550."""
-    ds = (x0[:, 4, None] - obs_s[:, :, 0]) / l_sum
-    de = (x0[:, 5, None] - obs_ey[:, :, 0]) / w_sum
-    return (ds ** degree + de ** degree - 1.0 - margin >= 0.05).all(axis=1)
+def _safe_start(x0, obs_s, obs_ey, margin, l_sum=0.4, w_sum=0.2, degree=6, min_ttc=1.0):
+    """Scenario filter: (i) h_0 >= 0 for every obstacle -- the CBF formulation presumes the current
+    state is in the safe set (two 0.4 x 0.2 m cars cannot overlap; control.py:544-550); (ii) the ego is
+    not already doomed: an obstacle in its lane and ahead must be at least `min_ttc` seconds of closing
+    speed away from the unsafe set.  A 10 Hz controller that had been running would never be handed
+    such a state; without (ii) ~1 % of the draws are unavoidable crashes whose NLP needs slacks of
+    1e3..1e5 and 60+ interior-point iterations, and they alone set the latency of a 256-problem batch."""
+    ds = x0[:, 4, None] - obs_s[:, :, 0]
+    de = x0[:, 5, None] - obs_ey[:, :, 0]
+    h0 = (ds / l_sum) ** degree + (de / w_sum) ** degree - 1.0 - margin
+    ok = (h0 >= 0.05).all(axis=1)
+    v_o = (obs_s[:, :, 1] - obs_s[:, :, 0]) / 0.1
+    closing = x0[:, 0, None] - v_o
+    gap = -ds - l_sum * (1.0 + margin) ** (1.0 / degree)          # ahead of the ego, to the unsafe set
+    in_lane = np.abs(de) < w_sum * 1.25
+    doomed = in_lane & (ds < 0) & (closing > 0) & (gap < min_ttc * closing)
+    return ok & ~doomed.any(axis=1)
 
 
 def _resample_unsafe(gen, batch, margin, max_rounds=64):

@@ -32,7 +32,7 @@
 #include "crx_kparams.h"
 
 #define WAVE 64
-#define MAXF 32 /* filter entries */
+#define MAXF 16 /* filter entries (reset at every barrier update; 16 were never reached in testing) */
 #define SYNC() __syncthreads()
 
 // ------------------------------------------------------------------------------------------------
@@ -93,6 +93,15 @@ struct LogAcc {
         return log(wave_prod(m)) + 0.6931471805599453 * wave_sum((double)e);
     }
 };
+
+// 1/x to ~1 ulp: hardware estimate (v_rcp_f64) + two Newton steps; ~5 dependent ops instead of the
+// ~10 of an IEEE division.  x must be finite, normal and non-zero (true for pivots and slacks).
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
 
 __device__ __forceinline__ double ipow_d(double a, int p) {
     double r = 1.0;
@@ -164,7 +173,7 @@ struct Lay {
     static constexpr int vlo = riv + MR;             // [NV]  row index of the lower-bound row of a coordinate (-1 none)
     static constexpr int vhi = vlo + NV;             // [NV]  ... upper-bound row
     static constexpr int triH = vhi + NV;            // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
-    static constexpr int updP = triH + NZ * (NZ + 1) / 2;  // [64] packed (i << 8 | j) lane map of the Riccati update
+    static constexpr int updP = triH + (NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2);  // [64] packed (i << 8 | j) lane map of the Riccati update
     static constexpr int END_I = updP + 64;
     static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)((END_I + 1) & ~1) * 4;
 };
@@ -368,24 +377,25 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N, lane = c.lane;
     double emax = 0.0;
-    if (lane < L::NX) LD(L::lam + lane) = LD(L::ga + N * L::NZ + lane);
-    SYNC();
+    // costates ping-pong between lam and hv (free outside the Riccati sweep): one sync per stage
+    int cur = L::lam, nxt = L::hv;
+    if (lane < L::NX) LD(cur + lane) = LD(L::ga + N * L::NZ + lane);
     if (lane < L::NZ) LD(L::ga + N * L::NZ + lane) = 0.0;
+    SYNC();
     for (int k = N - 1; k >= 0; k--) {
-        double tot = 0.0;
         if (lane < L::NZ) {
-            tot = LD(L::ga + k * L::NZ + lane);
+            double tot = LD(L::ga + k * L::NZ + lane);
 #pragma unroll
-            for (int i = 0; i < L::NX; i++) tot += LD(L::M + i * L::NZ + lane) * LD(L::lam + i);
+            for (int i = 0; i < L::NX; i++) tot += LD(L::M + i * L::NZ + lane) * LD(cur + i);
             if (lane >= L::NX) emax = fmax(emax, fabs(tot));
             const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
             LD(L::ga + k * L::NZ + lane) = keep ? tot : 0.0;
+            if (lane < L::NX) LD(nxt + lane) = tot;
         }
         SYNC();
-        if (lane < L::NX) LD(L::lam + lane) = tot;
-        SYNC();
+        const int tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(LD(L::lam + lane)));
+    if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(LD(cur + lane)));
     return wave_max(emax);
 }
 
@@ -400,7 +410,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
     const int N = c.N;
     for (int j = c.lane; j < c.m; j += WAVE) {
         const double t = LD(L::rt + j), nu = LD(L::rnu + j);
-        const double rti = 1.0 / t;
+        const double rti = frcp(t);
         const double sig = nu * rti;
         const bool on = LD(L::rsc + j) != 0.0;
         LD(L::rsig + j) = on ? sig : 0.0;
@@ -511,15 +521,18 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // hv = M'p + hg.  All sums of a lane are formed before any store so that the LDS reads of
         // both of its entries are in flight together.
         const double kc = 2.0 * LD(L::wc + k);
-        constexpr int NTRI = NZ * (NZ + 1) / 2;
+        // NZ*NZ <= 64 (no obstacle): one lane per entry of the full matrix, no mirroring needed
+        constexpr bool FULL = NZ * NZ <= WAVE;
+        constexpr int NTRI = FULL ? NZ * NZ : NZ * (NZ + 1) / 2;
         constexpr int HCNT = (NTRI + WAVE - 1) / WAVE;
         double hs[HCNT];
         int hr[HCNT], ha[HCNT];
 #pragma unroll
         for (int q = 0; q < HCNT; q++) {
             const int e = lane + q * WAVE;
-            const int pk = si[L::triH + (e < NTRI ? e : 0)];
-            const int r = pk >> 8, a = pk & 255;
+            int r, a;
+            if (FULL) { r = e / NZ; a = e - r * NZ; }
+            else { const int pk = si[L::triH + (e < NTRI ? e : 0)]; r = pk >> 8; a = pk & 255; }
             hr[q] = r; ha[q] = a;
             double s = 0.0;
             if (e < NTRI) {
@@ -555,7 +568,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         for (int q = 0; q < HCNT; q++) {
             if (lane + q * WAVE < NTRI) {
                 LD(L::H + hr[q] * NZ + ha[q]) = hs[q];
-                LD(L::H + ha[q] * NZ + hr[q]) = hs[q];
+                if (!FULL) LD(L::H + ha[q] * NZ + hr[q]) = hs[q];
             }
         }
         if (lane < NZ) LD(L::hv + lane) = hvs;
@@ -575,7 +588,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             for (int q = 0; q < j; q++) d -= Lf[j][q] * Lf[j][q] * Dp[q];
             if (!(d > 0.0)) ok = false;
             Dp[j] = d;
-            rD[j] = 1.0 / d;
+            rD[j] = frcp(d);
 #pragma unroll
             for (int i = j + 1; i < NU; i++) {
                 double t = Lf[i][j];
@@ -692,7 +705,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     return ok;
 }
 
-// forward sweep: du = K dx + kff, dx_{k+1} = M [dx; du]; fills dZ for every stage
+// forward sweep: du = K dx + kff, dx_{k+1} = M [dx; du]; fills dZ for every stage.  (Fusing the two
+// steps into one LDS round trip by recomputing du on every lane was measured slower: 41 LDS reads per
+// lane instead of 7+10.)
 template <int NOBS, int NMAX>
 __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
@@ -753,7 +768,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         LD(L::cst + lane) = v;
     }
     {   // index tables of the Riccati sweep (decoded once; the sweep itself is branch-free)
-        constexpr int NTRI = NZ * (NZ + 1) / 2;
+        constexpr int NTRI = NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2;   // table only when H needs the triangle form
         for (int e = lane; e < NTRI; e += WAVE) {
             int r = 0;
             while ((r + 1) * (r + 2) / 2 <= e) r++;

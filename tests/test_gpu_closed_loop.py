@@ -73,21 +73,28 @@ def test_mpccbf_racing(tmp_path):
     # closed_loop).  Steps 1..84 of that run are all certified solves; closed-loop feedback amplifies the
     # ~1e-6 solver differences, hence 1e-3.
     ref = np.load(conftest.GOLDEN + "/closed_loop_mpccbf.npz")
+    assert int(ref["steps"]) == 400
     n_ok = int(np.nonzero(~ref["solve_success"][1:])[0][0]) + 1
     assert n_ok >= 80
     np.testing.assert_allclose(e[:n_ok], ref["ego_xcurv"][:n_ok], atol=1e-3)
-    np.testing.assert_allclose(np.array(car1.xcurv_log)[:150], ref["car1_xcurv"], atol=1e-12)
+    # the whole 40 s: 23 of the 400 golden solves are not certified to 1e-11 (the reference then uses
+    # its solver's last iterate, as it does with IPOPT), so later steps are compared more loosely
+    np.testing.assert_allclose(e, ref["ego_xcurv"], atol=2e-2)
+    np.testing.assert_allclose(np.array(car1.xcurv_log), ref["car1_xcurv"], atol=1e-12)
+    np.testing.assert_allclose(np.array(car2.xcurv_log), ref["car2_xcurv"], atol=1e-12)
     prog = ego.laps * track.lap_length + ego.xcurv[4]
-    assert prog > 15.0, prog
+    assert abs(prog - 22.8996) < 0.05, prog       # the reference's own closed loop ends at s = 22.8996
     assert np.abs(e[:, 5]).max() <= 1.0 + 1e-6     # stays on the track
     lap = track.lap_length
-    for car in (car1, car2):
+    s_ego = np.unwrap(e[:, 4] * 2 * np.pi / lap) * lap / (2 * np.pi)
+    s_ref = np.unwrap(ref["ego_xcurv"][:, 4] * 2 * np.pi / lap) * lap / (2 * np.pi)
+    for car, key in ((car1, "car1_xcurv"), (car2, "car2_xcurv")):
         c = np.array(car.xcurv_log)
-        # unwrapped ego progress at each step vs the scripted car (which never wraps in 40 s)
-        s_ego = np.unwrap(e[:, 4] * 2 * np.pi / lap) * lap / (2 * np.pi)
-        ds = (s_ego - c[:, 4] + lap / 2) % lap - lap / 2
-        h = (ds / 0.4) ** 6 + ((e[:, 5] - c[:, 5]) / 0.2) ** 6
-        assert h.min() >= 1.0, (car.name, h.min())  # never inside the obstacle's super-ellipse
+        h = (((s_ego - c[:, 4] + lap / 2) % lap - lap / 2) / 0.4) ** 6 + ((e[:, 5] - c[:, 5]) / 0.2) ** 6
+        hr = (((s_ref - c[:, 4] + lap / 2) % lap - lap / 2) / 0.4) ** 6 + ((ref["ego_xcurv"][:, 5] - c[:, 5]) / 0.2) ** 6
+        # closest approach to each car equals the reference's (1.027 to car1, 0.948 to car2: the
+        # reference's controller itself grazes car2's super-ellipse -- plant/model mismatch)
+        assert abs(h.min() - hr.min()) < 0.05, (car.name, h.min(), hr.min())
 
 
 def test_overtake_step(golden_planner):
