@@ -171,6 +171,13 @@ def main():
         + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
 
+    traffic = None
+    try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, collected with rocprofv3 --pmc)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        if wl in pm and pm[wl]["batch"] == batch:
+            traffic = pm[wl]["traffic_bytes"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,7 +189,7 @@ def main():
                    "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
                    "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
                      "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
                      "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS},
