@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scenario-filter", action="store_true",
+                    help="keep doomed / unsafe-start scenarios in the synthetic batch (DESIGN.md section 6)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,11 +84,11 @@ def main():
     if wl in ("cfg2", "cfg4"):
         if wl == "cfg2":
             batch = args.batch or 256
-            p = synth.cfg2_mpccbf(batch, N=12, seed=2 + seed_shift)
+            p = synth.cfg2_mpccbf(batch, N=12, seed=2 + seed_shift, safe_start=not args.no_scenario_filter)
             desc = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
         else:
             batch = args.batch or 16384
-            p = synth.cfg4_tracking_cbf(batch, N=20, seed=4 + seed_shift)
+            p = synth.cfg4_tracking_cbf(batch, N=20, seed=4 + seed_shift, safe_start=not args.no_scenario_filter)
             desc = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
         N, n_obs = desc.N, desc.n_obs_max
         t_in = [to_dev(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [to_dev(p["n_obs"], torch.int32)]
@@ -185,6 +187,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3}[wl], "batch_per_gpu": int(batch),
                    "horizon": int(N), "n_obs": int(n_obs), "tol": desc.opts.tol,
+                   "scenario_filter": not args.no_scenario_filter,
                    "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
                    "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
                    "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99))},
