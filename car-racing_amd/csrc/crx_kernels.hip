@@ -103,10 +103,24 @@ __device__ __forceinline__ double frcp(double x) {
     return r;
 }
 
+// a^p for small p >= 0.  The exponent is wave-uniform (the CBF degree and degree-1, degree-2), so the
+// switch is a scalar branch; the generic loop costs ~40 cycles of branch overhead per factor.
 __device__ __forceinline__ double ipow_d(double a, int p) {
-    double r = 1.0;
-    for (int i = 0; i < p; i++) r *= a;
-    return r;
+    const double a2 = a * a;
+    switch (p) {
+        case 0: return 1.0;
+        case 1: return a;
+        case 2: return a2;
+        case 3: return a2 * a;
+        case 4: return a2 * a2;
+        case 5: return a2 * a2 * a;
+        case 6: return a2 * a2 * a2;
+        default: {
+            double r = a2 * a2 * a2;
+            for (int i = 6; i < p; i++) r *= a;
+            return r;
+        }
+    }
 }
 
 // scipy interp1d(kind="linear") (searchsorted-left, index clipped to [1,n-1], slope form)
@@ -334,34 +348,30 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         SYNC();
     }
     for (int e = c.lane; e < (N + 1) * L::NZ; e += WAVE) {
+        // selects instead of branches: every divergent region costs ~30 cycles on a lone wave
         const int k = e / L::NZ, a = e - k * L::NZ;
-        double g = 0.0;
-        const double z = LD(L::Z + e);
-        if (a < 6) {
-            g = 2.0 * LD(L::cst + a) * (z - LD(L::xr + k * 6 + a));
-            if (k == N && a == 4) g += c.lin_sN;
-        } else if (a < L::NX) {
-            if (k == 0 && (a - 6) < c.nobs) g = c.wsig;
-        } else if (k < N) {
-            if (a < L::NX + 2) g = 2.0 * LD(L::cst + 6 + (a - L::NX)) * z;
-            else if ((a - L::NX - 2) < c.nobs) g = c.wsig;
-        }
+        const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
+        const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
+        const bool sig_on = (o < c.nobs) && ((iss0 && k == 0) || (iss1 && k < N));
+        const double w2 = (isx || isu) ? 2.0 * LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
+        const double ref = isx ? LD(L::xr + k * 6 + (isx ? a : 0)) : 0.0;
+        double g = w2 * (LD(L::Z + e) - ref);
+        g += (k == N && a == 4) ? c.lin_sN : 0.0;
+        g += sig_on ? c.wsig : 0.0;
         const int rl = si[L::vlo + e], rh = si[L::vhi + e];
-        if (rl >= 0) g -= LD(L::rnu + rl);
-        if (rh >= 0) g += LD(L::rnu + rh);
-        if (k < N) {
-            const double wck = LD(L::wc + k);
-            if (wck != 0.0) {
-                const double de = LD(L::Z + (k + 1) * L::NZ + 5) - LD(L::Z + k * L::NZ + 5);
-                g += 2.0 * wck * de * (LD(L::M + 5 * L::NZ + a) - (a == 5 ? 1.0 : 0.0));
-            }
-            if (NOBS) {
+        const double nl = LD(L::rnu + (rl >= 0 ? rl : 0)), nh = LD(L::rnu + (rh >= 0 ? rh : 0));
+        g -= (rl >= 0) ? nl : 0.0;
+        g += (rh >= 0) ? nh : 0.0;
+        const int kk = k < N ? k : N - 1;                      // stage terms exist for k < N only
+        if (NOBS == 0) {
+            const double de = LD(L::Z + (kk + 1) * L::NZ + 5) - LD(L::Z + kk * L::NZ + 5);
+            g += (k < N) ? 2.0 * LD(L::wc + kk) * de * (LD(L::M + 5 * L::NZ + a) - (a == 5 ? 1.0 : 0.0)) : 0.0;
+        } else {
 #pragma unroll
-                for (int o = 0; o < NOBS; o++)
-                    g -= LD(L::rnu + k * L::NR + 8 + NOBS + o) * LD(L::Jc + (k * L::NO + o) * L::NZ + a);
-            }
+            for (int ob = 0; ob < NOBS; ob++)
+                g -= (k < N) ? LD(L::rnu + kk * L::NR + 8 + NOBS + ob) * LD(L::Jc + (kk * L::NO + ob) * L::NZ + a) : 0.0;
         }
-        if (k == N && a >= L::NX) g = 0.0;
+        g = (k == N && a >= L::NX) ? 0.0 : g;
         LD(L::ga + e) = g;
     }
     SYNC();
@@ -413,27 +423,31 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         const double rti = frcp(t);
         const double sig = nu * rti;
         const bool on = LD(L::rsc + j) != 0.0;
+        LD(L::rtt + j) = rti;                       // 1/t for the row-step pass (rtt is free until the line search)
         LD(L::rsig + j) = on ? sig : 0.0;
         LD(L::rw + j) = on ? (nu - mu * rti + sig * (LD(L::rc + j) - t)) : 0.0;
     }
     SYNC();
     for (int e = c.lane; e < (N + 1) * L::NZ; e += WAVE) {
         const int k = e / L::NZ, a = e - k * L::NZ;
-        double h = 0.0, g = LD(L::ga + e);
-        if (a < 6) h = 2.0 * LD(L::cst + a);
-        else if (a < L::NX) h = (k == 0 && (a - 6) >= c.nobs) ? 1.0 : 0.0;      // absent obstacle: pin sigma_0
-        else if (a < L::NX + 2) h = 2.0 * LD(L::cst + 6 + (a - L::NX));
-        else h = ((a - L::NX - 2) >= c.nobs) ? 1.0 : 0.0;                         // absent obstacle: pin sigma_{k+1}
+        const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
+        const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
+        double g = LD(L::ga + e);
+        double h = (isx || isu) ? 2.0 * LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
+        // absent obstacle: pin its sigma_0 (state copy at k = 0) and sigma_{k+1} (input copy)
+        h += ((iss0 && k == 0 && o >= c.nobs) || (iss1 && o >= c.nobs)) ? 1.0 : 0.0;
         const int rl = si[L::vlo + e], rh = si[L::vhi + e];
-        if (rl >= 0) { h += LD(L::rsig + rl); g += LD(L::rw + rl); }
-        if (rh >= 0) { h += LD(L::rsig + rh); g -= LD(L::rw + rh); }
-        if (NOBS && k < N) {
+        const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
+        h += ((rl >= 0) ? LD(L::rsig + il) : 0.0) + ((rh >= 0) ? LD(L::rsig + ih) : 0.0);
+        g += ((rl >= 0) ? LD(L::rw + il) : 0.0) - ((rh >= 0) ? LD(L::rw + ih) : 0.0);
+        if (NOBS) {
+            const int kk = k < N ? k : N - 1;
 #pragma unroll
-            for (int o = 0; o < NOBS; o++) {
-                const int j = k * L::NR + 8 + NOBS + o;
-                g += LD(L::Jc + (k * L::NO + o) * L::NZ + a) * LD(L::rw + j);
-                if (a == 4 || a == 5)
-                    h += LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (k * L::NO + o) * 8 + (a == 4 ? 6 : 7));
+            for (int ob = 0; ob < NOBS; ob++) {
+                const int j = kk * L::NR + 8 + NOBS + ob;
+                g += (k < N) ? LD(L::Jc + (kk * L::NO + ob) * L::NZ + a) * LD(L::rw + j) : 0.0;
+                const double cur = LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (kk * L::NO + ob) * 8 + (a == 4 ? 6 : 7));
+                h += (k < N && (a == 4 || a == 5)) ? cur : 0.0;
             }
         }
         if (k == N && a >= L::NX) { h = 0.0; g = 0.0; }
@@ -520,8 +534,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // H = M'T + stage terms, lower triangle only (NZ(NZ+1)/2 <= 105 entries), mirrored on store;
         // hv = M'p + hg.  All sums of a lane are formed before any store so that the LDS reads of
         // both of its entries are in flight together.
-        const double kc = 2.0 * LD(L::wc + k);
-        // NZ*NZ <= 64 (no obstacle): one lane per entry of the full matrix, no mirroring needed
+        // NZ*NZ <= 64 (no obstacle): one lane per entry of the full matrix, no mirroring needed.
+        // The body is branch-free (selects): every divergent region costs ~30 cycles of exec-mask
+        // traffic on a lone wave.
+        const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
         constexpr bool FULL = NZ * NZ <= WAVE;
         constexpr int NTRI = FULL ? NZ * NZ : NZ * (NZ + 1) / 2;
         constexpr int HCNT = (NTRI + WAVE - 1) / WAVE;
@@ -529,32 +545,27 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         int hr[HCNT], ha[HCNT];
 #pragma unroll
         for (int q = 0; q < HCNT; q++) {
-            const int e = lane + q * WAVE;
+            const int e0 = lane + q * WAVE;
+            const int e = e0 < NTRI ? e0 : 0;
             int r, a;
             if (FULL) { r = e / NZ; a = e - r * NZ; }
-            else { const int pk = si[L::triH + (e < NTRI ? e : 0)]; r = pk >> 8; a = pk & 255; }
+            else { const int pk = si[L::triH + e]; r = pk >> 8; a = pk & 255; }
             hr[q] = r; ha[q] = a;
             double s = 0.0;
-            if (e < NTRI) {
 #pragma unroll
-                for (int i = 0; i < NX; i++) s += LD(L::M + i * NZ + r) * LD(L::T + i * NZ + a);
-                if (r == a) {
-                    s += LD(L::Hd + k * NZ + r);
-                    if (r >= NX || (k == 0 && r >= 6)) s += dw;
-                }
-                if (NOBS) {
+            for (int i = 0; i < NX; i++) s += LD(L::M + i * NZ + r) * LD(L::T + i * NZ + a);
+            const double dg = LD(L::Hd + k * NZ + r) + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
+            s += (r == a) ? dg : 0.0;
+            if (NOBS) {
 #pragma unroll
-                    for (int o = 0; o < NOBS; o++) {
-                        const double* J = sm + L::Jc + (k * L::NO + o) * NZ;
-                        s += LD(L::rsig + k * L::NR + 8 + NOBS + o) * J[r] * J[a];
-                    }
+                for (int o = 0; o < NOBS; o++) {
+                    const double* J = sm + L::Jc + (k * L::NO + o) * NZ;
+                    s += LD(L::rsig + k * L::NR + 8 + NOBS + o) * J[r] * J[a];
                 }
-                if (kc != 0.0) {
-                    // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
-                    if (r == 5) s -= kc * LD(L::M + 5 * NZ + a);
-                    if (a == 5) s -= kc * LD(L::M + 5 * NZ + r);
-                    if (r == 5 && a == 5) s += kc;
-                }
+            } else {
+                // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
+                const double m5a = LD(L::M + 5 * NZ + a), m5r = LD(L::M + 5 * NZ + r);
+                s -= kc * (((r == 5) ? m5a : 0.0) + ((a == 5) ? m5r : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
             }
             hs[q] = s;
         }
@@ -608,47 +619,46 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         {
             constexpr int NP = NX * (NX + 1) / 2 + NX;
             const int pk = si[L::updP + lane];
-            const int i = pk >> 8, j = pk & 255;   // feedback lanes: column j, i unused
+            const int i = pk >> 8, j = pk & 255;   // feedback lanes: column j, i = 0 (unused)
             const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
-            if (isP || isK) {
-                double yi[NU], yj[NU];
+            const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
+            const double exS = (k >= 1) ? LD(L::kS + km) : 0.0;
+            const double exE = (k >= 1) ? LD(L::kE + km) + 2.0 * LD(L::wc + km) : 0.0;
+            // straight-line body with selects; only the two store regions are predicated
+            const bool gcol = j >= NX;             // gradient column
+            double yi[NU], yj[NU];
 #pragma unroll
-                for (int a = 0; a < NU; a++) {
-                    yi[a] = isP ? LD(L::H + (NX + a) * NZ + i) : 0.0;
-                    yj[a] = (j < NX) ? LD(L::H + (NX + a) * NZ + j) : LD(L::hv + NX + a);
+            for (int a = 0; a < NU; a++) {
+                yi[a] = LD(L::H + (NX + a) * NZ + i);
+                const double hj = LD(L::H + (NX + a) * NZ + (gcol ? 0 : j)), gj = LD(L::hv + NX + a);
+                yj[a] = gcol ? gj : hj;
+            }
+            const double hij = LD(L::H + i * NZ + (gcol ? 0 : j)), gi = LD(L::hv + i);
+            double s = gcol ? gi : hij;
+#pragma unroll
+            for (int a = 1; a < NU; a++) {
+#pragma unroll
+                for (int q = 0; q < a; q++) { yi[a] -= Lf[a][q] * yi[q]; yj[a] -= Lf[a][q] * yj[q]; }
+            }
+#pragma unroll
+            for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; s -= yi[a] * yj[a]; }
+            s += (!gcol && i == j) ? ((i == 4) ? exS : ((i == 5) ? exE : 0.0)) : 0.0;
+            if (isP) {
+                const int a1 = gcol ? L::pv + i : L::P + i * NX + j;
+                const int a2 = gcol ? L::pv + i : L::P + j * NX + i;
+                LD(a1) = s;
+                LD(a2) = s;
+            }
+            if (isK) {
+#pragma unroll
+                for (int a = NU - 2; a >= 0; a--) {
+#pragma unroll
+                    for (int q = a + 1; q < NU; q++) yj[a] -= Lf[q][a] * yj[q];
                 }
-                double s = 0.0;
-                if (isP) s = (j < NX) ? LD(L::H + i * NZ + j) : LD(L::hv + i);
+                const int base = gcol ? L::kf + k * NU : L::Kk + k * NU * NX + j;
+                const int stride = gcol ? 1 : NX;
 #pragma unroll
-                for (int a = 1; a < NU; a++) {
-#pragma unroll
-                    for (int q = 0; q < a; q++) { yi[a] -= Lf[a][q] * yi[q]; yj[a] -= Lf[a][q] * yj[q]; }
-                }
-#pragma unroll
-                for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; s -= yi[a] * yj[a]; }
-                if (isP) {
-                    if (j < NX) {
-                        if (k >= 1 && i == j) {  // stage k-1 extras on (s_k, ey_k)
-                            if (i == 4) s += LD(L::kS + k - 1);
-                            if (i == 5) s += LD(L::kE + k - 1) + 2.0 * LD(L::wc + k - 1);
-                        }
-                        LD(L::P + i * NX + j) = s;
-                        LD(L::P + j * NX + i) = s;
-                    } else {
-                        LD(L::pv + i) = s;
-                    }
-                } else {
-#pragma unroll
-                    for (int a = NU - 2; a >= 0; a--) {
-#pragma unroll
-                        for (int q = a + 1; q < NU; q++) yj[a] -= Lf[q][a] * yj[q];
-                    }
-#pragma unroll
-                    for (int a = 0; a < NU; a++) {
-                        if (j < NX) LD(L::Kk + (k * NU + a) * NX + j) = -yj[a];
-                        else LD(L::kf + k * NU + a) = -yj[a];
-                    }
-                }
+                for (int a = 0; a < NU; a++) LD(base + a * stride) = -yj[a];
             }
         }
         SYNC();
@@ -1003,10 +1013,12 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         riccati_forward<NOBS, NMAX>(sm, c);
         long long tc6 = clock64();
         // ---- row steps, step lengths, merit pieces ---------------------------------------------------
-        double a_p = 1.0, a_d = 1.0, theta = 0.0, Dphi = 0.0;
+        // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
+        double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
         LogAcc lg0;
         for (int j = lane; j < m; j += WAVE) {
             const double sc = LD(L::rsc + j);
+            const bool on = sc != 0.0;
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
             // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
             double jd = LD(L::rsg + j) * LD(L::dZ + si[L::riv + j]);
@@ -1019,20 +1031,23 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                     for (int a = 0; a < NZ; a++) jd += J[a] * LD(L::dZ + k * NZ + a);
                 }
             }
-            const double t = LD(L::rt + j), nu = LD(L::rnu + j);
+            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j);
             const double rp = LD(L::rc + j) - t;
-            const double dt = (sc != 0.0) ? jd + rp : 0.0;
+            const double dt = on ? jd + rp : 0.0;
             // dnu = (mu - t nu - nu dt)/t = mu/t - nu - Sigma dt = -w + Sigma (rp - dt)
-            const double dnu = (sc != 0.0) ? (-LD(L::rw + j) + LD(L::rsig + j) * (rp - dt)) : 0.0;
+            const double dnu = on ? (-LD(L::rw + j) + LD(L::rsig + j) * (rp - dt)) : 0.0;
             LD(L::rdt + j) = dt;
             LD(L::rdnu + j) = dnu;
-            if (dt < 0.0) a_p = fmin(a_p, -tau * t / dt);
-            if (dnu < 0.0) a_d = fmin(a_d, -tau * nu / dnu);
-            theta += (sc != 0.0) ? fabs(rp) : 0.0;
-            Dphi -= (sc != 0.0) ? mu * dt / t : 0.0;
+            const double dtr = dt * rti;                       // dt / t
+            rp_max = fmax(rp_max, -dtr);
+            rd_max = fmax(rd_max, on ? -dnu * frcp(nu) : 0.0);
+            theta += on ? fabs(rp) : 0.0;
+            Dphi -= on ? mu * dtr : 0.0;
             lg0.mul(t);
         }
-        a_p = wave_min(a_p); a_d = wave_min(a_d); theta = wave_sum(theta);
+        rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
+        const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
+        const double a_d = (rd_max > tau) ? tau / rd_max : 1.0;
         Dphi = wave_sum(Dphi) + cost_dir<NOBS, NMAX>(sm, c);
         const double phi0 = f - mu * lg0.wave_total();
         if (it == 0) {
@@ -1104,8 +1119,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         for (int j = lane; j < m; j += WAVE) {
             if (LD(L::rsc + j) == 0.0) continue;
             const double tn = LD(L::rtt + j);
+            const double mut = mu * frcp(tn);
             double nn = LD(L::rnu + j) + a_d * LD(L::rdnu + j);
-            nn = fmin(fmax(nn, mu / (kappa_sigma * tn)), kappa_sigma * mu / tn);
+            nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
             LD(L::rt + j) = tn;
             LD(L::rnu + j) = nn;
         }
@@ -1121,6 +1137,8 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         }
         numax = wave_max(numax); th = wave_max(th);
         first_order<NOBS, NMAX>(sm, si, c);
+        if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
+            kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (clock64() - tc8));   // slot 8: KKT rows + accept/first-order
         if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
     }
     if (infeas0) status = 2;
