@@ -61,3 +61,7 @@ def cbf_solve(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs):
 
 def select(desc, n_veh, X, obs_s, obs_ey, old_flag):
     return binding().select(desc, n_veh, X, obs_s, obs_ey, old_flag)
+
+
+def planner_plan(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag):
+    return binding().planner_plan(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag)

@@ -210,3 +210,34 @@ class Binding:
             _p(old_flag), _p(out["flag"]), _p(out["sel_cost"]), _p(out["best_X"]),
         )
         return out
+
+    def planner_plan(self, desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag):
+        """Fused planner step (crx_planner_plan): all region QPs of every scenario + the selection.
+        Arrays of the QP part have leading dimension S*(V+1), scenario-major.  Only libcrx exports it;
+        the oracle composes planner_solve + select (tests compare the two)."""
+        N, V = desc.N, sdesc.n_veh_max
+        n_veh = np.ascontiguousarray(n_veh, dtype=_I)
+        S = n_veh.shape[0]
+        Bn = S * (V + 1)
+        x0 = _in(x0, _D, (Bn, 6))
+        bez_s = _in(bez_s, _D, (Bn, N + 1))
+        bez_ey = _in(bez_ey, _D, (Bn, N + 1))
+        ey_lb = _in(ey_lb, _D, (Bn, N))
+        ey_ub = _in(ey_ub, _D, (Bn,))
+        obs_s = _in(obs_s, _D, (S, V, N + 1))
+        obs_ey = _in(obs_ey, _D, (S, V, N + 1))
+        old_flag = _in(old_flag, _I, (S,))
+        out = dict(
+            X=np.zeros((Bn, N + 1, 6)), U=np.zeros((Bn, N, 2)), cost=np.zeros(Bn),
+            status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn), iters=np.zeros(Bn, dtype=_I),
+            flag=np.zeros(S, dtype=_I), sel_cost=np.zeros((S, V + 1)), best_X=np.zeros((S, N + 1, 6)),
+        )
+        fn = getattr(self.lib, self.prefix + "planner_plan")
+        fn.restype = C.c_int
+        self._call(
+            "planner_plan", C.byref(desc), C.byref(sdesc), C.c_int(S), _p(x0), _p(bez_s), _p(bez_ey),
+            _p(ey_lb), _p(ey_ub), _p(n_veh), _p(obs_s), _p(obs_ey), _p(old_flag), _p(out["X"]),
+            _p(out["U"]), _p(out["cost"]), _p(out["status"]), _p(out["kkt"]), _p(out["iters"]),
+            _p(out["flag"]), _p(out["sel_cost"]), _p(out["best_X"]),
+        )
+        return out

@@ -428,4 +428,33 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     return CRX_OK;
 }
 
+// ---- fused planner step ------------------------------------------------------------------------------
+int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
+                         const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,
+                         const int32_t* n_veh, const double* obs_s, const double* obs_ey, const int32_t* old_flag,
+                         double* X, double* U, double* cost, int32_t* status, double* kkt, int32_t* iters,
+                         int32_t* flag, double* sel_cost, double* best_X, void* stream) {
+    if (!d || !sd) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (sd->N != d->N) return fail(CRX_ERR_ARG, "planner and selection horizons differ");
+    if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
+    const int R = sd->n_veh_max + 1;
+    if (int rc = crx_planner_solve_dev(d, n_scen * R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters, stream)) return rc;
+    return crx_select_dev(sd, n_scen, n_veh, X, obs_s, obs_ey, old_flag, flag, sel_cost, best_X, stream);
+}
+
+int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
+                     const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,
+                     const int32_t* n_veh, const double* obs_s, const double* obs_ey, const int32_t* old_flag,
+                     double* X, double* U, double* cost, int32_t* status, double* kkt, int32_t* iters,
+                     int32_t* flag, double* sel_cost, double* best_X) {
+    if (!d || !sd) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (sd->N != d->N) return fail(CRX_ERR_ARG, "planner and selection horizons differ");
+    if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
+    const int R = sd->n_veh_max + 1;
+    // host staging: the two host entry points back to back (X makes one extra PCIe round trip; the
+    // device-resident variant above keeps it in HBM)
+    if (int rc = crx_planner_solve(d, n_scen * R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters)) return rc;
+    return crx_select(sd, n_scen, n_veh, X, obs_s, obs_ey, old_flag, flag, sel_cost, best_X);
+}
+
 }  // extern "C"

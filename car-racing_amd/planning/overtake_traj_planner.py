@@ -99,10 +99,13 @@ class OvertakeTrajPlanner:
         desc = abi.planner_desc(N, p.matrix_A, p.matrix_B)
         x0 = np.repeat(np.asarray(ego.xcurv, dtype=float)[None], R, axis=0)  # raw state (:266, quirk Q5)
         t0 = datetime.datetime.now()
-        res = crx.planner_solve(desc, x0, self.bezier_xcurvs[:, :, 0], self.bezier_xcurvs[:, :, 1], lb[0], ub[0])
-        sel = crx.select(abi.select_desc(N, V, track.lap_length, ego.param.length, ego.param.width), np.array([V]),
-                         res["X"][None], obs_s[:, :V], obs_ey[:, :V],
-                         np.array([-1 if self.old_direction_flag is None else int(self.old_direction_flag)]))
+        # one fused call: every region QP (:248-379) and the selection (:205-246)
+        res = crx.planner_plan(
+            desc, abi.select_desc(N, V, track.lap_length, ego.param.length, ego.param.width), x0,
+            self.bezier_xcurvs[:, :, 0], self.bezier_xcurvs[:, :, 1], lb[0], ub[0], np.array([V]),
+            obs_s[:, :V], obs_ey[:, :V],
+            np.array([-1 if self.old_direction_flag is None else int(self.old_direction_flag)]))
+        sel = res
         dt = (datetime.datetime.now() - t0).total_seconds()
         # the reference wraps the stored predictions in place while selecting (:216-217,:230-231)
         for name in self.sorted_vehicles:

@@ -188,6 +188,24 @@ int crx_select_dev(const crx_select_desc* d, int n_scen, const int32_t* n_veh, c
                    int32_t* flag, double* sel_cost, double* best_X, void* stream);
 
 /*
+ * One planner step for n_scen scenarios: all V+1 region QPs of every scenario (crx_planner_solve with
+ * batch = n_scen*(V+1), scenario-major) followed by crx_select on the same stream, X staying on the
+ * device in between.  Replaces solve_optimization_problem (overtake_traj_planner.py:162-246).
+ * Arrays as in crx_planner_solve (leading dimension n_scen*(V+1)) and crx_select.
+ */
+int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
+                     const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,
+                     const int32_t* n_veh, const double* obs_s, const double* obs_ey, const int32_t* old_flag,
+                     double* X, double* U, double* cost, int32_t* status, double* kkt, int32_t* iters,
+                     int32_t* flag, double* sel_cost, double* best_X);
+int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
+                         const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,
+                         const int32_t* n_veh, const double* obs_s, const double* obs_ey,
+                         const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status,
+                         double* kkt, int32_t* iters, int32_t* flag, double* sel_cost, double* best_X,
+                         void* stream);
+
+/*
  * MPC-CBF NLPs.
  *   x0      [batch][6]
  *   xt      [batch][6] or [batch][N+1][6]   tracking target(s) (d->per_stage_target)

@@ -150,6 +150,12 @@ def test_synthetic_planner_batch_and_selection(gpu, orc, AB, N):
     # which may round the float cost differently in the last place
     np.testing.assert_allclose(sg["sel_cost"], so["sel_cost"], rtol=1e-13)
     np.testing.assert_array_equal(sg["best_X"], so["best_X"])
+    # the fused entry point is the same two launches on one stream: identical bits
+    pl = gpu.planner_plan(d, ds, *args, p["n_veh"], p["obs_s"], p["obs_ey"], p["old_flag"])
+    for k in ("X", "U", "status", "iters"):
+        np.testing.assert_array_equal(pl[k], rg[k])
+    for k in ("flag", "sel_cost", "best_X"):
+        np.testing.assert_array_equal(pl[k], sg[k])
 
 
 def test_edge_cases(gpu, orc, AB):
