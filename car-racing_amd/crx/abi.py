@@ -76,6 +76,23 @@ class CbfDesc(C.Structure):
     ]
 
 
+class LmpcDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("n_ss_max", C.c_int32),
+        ("Q", C.c_double * 6),
+        ("R", C.c_double * 2),
+        ("dR", C.c_double * 2),
+        ("x_track", C.c_double * 6),
+        ("v_max", C.c_double),
+        ("ey_max", C.c_double),
+        ("delta_max", C.c_double),
+        ("a_max", C.c_double),
+        ("w_elastic", C.c_double),
+        ("opts", IpmOpts),
+    ]
+
+
 class SelectDesc(C.Structure):
     _fields_ = [
         ("N", C.c_int32),
@@ -114,6 +131,14 @@ def cbf_desc(N, n_obs_max, A, B, Q=(10.0, 0.0, 0.0, 4.0, 0.0, 40.0), R=(0.1, 0.1
     )
 
 
+def lmpc_desc(N=12, n_ss_max=44, Q=(0.0,) * 6, R=(1.0, 0.25), dR=(4.0, 0.0), x_track=(5.0, 0, 0, 0, 0, 0),
+              v_max=10.0, ey_max=1.0, delta_max=0.5, a_max=1.0, w_elastic=1e5, opts=None):
+    """Defaults = LMPCRacingParam (utils/base.py:350-376), SystemParam (:708-713) and the literal
+    x_track of control.lmpc (control.py:649)."""
+    return LmpcDesc(int(N), int(n_ss_max), _arr(C.c_double, 6, Q), _arr(C.c_double, 2, R), _arr(C.c_double, 2, dR),
+                    _arr(C.c_double, 6, x_track), v_max, ey_max, delta_max, a_max, w_elastic, opts or default_opts())
+
+
 def select_desc(N, n_veh_max, lap_length, veh_length=0.4, veh_width=0.2):
     """overtake_traj_planner.py:209,223,243 literals."""
     return SelectDesc(int(N), int(n_veh_max), veh_length, veh_width, lap_length, 10.0, 100.0, 100.0)
@@ -139,9 +164,9 @@ class Binding:
 
     def __init__(self, lib, prefix):
         self.lib, self.prefix = lib, prefix
-        for name in ("planner_solve", "cbf_solve", "select"):
-            fn = getattr(lib, prefix + name)
-            fn.restype = C.c_int
+        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve"):
+            if hasattr(lib, prefix + name):
+                getattr(lib, prefix + name).restype = C.c_int
         self._check = None
 
     def _call(self, name, *args):
@@ -239,5 +264,29 @@ class Binding:
             _p(ey_lb), _p(ey_ub), _p(n_veh), _p(obs_s), _p(obs_ey), _p(old_flag), _p(out["X"]),
             _p(out["U"]), _p(out["cost"]), _p(out["status"]), _p(out["kkt"]), _p(out["iters"]),
             _p(out["flag"]), _p(out["sel_cost"]), _p(out["best_X"]),
+        )
+        return out
+
+    def lmpc_solve(self, desc, x0, u_old, A, B, Cm, ss, qfun, n_ss=None):
+        """crx_lmpc_solve.  A (Bn,N,6,6), B (Bn,N,6,2), Cm (Bn,N,6), ss (Bn,6,M), qfun (Bn,M)."""
+        N, M = desc.N, desc.n_ss_max
+        x0 = np.ascontiguousarray(x0, dtype=_D)
+        Bn = x0.shape[0]
+        x0 = _in(x0, _D, (Bn, 6))
+        u_old = _in(u_old, _D, (Bn, 2))
+        A = _in(np.asarray(A, dtype=_D).reshape(Bn, N, 36), _D, (Bn, N, 36))
+        B = _in(np.asarray(B, dtype=_D).reshape(Bn, N, 12), _D, (Bn, N, 12))
+        Cm = _in(np.asarray(Cm, dtype=_D).reshape(Bn, N, 6), _D, (Bn, N, 6))
+        ss = _in(ss, _D, (Bn, 6, M))
+        qfun = _in(qfun, _D, (Bn, M))
+        n_ss = np.full(Bn, M, dtype=_I) if n_ss is None else _in(n_ss, _I, (Bn,))
+        out = dict(
+            X=np.zeros((Bn, N + 1, 6)), U=np.zeros((Bn, N, 2)), lam=np.zeros((Bn, M)), cost=np.zeros(Bn),
+            status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn), iters=np.zeros(Bn, dtype=_I),
+        )
+        self._call(
+            "lmpc_solve", C.byref(desc), C.c_int(Bn), _p(x0), _p(u_old), _p(A), _p(B), _p(Cm), _p(ss), _p(qfun),
+            _p(n_ss), _p(out["X"]), _p(out["U"]), _p(out["lam"]), _p(out["cost"]), _p(out["status"]),
+            _p(out["kkt"]), _p(out["iters"]),
         )
         return out

@@ -428,6 +428,100 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     return CRX_OK;
 }
 
+// ---- learning-MPC QP ------------------------------------------------------------------------------
+void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->n_ss_max = n_ss_max;
+    d->R[0] = 1.0; d->R[1] = 0.25; d->dR[0] = 4.0; d->dR[1] = 0.0; d->x_track[0] = 5.0;
+    d->v_max = 10.0; d->ey_max = 1.0; d->delta_max = 0.5; d->a_max = 1.0; d->w_elastic = 1e5;
+    crx_ipm_opts_default(&d->opts);
+}
+
+static int fill_lmpc(crx_lmpc_kparams& kp, const crx_lmpc_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 2 || d->N > CRX_LMPC_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [2,%d]", d->N, CRX_LMPC_MAX_N);
+    if (d->n_ss_max < 1 || d->n_ss_max > CRX_MAX_SS) return fail(CRX_ERR_ARG, "n_ss_max=%d outside [1,%d]", d->n_ss_max, CRX_MAX_SS);
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (!(d->R[0] > 0.0 && d->R[1] > 0.0) || d->dR[0] < 0.0 || d->dR[1] < 0.0) return fail(CRX_ERR_ARG, "R must be positive, dR non-negative");
+    for (int c = 0; c < 6; c++)
+        if (d->Q[c] < 0.0) return fail(CRX_ERR_ARG, "Q must be non-negative");
+    if (!(d->w_elastic > 0.0)) return fail(CRX_ERR_ARG, "w_elastic must be positive");
+    if (int rc = check_opts(d->opts)) return rc;
+    memset(&kp, 0, sizeof(kp));
+    kp.N = d->N; kp.batch = batch; kp.n_ss_max = d->n_ss_max;
+    memcpy(kp.Q, d->Q, sizeof(kp.Q)); memcpy(kp.R, d->R, sizeof(kp.R)); memcpy(kp.dR, d->dR, sizeof(kp.dR));
+    memcpy(kp.x_track, d->x_track, sizeof(kp.x_track));
+    kp.v_max = d->v_max; kp.ey_max = d->ey_max; kp.delta_max = d->delta_max; kp.a_max = d->a_max;
+    kp.w_elastic = d->w_elastic; kp.opts = d->opts;
+    return 0;
+}
+
+// n_ss[] is validated on the device side of the boundary only by clamping is NOT acceptable (it indexes
+// LDS), so the host entry point checks it; the _dev variant documents the precondition 1 <= n_ss <= n_ss_max.
+int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
+                       const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
+                       double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
+                       int32_t* iters, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    crx_lmpc_kparams kp;
+    if (int rc = fill_lmpc(kp, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !u_old || !A || !B || !C || !ss || !qfun || !n_ss || !X || !U || !lambda || !cost || !status || !kkt || !iters)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
+    kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    timing_begin((hipStream_t)stream);
+    hipError_t e = crx_launch_lmpc(kp, (hipStream_t)stream);
+    timing_end((hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
+                   const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
+                   double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt, int32_t* iters) {
+    if (int rc = ensure_init()) return rc;
+    crx_lmpc_kparams chk;
+    if (int rc = fill_lmpc(chk, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !u_old || !A || !B || !C || !ss || !qfun || !n_ss || !X || !U || !lambda || !cost || !status || !kkt || !iters)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    for (int b = 0; b < batch; b++)
+        if (n_ss[b] < 1 || n_ss[b] > d->n_ss_max) return fail(CRX_ERR_ARG, "n_ss[%d]=%d outside [1,%d]", b, n_ss[b], d->n_ss_max);
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t Bn = (size_t)batch, N = (size_t)d->N, M = (size_t)d->n_ss_max;
+    const size_t n_A = Bn * N * 36, n_B = Bn * N * 12, n_C = Bn * N * 6, n_ss_ = Bn * 6 * M, n_q = Bn * M;
+    const size_t n_X = Bn * (N + 1) * 6, n_U = Bn * N * 2;
+    if (int rc = g_in.ensure((Bn * 8 + n_A + n_B + n_C + n_ss_ + n_q) * 8 + Bn * 4 + 12 * 256)) return rc;
+    if (int rc = g_out.ensure((n_X + n_U + n_q + 2 * Bn) * 8 + 2 * Bn * 4 + 10 * 256)) return rc;
+    Carver ci(g_in.p), co(g_out.p);
+    double* dx0 = ci.take<double>(Bn * 6); double* duo = ci.take<double>(Bn * 2);
+    double* dA = ci.take<double>(n_A); double* dB = ci.take<double>(n_B); double* dC = ci.take<double>(n_C);
+    double* dss = ci.take<double>(n_ss_); double* dq = ci.take<double>(n_q); int32_t* dn = ci.take<int32_t>(Bn);
+    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dl = co.take<double>(n_q);
+    double* dc = co.take<double>(Bn); double* dk = co.take<double>(Bn);
+    int32_t* ds = co.take<int32_t>(Bn); int32_t* di = co.take<int32_t>(Bn);
+    HIP_TRY(hipMemcpyAsync(dx0, x0, Bn * 48, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(duo, u_old, Bn * 16, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dA, A, n_A * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dB, B, n_B * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dC, C, n_C * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dss, ss, n_ss_ * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dq, qfun, n_q * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dn, n_ss, Bn * 4, hipMemcpyHostToDevice, g_stream));
+    if (int rc = crx_lmpc_solve_dev(d, batch, dx0, duo, dA, dB, dC, dss, dq, dn, dX, dU, dl, dc, ds, dk, di, g_stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(lambda, dl, n_q * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(cost, dc, Bn * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(kkt, dk, Bn * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(status, ds, Bn * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(iters, di, Bn * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return CRX_OK;
+}
+
 // ---- fused planner step ------------------------------------------------------------------------------
 int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
                          const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,

@@ -28,6 +28,17 @@ struct crx_kparams {
     int trace_problem, trace_rows;
 };
 
+struct crx_lmpc_kparams {
+    int N, batch, n_ss_max;
+    double Q[6], R[2], dR[2], x_track[6];
+    double v_max, ey_max, delta_max, a_max, w_elastic;
+    crx_ipm_opts opts;
+    const double *x0, *u_old, *A, *B, *C, *ss, *qfun;
+    const int32_t* n_ss;
+    double *X, *U, *lambda, *cost, *kkt;
+    int32_t *status, *iters;
+};
+
 struct crx_select_kparams {
     int N, V, n_scen;
     double veh_length, veh_width, lap_length, w_prog, w_coll, w_switch;
@@ -43,5 +54,7 @@ struct crx_select_kparams {
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
+size_t crx_lmpc_lds_bytes(int N);
 #endif
 #endif

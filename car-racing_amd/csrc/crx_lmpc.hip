@@ -1,0 +1,685 @@
+// crx_lmpc.hip -- gfx950 kernel for the learning-MPC QP of car-racing (SURVEY.md section 8f row 1;
+// reference: /root/reference/car_racing/control/control.py:610-730 `lmpc`).
+//
+// One QP per 64-lane wavefront, everything in that wave's LDS slice, FP64, no MFMA (largest dense
+// block 60x60, factorised once per iteration along a serial dependency chain).
+//
+//   variables   u_0..u_{N-1} (2N), lambd (M <= 60); states eliminated by the affine LTV roll-out
+//               x_k = xf_k + S_k u   (S_k = dx_k/du, built once per problem)
+//   rows        4N input-box rows, 3(N-1) state rows (vx_k <= v_max, |ey_k| <= w; k = 1..N-1),
+//               M rows lambd >= 0 (+ 12 rows p, q >= 0 in the elastic attempt)
+//   equalities  x_N - SS lambd (- p + q) = 0  (6),  1'lambd = 1
+//
+// Interior-point iteration: identical to oracle/crx_oracle_lmpc.c (slack form, monotone barrier,
+// fraction-to-the-boundary, filter line search, y updated with the primal step length).  Newton
+// system by block elimination, every factor a Cholesky:
+//   K_u = H_u + J_u' Sigma J_u  (2N x 2N)          -> L_u, with Phi and rhs_u carried as extra rows,
+//                                                      so  Y = L_u^-1 Phi',  z = L_u^-1 rhs_u  come for free
+//   W~  = Y Y' (+ 1/D_p + 1/D_q)   (6 x 6)          -> L_w   (per lane, registers)
+//   G   = D_lambda + T T',  T = SS' L_w^-T (M x 6) -> L_g, with the two right-hand sides as extra rows
+//   dy_1 from 1'dlambd = -e_1, then dlambd, dy_x, du, (dp, dq) by back substitution.
+// A Schur complement on the 7 equalities (E K^-1 E') is NOT used: the active lambd's carry no
+// curvature but the barrier's, so K^-1 spans 1e-16..1e16 near the solution; G stays well scaled.
+// Lane i owns row i of each factor (left-looking Cholesky: row j is read as an LDS broadcast), the
+// pivots are broadcast with v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "crx_kparams.h"
+#include "crx_wave.h"
+
+#define LMAXF 16
+
+template <int NMAX>
+struct LL {
+    static constexpr int NU2 = 2 * NMAX, LDK = NU2 + 1, KR = NU2 + 7;
+    static constexpr int MS = CRX_MAX_SS, LDG = MS + 1, GR = MS + 2;
+    static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS + 12;
+    // offsets in doubles
+    static constexpr int A = 0, B = A + 36 * NMAX, C = B + 12 * NMAX, xf = C + 6 * NMAX;
+    static constexpr int S = xf + 6 * (NMAX + 1);              // S[(k*6+c)*NU2 + a], k = 0..NMAX
+    static constexpr int Hu = S + 6 * (NMAX + 1) * NU2;        // NU2 x NU2, row-major, stride NU2
+    static constexpr int K = Hu + NU2 * NU2;                   // KR x LDK
+    static constexpr int G = K + KR * LDK;                     // GR x LDG
+    static constexpr int SS = G + GR * LDG;                    // [6][MS]
+    static constexpr int qf = SS + 6 * MS, T = qf + MS;        // T[j*6+c]
+    static constexpr int u = T + 6 * MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
+    static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS, cl = rl + MS;
+    static constexpr int pq = cl + MS, dpq = pq + 12, rpq = dpq + 12;
+    static constexpr int y = rpq + 12, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
+    static constexpr int ik = Wt + 36, ig = ik + NU2;          // inverse pivots of L_u, L_g
+    static constexpr int t = ig + MS, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
+    static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
+    static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
+    static constexpr int END = Fph + LMAXF;
+    static constexpr size_t BYTES = (size_t)END * 8;
+};
+
+struct LCtx {
+    int N, nu2, M, m, el, lane;
+    int r_st, r_lam, r_el;
+};
+
+#define LDS(i) sm[(i)]
+
+// rows c_j(v) for the current iterate; rp = c - t
+template <int NMAX>
+__device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc_kparams& kp) {
+    using L = LL<NMAX>;
+    for (int r = x.lane; r < x.m; r += WAVE) {
+        double cv;
+        if (r < x.r_st) {
+            int i = r >> 2, q = r & 3;
+            double ub = (q & 2) ? kp.a_max : kp.delta_max, uv = LDS(L::u + 2 * i + (q >> 1));
+            cv = (q & 1) ? ub - uv : uv + ub;
+        } else if (r < x.r_lam) {
+            int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1);
+            int comp = q ? 5 : 0;
+            double s = LDS(L::xf + 6 * k + comp);
+            const int so = L::S + (k * 6 + comp) * L::NU2;
+            for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+            cv = q == 0 ? kp.v_max - s : (q == 1 ? kp.ey_max - s : s + kp.ey_max);
+        } else if (r < x.r_el) {
+            cv = LDS(L::lam + (r - x.r_lam));
+        } else {
+            cv = LDS(L::pq + (r - x.r_el));
+        }
+        LDS(L::c + r) = cv;
+        LDS(L::rp + r) = cv - LDS(L::t + r);
+    }
+}
+
+// (ru, rl, rpq) = g + E'y - J'w   with w = the row array at offset `wo`
+template <int NMAX>
+__device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int wo) {
+    using L = LL<NMAX>;
+    if (x.lane >= 1 && x.lane < x.N) {
+        int k = x.lane, r = x.r_st + 3 * (k - 1);
+        LDS(L::w0 + k) = LDS(wo + r);
+        LDS(L::w5 + k) = LDS(wo + r + 1) - LDS(wo + r + 2);
+    }
+    SYNC();
+    if (x.lane < x.nu2) {
+        const int a = x.lane, i = a >> 1, cc = a & 1;
+        double s = LDS(L::gu + a);
+        for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + (x.N * 6 + c6) * L::NU2 + a), LDS(L::y + c6), s);
+        s -= LDS(wo + 4 * i + 2 * cc) - LDS(wo + 4 * i + 2 * cc + 1);
+        // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo)
+        for (int k = i + 1; k < x.N; k++) {
+            s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a), LDS(L::w0 + k), s);
+            s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s);
+        }
+        LDS(L::ru + a) = s;
+    }
+    if (x.lane < x.M) {
+        const int j = x.lane;
+        double s = LDS(L::qf + j) + LDS(L::y + 6) - LDS(wo + x.r_lam + j);
+        for (int c6 = 0; c6 < 6; c6++) s = fma(-LDS(L::SS + c6 * L::MS + j), LDS(L::y + c6), s);
+        LDS(L::rl + j) = s;
+    }
+    if (x.el && x.lane < 12) {
+        const int c6 = x.lane < 6 ? x.lane : x.lane - 6;
+        double yy = LDS(L::y + c6);
+        LDS(L::rpq + x.lane) = kp.w_elastic + (x.lane < 6 ? -yy : yy) - LDS(wo + x.r_el + x.lane);
+    }
+    SYNC();
+}
+
+// left-looking Cholesky, in place, of the leading n x n block (lower triangle) of a row-major array
+// (stride LD); rows n..n+extra-1 are carried along, i.e. forward-substituted right-hand sides.
+// Lane i owns row i.  Returns 0 if a pivot is not positive.
+template <int LD>
+__device__ __forceinline__ int l_chol(double* sm, int base, int inv, int n, int extra, int lane) {
+    int ok = 1;
+    const int rows = n + extra;
+    const int ri = base + lane * LD;
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+        if (lane >= j && lane < rows) {
+            s = sm[ri + j];
+            const int rj = base + j * LD;
+#pragma unroll 4
+            for (int k = 0; k < j; k++) s = fma(-sm[ri + k], sm[rj + k], s);
+        }
+        const double d = lane_f64(s, j);
+        if (!(d > 0.0)) { ok = 0; break; }
+        const double rinv = frsqrt(d);
+        if (lane >= j && lane < rows) sm[ri + j] = lane == j ? d * rinv : s * rinv;
+        if (lane == 0) sm[inv + j] = rinv;
+        SYNC();
+    }
+    return ok;
+}
+
+// x <- L^-T x for `NR` right-hand sides held one entry per lane (lane i = entry i), L as above
+template <int LD, int NR>
+__device__ __forceinline__ void l_backsub(const double* sm, int base, int inv, int n, int lane, double* b) {
+    for (int j = n - 1; j >= 0; j--) {
+        const double rinv = sm[inv + j];
+        const double lj = lane < j ? sm[base + j * LD + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const double xj = lane_f64(b[r], j) * rinv;
+            if (lane == j) b[r] = xj;
+            b[r] = fma(-lj, xj, b[r]);
+        }
+    }
+}
+
+template <int NMAX>
+__global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
+    using L = LL<NMAX>;
+    extern __shared__ double sm[];
+    const int pb = blockIdx.x;
+    if (pb >= kp.batch) return;
+    LCtx x;
+    x.lane = threadIdx.x;
+    x.N = kp.N;
+    x.nu2 = 2 * kp.N;
+    x.M = kp.n_ss[pb];
+    const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max;
+    const crx_ipm_opts& o = kp.opts;
+
+    // ---- load the problem (coalesced) --------------------------------------------------------------
+    for (int i = lane; i < 36 * N; i += WAVE) LDS(L::A + i) = kp.A[(size_t)36 * N * pb + i];
+    for (int i = lane; i < 12 * N; i += WAVE) LDS(L::B + i) = kp.B[(size_t)12 * N * pb + i];
+    for (int i = lane; i < 6 * N; i += WAVE) LDS(L::C + i) = kp.C[(size_t)6 * N * pb + i];
+    for (int i = lane; i < 6 * Mx; i += WAVE) {
+        int c6 = i / Mx, j = i - c6 * Mx;
+        if (j < M) LDS(L::SS + c6 * L::MS + j) = kp.ss[(size_t)6 * Mx * pb + i];
+    }
+    if (lane < M) LDS(L::qf + lane) = kp.qfun[(size_t)Mx * pb + lane];
+    if (lane < 6) LDS(L::xf + lane) = kp.x0[6 * pb + lane];
+    const double uold0 = kp.u_old[2 * pb], uold1 = kp.u_old[2 * pb + 1];
+    for (int i = lane; i < 6 * (NMAX + 1) * L::NU2; i += WAVE) LDS(L::S + i) = 0.0;
+    for (int i = lane; i < L::NU2 * L::NU2; i += WAVE) LDS(L::Hu + i) = 0.0;
+    SYNC();
+    // free response
+    for (int k = 0; k < N; k++) {
+        if (lane < 6) {
+            double s = LDS(L::C + 6 * k + lane);
+            for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * lane + c6), LDS(L::xf + 6 * k + c6), s);
+            LDS(L::xf + 6 * (k + 1) + lane) = s;
+        }
+        SYNC();
+    }
+    // sensitivities: lane a propagates column a of S
+    if (lane < nu2) {
+        const int a = lane, ka = a >> 1, ca = a & 1;
+        double col[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = ka; k < N; k++) {
+            double nc[6];
+            if (k == ka) {
+                for (int r = 0; r < 6; r++) nc[r] = LDS(L::B + 12 * k + 2 * r + ca);
+            } else {
+                for (int r = 0; r < 6; r++) {
+                    double s = 0.0;
+                    for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * r + c6), col[c6], s);
+                    nc[r] = s;
+                }
+            }
+            for (int r = 0; r < 6; r++) {
+                col[r] = nc[r];
+                LDS(L::S + ((k + 1) * 6 + r) * L::NU2 + a) = nc[r];
+            }
+        }
+    }
+    SYNC();
+    // cost: f = 1/2 u'Hu u + g0u'u + f0 + qf'lambd (+ rho 1'(p+q))
+    double f0 = 0.0;
+    {
+        const bool anyQ = kp.Q[0] != 0.0 || kp.Q[1] != 0.0 || kp.Q[2] != 0.0 || kp.Q[3] != 0.0 || kp.Q[4] != 0.0 || kp.Q[5] != 0.0;
+        if (lane < nu2) {
+            const int a = lane, i = a >> 1, cc = a & 1;
+            const double R = cc ? kp.R[1] : kp.R[0], dR = cc ? kp.dR[1] : kp.dR[0];
+            double dd = 2.0 * R + 2.0 * dR + (i + 1 < N ? 2.0 * dR : 0.0);
+            LDS(L::Hu + a * L::NU2 + a) = dd;
+            if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
+            if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
+            LDS(L::g0u + a) = i == 0 ? -2.0 * dR * (cc ? uold1 : uold0) : 0.0;
+        }
+        f0 = kp.dR[0] * uold0 * uold0 + kp.dR[1] * uold1 * uold1;
+        SYNC();
+        if (anyQ) {
+            for (int k = 1; k <= N; k++)
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double q = kp.Q[c6];
+                    if (q == 0.0) continue;
+                    const double r0 = LDS(L::xf + 6 * k + c6) - kp.x_track[c6];
+                    const int so = L::S + (k * 6 + c6) * L::NU2;
+                    if (lane < nu2) {
+                        const double sa = LDS(so + lane);
+                        LDS(L::g0u + lane) += 2.0 * q * r0 * sa;
+                        for (int b = 0; b < nu2; b++) LDS(L::Hu + lane * L::NU2 + b) += 2.0 * q * sa * LDS(so + b);
+                    }
+                    f0 += q * r0 * r0;
+                }
+            for (int c6 = 0; c6 < 6; c6++) {
+                const double r0 = LDS(L::xf + c6) - kp.x_track[c6];
+                f0 += kp.Q[c6] * r0 * r0;
+            }
+            SYNC();
+        }
+    }
+    // rows on the fixed x0 (i = 0) are constants: violated -> the reference's QP is infeasible
+    int bad0 = 0;
+    {
+        const double vx0 = LDS(L::xf + 0), ey0 = LDS(L::xf + 5);
+        if (kp.v_max - vx0 < -o.tol || kp.ey_max - ey0 < -o.tol || ey0 + kp.ey_max < -o.tol) bad0 = 1;
+    }
+    x.r_st = 4 * N;
+    x.r_lam = x.r_st + 3 * (N - 1);
+    x.r_el = x.r_lam + M;
+
+    int status = CRX_MAX_ITER, total_it = 0;
+    double E0 = HUGE_VAL, f = 0.0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        x.el = attempt;
+        x.m = x.r_el + (x.el ? 12 : 0);
+        const int m = x.m;
+        // ---- start point: v = 0, y = 0, t = max(|c|, push), nu = 1 (lambd / elastic rows: cost gradient) ----
+        if (lane < nu2) LDS(L::u + lane) = 0.0;
+        if (lane < L::MS) LDS(L::lam + lane) = 0.0;
+        if (lane < 12) LDS(L::pq + lane) = 0.0;
+        if (lane < 8) LDS(L::y + lane) = 0.0;
+        for (int r = lane; r < m; r += WAVE) LDS(L::t + r) = 0.0;
+        SYNC();
+        l_rows<NMAX>(sm, x, kp);
+        SYNC();
+        for (int r = lane; r < m; r += WAVE) {
+            LDS(L::t + r) = fmax(fabs(LDS(L::c + r)), o.slack_push);
+            double nn = 1.0;
+            if (r >= x.r_lam) {
+                const double gg = r < x.r_el ? LDS(L::qf + (r - x.r_lam)) : kp.w_elastic;
+                if (gg > 1.0) nn = gg;
+            }
+            LDS(L::nu + r) = nn;
+        }
+        SYNC();
+        double mu = o.mu_init, theta_min = 0.0, theta_max = HUGE_VAL;
+        int nf = 0, it = 0;
+        status = CRX_MAX_ITER;
+        f = f0;
+        for (it = 0;; it++) {
+            // ---- rows, gradient, equality residual ----
+            l_rows<NMAX>(sm, x, kp);
+            if (lane < nu2) {
+                double s = LDS(L::g0u + lane);
+                for (int b = 0; b < nu2; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::u + b), s);
+                LDS(L::gu + lane) = s;
+            }
+            if (lane < 7) {
+                double s;
+                if (lane < 6) {
+                    s = LDS(L::xf + 6 * N + lane);
+                    const int so = L::S + (N * 6 + lane) * L::NU2;
+                    for (int a = 0; a < nu2; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+                    for (int j = 0; j < M; j++) s = fma(-LDS(L::SS + lane * L::MS + j), LDS(L::lam + j), s);
+                    if (x.el) s += LDS(L::pq + 6 + lane) - LDS(L::pq + lane);
+                } else {
+                    s = -1.0;
+                    for (int j = 0; j < M; j++) s += LDS(L::lam + j);
+                }
+                LDS(L::e + lane) = s;
+            }
+            SYNC();
+            // ---- error measure ----
+            l_lagr<NMAX>(sm, x, kp, L::nu);
+            double nus = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
+            for (int r = lane; r < m; r += WAVE) {
+                const double tt = LDS(L::t + r), nn = LDS(L::nu + r), rr = fabs(LDS(L::rp + r));
+                nus += nn;
+                e_p = fmax(e_p, rr);
+                theta += rr;
+                e_c = fmax(e_c, tt * nn);
+            }
+            double ys = 0.0, e_d = 0.0;
+            if (lane < 7) {
+                const double ee = fabs(LDS(L::e + lane));
+                ys = fabs(LDS(L::y + lane));
+                e_p = fmax(e_p, ee);
+                theta += ee;
+            }
+            if (lane < nu2) e_d = fabs(LDS(L::ru + lane));
+            if (lane < M) e_d = fmax(e_d, fabs(LDS(L::rl + lane)));
+            if (x.el && lane < 12) e_d = fmax(e_d, fabs(LDS(L::rpq + lane)));
+            nus = wave_sum(nus);
+            ys = wave_sum(ys);
+            theta = wave_sum(theta);
+            e_p = wave_max(e_p);
+            e_c = wave_max(e_c);
+            e_d = wave_max(e_d);
+            const double sd = fmax(100.0, (nus + ys) / (m + 7)) / 100.0, sc = fmax(100.0, nus / m) / 100.0;
+            e_d /= sd;
+            e_c /= sc;
+            E0 = fmax(e_d, fmax(e_p, e_c));
+            if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
+            if (it >= o.max_iter) break;
+            // ---- barrier update ----
+            for (;;) {
+                double e_cm = 0.0;
+                for (int r = lane; r < m; r += WAVE) e_cm = fmax(e_cm, fabs(LDS(L::t + r) * LDS(L::nu + r) - mu));
+                e_cm = wave_max(e_cm) / sc;
+                if (fmax(e_d, fmax(e_p, e_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+                    mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                    nf = 0;
+                } else
+                    break;
+            }
+            const double tau = fmax(o.tau_min, 1.0 - mu);
+            // ---- Sigma (in dnu), omega = mu/t - Sigma rp (in wv); rhs = -(g + E'y - J'omega) ----
+            for (int r = lane; r < m; r += WAVE) {
+                const double ti = frcp(LDS(L::t + r)), sg = LDS(L::nu + r) * ti;
+                LDS(L::dnu + r) = sg;
+                LDS(L::wv + r) = fma(-sg, LDS(L::rp + r), mu * ti);
+            }
+            SYNC();
+            l_lagr<NMAX>(sm, x, kp, L::wv);   // ru, rl, rpq = -(rhs)
+            // stage weights of the state rows for K_u
+            if (lane >= 1 && lane < N) {
+                const int r = x.r_st + 3 * (lane - 1);
+                LDS(L::w0 + lane) = LDS(L::dnu + r);
+                LDS(L::w5 + lane) = LDS(L::dnu + r + 1) + LDS(L::dnu + r + 2);
+            }
+            SYNC();
+            // ---- K_u (lower triangle) + extra rows Phi (6) and rhs_u ----
+            for (int en = lane; en < nu2 * (nu2 + 1) / 2; en += WAVE) {
+                int a = (int)((sqrt(8.0 * en + 1.0) - 1.0) * 0.5);
+                if (a * (a + 1) / 2 > en) a--;
+                if ((a + 1) * (a + 2) / 2 <= en) a++;
+                const int b = en - a * (a + 1) / 2;
+                double s = LDS(L::Hu + a * L::NU2 + b);
+                if (a == b) s += LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1)) + LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1) + 1);
+                for (int k = (a >> 1) + 1; k < N; k++) {
+                    s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a) * LDS(L::w0 + k), LDS(L::S + (k * 6 + 0) * L::NU2 + b), s);
+                    s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a) * LDS(L::w5 + k), LDS(L::S + (k * 6 + 5) * L::NU2 + b), s);
+                }
+                LDS(L::K + a * L::LDK + b) = s;
+            }
+            for (int en = lane; en < 7 * nu2; en += WAVE) {
+                const int r = en / nu2, j = en - r * nu2;
+                LDS(L::K + (nu2 + r) * L::LDK + j) = r < 6 ? LDS(L::S + (N * 6 + r) * L::NU2 + j) : -LDS(L::ru + j);
+            }
+            SYNC();
+            int ok = l_chol<L::LDK>(sm, L::K, L::ik, nu2, 7, lane);
+            if (!ok) break;
+            // ---- W~ and b_x ----
+            if (lane < 27) {
+                double s = 0.0;
+                if (lane < 21) {
+                    int r = 0, q = lane;
+                    while (q > r) { q -= r + 1; r++; }   // lane -> (r, q), q <= r
+                    const int ro = L::K + (nu2 + r) * L::LDK, qo = L::K + (nu2 + q) * L::LDK;
+                    for (int j = 0; j < nu2; j++) s = fma(LDS(ro + j), LDS(qo + j), s);
+                    if (x.el && r == q) s += frcp(LDS(L::dnu + x.r_el + r)) + frcp(LDS(L::dnu + x.r_el + 6 + r));
+                    LDS(L::Wt + 6 * r + q) = s;
+                    LDS(L::Wt + 6 * q + r) = s;
+                } else {
+                    const int r = lane - 21;
+                    s = LDS(L::e + r);
+                    const int ro = L::K + (nu2 + r) * L::LDK, zo = L::K + (nu2 + 6) * L::LDK;
+                    for (int j = 0; j < nu2; j++) s = fma(LDS(ro + j), LDS(zo + j), s);
+                    if (x.el) s += LDS(L::rpq + r) * frcp(LDS(L::dnu + x.r_el + r)) - LDS(L::rpq + 6 + r) * frcp(LDS(L::dnu + x.r_el + 6 + r));
+                    LDS(L::bx + r) = s;
+                }
+            }
+            SYNC();
+            // ---- L_w (6x6, per lane), T_j = L_w^-1 ss_j, tbx = L_w^-1 b_x ----
+            double Lw[6][6], iw[6], tbx[6], Tj[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+#pragma unroll
+                for (int i = j; i < 6; i++) {
+                    double s = LDS(L::Wt + 6 * i + j);
+#pragma unroll
+                    for (int k = 0; k < j; k++) s = fma(-Lw[i][k], Lw[j][k], s);
+                    Lw[i][j] = s;
+                }
+                if (!(Lw[j][j] > 0.0)) ok = 0;
+                iw[j] = frsqrt(fmax(Lw[j][j], 1e-300));
+#pragma unroll
+                for (int i = j; i < 6; i++) Lw[i][j] *= iw[j];
+            }
+            if (!ok) break;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double s = LDS(L::bx + i), sj = lane < M ? LDS(L::SS + i * L::MS + lane) : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) {
+                    s = fma(-Lw[i][k], tbx[k], s);
+                    sj = fma(-Lw[i][k], Tj[k], sj);
+                }
+                tbx[i] = s * iw[i];
+                Tj[i] = sj * iw[i];
+            }
+            if (lane < M) {
+                double s = -LDS(L::rl + lane);
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) {
+                    LDS(L::T + 6 * lane + c6) = Tj[c6];
+                    s = fma(Tj[c6], tbx[c6], s);
+                }
+                LDS(L::cl + lane) = s;
+            }
+            SYNC();
+            // ---- G = D_lambda + T T' (lower triangle, lane i = row i) with extra rows cl and 1 ----
+            if (lane < M) {
+                const int go = L::G + lane * L::LDG;
+                for (int j = 0; j <= lane; j++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], LDS(L::T + 6 * j + c6), s);
+                    LDS(go + j) = s;
+                }
+                LDS(go + lane) += LDS(L::dnu + x.r_lam + lane);
+                LDS(L::G + M * L::LDG + lane) = LDS(L::cl + lane);
+                LDS(L::G + (M + 1) * L::LDG + lane) = 1.0;
+            }
+            SYNC();
+            ok = l_chol<L::LDG>(sm, L::G, L::ig, M, 2, lane);
+            if (!ok) break;
+            {
+                double b2[2];
+                b2[0] = lane < M ? LDS(L::G + M * L::LDG + lane) : 0.0;
+                b2[1] = lane < M ? LDS(L::G + (M + 1) * L::LDG + lane) : 0.0;
+                l_backsub<L::LDG, 2>(sm, L::G, L::ig, M, lane, b2);
+                const double s1 = wave_sum(lane < M ? b2[0] : 0.0), s2 = wave_sum(lane < M ? b2[1] : 0.0);
+                const double dy1 = (s1 + LDS(L::e + 6)) / s2;
+                const double dl = lane < M ? b2[0] - b2[1] * dy1 : 0.0;
+                if (lane < M) LDS(L::dlam + lane) = dl;
+                double tb[6], dyx[6];
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) tb[c6] = tbx[c6] - wave_sum(Tj[c6] * dl);
+#pragma unroll
+                for (int i = 5; i >= 0; i--) {
+                    double s = tb[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; k++) s = fma(-Lw[k][i], dyx[k], s);
+                    dyx[i] = s * iw[i];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c6 = 0; c6 < 6; c6++) LDS(L::dy + c6) = dyx[c6];
+                    LDS(L::dy + 6) = dy1;
+                }
+                // du = L_u^-T (z - Y' dy_x)
+                double b1[1];
+                b1[0] = 0.0;
+                if (lane < nu2) {
+                    double s = LDS(L::K + (nu2 + 6) * L::LDK + lane);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nu2 + r) * L::LDK + lane), dyx[r], s);
+                    b1[0] = s;
+                }
+                l_backsub<L::LDK, 1>(sm, L::K, L::ik, nu2, lane, b1);
+                if (lane < nu2) LDS(L::du + lane) = b1[0];
+                if (x.el && lane < 12) {
+                    const int c6 = lane < 6 ? lane : lane - 6;
+                    const double rr = -LDS(L::rpq + lane) + (lane < 6 ? dyx[c6] : -dyx[c6]);
+                    LDS(L::dpq + lane) = rr * frcp(LDS(L::dnu + x.r_el + lane));
+                }
+            }
+            SYNC();
+            // ---- row steps ----
+            double rp_max = 0.0, rd_max = 0.0, Dphi = 0.0;
+            for (int r = lane; r < m; r += WAVE) {
+                double jd;
+                if (r < x.r_st) {
+                    const double d = LDS(L::du + 2 * (r >> 2) + ((r & 3) >> 1));
+                    jd = (r & 1) ? -d : d;
+                } else if (r < x.r_lam) {
+                    const int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
+                    double s = 0.0;
+                    for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
+                    jd = q == 2 ? s : -s;
+                } else if (r < x.r_el) {
+                    jd = LDS(L::dlam + (r - x.r_lam));
+                } else {
+                    jd = LDS(L::dpq + (r - x.r_el));
+                }
+                const double tt = LDS(L::t + r), nn = LDS(L::nu + r), ti = frcp(tt);
+                const double dtt = LDS(L::rp + r) + jd;
+                const double dn = (mu - tt * nn - nn * dtt) * ti;
+                LDS(L::wv + r) = jd;
+                LDS(L::dt + r) = dtt;
+                const double sg = LDS(L::dnu + r);
+                (void)sg;
+                rp_max = fmax(rp_max, -dtt * ti);
+                rd_max = fmax(rd_max, -dn * frcp(nn));
+                Dphi = fma(-mu * dtt, ti, Dphi);
+                LDS(L::c + r) = dn;   // dnu parked in c (c is recomputed at the top of the next iteration)
+            }
+            double gdv = 0.0, qd = 0.0;
+            if (lane < nu2) {
+                const double d = LDS(L::du + lane);
+                gdv = LDS(L::gu + lane) * d;
+                double s = 0.0;
+                for (int b = 0; b < nu2; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::du + b), s);
+                qd = s * d;
+            }
+            if (lane < M) gdv = fma(LDS(L::qf + lane), LDS(L::dlam + lane), gdv);
+            if (x.el && lane < 12) gdv = fma(kp.w_elastic, LDS(L::dpq + lane), gdv);
+            rp_max = wave_max(rp_max);
+            rd_max = wave_max(rd_max);
+            gdv = wave_sum(gdv);
+            qd = wave_sum(qd);
+            Dphi = wave_sum(Dphi) + gdv;
+            const double a_p = rp_max > tau ? tau / rp_max : 1.0, a_d = rd_max > tau ? tau / rd_max : 1.0;
+            double esum = 0.0;
+            if (lane < 7) esum = fabs(LDS(L::e + lane));
+            esum = wave_sum(esum);
+            LogAcc la0;
+            for (int r = lane; r < m; r += WAVE) la0.mul(LDS(L::t + r));
+            const double phi0 = f - mu * la0.wave_total();
+            if (it == 0) {
+                theta_min = 1e-4 * fmax(1.0, theta);
+                theta_max = 1e4 * fmax(1.0, theta);
+            }
+            // ---- filter line search (all rows linear: c(v + al dv) = c + al J dv) ----
+            double al = a_p, fn = f;
+            int acc = 0, ftype = 0;
+            for (int ls = 0; ls < 40; ls++) {
+                fn = f + al * (gdv + 0.5 * al * qd);
+                double thn = 0.0;
+                LogAcc la;
+                for (int r = lane; r < m; r += WAVE) {
+                    const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
+                    double tn = fma(al, LDS(L::dt + r), LDS(L::t + r));
+                    tn = fmax(tn, cj);
+                    la.mul(tn);
+                    thn += fabs(cj - tn);
+                }
+                thn = wave_sum(thn) + (1.0 - al) * esum;
+                const double phin = fn - mu * la.wave_total();
+                int okf = (thn <= theta_max) && (phin == phin);
+                for (int i = 0; i < nf && okf; i++)
+                    if (!(thn < LDS(L::Fth + i) || phin < LDS(L::Fph + i))) okf = 0;
+                if (okf) {
+                    const int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                    if (theta <= theta_min && sw) {
+                        if (phin <= phi0 + 1e-8 * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                    } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
+                        acc = 1;
+                    }
+                }
+                if (acc) break;
+                al *= 0.5;
+            }
+            if (acc && !ftype && nf < LMAXF) {
+                if (lane == 0) {
+                    LDS(L::Fth + nf) = (1.0 - 1e-5) * theta;
+                    LDS(L::Fph + nf) = phi0 - 1e-8 * theta;
+                }
+                nf++;
+            }
+            if (!acc) break;
+            // ---- accept ----
+            double numax = 0.0;
+            for (int r = lane; r < m; r += WAVE) {
+                const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
+                const double tn = fmax(fma(al, LDS(L::dt + r), LDS(L::t + r)), cj);
+                double nn = fma(a_d, LDS(L::c + r), LDS(L::nu + r));
+                const double mut = mu * frcp(tn);
+                nn = fmin(fmax(nn, mut * 1e-10), mut * 1e10);
+                LDS(L::t + r) = tn;
+                LDS(L::nu + r) = nn;
+                numax = fmax(numax, nn);
+            }
+            if (lane < nu2) LDS(L::u + lane) = fma(al, LDS(L::du + lane), LDS(L::u + lane));
+            if (lane < M) LDS(L::lam + lane) = fma(al, LDS(L::dlam + lane), LDS(L::lam + lane));
+            if (x.el && lane < 12) LDS(L::pq + lane) = fma(al, LDS(L::dpq + lane), LDS(L::pq + lane));
+            if (lane < 7) LDS(L::y + lane) = fma(al, LDS(L::dy + lane), LDS(L::y + lane));
+            f = fn;
+            numax = wave_max(numax);
+            SYNC();
+            if (numax > 1e12 && theta > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+        }
+        total_it += it;
+        SYNC();
+        if (attempt == 0 && status == CRX_CONVERGED && !bad0) break;
+        if (attempt == 1) {
+            double els = 0.0;
+            if (lane < 12) els = fabs(LDS(L::pq + lane));
+            els = wave_sum(els);
+            if (status == CRX_CONVERGED && (els > 1e-7 || bad0)) status = CRX_INFEASIBLE;
+            f -= kp.w_elastic * els;
+        }
+    }
+    // ---- write back ----
+    for (int i = lane; i < 6 * (N + 1); i += WAVE) {
+        const int k = i / 6, c6 = i - 6 * k;
+        double s = LDS(L::xf + i);
+        const int so = L::S + (k * 6 + c6) * L::NU2;
+        for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+        kp.X[(size_t)6 * (N + 1) * pb + i] = s;
+    }
+    if (lane < nu2) kp.U[(size_t)nu2 * pb + lane] = LDS(L::u + lane);
+    if (lane < Mx) kp.lambda[(size_t)Mx * pb + lane] = lane < M ? LDS(L::lam + lane) : 0.0;
+    if (lane == 0) {
+        double ql = 0.0;
+        for (int j = 0; j < M; j++) ql = fma(LDS(L::qf + j), LDS(L::lam + j), ql);
+        (void)ql;
+        kp.cost[pb] = f;
+        kp.status[pb] = status;
+        kp.kkt[pb] = E0;
+        kp.iters[pb] = total_it;
+    }
+}
+
+template <int NMAX>
+static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
+    const size_t bytes = LL<NMAX>::BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(crx_lmpc_kernel<NMAX>, dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    return hipGetLastError();
+}
+
+hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
+    if (kp.batch == 0) return hipSuccess;
+    return kp.N <= 12 ? launch_l<12>(kp, st) : launch_l<CRX_LMPC_MAX_N>(kp, st);
+}
+
+size_t crx_lmpc_lds_bytes(int N) { return N <= 12 ? LL<12>::BYTES : LL<CRX_LMPC_MAX_N>::BYTES; }
+static_assert(LL<CRX_LMPC_MAX_N>::BYTES <= 160 * 1024, "LDS budget");

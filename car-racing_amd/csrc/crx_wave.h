@@ -1,0 +1,86 @@
+// crx_wave.h -- wave-level primitives shared by the gfx950 kernels of libcrx (crx_kernels.hip,
+// crx_lmpc.hip).  64-lane wavefronts only.
+#ifndef CRX_WAVE_H
+#define CRX_WAVE_H
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define WAVE 64
+#define SYNC() __syncthreads()
+
+// ------------------------------------------------------------------------------------------------
+// (1) wave primitives: DPP butterflies inside each 16-lane row, then the four row totals are read
+// as scalars -- ~10 VALU ops instead of the 12 ds_bpermute round trips __shfl_xor lowers to.
+// Every lane returns the full-wave result (wave-uniform).
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+#define ROW_REDUCE(v, OP)                                                         \
+    v = OP(v, dpp_f64<0xB1>(v));  /* quad_perm [1,0,3,2] */                       \
+    v = OP(v, dpp_f64<0x4E>(v));  /* quad_perm [2,3,0,1] */                       \
+    v = OP(v, dpp_f64<0x141>(v)); /* row_half_mirror     */                       \
+    v = OP(v, dpp_f64<0x140>(v)); /* row_mirror          */
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double op_mul(double a, double b) { return a * b; }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double wave_sum(double v) {
+    ROW_REDUCE(v, op_add)
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_prod(double v) {
+    ROW_REDUCE(v, op_mul)
+    return (lane_f64(v, 0) * lane_f64(v, 16)) * (lane_f64(v, 32) * lane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+    ROW_REDUCE(v, op_max)
+    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave_min(double v) {
+    ROW_REDUCE(v, op_min)
+    return fmin(fmin(lane_f64(v, 0), lane_f64(v, 16)), fmin(lane_f64(v, 32), lane_f64(v, 48)));
+}
+
+// sum over the wave of log(v), v > 0: mantissas multiplied, exponents added, ONE log per wave
+// (a product of <= 6*64 mantissas in [0.5,1) cannot underflow: 2^-384)
+struct LogAcc {
+    double m;
+    int e;
+    __device__ __forceinline__ LogAcc() : m(1.0), e(0) {}
+    __device__ __forceinline__ void mul(double v) {
+        int ex;
+        m *= frexp(v, &ex);
+        e += ex;
+    }
+    __device__ __forceinline__ double wave_total() {
+        return log(wave_prod(m)) + 0.6931471805599453 * wave_sum((double)e);
+    }
+};
+
+// 1/x to ~1 ulp: hardware estimate (v_rcp_f64) + two Newton steps; ~5 dependent ops instead of the
+// ~10 of an IEEE division.  x must be finite, normal and non-zero (true for pivots and slacks).
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 + two Newton steps.  x finite, normal, > 0.
+__device__ __forceinline__ double frsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+#endif

@@ -50,6 +50,8 @@ extern "C" {
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
 #define CRX_MAX_OBS 3      /* obstacles per NLP / vehicles of interest per scenario */
 #define CRX_MAX_REGIONS (CRX_MAX_OBS + 1)
+#define CRX_LMPC_MAX_N 16 /* horizon limit of crx_lmpc_solve (its dense factors share one LDS slice) */
+#define CRX_MAX_SS 60      /* safe-set points per learning-MPC QP (reference: 44) */
 
 typedef enum crx_err {
     CRX_OK = 0,
@@ -120,6 +122,22 @@ typedef struct crx_cbf_desc {
     crx_ipm_opts opts;
 } crx_cbf_desc;
 
+/* ---- learning-MPC QP (control.py:610-730) ------------------------------------------------------ */
+typedef struct crx_lmpc_desc {
+    int32_t N;             /* lmpc_param.num_horizon (utils/base.py:359), 12 */
+    int32_t n_ss_max;      /* leading dimension of ss / qfun / lambda (num_ss_points, utils/base.py:357), <= CRX_MAX_SS */
+    double Q[6];           /* diag(matrix_Q)  (utils/base.py:353; zero by default) */
+    double R[2];           /* diag(matrix_R)  (:354)  [1, 0.25] */
+    double dR[2];          /* diag(matrix_dR) (:356)  [4, 0] */
+    double x_track[6];     /* [5,0,0,0,0,0] (control.py:649) */
+    double v_max;          /* vx_i <= v_max, i < N      (control.py:658) */
+    double ey_max;         /* |ey_i| <= lap_width, i < N (:659-660) */
+    double delta_max;      /* (:662-663) */
+    double a_max;          /* (:665-666) */
+    double w_elastic;      /* 1e5: L1 weight of the elastic terminal constraint used by the second attempt only */
+    crx_ipm_opts opts;
+} crx_lmpc_desc;
+
 /* ---- region selection (overtake_traj_planner.py:205-246) ------------------------------------- */
 typedef struct crx_select_desc {
     int32_t N;
@@ -145,6 +163,7 @@ void crx_ipm_opts_default(crx_ipm_opts* o);
 void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B);
 void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B);
 void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length);
+void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max);
 
 /*
  * Planner region QPs.  One problem per (scenario, region).
@@ -204,6 +223,29 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
                          const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status,
                          double* kkt, int32_t* iters, int32_t* flag, double* sel_cost, double* best_X,
                          void* stream);
+
+/*
+ * Learning-MPC QPs: control.lmpc (control.py:610-730) after its safe-set
+ * selection (:625-639), one problem per batch entry.  LTV affine model x_{i+1} = A_i x_i + B_i u_i + C_i
+ * as estimated by the caller (utils/base.py:585-622).
+ *   x0 [batch][6], u_old [batch][2]; A [batch][N][36], B [batch][N][12], C [batch][N][6] (row-major);
+ *   ss [batch][6][n_ss_max] (columns = safe-set points, :636-638), qfun [batch][n_ss_max], n_ss [batch] in
+ *   [1, n_ss_max].
+ *   X [batch][N+1][6], U [batch][N][2], lambda [batch][n_ss_max], cost [batch] (the reference's cost :698).
+ * status: CRX_CONVERGED = KKT point of the reference's QP (terminal state inside the safe-set hull).
+ *   The reference pins its terminal slack to zero (:694-695), so the QP is infeasible whenever the model
+ *   cannot reach the hull; the reference then applies IPOPT's restoration state (:711-722).  libcrx
+ *   instead repeats such a problem with the terminal equality made elastic (L1 weight w_elastic) and
+ *   returns that minimiser with status CRX_INFEASIBLE.
+ */
+int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
+                   const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
+                   double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
+                   int32_t* iters);
+int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
+                       const double* B, const double* C, const double* ss, const double* qfun,
+                       const int32_t* n_ss, double* X, double* U, double* lambda, double* cost,
+                       int32_t* status, double* kkt, int32_t* iters, void* stream);
 
 /*
  * MPC-CBF NLPs.

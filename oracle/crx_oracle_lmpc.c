@@ -1,0 +1,584 @@
+/*
+ * crx_oracle_lmpc.c -- CPU restatement (plain C, double) of the learning-MPC QP of car-racing
+ * (SURVEY.md section 8f row 1).  Part of liboracle.so: TEST INFRASTRUCTURE, see crx_oracle.c.
+ *
+ * Problem, as /root/reference/car_racing/control/control.py:610-730 (`lmpc`) builds it:
+ *   variables  x (6 x N+1), u (2 x N), lambd (M), slack (6)                       (:641-644)
+ *   x_0 = xcurv (:650);  x_{i+1} = A_i x_i + B_i u_i + C_i  (LTV, affine)          (:653-656)
+ *   vx_i <= v_max, |ey_i| <= lap_width, |delta_i| <= delta_max, |a_i| <= a_max, i < N  (:658-668)
+ *   cost  sum_{i<=N} (x_i-x_track)'Q(x_i-x_track) + sum_{i<N} u_i'R u_i
+ *         + sum_{i<N} (u_i-u_{i-1})'dR(u_i-u_{i-1}),  u_{-1} = u_old             (:670-688)
+ *         + slack'Qslack slack + Qfun'lambd                                        (:689,697)
+ *   lambd >= 0 (:690);  x_N = SS lambd (:691-692);  1'lambd = 1 (:693);  slack = 0 (:694-695)
+ * The slack is pinned to zero by the reference itself, so it and Qslack drop out.
+ *
+ * Solver: the same IPOPT-style interior-point method as crx_oracle.c (slack form, monotone barrier,
+ * fraction-to-the-boundary, filter line search; Waechter & Biegler 2006), extended by the equality
+ * block (multipliers y, primal step length for y, theta includes |e|).  Linear algebra: states are
+ * eliminated by the affine roll-out, the reduced KKT matrix K = H + J'Sigma J over v = [u, lambd]
+ * is factorised DENSE, the 7 equalities go through the Schur complement E K^-1 E'.
+ *
+ * Infeasible instances.  Because the slack is pinned, the reference's QP is infeasible whenever the
+ * regression model cannot reach the selected safe-set hull; the reference then applies whatever
+ * IPOPT's restoration phase left in opti.debug (:711-722), which is solver-internal state and not
+ * restatable.  Here (and in libcrx, same rule) a failed first attempt is repeated with the terminal
+ * equality made elastic,  x_N - SS lambd = p - q,  p, q >= 0,  cost += w_elastic * 1'(p+q);  the
+ * result is reported with status CRX_INFEASIBLE unless the elastic variables vanish.  No parity with
+ * the reference is claimed for those instances (parity unpinned); feasible instances have a unique
+ * (x, u) and are pinned by tests/golden/racing_game.npz.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/crx.h"
+
+#define LN CRX_MAX_N
+#define LM CRX_MAX_SS
+#define LNV (2 * LN + LM + 12)
+#define LMR (4 * LN + 3 * LN + LM + 12)
+#define LNE 7
+
+typedef struct {
+    int N, M, n, m, nu2, elastic;
+    double x0[6], uold[2];
+    const double *A, *B, *C, *ss, *qf;
+    const crx_lmpc_desc* d;
+    double S[LN + 1][6][2 * LN]; /* dx_k/du */
+    double xf[LN + 1][6];        /* free response (u = 0) */
+    double H[LNV][LNV], g0[LNV]; /* f = 1/2 v'Hv + g0'v + f0 */
+    double f0;
+    double J[LMR][LNV], jb[LMR]; /* rows c = J v + jb >= 0 */
+    double E[LNE][LNV], eb[LNE]; /* equalities E v + eb = 0 */
+    double v[LNV], t[LMR], nu[LMR], y[LNE];
+    double K[LNV][LNV];
+} lw_t;
+
+typedef struct {
+    int status, iters;
+    double kkt, cost;
+} lres_t;
+
+static int lv = 0;
+void crx_oracle_lmpc_set_verbose(int v) { lv = v; }
+
+/* condensing: sensitivities, cost, rows, equalities.  Returns 1 if a row on the fixed x0 is violated. */
+static int lmpc_setup(lw_t* w, int elastic) {
+    const crx_lmpc_desc* d = w->d;
+    const int N = w->N, M = w->M, nu2 = 2 * N;
+    w->nu2 = nu2;
+    w->elastic = elastic;
+    w->n = nu2 + M + (elastic ? 12 : 0);
+    const int n = w->n;
+    memset(w->S, 0, sizeof(w->S));
+    memcpy(w->xf[0], w->x0, sizeof(w->x0));
+    for (int k = 0; k < N; k++) {
+        const double *A = w->A + 36 * k, *B = w->B + 12 * k, *C = w->C + 6 * k;
+        for (int r = 0; r < 6; r++) {
+            double s = C[r];
+            for (int c = 0; c < 6; c++) s += A[6 * r + c] * w->xf[k][c];
+            w->xf[k + 1][r] = s;
+            for (int a = 0; a < 2 * k; a++) {
+                double q = 0.0;
+                for (int c = 0; c < 6; c++) q += A[6 * r + c] * w->S[k][c][a];
+                w->S[k + 1][r][a] = q;
+            }
+            w->S[k + 1][r][2 * k] = B[2 * r];
+            w->S[k + 1][r][2 * k + 1] = B[2 * r + 1];
+        }
+    }
+    /* cost */
+    for (int a = 0; a < n; a++) {
+        memset(w->H[a], 0, sizeof(double) * n);
+        w->g0[a] = 0.0;
+    }
+    w->f0 = 0.0;
+    for (int k = 0; k <= N; k++)
+        for (int c = 0; c < 6; c++) {
+            double q = d->Q[c];
+            if (q == 0.0) continue;
+            double r0 = w->xf[k][c] - d->x_track[c];
+            w->f0 += q * r0 * r0;
+            for (int a = 0; a < 2 * k; a++) {
+                w->g0[a] += 2.0 * q * r0 * w->S[k][c][a];
+                for (int b = 0; b < 2 * k; b++) w->H[a][b] += 2.0 * q * w->S[k][c][a] * w->S[k][c][b];
+            }
+        }
+    for (int i = 0; i < N; i++)
+        for (int c = 0; c < 2; c++) {
+            int a = 2 * i + c;
+            w->H[a][a] += 2.0 * d->R[c];
+            /* (u_i - u_{i-1})' dR (u_i - u_{i-1}) */
+            w->H[a][a] += 2.0 * d->dR[c];
+            if (i == 0) {
+                w->g0[a] += -2.0 * d->dR[c] * w->uold[c];
+                w->f0 += d->dR[c] * w->uold[c] * w->uold[c];
+            } else {
+                int p = a - 2;
+                w->H[p][p] += 2.0 * d->dR[c];
+                w->H[a][p] -= 2.0 * d->dR[c];
+                w->H[p][a] -= 2.0 * d->dR[c];
+            }
+        }
+    for (int j = 0; j < M; j++) w->g0[nu2 + j] = w->qf[j];
+    if (elastic)
+        for (int c = 0; c < 12; c++) w->g0[nu2 + M + c] = d->w_elastic;
+    /* rows */
+    int m = 0, bad0 = 0;
+#define NEWROW() do { memset(w->J[m], 0, sizeof(double) * n); w->jb[m] = 0.0; } while (0)
+    for (int i = 0; i < N; i++) {
+        const double ub[2] = {d->delta_max, d->a_max};
+        for (int c = 0; c < 2; c++) {
+            NEWROW(); w->J[m][2 * i + c] = 1.0; w->jb[m] = ub[c]; m++;   /* -ub <= u (:664,667) */
+            NEWROW(); w->J[m][2 * i + c] = -1.0; w->jb[m] = ub[c]; m++;  /* u <= ub  (:665,668) */
+        }
+    }
+    for (int i = 0; i < N; i++) {
+        /* vx_i <= v_max (:660); ey_i <= w (:661); -w <= ey_i (:662) */
+        const int comp[3] = {0, 5, 5};
+        const double sgn[3] = {-1.0, -1.0, 1.0};
+        const double bnd[3] = {d->v_max, d->ey_max, d->ey_max};
+        for (int q = 0; q < 3; q++) {
+            if (i == 0) {
+                if (sgn[q] * w->x0[comp[q]] + bnd[q] < -w->d->opts.tol) bad0 = 1;
+                continue;
+            }
+            NEWROW();
+            for (int a = 0; a < 2 * i; a++) w->J[m][a] = sgn[q] * w->S[i][comp[q]][a];
+            w->jb[m] = sgn[q] * w->xf[i][comp[q]] + bnd[q];
+            m++;
+        }
+    }
+    for (int j = 0; j < M; j++) { NEWROW(); w->J[m][nu2 + j] = 1.0; m++; }   /* lambd >= 0 (:690) */
+    if (elastic)
+        for (int c = 0; c < 12; c++) { NEWROW(); w->J[m][nu2 + M + c] = 1.0; m++; }
+#undef NEWROW
+    w->m = m;
+    /* equalities: x_N - SS lambd (- p + q) = 0 (:691-692), 1'lambd - 1 = 0 (:693) */
+    for (int r = 0; r < LNE; r++) memset(w->E[r], 0, sizeof(double) * n);
+    for (int r = 0; r < 6; r++) {
+        for (int a = 0; a < nu2; a++) w->E[r][a] = w->S[N][r][a];
+        for (int j = 0; j < M; j++) w->E[r][nu2 + j] = -w->ss[(size_t)r * w->d->n_ss_max + j];
+        if (elastic) { w->E[r][nu2 + M + r] = -1.0; w->E[r][nu2 + M + 6 + r] = 1.0; }
+        w->eb[r] = w->xf[N][r];
+    }
+    for (int j = 0; j < M; j++) w->E[6][nu2 + j] = 1.0;
+    w->eb[6] = -1.0;
+    return bad0;
+}
+
+static double lmpc_f(const lw_t* w, const double* v) {
+    double f = w->f0;
+    for (int a = 0; a < w->n; a++) {
+        double s = 0.0;
+        for (int b = 0; b < w->nu2; b++) s += w->H[a][b] * v[b];   /* H is zero outside the u block */
+        f += v[a] * (0.5 * s + w->g0[a]);
+    }
+    return f;
+}
+
+/* Second linear-algebra route (selected by crx_oracle_lmpc_set_linalg(1)): the block elimination the
+ * HIP kernel uses, K_u -> W~ = Phi K_u^-1 Phi' (+ elastic) -> G = D_lambda + SS' W~^-1 SS -> dy_1,
+ * all by Cholesky.  Kept here to bisect kernel/oracle disagreements on the CPU.  w->K holds the
+ * lower triangle of K = H + J'Sigma J on entry. */
+static int g_block = 0;
+void crx_oracle_lmpc_set_linalg(int block) { g_block = block; }
+
+static int chol_in(int n, int ld, double* Mt) {
+    for (int j = 0; j < n; j++) {
+        double dd = Mt[j * ld + j];
+        for (int k = 0; k < j; k++) dd -= Mt[j * ld + k] * Mt[j * ld + k];
+        if (!(dd > 0.0)) return 0;
+        dd = sqrt(dd);
+        Mt[j * ld + j] = dd;
+        for (int i = j + 1; i < n; i++) {
+            double s = Mt[i * ld + j];
+            for (int k = 0; k < j; k++) s -= Mt[i * ld + k] * Mt[j * ld + k];
+            Mt[i * ld + j] = s / dd;
+        }
+    }
+    return 1;
+}
+static void fsub(int n, int ld, const double* L, double* b) {
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i * ld + k] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+}
+static void bsub(int n, int ld, const double* L, double* b) {
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * ld + i] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+}
+
+static int block_solve(lw_t* w, const double* rhs, const double* e, double* dv, double* dy) {
+    const int nu2 = w->nu2, M = w->M, el = w->elastic;
+    static _Thread_local double Ku[2 * LN][2 * LN], Y[6][2 * LN], z[2 * LN], Wt[6][6], T[LM][6], G[LM][LM], bx[6],
+        cl[LM], one[LM], tb[6];
+    for (int a = 0; a < nu2; a++)
+        for (int b = 0; b <= a; b++) Ku[a][b] = w->K[a][b];
+    if (!chol_in(nu2, 2 * LN, &Ku[0][0])) return 0;
+    for (int r = 0; r < 6; r++) {                      /* Y_r = L^-1 Phi_r' */
+        for (int a = 0; a < nu2; a++) Y[r][a] = w->E[r][a];
+        fsub(nu2, 2 * LN, &Ku[0][0], Y[r]);
+    }
+    for (int a = 0; a < nu2; a++) z[a] = rhs[a];
+    fsub(nu2, 2 * LN, &Ku[0][0], z);
+    const double* Dl = NULL; (void)Dl;
+    double Dp[6], Dq[6];
+    for (int c = 0; c < 6; c++) { Dp[c] = Dq[c] = 0.0; }
+    for (int r = 0; r < 6; r++) {
+        for (int q = 0; q <= r; q++) {
+            double s = 0.0;
+            for (int a = 0; a < nu2; a++) s += Y[r][a] * Y[q][a];
+            Wt[r][q] = s;
+        }
+        double s = e[r];
+        for (int a = 0; a < nu2; a++) s += Y[r][a] * z[a];
+        bx[r] = s;
+    }
+    if (el)
+        for (int c = 0; c < 6; c++) {
+            Dp[c] = w->K[nu2 + M + c][nu2 + M + c];
+            Dq[c] = w->K[nu2 + M + 6 + c][nu2 + M + 6 + c];
+            Wt[c][c] += 1.0 / Dp[c] + 1.0 / Dq[c];
+            bx[c] += -rhs[nu2 + M + c] / Dp[c] + rhs[nu2 + M + 6 + c] / Dq[c];
+        }
+    if (!chol_in(6, 6, &Wt[0][0])) return 0;
+    fsub(6, 6, &Wt[0][0], bx);                         /* L_w^-1 b_x */
+    for (int j = 0; j < M; j++) {
+        for (int c = 0; c < 6; c++) T[j][c] = -w->E[c][nu2 + j];   /* ss_j */
+        fsub(6, 6, &Wt[0][0], T[j]);
+    }
+    for (int i = 0; i < M; i++) {
+        for (int j = 0; j <= i; j++) {
+            double s = 0.0;
+            for (int c = 0; c < 6; c++) s += T[i][c] * T[j][c];
+            G[i][j] = s;
+        }
+        G[i][i] += w->K[nu2 + i][nu2 + i];
+        double s = rhs[nu2 + i];
+        for (int c = 0; c < 6; c++) s += T[i][c] * bx[c];
+        cl[i] = s;
+        one[i] = 1.0;
+    }
+    if (!chol_in(M, LM, &G[0][0])) return 0;
+    fsub(M, LM, &G[0][0], cl); bsub(M, LM, &G[0][0], cl);
+    fsub(M, LM, &G[0][0], one); bsub(M, LM, &G[0][0], one);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < M; i++) { s1 += cl[i]; s2 += one[i]; }
+    double dy1 = (s1 + e[6]) / s2;
+    for (int i = 0; i < M; i++) dv[nu2 + i] = cl[i] - one[i] * dy1;
+    dy[6] = dy1;
+    /* dy_x = W~^-1 (b_x - SS dlam) */
+    for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+        for (int i = 0; i < M; i++) s += T[i][c] * dv[nu2 + i];
+        tb[c] = bx[c] - s;
+    }
+    bsub(6, 6, &Wt[0][0], tb);
+    for (int c = 0; c < 6; c++) dy[c] = tb[c];
+    for (int a = 0; a < nu2; a++) {
+        double s = z[a];
+        for (int r = 0; r < 6; r++) s -= Y[r][a] * dy[r];
+        dv[a] = s;
+    }
+    bsub(nu2, 2 * LN, &Ku[0][0], dv);
+    if (el)
+        for (int c = 0; c < 6; c++) {
+            dv[nu2 + M + c] = (rhs[nu2 + M + c] + dy[c]) / Dp[c];
+            dv[nu2 + M + 6 + c] = (rhs[nu2 + M + 6 + c] - dy[c]) / Dq[c];
+        }
+    return 1;
+}
+
+static void lmpc_ipm(lw_t* w, lres_t* res) {
+    const crx_ipm_opts* o = &w->d->opts;
+    const int n = w->n, m = w->m;
+    const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
+    static _Thread_local double c[LMR], g[LNV], rp[LMR], dt[LMR], dnu[LMR], rhs[LNV], dv[LNV], e[LNE], dy[LNE],
+        vtr[LNV], ttr[LMR];
+    memset(w->v, 0, sizeof(double) * n);
+    memset(w->y, 0, sizeof(w->y));
+    for (int j = 0; j < m; j++) {
+        double cj = w->jb[j];
+        w->t[j] = fmax(fabs(cj), o->slack_push);
+        w->nu[j] = 1.0;
+    }
+    /* simple-bound rows whose cost gradient pushes against the bound start dual-feasible (as crx_oracle.c) */
+    {
+        int j0 = 4 * w->N + 3 * (w->N - 1);
+        for (int j = j0; j < m; j++) {
+            double gg = w->g0[w->nu2 + (j - j0)];
+            if (gg > 1.0) w->nu[j] = gg;
+        }
+    }
+    double mu = o->mu_init, E0 = HUGE_VAL, theta_min = 0.0, theta_max = HUGE_VAL;
+    enum { MAXF = 16 };
+    double Fth[MAXF], Fph[MAXF];
+    int nf = 0, status = CRX_MAX_ITER, it = 0;
+    double f = lmpc_f(w, w->v);
+    for (it = 0;; it++) {
+        for (int j = 0; j < m; j++) {
+            double s = w->jb[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * w->v[a];
+            c[j] = s;
+        }
+        for (int r = 0; r < LNE; r++) {
+            double s = w->eb[r];
+            for (int a = 0; a < n; a++) s += w->E[r][a] * w->v[a];
+            e[r] = s;
+        }
+        for (int a = 0; a < n; a++) {
+            double s = w->g0[a];
+            for (int b = 0; b < w->nu2; b++) s += w->H[a][b] * w->v[b];
+            g[a] = s;
+        }
+        double nus = 0.0, ys = 0.0;
+        for (int j = 0; j < m; j++) nus += fabs(w->nu[j]);
+        for (int r = 0; r < LNE; r++) ys += fabs(w->y[r]);
+        double sd = fmax(smax, (nus + ys) / (m + LNE)) / smax, sc = fmax(smax, nus / m) / smax;
+        double e_d = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
+        for (int a = 0; a < n; a++) {
+            double s = g[a];
+            for (int j = 0; j < m; j++) s -= w->J[j][a] * w->nu[j];
+            for (int r = 0; r < LNE; r++) s += w->E[r][a] * w->y[r];
+            e_d = fmax(e_d, fabs(s));
+        }
+        e_d /= sd;
+        for (int j = 0; j < m; j++) {
+            rp[j] = c[j] - w->t[j];
+            e_p = fmax(e_p, fabs(rp[j]));
+            theta += fabs(rp[j]);
+            e_c = fmax(e_c, fabs(w->t[j] * w->nu[j]));
+        }
+        for (int r = 0; r < LNE; r++) { e_p = fmax(e_p, fabs(e[r])); theta += fabs(e[r]); }
+        e_c /= sc;
+        E0 = fmax(e_d, fmax(e_p, e_c));
+        if (lv) fprintf(stderr, "it %3d f %.10e ed %.2e ep %.2e ec %.2e mu %.1e theta %.2e nf %d sd %.1f\n", it, f, e_d, e_p, e_c, mu, theta, nf, sd);
+        if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
+        if (it >= o->max_iter) break;
+        for (;;) {
+            double e_cm = 0.0;
+            for (int j = 0; j < m; j++) e_cm = fmax(e_cm, fabs(w->t[j] * w->nu[j] - mu));
+            e_cm /= sc;
+            if (fmax(e_d, fmax(e_p, e_cm)) <= o->kappa_eps * mu && mu > o->tol / 10.0) {
+                mu = fmax(o->tol / 10.0, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
+                nf = 0;
+            } else
+                break;
+        }
+        double tau = fmax(o->tau_min, 1.0 - mu);
+        /* K = H + J' Sigma J ; rhs = -g - E'y + J'(mu/t - Sigma rp) */
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b <= a; b++) w->K[a][b] = w->H[a][b];
+        for (int j = 0; j < m; j++) {
+            double sg = w->nu[j] / w->t[j];
+            const double* Jr = w->J[j];
+            for (int a = 0; a < n; a++) {
+                if (Jr[a] == 0.0) continue;
+                double sa = sg * Jr[a];
+                for (int b = 0; b <= a; b++) w->K[a][b] += sa * Jr[b];
+            }
+        }
+        for (int a = 0; a < n; a++) {
+            double s = -g[a];
+            for (int r = 0; r < LNE; r++) s -= w->E[r][a] * w->y[r];
+            for (int j = 0; j < m; j++) s += w->J[j][a] * (mu / w->t[j] - w->nu[j] / w->t[j] * rp[j]);
+            rhs[a] = s;
+        }
+        if (g_block) {
+            if (!block_solve(w, rhs, e, dv, dy)) { if (lv) fprintf(stderr, "block elimination failed\n"); break; }
+        } else
+        /* full reduced KKT system  [K E'; E 0] [dv; dy] = [rhs; -e]  by LU with partial pivoting on the
+         * symmetrically equilibrated matrix + one step of iterative refinement.  (A Schur complement
+         * E K^-1 E' is useless here: the active lambd's have no curvature but the barrier's, so K^-1
+         * spans 1e-16..1e16 near the solution.) */
+        {
+            enum { NK = LNV + LNE };
+            static _Thread_local double Mx[NK][NK], Mo[NK][NK], sc[NK], bb[NK], xx[NK], rr[NK];
+            static _Thread_local int piv[NK];
+            const int nk = n + LNE;
+            for (int a = 0; a < n; a++) {
+                for (int b = 0; b <= a; b++) { Mo[a][b] = w->K[a][b]; Mo[b][a] = w->K[a][b]; }
+                for (int r = 0; r < LNE; r++) { Mo[a][n + r] = w->E[r][a]; Mo[n + r][a] = w->E[r][a]; }
+            }
+            for (int r = 0; r < LNE; r++)
+                for (int q = 0; q < LNE; q++) Mo[n + r][n + q] = 0.0;
+            for (int a = 0; a < nk; a++) {
+                double mx = 0.0;
+                for (int b = 0; b < nk; b++) mx = fmax(mx, fabs(Mo[a][b]));
+                sc[a] = mx > 0.0 ? 1.0 / sqrt(mx) : 1.0;
+            }
+            for (int a = 0; a < nk; a++)
+                for (int b = 0; b < nk; b++) Mx[a][b] = Mo[a][b] * sc[a] * sc[b];
+            int sing = 0;
+            for (int k = 0; k < nk; k++) {
+                int pk = k;
+                double mx = fabs(Mx[k][k]);
+                for (int i = k + 1; i < nk; i++)
+                    if (fabs(Mx[i][k]) > mx) { mx = fabs(Mx[i][k]); pk = i; }
+                piv[k] = pk;
+                if (mx == 0.0) { sing = 1; break; }
+                if (pk != k)
+                    for (int b = 0; b < nk; b++) { double tsw = Mx[k][b]; Mx[k][b] = Mx[pk][b]; Mx[pk][b] = tsw; }
+                for (int i = k + 1; i < nk; i++) {
+                    double l = Mx[i][k] / Mx[k][k];
+                    Mx[i][k] = l;
+                    if (l != 0.0)
+                        for (int b = k + 1; b < nk; b++) Mx[i][b] -= l * Mx[k][b];
+                }
+            }
+            if (sing) { if (lv) fprintf(stderr, "KKT matrix singular\n"); break; }
+            for (int a = 0; a < n; a++) bb[a] = rhs[a];
+            for (int r = 0; r < LNE; r++) bb[n + r] = -e[r];
+            memset(xx, 0, sizeof(double) * nk);
+            for (int pass = 0; pass < 2; pass++) {
+                for (int a = 0; a < nk; a++) {
+                    double s = bb[a];
+                    if (pass)
+                        for (int b = 0; b < nk; b++) s -= Mo[a][b] * xx[b];
+                    rr[a] = s * sc[a];
+                }
+                for (int k = 0; k < nk; k++)
+                    if (piv[k] != k) { double tsw = rr[k]; rr[k] = rr[piv[k]]; rr[piv[k]] = tsw; }
+                for (int k = 0; k < nk; k++)
+                    for (int i = k + 1; i < nk; i++) rr[i] -= Mx[i][k] * rr[k];
+                for (int i = nk - 1; i >= 0; i--) {
+                    double s = rr[i];
+                    for (int b = i + 1; b < nk; b++) s -= Mx[i][b] * rr[b];
+                    rr[i] = s / Mx[i][i];
+                }
+                for (int a = 0; a < nk; a++) xx[a] += rr[a] * sc[a];
+            }
+            for (int a = 0; a < n; a++) dv[a] = xx[a];
+            for (int r = 0; r < LNE; r++) dy[r] = xx[n + r];
+        }
+        double a_p = 1.0, a_d = 1.0, Dphi = 0.0;
+        for (int j = 0; j < m; j++) {
+            double s = rp[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * dv[a];
+            dt[j] = s;
+            dnu[j] = (mu - w->t[j] * w->nu[j] - w->nu[j] * s) / w->t[j];
+            if (s < 0.0) a_p = fmin(a_p, -tau * w->t[j] / s);
+            if (dnu[j] < 0.0) a_d = fmin(a_d, -tau * w->nu[j] / dnu[j]);
+            Dphi -= mu * s / w->t[j];
+        }
+        for (int a = 0; a < n; a++) Dphi += g[a] * dv[a];
+        double phi0 = f;
+        for (int j = 0; j < m; j++) phi0 -= mu * log(w->t[j]);
+        if (it == 0) {
+            theta_min = 1e-4 * fmax(1.0, theta);
+            theta_max = 1e4 * fmax(1.0, theta);
+        }
+        double al = a_p, fn = f;
+        int acc = 0, ftype = 0;
+        for (int ls = 0; ls < 40; ls++) {
+            for (int a = 0; a < n; a++) vtr[a] = w->v[a] + al * dv[a];
+            fn = lmpc_f(w, vtr);
+            double phin = fn, thn = 0.0;
+            for (int j = 0; j < m; j++) {
+                double cj = w->jb[j];
+                for (int a = 0; a < n; a++) cj += w->J[j][a] * vtr[a];
+                double tn = w->t[j] + al * dt[j];
+                if (cj > tn) tn = cj;
+                ttr[j] = tn;
+                phin -= mu * log(tn);
+                thn += fabs(cj - tn);
+            }
+            for (int r = 0; r < LNE; r++) thn += fabs((1.0 - al) * e[r]);
+            int okf = (thn <= theta_max) && (phin == phin);
+            for (int i = 0; i < nf && okf; i++)
+                if (!(thn < Fth[i] || phin < Fph[i])) okf = 0;
+            if (okf) {
+                int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                if (theta <= theta_min && sw) {
+                    if (phin <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
+                    acc = 1;
+                }
+            }
+            if (acc) break;
+            al *= 0.5;
+        }
+        if (lv) fprintf(stderr, "      a_p %.3e a_d %.3e alpha %.3e acc %d ftype %d Dphi %.3e\n", a_p, a_d, al, acc, ftype, Dphi);
+        if (acc && !ftype && nf < MAXF) {
+            Fth[nf] = (1.0 - 1e-5) * theta;
+            Fph[nf] = phi0 - 1e-8 * theta;
+            nf++;
+        }
+        if (!acc) break;
+        memcpy(w->v, vtr, sizeof(double) * n);
+        memcpy(w->t, ttr, sizeof(double) * m);
+        f = fn;
+        for (int r = 0; r < LNE; r++) w->y[r] += al * dy[r];
+        double numax = 0.0;
+        for (int j = 0; j < m; j++) {
+            double nn = w->nu[j] + a_d * dnu[j];
+            nn = fmin(fmax(nn, mu / (kappa_sigma * w->t[j])), kappa_sigma * mu / w->t[j]);
+            w->nu[j] = nn;
+            numax = fmax(numax, nn);
+        }
+        if (numax > 1e12 && theta > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+    }
+    res->status = status;
+    res->iters = it;
+    res->kkt = E0;
+    res->cost = f;
+}
+
+int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
+                          const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
+                          double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
+                          int32_t* iters) {
+    if (!d || d->N < 2 || d->N > LN || d->n_ss_max < 1 || d->n_ss_max > LM || batch < 0) return CRX_ERR_ARG;
+    const int N = d->N, Mx = d->n_ss_max;
+    for (int b = 0; b < batch; b++)
+        if (n_ss[b] < 1 || n_ss[b] > Mx) return CRX_ERR_ARG;
+#pragma omp parallel
+    {
+        lw_t* w = (lw_t*)malloc(sizeof(lw_t));
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < batch; b++) {
+            w->d = d; w->N = N; w->M = n_ss[b];
+            memcpy(w->x0, x0 + 6 * b, sizeof(w->x0));
+            memcpy(w->uold, u_old + 2 * b, sizeof(w->uold));
+            w->A = A + (size_t)36 * N * b; w->B = B + (size_t)12 * N * b; w->C = C + (size_t)6 * N * b;
+            w->ss = ss + (size_t)6 * Mx * b; w->qf = qfun + (size_t)Mx * b;
+            lres_t r;
+            int bad0 = lmpc_setup(w, 0), total = 0;
+            lmpc_ipm(w, &r);
+            total = r.iters;
+            if (r.status != CRX_CONVERGED || bad0) {
+                lmpc_setup(w, 1);
+                lmpc_ipm(w, &r);
+                total += r.iters;
+                double el = 0.0;
+                for (int c = 0; c < 12; c++) el += fabs(w->v[w->nu2 + w->M + c]);
+                if (r.status == CRX_CONVERGED && (el > 1e-7 || bad0)) r.status = CRX_INFEASIBLE;
+            }
+            double* Xb = X + (size_t)(N + 1) * 6 * b;
+            double* Ub = U + (size_t)N * 2 * b;
+            memcpy(Ub, w->v, sizeof(double) * 2 * N);
+            for (int k = 0; k <= N; k++)
+                for (int c = 0; c < 6; c++) {
+                    double s = w->xf[k][c];
+                    for (int a = 0; a < 2 * k; a++) s += w->S[k][c][a] * w->v[a];
+                    Xb[6 * k + c] = s;
+                }
+            for (int j = 0; j < Mx; j++) lambda[(size_t)Mx * b + j] = j < w->M ? w->v[w->nu2 + j] : 0.0;
+            double el = 0.0;
+            if (w->elastic)
+                for (int c = 0; c < 12; c++) el += w->v[w->nu2 + w->M + c];
+            cost[b] = r.cost - (w->elastic ? d->w_elastic * el : 0.0);   /* the reference's cost, without the elastic term */
+            status[b] = r.status; kkt[b] = r.kkt; iters[b] = total;
+        }
+        free(w);
+    }
+    return CRX_OK;
+}

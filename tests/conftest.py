@@ -48,3 +48,8 @@ def golden_mpccbf():
 @pytest.fixture(scope="session")
 def golden_planner():
     return Golden(os.path.join(GOLDEN, "planner.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_racing_game():
+    return np.load(os.path.join(GOLDEN, "racing_game.npz"), allow_pickle=False)

@@ -52,8 +52,12 @@ def golden_solver(opti):
         info["lp_status"] = int(res.status)
         if res.status == 2:
             info["reason"] = "infeasible (HiGHS)"
-            RECORDS.append((opti, np.zeros(n), info))
-            return np.zeros(n), info
+            z = np.zeros(n)
+            if ELASTIC_ON_INFEASIBLE[0]:
+                z = elastic_qp(opti, ELASTIC_ON_INFEASIBLE[0])
+                info["reason"] += "; returned the exact-L1-penalty minimiser as the 'non-converged iterate'"
+            RECORDS.append((opti, z, info))
+            return z, info
     gopts = ipm_dense.Opts()
     gopts.tol = 1e-11  # goldens are solved two orders tighter than the product default (1e-8)
     r = ipm_dense.solve_recorded(opti, gopts)
@@ -88,6 +92,50 @@ def golden_solver(opti):
             r["status"], r["const_violation"], cert["stationarity"])
     RECORDS.append((opti, z, info))
     return z, info
+
+
+# What IPOPT leaves in opti.debug after "Converged to a point of local infeasibility" is the state
+# of its restoration phase and cannot be restated.  Where a closed-loop generator has to continue
+# past an infeasible QP (the LMPC laps: the reference pins its terminal slack to zero,
+# control.py:689-690, so its own QP is infeasible whenever the learned model cannot reach the safe
+# set), the stand-in below returns the minimiser of  cost + rho * ||equality violation||_1  subject to
+# the inequalities.  Such steps are flagged (success = False) and no parity claim is made on them.
+ELASTIC_ON_INFEASIBLE = [0.0]
+
+
+def elastic_qp(opti, rho):
+    n = opti.nvar
+    f0, g0, ce0, Je, ci0, Ji = opti.eval_all(np.zeros(n))
+    H = np.zeros((n, n))
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = 1.0
+        H[:, i] = opti.eval_all(e)[1] - g0
+    H = 0.5 * (H + H.T)
+    me = Je.shape[0]
+    # variables w = (z, p, q):  Je z + ce0 + p - q = 0,  p, q >= 0
+    Ae = np.hstack([Je, np.eye(me), -np.eye(me)])
+    nw = n + 2 * me
+    _, S, Vt = np.linalg.svd(Ae)
+    Z = Vt[me:].T
+    wp = np.linalg.lstsq(Ae, -ce0, rcond=None)[0]
+    Jw = np.zeros((len(ci0) + 2 * me, nw))
+    Jw[: len(ci0), :n] = Ji
+    Jw[len(ci0):, n:] = np.eye(2 * me)
+    c0 = np.concatenate([ci0, np.zeros(2 * me)])
+    Hw = np.zeros((nw, nw))
+    Hw[:n, :n] = H
+    gw = np.concatenate([g0, rho * np.ones(2 * me)])
+    Hr, JZ = Z.T @ Hw @ Z, Jw @ Z
+
+    def fun(v):
+        w = wp + Z @ v
+        return 0.5 * w @ Hw @ w + gw @ w, Z.T @ (Hw @ w + gw), c0 + Jw @ w, JZ
+
+    o = ipm_dense.Opts()
+    o.tol = 1e-9
+    r = ipm_dense.solve(fun, lambda v, nu: Hr, np.zeros(Z.shape[1]), opts=o)
+    return (wp + Z @ r["v"])[:n]
 
 
 casadi.Opti.solver_fn = staticmethod(golden_solver)
@@ -428,8 +476,117 @@ def gen_closed_loop(steps=int(os.environ.get("CRX_GOLDEN_STEPS", "150"))):
         steps, ok.sum(), nobs.max(), ego.xcurv[4]))
 
 
+def gen_racing_game(laps=int(os.environ.get("CRX_GOLDEN_LAPS", "4")),
+                    keep_every=int(os.environ.get("CRX_GOLDEN_LMPC_EVERY", "8"))):
+    """The scenario of the reference's tests/auto_racing_game_test.py:11-113 (zero noise) without its
+    plotting tail: lap 0 PID, lap 1 mpc-lti, lap 2 LMPC, lap 3 LMPC + overtaking of two cars.
+    Stores the closed-loop logs, and for every `keep_every`-th control.lmpc call the complete
+    problem data (LTV model from the reference's regression, safe-set points, Q-function, u_old) and
+    the certified solution."""
+    from control import lmpc_helper
+
+    track = make_track(1.0)
+    opti_xglob = np.genfromtxt("data/optimal_traj/xglob_l_shape.csv", delimiter=",")
+    timestep = 0.1
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
+    ego.set_timestep(timestep)
+    pid = offboard.PIDTracking(vt=0.7, eyt=0.0); pid.set_timestep(timestep)
+    ego.set_ctrl_policy(pid); pid.set_track(track)
+    ego.set_state_curvilinear(np.zeros((6,))); ego.set_state_global(np.zeros((6,))); ego.start_logging(); ego.set_track(track)
+    mpc_lti = offboard.MPCTracking(base.MPCTrackingParam(vt=0.7, eyt=0.0), ego.system_param)
+    mpc_lti.set_timestep(timestep); mpc_lti.set_track(track)
+    ego.set_zero_noise()
+    time_lmpc = 10000 * timestep
+    lmpc_param = base.LMPCRacingParam(timestep=timestep, lap_number=laps, time_lmpc=time_lmpc)
+    game_param = base.RacingGameParam(timestep=timestep, alpha=0.8, num_horizon_planner=10)
+    lmpc_ctrl = offboard.LMPCRacingGame(lmpc_param, racing_game_param=game_param, system_param=ego.system_param)
+    lmpc_ctrl.set_track(track); lmpc_ctrl.set_timestep(timestep); lmpc_ctrl.set_opti_traj(OPTI_XCURV, opti_xglob)
+    lmpc_ctrl.openloop_prediction = lmpc_helper.LMPCPrediction(lap_number=laps)
+    sim = offboard.CarRacingSim(); sim.set_timestep(timestep); sim.set_track(track); sim.add_vehicle(ego)
+    sim.set_opti_traj(opti_xglob)
+    cars = []
+    for index in range(2):
+        c = offboard.NoDynamicsModel(name="car%d" % (index + 1), param=base.CarParam(edgecolor="orange"))
+        c.set_track(track)
+        cars.append(c)
+    for c in (pid, mpc_lti, lmpc_ctrl):
+        c.set_racing_sim(sim)
+    lmpc_ctrl.set_vehicles_track()
+
+    # record every control.lmpc call: inputs, outputs, certificate of the recorded QP
+    calls = []
+    ref_lmpc = control.lmpc
+
+    def lmpc_rec(xcurv, par, Atv, Btv, Ctv, ss_curv, Qfun, it, lap_length, lap_width, u_old, system_param):
+        n0 = len(RECORDS)
+        out = ref_lmpc(xcurv, par, Atv, Btv, Ctv, ss_curv, Qfun, it, lap_length, lap_width, u_old, system_param)
+        opti, z, info = RECORDS[-1]
+        assert len(RECORDS) == n0 + 1
+        if not info["success"] and os.environ.get("CRX_GOLDEN_DEBUG") == "stop":
+            print("LMPC solve not certified:", {k: v for k, v in info.items()}, flush=True)
+            import pickle
+            pickle.dump(dict(x=xcurv, A=Atv, B=Btv, C=Ctv, ss=out[2], qfun=out[3], u_old=u_old, z=z), open("/tmp/lmpc_fail.pkl", "wb"))
+            raise SystemExit(1)
+        calls.append(dict(
+            x=np.array(xcurv, float), A=np.array(Atv, float), B=np.array(Btv, float),
+            C=np.array(Ctv, float).reshape(len(Ctv), 6), ss=np.array(out[2], float), qfun=np.array(out[3], float),
+            u_old=np.array(u_old, float).reshape(2), U=np.array(out[0], float), X=np.array(out[1], float),
+            success=info["success"], cert=cert_fields(info), lap=int(it), lap_width=float(lap_width),
+            z_tail=np.array(z[6 * 13 + 2 * 12:], float)))
+        return out
+
+    control.lmpc = lmpc_rec
+    ELASTIC_ON_INFEASIBLE[0] = 1e5
+    del RECORDS[:]
+    # laps 0 (PID) and 1 (mpc-lti): every solve certified -> full closed-loop fixture
+    sim.sim(sim_time=90, one_lap=True, one_lap_name="ego")
+    ego.set_ctrl_policy(mpc_lti)
+    sim.sim(sim_time=90, one_lap=True, one_lap_name="ego")
+    n_lti = len(RECORDS)
+    lti_ok = np.array([r[2]["success"] for r in RECORDS])
+    lti_u = np.array([r[1][78:80] for r in RECORDS])
+    print("laps 0/1: %d + %d steps, mpc-lti solves %d (certified %d)" % (
+        len(ego.xcurvs[0]) - 1, len(ego.xcurvs[1]) - 1, n_lti, lti_ok.sum()), flush=True)
+    # lap 2 (LMPC).  The reference pins its terminal slack to zero (control.py:689-690), so its QP is
+    # infeasible whenever the regression model cannot reach the safe set; what the reference applies
+    # then is IPOPT's restoration-phase state, which cannot be restated.  The loop is continued with
+    # the elastic stand-in only to harvest further reference-built problem instances; nothing after
+    # the first uncertified step is a closed-loop parity target.
+    lmpc_ctrl.add_trajectory(ego, 0)
+    lmpc_ctrl.add_trajectory(ego, 1)
+    ss_after_two = dict(time_ss=np.array(lmpc_ctrl.time_ss), Qfun0=lmpc_ctrl.Qfun[:600].copy(),
+                        ss0=lmpc_ctrl.ss_xcurv[:600].copy(), u0=lmpc_ctrl.u_ss[:600].copy())
+    ego.set_ctrl_policy(lmpc_ctrl)
+    crashed = ""
+    try:
+        sim.sim(sim_time=float(os.environ.get("CRX_GOLDEN_LMPC_TIME", "12.0")), one_lap=True, one_lap_name="ego")
+    except Exception as e:  # the reference's own regression raises once the state leaves its data
+        crashed = repr(e)
+    control.lmpc = ref_lmpc
+    ok = np.array([c["success"] for c in calls])
+    first_bad = int(np.argmin(ok)) if not ok.all() else len(ok)
+    out = dict(lap_length=track.lap_length, timestep=timestep, crashed=crashed)
+    for it in range(2):
+        out["lap%d/xcurv" % it] = np.array(ego.xcurvs[it], float)
+        out["lap%d/xglob" % it] = np.array(ego.xglobs[it], float)
+        out["lap%d/u" % it] = np.array(ego.inputs[it], float)
+        out["lap%d/times" % it] = np.array(ego.times[it], float)
+    out["lti_success"], out["lti_u"] = lti_ok, lti_u
+    for k, v in ss_after_two.items():
+        out["ss/" + k] = v
+    out["lmpc_success"] = ok
+    out["lmpc_first_uncertified"] = first_bad
+    for k in ("x", "A", "B", "C", "ss", "qfun", "u_old", "U", "X", "cert", "lap_width", "lap"):
+        out["lmpc/" + k] = np.array([c[k] for c in calls])
+    np.savez_compressed(os.path.join(OUT, "racing_game.npz"), **out)
+    print("racing game: lmpc calls %d, certified %d, first uncertified step %d, stopped by: %s" % (
+        len(calls), int(ok.sum()), first_bad, crashed or "time limit"))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mpccbf", "planner", "harness"]
+    if "racing_game" in which:
+        gen_racing_game()
     if "closed_loop" in which:
         gen_closed_loop()
     if "harness" in which:

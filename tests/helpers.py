@@ -43,3 +43,11 @@ def mma_inputs(g, A, B):
                      ey_max=float(g["width"]), per_stage_target=True)
     xt = hostprep.tracking_targets(g["x_wrapped"], g["traj_xcurv"], N)[None]
     return d, (x, xt, ps, pe, po, n)
+
+
+def lmpc_inputs(g, idx=None):
+    """Learning-MPC QPs recorded from the reference's control.lmpc (tests/golden/racing_game.npz)."""
+    sl = slice(None) if idx is None else idx
+    d = abi.lmpc_desc(N=g["lmpc/A"].shape[1], n_ss_max=g["lmpc/ss"].shape[2], ey_max=float(g["lmpc/lap_width"][0]))
+    return d, (g["lmpc/x"][sl], g["lmpc/u_old"][sl], g["lmpc/A"][sl], g["lmpc/B"][sl], g["lmpc/C"][sl],
+               g["lmpc/ss"][sl], g["lmpc/qfun"][sl])

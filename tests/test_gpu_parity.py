@@ -158,6 +158,28 @@ def test_synthetic_planner_batch_and_selection(gpu, orc, AB, N):
         np.testing.assert_array_equal(pl[k], sg[k])
 
 
+def test_golden_lmpc(gpu, orc, golden_racing_game):
+    """Learning-MPC QPs recorded from the reference's LMPC lap: kernel (block Cholesky in LDS) vs the
+    oracle (full KKT LU) vs the certified goldens."""
+    g = golden_racing_game
+    d, args = helpers.lmpc_inputs(g)
+    rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
+    ok = g["lmpc_success"]
+    assert (rg["status"][ok] == 0).all(), rg["status"][ok]
+    assert rg["kkt"][ok].max() <= 1e-8
+    assert np.abs(rg["X"][ok] - g["lmpc/X"][ok]).max() <= 5e-6
+    assert np.abs(rg["U"][ok] - g["lmpc/U"][ok]).max() <= 5e-6
+    assert np.abs(rg["X"][ok] - ro["X"][ok]).max() <= 5e-6
+    rel = np.abs(rg["cost"][ok] - ro["cost"][ok]) / np.abs(ro["cost"][ok])
+    assert rel.max() <= 1e-8
+    # same verdict on every instance the oracle converges or declares infeasible on
+    same = (ro["status"] == 0) | (ro["status"] == 2)
+    assert (rg["status"][same] == ro["status"][same]).mean() >= 0.95
+    # batch entries are independent
+    r1 = gpu.lmpc_solve(d, *[a[3:9] for a in args])
+    np.testing.assert_array_equal(r1["X"], rg["X"][3:9])
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 

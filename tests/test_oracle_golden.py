@@ -116,3 +116,34 @@ def test_mpc_multi_agents(orc, AB, golden_planner, T):
         np.testing.assert_allclose(r["X"][0], g["mma_x_pred"], atol=T["x"], err_msg=name)
         n += 1
     assert n >= 7
+
+
+@pytest.mark.parametrize("linalg", [0, 1], ids=["kkt-lu", "block-cholesky"])
+def test_lmpc_qps(orc, golden_racing_game, linalg):
+    """Learning-MPC QPs (control.py:610-730) exactly as the reference built them in its LMPC lap --
+    LTV model from its own safe-set regression, safe-set hull, Q-function -- against the certified
+    solutions.  Both linear-algebra routes of the oracle (full KKT LU; the kernel's block Cholesky)."""
+    g = golden_racing_game
+    d, args = helpers.lmpc_inputs(g)
+    orc.lib.crx_oracle_lmpc_set_linalg(linalg)
+    try:
+        r = orc.lmpc_solve(d, *args)
+    finally:
+        orc.lib.crx_oracle_lmpc_set_linalg(0)
+    ok = g["lmpc_success"]
+    assert ok.sum() >= 30
+    assert (r["status"][ok] == 0).all(), r["status"][ok]
+    assert r["kkt"][ok].max() <= 1e-8
+    # feasible instances: strictly convex in u -> unique (x, u)
+    assert np.abs(r["X"][ok] - g["lmpc/X"][ok]).max() <= 5e-6
+    assert np.abs(r["U"][ok] - g["lmpc/U"][ok]).max() <= 5e-6
+    rel = np.abs(r["cost"][ok] - g["lmpc/cert"][ok, 0]) / np.abs(g["lmpc/cert"][ok, 0])
+    assert rel.max() <= 1e-8
+    # the terminal state sits in the hull of the selected safe-set points: x_N = SS lambd, lambd in the simplex
+    lam = r["lam"][ok]
+    assert lam.min() >= -1e-9 and np.abs(lam.sum(1) - 1).max() <= 1e-8
+    xN = np.einsum("bcm,bm->bc", g["lmpc/ss"][ok], lam)
+    assert np.abs(xN - r["X"][ok][:, -1]).max() <= 1e-7
+    # the first instance HiGHS proved infeasible (the reference pins its terminal slack to zero): reported, not hidden
+    first_bad = int(g["lmpc_first_uncertified"])
+    assert r["status"][first_bad] == 2
