@@ -4,6 +4,7 @@ bodies marshal arrays into the crx C ABI instead of building a CasADi Opti probl
   mpccbf            <- reference control/control.py:476-607
   mpc_multi_agents  <- reference control/control.py:251-473
   mpc_lti           <- reference control/control.py:198-248   (same NLP family with no obstacle)
+  lmpc              <- reference control/control.py:610-730   (QP on the GPU, crx_lmpc_solve)
   pid               <- reference control/control.py:15-25
 
 There is no CPU path: without libcrx / a GPU these raise crx.CrxUnavailable.
@@ -129,6 +130,42 @@ def _out_of_scope(name):
     return f
 
 
+def lmpc(xcurv, lmpc_param, matrix_Atv, matrix_Btv, matrix_Ctv, ss_curv, Qfun, iter, lap_length, lap_width, u_old,
+         system_param):
+    """Learning MPC step (reference control/control.py:610-730): safe-set selection on the host
+    (:625-639), the QP on the GPU (crx_lmpc_solve).  Returns (u_pred (N,2), x_pred (N+1,6),
+    ss_point_selected_tot (6,M), Qfun_selected_tot (M,), lin_points (N+1,6), lin_input (N,2)) like
+    the reference.  Where the reference's QP is infeasible (its terminal slack is pinned to zero,
+    :694-695) the reference applies IPOPT's restoration state; here the plan from a minimally
+    relaxed initial state comes back instead (include/crx.h, crx_lmpc_solve) and the same message is
+    printed."""
+    from control import lmpc_helper
+
+    start = datetime.datetime.now()
+    N = lmpc_param.num_horizon
+    pts, qs = [], []
+    for jj in range(lmpc_param.num_ss_iter):
+        p, q = lmpc_helper.select_points(ss_curv, Qfun, iter - jj - 1, xcurv,
+                                         lmpc_param.num_ss_points / lmpc_param.num_ss_iter, lmpc_param.shift)
+        pts.append(p)
+        qs.append(q)
+    ss_sel, q_sel = np.concatenate(pts, axis=1), np.concatenate(qs, axis=0)
+    M = q_sel.shape[0]
+    desc = abi.lmpc_desc(
+        N=N, n_ss_max=M, Q=np.diag(lmpc_param.matrix_Q), R=np.diag(lmpc_param.matrix_R),
+        dR=np.diag(lmpc_param.matrix_dR), v_max=system_param.v_max, ey_max=lap_width,
+        delta_max=system_param.delta_max, a_max=system_param.a_max)
+    r = crx.lmpc_solve(desc, np.asarray(xcurv, dtype=float)[None], np.asarray(u_old, dtype=float).reshape(1, 2),
+                       np.asarray(matrix_Atv, dtype=float)[None], np.asarray(matrix_Btv, dtype=float)[None],
+                       np.asarray(matrix_Ctv, dtype=float).reshape(1, N, X_DIM), ss_sel[None], q_sel[None])
+    if r["status"][0] != 0:
+        print("solver fail to find the solution, the non-converged solution is used")
+    x_pred, u_pred = r["X"][0], r["U"][0]
+    lin_points = np.concatenate((x_pred[1:, :], x_pred[-1:, :]), axis=0)
+    lin_input = np.vstack((u_pred[1:, :], u_pred[-1, :]))
+    print("solver time: {}".format((datetime.datetime.now() - start).total_seconds()))
+    return u_pred, x_pred, ss_sel, q_sel, lin_points, lin_input
+
+
 lqr = _out_of_scope("lqr")
 ilqr = _out_of_scope("ilqr")
-lmpc = _out_of_scope("lmpc")

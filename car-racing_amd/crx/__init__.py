@@ -65,3 +65,7 @@ def select(desc, n_veh, X, obs_s, obs_ey, old_flag):
 
 def planner_plan(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag):
     return binding().planner_plan(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag)
+
+
+def lmpc_solve(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss=None):
+    return binding().lmpc_solve(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss)

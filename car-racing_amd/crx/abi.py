@@ -88,7 +88,7 @@ class LmpcDesc(C.Structure):
         ("ey_max", C.c_double),
         ("delta_max", C.c_double),
         ("a_max", C.c_double),
-        ("w_elastic", C.c_double),
+        ("w_x0", C.c_double),
         ("opts", IpmOpts),
     ]
 
@@ -132,11 +132,11 @@ def cbf_desc(N, n_obs_max, A, B, Q=(10.0, 0.0, 0.0, 4.0, 0.0, 40.0), R=(0.1, 0.1
 
 
 def lmpc_desc(N=12, n_ss_max=44, Q=(0.0,) * 6, R=(1.0, 0.25), dR=(4.0, 0.0), x_track=(5.0, 0, 0, 0, 0, 0),
-              v_max=10.0, ey_max=1.0, delta_max=0.5, a_max=1.0, w_elastic=1e5, opts=None):
+              v_max=10.0, ey_max=1.0, delta_max=0.5, a_max=1.0, w_x0=1e4, opts=None):
     """Defaults = LMPCRacingParam (utils/base.py:350-376), SystemParam (:708-713) and the literal
     x_track of control.lmpc (control.py:649)."""
     return LmpcDesc(int(N), int(n_ss_max), _arr(C.c_double, 6, Q), _arr(C.c_double, 2, R), _arr(C.c_double, 2, dR),
-                    _arr(C.c_double, 6, x_track), v_max, ey_max, delta_max, a_max, w_elastic, opts or default_opts())
+                    _arr(C.c_double, 6, x_track), v_max, ey_max, delta_max, a_max, w_x0, opts or default_opts())
 
 
 def select_desc(N, n_veh_max, lap_length, veh_length=0.4, veh_width=0.2):

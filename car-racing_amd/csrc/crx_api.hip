@@ -433,7 +433,7 @@ void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max) {
     memset(d, 0, sizeof(*d));
     d->N = N; d->n_ss_max = n_ss_max;
     d->R[0] = 1.0; d->R[1] = 0.25; d->dR[0] = 4.0; d->dR[1] = 0.0; d->x_track[0] = 5.0;
-    d->v_max = 10.0; d->ey_max = 1.0; d->delta_max = 0.5; d->a_max = 1.0; d->w_elastic = 1e5;
+    d->v_max = 10.0; d->ey_max = 1.0; d->delta_max = 0.5; d->a_max = 1.0; d->w_x0 = 1e4;
     crx_ipm_opts_default(&d->opts);
 }
 
@@ -445,14 +445,14 @@ static int fill_lmpc(crx_lmpc_kparams& kp, const crx_lmpc_desc* d, int batch) {
     if (!(d->R[0] > 0.0 && d->R[1] > 0.0) || d->dR[0] < 0.0 || d->dR[1] < 0.0) return fail(CRX_ERR_ARG, "R must be positive, dR non-negative");
     for (int c = 0; c < 6; c++)
         if (d->Q[c] < 0.0) return fail(CRX_ERR_ARG, "Q must be non-negative");
-    if (!(d->w_elastic > 0.0)) return fail(CRX_ERR_ARG, "w_elastic must be positive");
+    if (!(d->w_x0 > 0.0)) return fail(CRX_ERR_ARG, "w_x0 must be positive");
     if (int rc = check_opts(d->opts)) return rc;
     memset(&kp, 0, sizeof(kp));
     kp.N = d->N; kp.batch = batch; kp.n_ss_max = d->n_ss_max;
     memcpy(kp.Q, d->Q, sizeof(kp.Q)); memcpy(kp.R, d->R, sizeof(kp.R)); memcpy(kp.dR, d->dR, sizeof(kp.dR));
     memcpy(kp.x_track, d->x_track, sizeof(kp.x_track));
     kp.v_max = d->v_max; kp.ey_max = d->ey_max; kp.delta_max = d->delta_max; kp.a_max = d->a_max;
-    kp.w_elastic = d->w_elastic; kp.opts = d->opts;
+    kp.w_x0 = d->w_x0; kp.opts = d->opts;
     return 0;
 }
 

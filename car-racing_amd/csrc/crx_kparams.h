@@ -31,7 +31,7 @@ struct crx_kparams {
 struct crx_lmpc_kparams {
     int N, batch, n_ss_max;
     double Q[6], R[2], dR[2], x_track[6];
-    double v_max, ey_max, delta_max, a_max, w_elastic;
+    double v_max, ey_max, delta_max, a_max, w_x0;
     crx_ipm_opts opts;
     const double *x0, *u_old, *A, *B, *C, *ss, *qfun;
     const int32_t* n_ss;

@@ -7,17 +7,19 @@
 //   variables   u_0..u_{N-1} (2N), lambd (M <= 60); states eliminated by the affine LTV roll-out
 //               x_k = xf_k + S_k u   (S_k = dx_k/du, built once per problem)
 //   rows        4N input-box rows, 3(N-1) state rows (vx_k <= v_max, |ey_k| <= w; k = 1..N-1),
-//               M rows lambd >= 0 (+ 12 rows p, q >= 0 in the elastic attempt)
-//   equalities  x_N - SS lambd (- p + q) = 0  (6),  1'lambd = 1
+//               M rows lambd >= 0
+//   equalities  x_N - SS lambd = 0  (6),  1'lambd = 1
+//   second attempt (include/crx.h, crx_lmpc_solve): x_0 = xcurv + w with cost w_x0 w'w; the six w's are
+//               appended to the u block (columns 2N..2N+5 of S hold dx_k/dx_0)
 //
 // Interior-point iteration: identical to oracle/crx_oracle_lmpc.c (slack form, monotone barrier,
 // fraction-to-the-boundary, filter line search, y updated with the primal step length).  Newton
 // system by block elimination, every factor a Cholesky:
 //   K_u = H_u + J_u' Sigma J_u  (2N x 2N)          -> L_u, with Phi and rhs_u carried as extra rows,
 //                                                      so  Y = L_u^-1 Phi',  z = L_u^-1 rhs_u  come for free
-//   W~  = Y Y' (+ 1/D_p + 1/D_q)   (6 x 6)          -> L_w   (per lane, registers)
+//   W   = Y Y'                     (6 x 6)          -> L_w   (per lane, registers)
 //   G   = D_lambda + T T',  T = SS' L_w^-T (M x 6) -> L_g, with the two right-hand sides as extra rows
-//   dy_1 from 1'dlambd = -e_1, then dlambd, dy_x, du, (dp, dq) by back substitution.
+//   dy_1 from 1'dlambd = -e_1, then dlambd, dy_x, du by back substitution.
 // A Schur complement on the 7 equalities (E K^-1 E') is NOT used: the active lambd's carry no
 // curvature but the barrier's, so K^-1 spans 1e-16..1e16 near the solution; G stays well scaled.
 // Lane i owns row i of each factor (left-looking Cholesky: row j is read as an LDS broadcast), the
@@ -33,9 +35,9 @@
 
 template <int NMAX>
 struct LL {
-    static constexpr int NU2 = 2 * NMAX, LDK = NU2 + 1, KR = NU2 + 7;
+    static constexpr int NU2 = 2 * NMAX + 6 /* inputs + initial-state relaxation */, LDK = NU2 + 1, KR = NU2 + 7;
     static constexpr int MS = CRX_MAX_SS, LDG = MS + 1, GR = MS + 2;
-    static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS + 12;
+    static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS;
     // offsets in doubles
     static constexpr int A = 0, B = A + 36 * NMAX, C = B + 12 * NMAX, xf = C + 6 * NMAX;
     static constexpr int S = xf + 6 * (NMAX + 1);              // S[(k*6+c)*NU2 + a], k = 0..NMAX
@@ -46,8 +48,7 @@ struct LL {
     static constexpr int qf = SS + 6 * MS, T = qf + MS;        // T[j*6+c]
     static constexpr int u = T + 6 * MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
     static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS, cl = rl + MS;
-    static constexpr int pq = cl + MS, dpq = pq + 12, rpq = dpq + 12;
-    static constexpr int y = rpq + 12, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
+    static constexpr int y = cl + MS, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
     static constexpr int ik = Wt + 36, ig = ik + NU2;          // inverse pivots of L_u, L_g
     static constexpr int t = ig + MS, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
     static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
@@ -57,7 +58,7 @@ struct LL {
 };
 
 struct LCtx {
-    int N, nu2, M, m, el, lane;
+    int N, nu2, nv, M, m, el, lane;
     int r_st, r_lam, r_el;
 };
 
@@ -79,18 +80,17 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
             double s = LDS(L::xf + 6 * k + comp);
             const int so = L::S + (k * 6 + comp) * L::NU2;
             for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+            for (int a = x.nu2; a < x.nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
             cv = q == 0 ? kp.v_max - s : (q == 1 ? kp.ey_max - s : s + kp.ey_max);
-        } else if (r < x.r_el) {
-            cv = LDS(L::lam + (r - x.r_lam));
         } else {
-            cv = LDS(L::pq + (r - x.r_el));
+            cv = LDS(L::lam + (r - x.r_lam));
         }
         LDS(L::c + r) = cv;
         LDS(L::rp + r) = cv - LDS(L::t + r);
     }
 }
 
-// (ru, rl, rpq) = g + E'y - J'w   with w = the row array at offset `wo`
+// (ru, rl) = g + E'y - J'w   with w = the row array at offset `wo`
 template <int NMAX>
 __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int wo) {
     using L = LL<NMAX>;
@@ -100,13 +100,13 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
         LDS(L::w5 + k) = LDS(wo + r + 1) - LDS(wo + r + 2);
     }
     SYNC();
-    if (x.lane < x.nu2) {
+    if (x.lane < x.nv) {
         const int a = x.lane, i = a >> 1, cc = a & 1;
         double s = LDS(L::gu + a);
         for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + (x.N * 6 + c6) * L::NU2 + a), LDS(L::y + c6), s);
-        s -= LDS(wo + 4 * i + 2 * cc) - LDS(wo + 4 * i + 2 * cc + 1);
+        if (a < x.nu2) s -= LDS(wo + 4 * i + 2 * cc) - LDS(wo + 4 * i + 2 * cc + 1);
         // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo)
-        for (int k = i + 1; k < x.N; k++) {
+        for (int k = a < x.nu2 ? i + 1 : 1; k < x.N; k++) {
             s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a), LDS(L::w0 + k), s);
             s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s);
         }
@@ -117,11 +117,6 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
         double s = LDS(L::qf + j) + LDS(L::y + 6) - LDS(wo + x.r_lam + j);
         for (int c6 = 0; c6 < 6; c6++) s = fma(-LDS(L::SS + c6 * L::MS + j), LDS(L::y + c6), s);
         LDS(L::rl + j) = s;
-    }
-    if (x.el && x.lane < 12) {
-        const int c6 = x.lane < 6 ? x.lane : x.lane - 6;
-        double yy = LDS(L::y + c6);
-        LDS(L::rpq + x.lane) = kp.w_elastic + (x.lane < 6 ? -yy : yy) - LDS(wo + x.r_el + x.lane);
     }
     SYNC();
 }
@@ -204,7 +199,27 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         }
         SYNC();
     }
-    // sensitivities: lane a propagates column a of S
+    // sensitivities: lane a propagates column a of S (columns 2N..2N+5: dx_k/dx_0, used by the second attempt)
+    if (lane >= nu2 && lane < nu2 + 6) {
+        const int a = lane, c0 = lane - nu2;
+        double col[6];
+        for (int r = 0; r < 6; r++) {
+            col[r] = r == c0 ? 1.0 : 0.0;
+            LDS(L::S + (0 * 6 + r) * L::NU2 + a) = col[r];
+        }
+        for (int k = 0; k < N; k++) {
+            double nc[6];
+            for (int r = 0; r < 6; r++) {
+                double s = 0.0;
+                for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * r + c6), col[c6], s);
+                nc[r] = s;
+            }
+            for (int r = 0; r < 6; r++) {
+                col[r] = nc[r];
+                LDS(L::S + ((k + 1) * 6 + r) * L::NU2 + a) = nc[r];
+            }
+        }
+    }
     if (lane < nu2) {
         const int a = lane, ka = a >> 1, ca = a & 1;
         double col[6] = {0, 0, 0, 0, 0, 0};
@@ -238,6 +253,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
             if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
             LDS(L::g0u + a) = i == 0 ? -2.0 * dR * (cc ? uold1 : uold0) : 0.0;
+        } else if (lane < nu2 + 6) {
+            LDS(L::Hu + lane * L::NU2 + lane) = 2.0 * kp.w_x0;
+            LDS(L::g0u + lane) = 0.0;
         }
         f0 = kp.dR[0] * uold0 * uold0 + kp.dR[1] * uold1 * uold1;
         SYNC();
@@ -248,10 +266,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     if (q == 0.0) continue;
                     const double r0 = LDS(L::xf + 6 * k + c6) - kp.x_track[c6];
                     const int so = L::S + (k * 6 + c6) * L::NU2;
-                    if (lane < nu2) {
+                    if (lane < nu2 + 6) {
                         const double sa = LDS(so + lane);
                         LDS(L::g0u + lane) += 2.0 * q * r0 * sa;
-                        for (int b = 0; b < nu2; b++) LDS(L::Hu + lane * L::NU2 + b) += 2.0 * q * sa * LDS(so + b);
+                        for (int b = 0; b < nu2 + 6; b++) LDS(L::Hu + lane * L::NU2 + b) += 2.0 * q * sa * LDS(so + b);
                     }
                     f0 += q * r0 * r0;
                 }
@@ -276,12 +294,12 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     double E0 = HUGE_VAL, f = 0.0;
     for (int attempt = 0; attempt < 2; attempt++) {
         x.el = attempt;
-        x.m = x.r_el + (x.el ? 12 : 0);
-        const int m = x.m;
+        x.nv = nu2 + (attempt ? 6 : 0);
+        x.m = x.r_el;
+        const int m = x.m, nv = x.nv;
         // ---- start point: v = 0, y = 0, t = max(|c|, push), nu = 1 (lambd / elastic rows: cost gradient) ----
-        if (lane < nu2) LDS(L::u + lane) = 0.0;
+        if (lane < L::NU2) LDS(L::u + lane) = 0.0;
         if (lane < L::MS) LDS(L::lam + lane) = 0.0;
-        if (lane < 12) LDS(L::pq + lane) = 0.0;
         if (lane < 8) LDS(L::y + lane) = 0.0;
         for (int r = lane; r < m; r += WAVE) LDS(L::t + r) = 0.0;
         SYNC();
@@ -291,7 +309,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             LDS(L::t + r) = fmax(fabs(LDS(L::c + r)), o.slack_push);
             double nn = 1.0;
             if (r >= x.r_lam) {
-                const double gg = r < x.r_el ? LDS(L::qf + (r - x.r_lam)) : kp.w_elastic;
+                const double gg = LDS(L::qf + (r - x.r_lam));
                 if (gg > 1.0) nn = gg;
             }
             LDS(L::nu + r) = nn;
@@ -304,9 +322,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         for (it = 0;; it++) {
             // ---- rows, gradient, equality residual ----
             l_rows<NMAX>(sm, x, kp);
-            if (lane < nu2) {
+            if (lane < nv) {
                 double s = LDS(L::g0u + lane);
-                for (int b = 0; b < nu2; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::u + b), s);
+                for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::u + b), s);
                 LDS(L::gu + lane) = s;
             }
             if (lane < 7) {
@@ -314,9 +332,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 if (lane < 6) {
                     s = LDS(L::xf + 6 * N + lane);
                     const int so = L::S + (N * 6 + lane) * L::NU2;
-                    for (int a = 0; a < nu2; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+                    for (int a = 0; a < nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
                     for (int j = 0; j < M; j++) s = fma(-LDS(L::SS + lane * L::MS + j), LDS(L::lam + j), s);
-                    if (x.el) s += LDS(L::pq + 6 + lane) - LDS(L::pq + lane);
                 } else {
                     s = -1.0;
                     for (int j = 0; j < M; j++) s += LDS(L::lam + j);
@@ -341,9 +358,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 e_p = fmax(e_p, ee);
                 theta += ee;
             }
-            if (lane < nu2) e_d = fabs(LDS(L::ru + lane));
+            if (lane < nv) e_d = fabs(LDS(L::ru + lane));
             if (lane < M) e_d = fmax(e_d, fabs(LDS(L::rl + lane)));
-            if (x.el && lane < 12) e_d = fmax(e_d, fabs(LDS(L::rpq + lane)));
             nus = wave_sum(nus);
             ys = wave_sum(ys);
             theta = wave_sum(theta);
@@ -375,7 +391,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::wv + r) = fma(-sg, LDS(L::rp + r), mu * ti);
             }
             SYNC();
-            l_lagr<NMAX>(sm, x, kp, L::wv);   // ru, rl, rpq = -(rhs)
+            l_lagr<NMAX>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
             // stage weights of the state rows for K_u
             if (lane >= 1 && lane < N) {
                 const int r = x.r_st + 3 * (lane - 1);
@@ -384,25 +400,25 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             }
             SYNC();
             // ---- K_u (lower triangle) + extra rows Phi (6) and rhs_u ----
-            for (int en = lane; en < nu2 * (nu2 + 1) / 2; en += WAVE) {
+            for (int en = lane; en < nv * (nv + 1) / 2; en += WAVE) {
                 int a = (int)((sqrt(8.0 * en + 1.0) - 1.0) * 0.5);
                 if (a * (a + 1) / 2 > en) a--;
                 if ((a + 1) * (a + 2) / 2 <= en) a++;
                 const int b = en - a * (a + 1) / 2;
                 double s = LDS(L::Hu + a * L::NU2 + b);
-                if (a == b) s += LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1)) + LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1) + 1);
-                for (int k = (a >> 1) + 1; k < N; k++) {
+                if (a == b && a < nu2) s += LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1)) + LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1) + 1);
+                for (int k = a < nu2 ? (a >> 1) + 1 : 1; k < N; k++) {
                     s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a) * LDS(L::w0 + k), LDS(L::S + (k * 6 + 0) * L::NU2 + b), s);
                     s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a) * LDS(L::w5 + k), LDS(L::S + (k * 6 + 5) * L::NU2 + b), s);
                 }
                 LDS(L::K + a * L::LDK + b) = s;
             }
-            for (int en = lane; en < 7 * nu2; en += WAVE) {
-                const int r = en / nu2, j = en - r * nu2;
-                LDS(L::K + (nu2 + r) * L::LDK + j) = r < 6 ? LDS(L::S + (N * 6 + r) * L::NU2 + j) : -LDS(L::ru + j);
+            for (int en = lane; en < 7 * nv; en += WAVE) {
+                const int r = en / nv, j = en - r * nv;
+                LDS(L::K + (nv + r) * L::LDK + j) = r < 6 ? LDS(L::S + (N * 6 + r) * L::NU2 + j) : -LDS(L::ru + j);
             }
             SYNC();
-            int ok = l_chol<L::LDK>(sm, L::K, L::ik, nu2, 7, lane);
+            int ok = l_chol<L::LDK>(sm, L::K, L::ik, nv, 7, lane);
             if (!ok) break;
             // ---- W~ and b_x ----
             if (lane < 27) {
@@ -410,17 +426,15 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 if (lane < 21) {
                     int r = 0, q = lane;
                     while (q > r) { q -= r + 1; r++; }   // lane -> (r, q), q <= r
-                    const int ro = L::K + (nu2 + r) * L::LDK, qo = L::K + (nu2 + q) * L::LDK;
-                    for (int j = 0; j < nu2; j++) s = fma(LDS(ro + j), LDS(qo + j), s);
-                    if (x.el && r == q) s += frcp(LDS(L::dnu + x.r_el + r)) + frcp(LDS(L::dnu + x.r_el + 6 + r));
+                    const int ro = L::K + (nv + r) * L::LDK, qo = L::K + (nv + q) * L::LDK;
+                    for (int j = 0; j < nv; j++) s = fma(LDS(ro + j), LDS(qo + j), s);
                     LDS(L::Wt + 6 * r + q) = s;
                     LDS(L::Wt + 6 * q + r) = s;
                 } else {
                     const int r = lane - 21;
                     s = LDS(L::e + r);
-                    const int ro = L::K + (nu2 + r) * L::LDK, zo = L::K + (nu2 + 6) * L::LDK;
-                    for (int j = 0; j < nu2; j++) s = fma(LDS(ro + j), LDS(zo + j), s);
-                    if (x.el) s += LDS(L::rpq + r) * frcp(LDS(L::dnu + x.r_el + r)) - LDS(L::rpq + 6 + r) * frcp(LDS(L::dnu + x.r_el + 6 + r));
+                    const int ro = L::K + (nv + r) * L::LDK, zo = L::K + (nv + 6) * L::LDK;
+                    for (int j = 0; j < nv; j++) s = fma(LDS(ro + j), LDS(zo + j), s);
                     LDS(L::bx + r) = s;
                 }
             }
@@ -506,19 +520,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 // du = L_u^-T (z - Y' dy_x)
                 double b1[1];
                 b1[0] = 0.0;
-                if (lane < nu2) {
-                    double s = LDS(L::K + (nu2 + 6) * L::LDK + lane);
+                if (lane < nv) {
+                    double s = LDS(L::K + (nv + 6) * L::LDK + lane);
 #pragma unroll
-                    for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nu2 + r) * L::LDK + lane), dyx[r], s);
+                    for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nv + r) * L::LDK + lane), dyx[r], s);
                     b1[0] = s;
                 }
-                l_backsub<L::LDK, 1>(sm, L::K, L::ik, nu2, lane, b1);
-                if (lane < nu2) LDS(L::du + lane) = b1[0];
-                if (x.el && lane < 12) {
-                    const int c6 = lane < 6 ? lane : lane - 6;
-                    const double rr = -LDS(L::rpq + lane) + (lane < 6 ? dyx[c6] : -dyx[c6]);
-                    LDS(L::dpq + lane) = rr * frcp(LDS(L::dnu + x.r_el + lane));
-                }
+                l_backsub<L::LDK, 1>(sm, L::K, L::ik, nv, lane, b1);
+                if (lane < nv) LDS(L::du + lane) = b1[0];
             }
             SYNC();
             // ---- row steps ----
@@ -532,11 +541,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     const int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
                     double s = 0.0;
                     for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
+                    for (int a = nu2; a < nv; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
                     jd = q == 2 ? s : -s;
-                } else if (r < x.r_el) {
-                    jd = LDS(L::dlam + (r - x.r_lam));
                 } else {
-                    jd = LDS(L::dpq + (r - x.r_el));
+                    jd = LDS(L::dlam + (r - x.r_lam));
                 }
                 const double tt = LDS(L::t + r), nn = LDS(L::nu + r), ti = frcp(tt);
                 const double dtt = LDS(L::rp + r) + jd;
@@ -551,15 +559,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::c + r) = dn;   // dnu parked in c (c is recomputed at the top of the next iteration)
             }
             double gdv = 0.0, qd = 0.0;
-            if (lane < nu2) {
+            if (lane < nv) {
                 const double d = LDS(L::du + lane);
                 gdv = LDS(L::gu + lane) * d;
                 double s = 0.0;
-                for (int b = 0; b < nu2; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::du + b), s);
+                for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::du + b), s);
                 qd = s * d;
             }
             if (lane < M) gdv = fma(LDS(L::qf + lane), LDS(L::dlam + lane), gdv);
-            if (x.el && lane < 12) gdv = fma(kp.w_elastic, LDS(L::dpq + lane), gdv);
             rp_max = wave_max(rp_max);
             rd_max = wave_max(rd_max);
             gdv = wave_sum(gdv);
@@ -626,9 +633,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::nu + r) = nn;
                 numax = fmax(numax, nn);
             }
-            if (lane < nu2) LDS(L::u + lane) = fma(al, LDS(L::du + lane), LDS(L::u + lane));
+            if (lane < nv) LDS(L::u + lane) = fma(al, LDS(L::du + lane), LDS(L::u + lane));
             if (lane < M) LDS(L::lam + lane) = fma(al, LDS(L::dlam + lane), LDS(L::lam + lane));
-            if (x.el && lane < 12) LDS(L::pq + lane) = fma(al, LDS(L::dpq + lane), LDS(L::pq + lane));
             if (lane < 7) LDS(L::y + lane) = fma(al, LDS(L::dy + lane), LDS(L::y + lane));
             f = fn;
             numax = wave_max(numax);
@@ -638,13 +644,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         total_it += it;
         SYNC();
         if (attempt == 0 && status == CRX_CONVERGED && !bad0) break;
-        if (attempt == 1) {
-            double els = 0.0;
-            if (lane < 12) els = fabs(LDS(L::pq + lane));
-            els = wave_sum(els);
-            if (status == CRX_CONVERGED && (els > 1e-7 || bad0)) status = CRX_INFEASIBLE;
-            f -= kp.w_elastic * els;
-        }
+        if (attempt == 1 && status == CRX_CONVERGED) status = CRX_INFEASIBLE;   // the reference's (pinned) QP was not solved
     }
     // ---- write back ----
     for (int i = lane; i < 6 * (N + 1); i += WAVE) {
@@ -652,6 +652,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         double s = LDS(L::xf + i);
         const int so = L::S + (k * 6 + c6) * L::NU2;
         for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+        for (int a = nu2; a < x.nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);   // second attempt: the plan starts at xcurv + w
         kp.X[(size_t)6 * (N + 1) * pb + i] = s;
     }
     if (lane < nu2) kp.U[(size_t)nu2 * pb + lane] = LDS(L::u + lane);

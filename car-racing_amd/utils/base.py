@@ -1,7 +1,6 @@
 """Controller / vehicle / simulator classes with the reference's surface (utils/base.py), so that
 the reference's drivers (tests/auto_mpccbf_test.py, car_racing/tests/mpccbf_test.py) run against
-this package unchanged.  Only what the accelerated hot path and its harness need is here; the
-LMPC learning controller, LQR and iLQR are out of scope and raise.
+this package unchanged.  LQR and iLQR are out of scope and raise.
 
 Objects stay picklable: the GPU library handle lives in the `crx` module, never in instance state
 (the reference pickles its simulator, tests/auto_mpccbf_test.py:42-43).
@@ -11,7 +10,7 @@ import os
 
 import numpy as np
 
-from control import control
+from control import control, lmpc_helper
 from planning import overtake_traj_planner
 from system import vehicle_dynamics
 from utils import racing_env
@@ -174,9 +173,11 @@ class LMPCRacingParam:
 
 
 class LMPCRacingGame(ControlBase):
-    """Overtaking branch of the reference's racing-game controller (base.py:518-582): planner fan-out
-    + tracking NLP, both on the GPU.  The learning-MPC branch (no vehicle nearby, base.py:468-517)
-    needs control.lmpc and the safe-set regression, which are 'next' rows."""
+    """The reference's racing-game controller (utils/base.py:410-682): learning MPC on the safe set
+    of earlier laps while the road is free (:468-517), overtaking planner + tracking NLP while another
+    vehicle is of interest (:518-582).  All three solves (crx_lmpc_solve; crx_planner_plan;
+    crx_cbf_solve) run on the GPU; safe-set bookkeeping and the local model regression stay on the
+    host (control/lmpc_helper.py)."""
 
     def __init__(self, lmpc_param, racing_game_param=None, system_param=None):
         ControlBase.__init__(self)
@@ -184,6 +185,19 @@ class LMPCRacingGame(ControlBase):
         self.lmpc_param, self.racing_game_param, self.system_param = lmpc_param, racing_game_param, system_param
         self.overtake_planner = overtake_traj_planner.OvertakeTrajPlanner(racing_game_param)
         self.x_pred = self.u_pred = None
+        self.lin_points = self.lin_input = None
+        self.ss_point_selected_tot = self.Qfun_selected_tot = None
+        laps = lmpc_param.lap_number
+        num_points = int(lmpc_param.time_lmpc / lmpc_param.timestep) + 1
+        # sampled safe set (:432-443): states, inputs, cost-to-go and completion time of every lap
+        self.time_ss = 10000 * np.ones(laps).astype(int)
+        self.ss_xcurv = 10000 * np.ones((num_points, X_DIM, laps))
+        self.u_ss = 10000 * np.ones((num_points, U_DIM, laps))
+        self.Qfun = 0 * np.ones((num_points, laps))
+        self.ss_glob = 10000 * np.ones((num_points, X_DIM, laps))
+        self.iter = 0
+        self.time_in_iter = 0
+        self.openloop_prediction = None
         self.old_ey = self.old_direction_flag = None
 
     def set_vehicles_track(self):
@@ -194,40 +208,107 @@ class LMPCRacingGame(ControlBase):
             vehicles = self.vehicles
         self.overtake_planner.vehicles = vehicles
 
-    def calc_input(self):
-        pl = self.overtake_planner
-        pl.agent_name, pl.opti_traj_xcurv = self.agent_name, self.opti_traj_xcurv
-        x = copy.deepcopy(self.x)
-        while x[4] > self.lap_length:
-            x[4] = x[4] - self.lap_length
-        overtake_flag, vehicles_interest = pl.get_overtake_flag(x)
-        ego = pl.vehicles["ego"]
-        if not overtake_flag:
-            raise NotImplementedError("LMPC branch (control.lmpc) is a 'next' row; only the overtaking branch is accelerated")
-        (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
-         all_traj_xglob) = pl.get_local_traj(x, self.time, vehicles_interest, None, None, None, self.old_ey,
-                                             self.old_direction_flag)
-        self.old_ey, self.old_direction_flag = traj_xcurv[-1, 5], direction_flag
-        ego.local_trajs.append(traj_xglob)
-        ego.vehicles_interest.append(vehicles_interest)
-        ego.splines.append(bezier_xglob)
-        ego.solver_time.append(solve_time)
-        ego.all_splines.append(all_bezier_xglob)
-        ego.all_local_trajs.append(all_traj_xglob)
-        self.u, x_pred = control.mpc_multi_agents(
-            x, self.racing_game_param, self.track, None, None, None, self.system_param, target_traj_xcurv=traj_xcurv,
-            vehicles=pl.vehicles, agent_name=self.agent_name, direction_flag=direction_flag,
-            target_traj_xglob=traj_xglob, sorted_vehicles=sorted_vehicles)
-        self.x_pred = x_pred
+    def _prediction_xglob(self, x_pred):
         n = x_pred.shape[0]
         pred_glob = np.zeros((n, X_DIM))
         for j in range(n):
             pred_glob[j, 0:3] = x_pred[j, 0:3]
             pred_glob[j, 3] = self.track.get_orientation(x_pred[j, 4], x_pred[j, 5])
             pred_glob[j, 4], pred_glob[j, 5] = self.track.get_global_position(x_pred[j, 4], x_pred[j, 5])
-        ego.lmpc_prediction.append(None)
-        ego.mpc_cbf_prediction.append(pred_glob)
+        return pred_glob
+
+    def calc_input(self):
+        pl = self.overtake_planner
+        pl.agent_name, pl.opti_traj_xcurv = self.agent_name, self.opti_traj_xcurv
+        matrix_Atv, matrix_Btv, matrix_Ctv, _ = self.estimate_ABC()
+        x = copy.deepcopy(self.x)
+        while x[4] > self.lap_length:
+            x[4] = x[4] - self.lap_length
+        u_old = np.zeros((1, 2)) if self.u_pred is None else copy.deepcopy(self.u_pred[0, :])
+        overtake_flag, vehicles_interest = pl.get_overtake_flag(x)
+        ego = pl.vehicles["ego"]
+        if not overtake_flag:
+            (self.u_pred, self.x_pred, self.ss_point_selected_tot, self.Qfun_selected_tot, self.lin_points,
+             self.lin_input) = control.lmpc(x, self.lmpc_param, matrix_Atv, matrix_Btv, matrix_Ctv, self.ss_xcurv,
+                                            self.Qfun, self.iter, self.lap_length, self.lap_width, u_old,
+                                            self.system_param)
+            self.u = self.u_pred[0, :]
+            self.old_ey = self.old_direction_flag = None
+            log = self.openloop_prediction
+            if log is not None:
+                log.predicted_xcurv[:, :, self.time_in_iter, self.iter] = self.x_pred
+                log.predicted_u[:, :, self.time_in_iter, self.iter] = self.u_pred
+                log.ss_used[:, :, self.time_in_iter, self.iter] = self.ss_point_selected_tot
+                log.Qfun_used[:, self.time_in_iter, self.iter] = self.Qfun_selected_tot
+            self.add_point(self.x, self.u, self.time_in_iter)
+            self.time_in_iter = self.time_in_iter + 1
+            for lst in (ego.local_trajs, ego.vehicles_interest, ego.splines, ego.solver_time, ego.all_splines,
+                        ego.all_local_trajs):
+                lst.append(None)
+            ego.lmpc_prediction.append(self._prediction_xglob(self.x_pred))
+            ego.mpc_cbf_prediction.append(None)
+        else:
+            (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
+             all_traj_xglob) = pl.get_local_traj(x, self.time, vehicles_interest, matrix_Atv, matrix_Btv, matrix_Ctv,
+                                                 self.old_ey, self.old_direction_flag)
+            self.old_ey, self.old_direction_flag = traj_xcurv[-1, 5], direction_flag
+            ego.local_trajs.append(traj_xglob)
+            ego.vehicles_interest.append(vehicles_interest)
+            ego.splines.append(bezier_xglob)
+            ego.solver_time.append(solve_time)
+            ego.all_splines.append(all_bezier_xglob)
+            ego.all_local_trajs.append(all_traj_xglob)
+            self.u, x_pred = control.mpc_multi_agents(
+                x, self.racing_game_param, self.track, matrix_Atv, matrix_Btv, matrix_Ctv, self.system_param,
+                target_traj_xcurv=traj_xcurv, vehicles=pl.vehicles, agent_name=self.agent_name,
+                direction_flag=direction_flag, target_traj_xglob=traj_xglob, sorted_vehicles=sorted_vehicles)
+            ego.lmpc_prediction.append(None)
+            ego.mpc_cbf_prediction.append(self._prediction_xglob(x_pred))
         self.time += self.timestep
+
+    def estimate_ABC(self):
+        """One local model per horizon stage from the two previous laps (:585-622)."""
+        used_iter = range(self.iter - 2, self.iter)
+        Atv, Btv, Ctv, index_used = [], [], [], []
+        for i in range(self.lmpc_param.num_horizon):
+            Ai, Bi, Ci, idx = lmpc_helper.regression_and_linearization(
+                self.lin_points, self.lin_input, used_iter, self.ss_xcurv, self.u_ss, self.time_ss, 40, None, None,
+                self.point_and_tangent, self.timestep, i)
+            Atv.append(Ai)
+            Btv.append(Bi)
+            Ctv.append(Ci)
+            index_used.append(idx)
+        return Atv, Btv, Ctv, index_used
+
+    def add_point(self, x, u, i):
+        """Extend the previous lap's safe set past the finish line with the running lap (:624-629)."""
+        counter = self.time_ss[self.iter - 1]
+        self.ss_xcurv[counter + i + 1, :, self.iter - 1] = x + np.array([0, 0, 0, 0, self.lap_length, 0])
+        self.u_ss[counter + i + 1, :, self.iter - 1] = u[:]
+
+    def add_trajectory(self, ego, lap_number):
+        """Store a completed lap in the safe set (:631-656)."""
+        it = self.iter
+        end_iter = int(round((ego.times[lap_number][-1] - ego.times[lap_number][0]) / ego.timestep))
+        self.time_ss[it] = end_iter
+        xcurvs = np.stack(ego.xcurvs[lap_number], axis=0)
+        xglobs = np.stack(ego.xglobs[lap_number], axis=0)
+        inputs = np.stack(ego.inputs[lap_number], axis=0)
+        self.ss_xcurv[0:end_iter + 1, :, it] = xcurvs[0:end_iter + 1, :]
+        self.ss_glob[0:end_iter + 1, :, it] = xglobs[0:end_iter + 1, :]
+        self.u_ss[0:end_iter, :, it] = inputs[0:end_iter, :]
+        self.Qfun[0:end_iter + 1, it] = lmpc_helper.compute_cost(xcurvs[0:end_iter + 1, :], inputs[0:end_iter, :],
+                                                                  self.lap_length)
+        # beyond the finish line the cost-to-go keeps counting down (:647-649)
+        q = self.Qfun[:, it]
+        for i in np.nonzero(q[0:end_iter + 1] == 0)[0]:
+            q[i] = q[i - 1] - 1
+        q[end_iter + 1:] = q[end_iter] - np.arange(1, q.shape[0] - end_iter)
+        if self.iter == 0:
+            self.lin_points = self.ss_xcurv[1:self.lmpc_param.num_horizon + 2, :, it]
+            self.lin_input = self.u_ss[1:self.lmpc_param.num_horizon + 1, :, it]
+        self.iter = self.iter + 1
+        self.time_in_iter = 0
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -134,7 +134,8 @@ typedef struct crx_lmpc_desc {
     double ey_max;         /* |ey_i| <= lap_width, i < N (:659-660) */
     double delta_max;      /* (:662-663) */
     double a_max;          /* (:665-666) */
-    double w_elastic;      /* 1e5: L1 weight of the elastic terminal constraint used by the second attempt only */
+    double w_x0;           /* 1e4: weight of the squared initial-state relaxation, used by the second attempt only
+                              (see crx_lmpc_solve) */
     crx_ipm_opts opts;
 } crx_lmpc_desc;
 
@@ -233,10 +234,13 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
  *   [1, n_ss_max].
  *   X [batch][N+1][6], U [batch][N][2], lambda [batch][n_ss_max], cost [batch] (the reference's cost :698).
  * status: CRX_CONVERGED = KKT point of the reference's QP (terminal state inside the safe-set hull).
- *   The reference pins its terminal slack to zero (:694-695), so the QP is infeasible whenever the model
- *   cannot reach the hull; the reference then applies IPOPT's restoration state (:711-722).  libcrx
- *   instead repeats such a problem with the terminal equality made elastic (L1 weight w_elastic) and
- *   returns that minimiser with status CRX_INFEASIBLE.
+ *   The reference pins its terminal slack to zero (:694-695), so its QP is infeasible whenever the
+ *   regression model cannot reach the hull from xcurv; the reference then applies IPOPT's restoration
+ *   state (:711-722), which is solver-internal: a least-violation point of ALL equalities of the
+ *   full-space problem.  On the recorded infeasible instances the cheapest such violation is a ~1e-2
+ *   shift of the initial-state equality (:650).  libcrx therefore repeats a failed problem with that
+ *   equality relaxed, x_0 = xcurv + w, cost += w_x0 * w'w, terminal constraint kept; X is the plan from
+ *   xcurv + w, U its inputs, status CRX_INFEASIBLE.
  */
 int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
                    const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,

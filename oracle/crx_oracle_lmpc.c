@@ -21,11 +21,15 @@
  * Infeasible instances.  Because the slack is pinned, the reference's QP is infeasible whenever the
  * regression model cannot reach the selected safe-set hull; the reference then applies whatever
  * IPOPT's restoration phase left in opti.debug (:711-722), which is solver-internal state and not
- * restatable.  Here (and in libcrx, same rule) a failed first attempt is repeated with the terminal
- * equality made elastic,  x_N - SS lambd = p - q,  p, q >= 0,  cost += w_elastic * 1'(p+q);  the
- * result is reported with status CRX_INFEASIBLE unless the elastic variables vanish.  No parity with
- * the reference is claimed for those instances (parity unpinned); feasible instances have a unique
- * (x, u) and are pinned by tests/golden/racing_game.npz.
+ * restatable -- but its restoration phase minimises the violation of ALL equalities of the full-space
+ * problem, and on the recorded infeasible instances the cheapest violation (HiGHS, make_golden.py) is
+ * a ~1e-2 shift of the initial-state equality x_0 = xcurv (:650), which the ill-conditioned regression
+ * model amplifies into reachability of the hull.  Here (and in libcrx, same rule) a failed first
+ * attempt is therefore repeated with exactly that equality relaxed:  x_0 = xcurv + w,
+ * cost += w_x0 * w'w,  terminal constraint kept hard; the returned plan starts at xcurv + w and the
+ * result is reported with status CRX_INFEASIBLE.  No parity with the reference is claimed for those
+ * instances (parity unpinned); feasible instances have a unique (x, u) and are pinned by
+ * tests/golden/racing_game.npz.
  */
 #include <math.h>
 #include <stdint.h>
@@ -47,6 +51,7 @@ typedef struct {
     const double *A, *B, *C, *ss, *qf;
     const crx_lmpc_desc* d;
     double S[LN + 1][6][2 * LN]; /* dx_k/du */
+    double P[LN + 1][6][6];      /* dx_k/dx_0 */
     double xf[LN + 1][6];        /* free response (u = 0) */
     double H[LNV][LNV], g0[LNV]; /* f = 1/2 v'Hv + g0'v + f0 */
     double f0;
@@ -70,7 +75,7 @@ static int lmpc_setup(lw_t* w, int elastic) {
     const int N = w->N, M = w->M, nu2 = 2 * N;
     w->nu2 = nu2;
     w->elastic = elastic;
-    w->n = nu2 + M + (elastic ? 12 : 0);
+    w->n = nu2 + M + (elastic ? 6 : 0);
     const int n = w->n;
     memset(w->S, 0, sizeof(w->S));
     memcpy(w->xf[0], w->x0, sizeof(w->x0));
@@ -89,6 +94,15 @@ static int lmpc_setup(lw_t* w, int elastic) {
             w->S[k + 1][r][2 * k + 1] = B[2 * r + 1];
         }
     }
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) w->P[0][r][c] = r == c ? 1.0 : 0.0;
+    for (int k = 0; k < N; k++)
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++) {
+                double q = 0.0;
+                for (int j = 0; j < 6; j++) q += w->A[36 * k + 6 * r + j] * w->P[k][j][c];
+                w->P[k + 1][r][c] = q;
+            }
     /* cost */
     for (int a = 0; a < n; a++) {
         memset(w->H[a], 0, sizeof(double) * n);
@@ -124,7 +138,7 @@ static int lmpc_setup(lw_t* w, int elastic) {
         }
     for (int j = 0; j < M; j++) w->g0[nu2 + j] = w->qf[j];
     if (elastic)
-        for (int c = 0; c < 12; c++) w->g0[nu2 + M + c] = d->w_elastic;
+        for (int c = 0; c < 6; c++) w->H[nu2 + M + c][nu2 + M + c] = 2.0 * d->w_x0;
     /* rows */
     int m = 0, bad0 = 0;
 #define NEWROW() do { memset(w->J[m], 0, sizeof(double) * n); w->jb[m] = 0.0; } while (0)
@@ -146,22 +160,23 @@ static int lmpc_setup(lw_t* w, int elastic) {
                 continue;
             }
             NEWROW();
+            if (elastic)
+                for (int c = 0; c < 6; c++) w->J[m][nu2 + M + c] = sgn[q] * w->P[i][comp[q]][c];
             for (int a = 0; a < 2 * i; a++) w->J[m][a] = sgn[q] * w->S[i][comp[q]][a];
             w->jb[m] = sgn[q] * w->xf[i][comp[q]] + bnd[q];
             m++;
         }
     }
     for (int j = 0; j < M; j++) { NEWROW(); w->J[m][nu2 + j] = 1.0; m++; }   /* lambd >= 0 (:690) */
-    if (elastic)
-        for (int c = 0; c < 12; c++) { NEWROW(); w->J[m][nu2 + M + c] = 1.0; m++; }
 #undef NEWROW
     w->m = m;
-    /* equalities: x_N - SS lambd (- p + q) = 0 (:691-692), 1'lambd - 1 = 0 (:693) */
+    /* equalities: x_N - SS lambd = 0 (:691-692), 1'lambd - 1 = 0 (:693) */
     for (int r = 0; r < LNE; r++) memset(w->E[r], 0, sizeof(double) * n);
     for (int r = 0; r < 6; r++) {
         for (int a = 0; a < nu2; a++) w->E[r][a] = w->S[N][r][a];
         for (int j = 0; j < M; j++) w->E[r][nu2 + j] = -w->ss[(size_t)r * w->d->n_ss_max + j];
-        if (elastic) { w->E[r][nu2 + M + r] = -1.0; w->E[r][nu2 + M + 6 + r] = 1.0; }
+        if (elastic)
+            for (int c = 0; c < 6; c++) w->E[r][nu2 + M + c] = w->P[N][r][c];
         w->eb[r] = w->xf[N][r];
     }
     for (int j = 0; j < M; j++) w->E[6][nu2 + j] = 1.0;
@@ -173,14 +188,14 @@ static double lmpc_f(const lw_t* w, const double* v) {
     double f = w->f0;
     for (int a = 0; a < w->n; a++) {
         double s = 0.0;
-        for (int b = 0; b < w->nu2; b++) s += w->H[a][b] * v[b];   /* H is zero outside the u block */
+        for (int b = 0; b < w->n; b++) s += w->H[a][b] * v[b];
         f += v[a] * (0.5 * s + w->g0[a]);
     }
     return f;
 }
 
 /* Second linear-algebra route (selected by crx_oracle_lmpc_set_linalg(1)): the block elimination the
- * HIP kernel uses, K_u -> W~ = Phi K_u^-1 Phi' (+ elastic) -> G = D_lambda + SS' W~^-1 SS -> dy_1,
+ * HIP kernel uses, K_u -> W = Phi K_u^-1 Phi' -> G = D_lambda + SS' W^-1 SS -> dy_1,
  * all by Cholesky.  Kept here to bisect kernel/oracle disagreements on the CPU.  w->K holds the
  * lower triangle of K = H + J'Sigma J on entry. */
 static int g_block = 0;
@@ -217,38 +232,30 @@ static void bsub(int n, int ld, const double* L, double* b) {
 }
 
 static int block_solve(lw_t* w, const double* rhs, const double* e, double* dv, double* dy) {
-    const int nu2 = w->nu2, M = w->M, el = w->elastic;
-    static _Thread_local double Ku[2 * LN][2 * LN], Y[6][2 * LN], z[2 * LN], Wt[6][6], T[LM][6], G[LM][LM], bx[6],
-        cl[LM], one[LM], tb[6];
-    for (int a = 0; a < nu2; a++)
-        for (int b = 0; b <= a; b++) Ku[a][b] = w->K[a][b];
-    if (!chol_in(nu2, 2 * LN, &Ku[0][0])) return 0;
+    const int nu2 = w->nu2, M = w->M, nv = nu2 + (w->elastic ? 6 : 0);
+    enum { NVX = 2 * LN + 6 };
+    static _Thread_local double Ku[NVX][NVX], Y[6][NVX], z[NVX], Wt[6][6], T[LM][6], G[LM][LM], bx[6], cl[LM], one[LM], tb[6];
+    int ub[NVX];   /* the "u block": inputs, then (second attempt) the initial-state relaxation w */
+    for (int a = 0; a < nv; a++) ub[a] = a < nu2 ? a : nu2 + M + (a - nu2);
+    for (int a = 0; a < nv; a++)
+        for (int b = 0; b <= a; b++) Ku[a][b] = ub[a] >= ub[b] ? w->K[ub[a]][ub[b]] : w->K[ub[b]][ub[a]];
+    if (!chol_in(nv, NVX, &Ku[0][0])) return 0;
     for (int r = 0; r < 6; r++) {                      /* Y_r = L^-1 Phi_r' */
-        for (int a = 0; a < nu2; a++) Y[r][a] = w->E[r][a];
-        fsub(nu2, 2 * LN, &Ku[0][0], Y[r]);
+        for (int a = 0; a < nv; a++) Y[r][a] = w->E[r][ub[a]];
+        fsub(nv, NVX, &Ku[0][0], Y[r]);
     }
-    for (int a = 0; a < nu2; a++) z[a] = rhs[a];
-    fsub(nu2, 2 * LN, &Ku[0][0], z);
-    const double* Dl = NULL; (void)Dl;
-    double Dp[6], Dq[6];
-    for (int c = 0; c < 6; c++) { Dp[c] = Dq[c] = 0.0; }
+    for (int a = 0; a < nv; a++) z[a] = rhs[ub[a]];
+    fsub(nv, NVX, &Ku[0][0], z);
     for (int r = 0; r < 6; r++) {
         for (int q = 0; q <= r; q++) {
             double s = 0.0;
-            for (int a = 0; a < nu2; a++) s += Y[r][a] * Y[q][a];
+            for (int a = 0; a < nv; a++) s += Y[r][a] * Y[q][a];
             Wt[r][q] = s;
         }
         double s = e[r];
-        for (int a = 0; a < nu2; a++) s += Y[r][a] * z[a];
+        for (int a = 0; a < nv; a++) s += Y[r][a] * z[a];
         bx[r] = s;
     }
-    if (el)
-        for (int c = 0; c < 6; c++) {
-            Dp[c] = w->K[nu2 + M + c][nu2 + M + c];
-            Dq[c] = w->K[nu2 + M + 6 + c][nu2 + M + 6 + c];
-            Wt[c][c] += 1.0 / Dp[c] + 1.0 / Dq[c];
-            bx[c] += -rhs[nu2 + M + c] / Dp[c] + rhs[nu2 + M + 6 + c] / Dq[c];
-        }
     if (!chol_in(6, 6, &Wt[0][0])) return 0;
     fsub(6, 6, &Wt[0][0], bx);                         /* L_w^-1 b_x */
     for (int j = 0; j < M; j++) {
@@ -275,25 +282,20 @@ static int block_solve(lw_t* w, const double* rhs, const double* e, double* dv, 
     double dy1 = (s1 + e[6]) / s2;
     for (int i = 0; i < M; i++) dv[nu2 + i] = cl[i] - one[i] * dy1;
     dy[6] = dy1;
-    /* dy_x = W~^-1 (b_x - SS dlam) */
-    for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < 6; c++) {                      /* dy_x = W^-1 (b_x - SS dlam) */
         double s = 0.0;
         for (int i = 0; i < M; i++) s += T[i][c] * dv[nu2 + i];
         tb[c] = bx[c] - s;
     }
     bsub(6, 6, &Wt[0][0], tb);
     for (int c = 0; c < 6; c++) dy[c] = tb[c];
-    for (int a = 0; a < nu2; a++) {
+    for (int a = 0; a < nv; a++) {
         double s = z[a];
         for (int r = 0; r < 6; r++) s -= Y[r][a] * dy[r];
-        dv[a] = s;
+        z[a] = s;
     }
-    bsub(nu2, 2 * LN, &Ku[0][0], dv);
-    if (el)
-        for (int c = 0; c < 6; c++) {
-            dv[nu2 + M + c] = (rhs[nu2 + M + c] + dy[c]) / Dp[c];
-            dv[nu2 + M + 6 + c] = (rhs[nu2 + M + 6 + c] - dy[c]) / Dq[c];
-        }
+    bsub(nv, NVX, &Ku[0][0], z);
+    for (int a = 0; a < nv; a++) dv[ub[a]] = z[a];
     return 1;
 }
 
@@ -336,7 +338,7 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
         }
         for (int a = 0; a < n; a++) {
             double s = w->g0[a];
-            for (int b = 0; b < w->nu2; b++) s += w->H[a][b] * w->v[b];
+            for (int b = 0; b < n; b++) s += w->H[a][b] * w->v[b];
             g[a] = s;
         }
         double nus = 0.0, ys = 0.0;
@@ -408,8 +410,9 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
                 for (int b = 0; b <= a; b++) { Mo[a][b] = w->K[a][b]; Mo[b][a] = w->K[a][b]; }
                 for (int r = 0; r < LNE; r++) { Mo[a][n + r] = w->E[r][a]; Mo[n + r][a] = w->E[r][a]; }
             }
-            for (int r = 0; r < LNE; r++)
+            for (int r = 0; r < LNE; r++) {
                 for (int q = 0; q < LNE; q++) Mo[n + r][n + q] = 0.0;
+            }
             for (int a = 0; a < nk; a++) {
                 double mx = 0.0;
                 for (int b = 0; b < nk; b++) mx = fmax(mx, fabs(Mo[a][b]));
@@ -558,9 +561,7 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
                 lmpc_setup(w, 1);
                 lmpc_ipm(w, &r);
                 total += r.iters;
-                double el = 0.0;
-                for (int c = 0; c < 12; c++) el += fabs(w->v[w->nu2 + w->M + c]);
-                if (r.status == CRX_CONVERGED && (el > 1e-7 || bad0)) r.status = CRX_INFEASIBLE;
+                if (r.status == CRX_CONVERGED) r.status = CRX_INFEASIBLE;   /* the reference's (pinned) QP was not solved */
             }
             double* Xb = X + (size_t)(N + 1) * 6 * b;
             double* Ub = U + (size_t)N * 2 * b;
@@ -569,13 +570,12 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
                 for (int c = 0; c < 6; c++) {
                     double s = w->xf[k][c];
                     for (int a = 0; a < 2 * k; a++) s += w->S[k][c][a] * w->v[a];
+                    if (w->elastic)   /* the plan starts from the relaxed initial state */
+                        for (int j = 0; j < 6; j++) s += w->P[k][c][j] * w->v[w->nu2 + w->M + j];
                     Xb[6 * k + c] = s;
                 }
             for (int j = 0; j < Mx; j++) lambda[(size_t)Mx * b + j] = j < w->M ? w->v[w->nu2 + j] : 0.0;
-            double el = 0.0;
-            if (w->elastic)
-                for (int c = 0; c < 12; c++) el += w->v[w->nu2 + w->M + c];
-            cost[b] = r.cost - (w->elastic ? d->w_elastic * el : 0.0);   /* the reference's cost, without the elastic term */
+            cost[b] = r.cost;
             status[b] = r.status; kkt[b] = r.kkt; iters[b] = total;
         }
         free(w);

@@ -4,6 +4,10 @@ test_mpccbf_racing      the scenario of the reference's tests/auto_mpccbf_test.p
                         MPC-CBF at vt = 0.8, two scripted cars), written against the SAME import names; the
                         reference asserts nothing, so the properties its CBF is designed to give are checked
                         instead: the run completes, the ego overtakes, and never enters the unsafe set.
+test_racing_game        the scenario of the reference's tests/auto_racing_game_test.py:11-113 (PID lap, mpc-lti lap,
+                        learning-MPC lap, learning-MPC + overtaking of two cars), same import names: laps 0 and 1
+                        step by step against the reference's own closed loop, the first LMPC steps likewise, all
+                        four laps complete with falling lap times and no contact.
 test_overtake_step      planner fan-out + selection + tracking NLP through OvertakeTrajPlanner /
                         control.mpc_multi_agents on the scenarios recorded from the reference (planner.npz):
                         same direction_flag, same trajectory, same applied input.
@@ -145,3 +149,115 @@ def test_overtake_step(golden_planner):
         np.testing.assert_allclose(x_pred[:, [0, 4, 5]], g["mma_x_pred"][:, [0, 4, 5]], atol=1e-5, err_msg=name)
         checked += 1
     assert checked >= 7
+
+
+def test_racing_game(capsys):
+    import sympy as sp
+
+    from control.lmpc_helper import LMPCPrediction
+    from racing import offboard
+    from utils import base, racing_env
+    from utils.constants import X_DIM
+
+    # ---- reference tests/auto_racing_game_test.py:11-45 ----
+    track_spec = np.genfromtxt(conftest.ROOT + "/data/track_layout/l_shape.csv", delimiter=",")
+    track = racing_env.ClosedTrack(track_spec, track_width=1.0)
+    lap_number = 4
+    opti_traj_xcurv = np.genfromtxt(conftest.ROOT + "/data/optimal_traj/xcurv_l_shape.csv", delimiter=",")
+    opti_traj_xglob = np.genfromtxt(conftest.ROOT + "/data/optimal_traj/xglob_l_shape.csv", delimiter=",")
+    num_veh, alpha, timestep = 2, 0.8, 1.0 / 10.0
+    # set_up_ego (:116-135)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
+    ego.set_timestep(timestep)
+    pid_controller = offboard.PIDTracking(vt=0.7, eyt=0.0)
+    pid_controller.set_timestep(timestep)
+    ego.set_ctrl_policy(pid_controller)
+    pid_controller.set_track(track)
+    ego.set_state_curvilinear(np.zeros((X_DIM,)))
+    ego.set_state_global(np.zeros((X_DIM,)))
+    ego.start_logging()
+    ego.set_track(track)
+    mpc_lti_controller = offboard.MPCTracking(base.MPCTrackingParam(vt=0.7, eyt=0.0), ego.system_param)
+    mpc_lti_controller.set_timestep(timestep)
+    mpc_lti_controller.set_track(track)
+    ego.set_zero_noise()
+    # set_up_lmpc (:138-147)
+    time_lmpc = 10000 * timestep
+    lmpc_param = base.LMPCRacingParam(timestep=timestep, lap_number=lap_number, time_lmpc=time_lmpc)
+    racing_game_param = base.RacingGameParam(timestep=timestep, alpha=alpha, num_horizon_planner=10)
+    lmpc_controller = offboard.LMPCRacingGame(lmpc_param, racing_game_param=racing_game_param, system_param=ego.system_param)
+    lmpc_controller.set_track(track)
+    lmpc_controller.set_timestep(timestep)
+    lmpc_controller.set_opti_traj(opti_traj_xcurv, opti_traj_xglob)
+    lmpc_controller.openloop_prediction = LMPCPrediction(lap_number=lap_number)
+    simulator = offboard.CarRacingSim()
+    simulator.set_timestep(timestep)
+    simulator.set_track(track)
+    simulator.add_vehicle(ego)
+    simulator.set_opti_traj(opti_traj_xglob)
+    t_symbol = sp.symbols("t")
+    vehicles = []
+    for index in range(num_veh):   # set_up_other_vehicles (:150-159)
+        vehicles.append(offboard.NoDynamicsModel(name="car" + str(index + 1), param=base.CarParam(edgecolor="orange")))
+        vehicles[index].set_track(track)
+    pid_controller.set_racing_sim(simulator)
+    mpc_lti_controller.set_racing_sim(simulator)
+    lmpc_controller.set_racing_sim(simulator)
+    lmpc_controller.set_vehicles_track()
+    # ---- :46-100 ----
+    for iter in range(lap_number):
+        if iter == 0:
+            simulator.sim(sim_time=90, one_lap=True, one_lap_name="ego")
+        elif iter == 1:
+            ego.set_ctrl_policy(mpc_lti_controller)
+            simulator.sim(sim_time=90, one_lap=True, one_lap_name="ego")
+        elif iter == 2:
+            lmpc_controller.add_trajectory(ego, 0)
+            lmpc_controller.add_trajectory(ego, 1)
+            ego.set_ctrl_policy(lmpc_controller)
+            simulator.sim(sim_time=time_lmpc, one_lap=True, one_lap_name="ego")
+            ego.ctrl_policy.add_trajectory(ego, 2)
+        else:
+            if iter == 3:
+                for index in range(0, num_veh):
+                    vehicles[index].set_state_curvilinear_func(
+                        t_symbol, (0.7 + index * 0.02) * t_symbol + 5.5 + index * 2, -0.5 + index * 0.3 + 0.0 * t_symbol)
+                    vehicles[index].start_logging()
+                    simulator.add_vehicle(vehicles[index])
+                ego.solver_time, ego.all_local_trajs, ego.all_splines = [], [], []
+                ego.xcurv_log, ego.lmpc_prediction, ego.mpc_cbf_prediction = [], [], []
+            simulator.sim(sim_time=time_lmpc, one_lap=True, one_lap_name="ego")
+            ego.ctrl_policy.add_trajectory(ego, iter)
+    simulator.plot_simulation()
+    simulator.plot_state("ego")
+    simulator.plot_input("ego")
+    simulator.animate(filename="racing_game_m_shape", ani_time=50, racing_game=True, imagemagick=True)
+
+    out = capsys.readouterr().out
+    g = np.load(conftest.GOLDEN + "/racing_game.npz")
+    # laps 0 (PID) and 1 (mpc-lti, 260 GPU solves in closed loop) against the reference's own run
+    for lap, tol in ((0, 1e-12), (1, 1e-5)):
+        mine, ref = np.array(ego.xcurvs[lap]), g["lap%d/xcurv" % lap]
+        assert mine.shape == ref.shape
+        np.testing.assert_allclose(mine, ref, atol=tol)
+        np.testing.assert_allclose(np.array(ego.inputs[lap]), g["lap%d/u" % lap], atol=max(tol, 1e-5))
+    assert bool(g["lti_success"].all())
+    # learning-MPC lap: every step up to the reference's first infeasible QP (its model cannot reach the safe set)
+    n = int(g["lmpc_first_uncertified"])
+    np.testing.assert_allclose(np.array(ego.xcurvs[2])[:n + 1], g["lmpc/x"][:n + 1], atol=1e-5)
+    np.testing.assert_allclose(np.array(ego.inputs[2])[:n], g["lmpc/U"][:n, 0], atol=1e-5)
+    # the game: four laps, learning shortens them
+    lap_time = [lmpc_controller.Qfun[0, i] * timestep for i in range(lmpc_controller.iter)]
+    assert lmpc_controller.iter == 4 and ego.laps == 4
+    assert lap_time[0] > lap_time[1] > lap_time[2] > lap_time[3], lap_time
+    assert lap_time[2] < 20.0 and lap_time[3] < 15.0
+    # overtaking lap: the planner was used, both cars were passed, no contact (super-ellipse of :527-536 >= 1)
+    assert out.count("overtaking") >= 10
+    e3 = np.array(ego.xcurvs[3])
+    L = track.lap_length
+    for car in vehicles:
+        c = np.array(car.xcurv_log)[: len(e3) - 1]
+        ds = (e3[1:len(c) + 1, 4] - c[:, 4] + 0.5 * L) % L - 0.5 * L
+        dey = e3[1:len(c) + 1, 5] - c[:, 5]
+        assert ds[0] < 0 < ds[-1], (car.name, ds[0], ds[-1])
+        assert ((ds / 0.4) ** 6 + (dey / 0.2) ** 6).min() >= 1.0, car.name

@@ -117,3 +117,57 @@ def test_bezier_sort_and_bounds_vs_reference(golden_planner):
         while want[i] > lap:
             want[i] -= lap
     np.testing.assert_allclose(hostprep.wrap_above(s, lap), want, atol=1e-12)
+
+
+def test_lmpc_regression_and_safe_set(golden_racing_game):
+    """control/lmpc_helper.py against the LTV models the reference's own regression produced in its
+    LMPC lap (reference lmpc_helper.py:26-189 driven by utils/base.py:585-622), replayed call by
+    call: linearisation points from the previous solution, safe set extended by add_point.
+
+    The reference's normal equations are ill-conditioned by construction (vy ~ 0.1 wz along the whole
+    data set, lamb = 0: cond(Q) reaches 3e11), so individual coefficients are only determined to
+    ~cond*eps ~ 1e-4 relative -- between ANY two LAPACK routes, cvxopt's included.  What the fit
+    predicts at its own query point is well determined and must agree tightly."""
+    import os
+
+    from control import lmpc_helper
+    from utils import racing_env
+
+    g = golden_racing_game
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(root, "data/track_layout/l_shape.csv"), delimiter=","),
+                                   track_width=1.0)
+    n = g["ss/ss0"].shape[0]
+    ss, us = np.full((n + 100, 6, 4), 10000.0), np.full((n + 100, 2, 4), 10000.0)
+    ss[:n], us[:n] = g["ss/ss0"], g["ss/u0"]
+    time_ss, N, L = g["ss/time_ss"], 12, float(g["lap_length"])
+    # cost-to-go of the two stored laps (reference compute_cost + the count-down past the line)
+    for lap in (0, 1):
+        T = int(time_ss[lap])
+        q = lmpc_helper.compute_cost(ss[:T + 1, :, lap], us[:T, :, lap], L)
+        np.testing.assert_array_equal(q, g["ss/Qfun0"][:T + 1, lap])
+    lin_points, lin_input = ss[1:N + 2, :, 0].copy(), us[1:N + 1, :, 0].copy()
+    for c in range(int(g["lmpc_first_uncertified"]) + 1):
+        for i in range(N):
+            Ai, Bi, Ci, _ = lmpc_helper.regression_and_linearization(
+                lin_points, lin_input, range(0, 2), ss, us, time_ss, 40, None, None, track.point_and_tangent, 0.1, i)
+            Ag, Bg, Cg = g["lmpc/A"][c, i], g["lmpc/B"][c, i], g["lmpc/C"][c, i]
+            # kinematic rows are closed-form
+            np.testing.assert_allclose(Ai[3:], Ag[3:], atol=1e-12)
+            np.testing.assert_allclose(Ci[3:, 0], Cg[3:], atol=1e-12)
+            scale = max(1.0, np.abs(Ag).max())
+            assert np.abs(Ai - Ag).max() <= (1e-8 if c < 2 else 2e-5) * scale, (c, i)
+            pred = Ai @ lin_points[i] + Bi @ lin_input[i] + Ci[:, 0]
+            pred_g = Ag @ lin_points[i] + Bg @ lin_input[i] + Cg
+            np.testing.assert_allclose(pred, pred_g, atol=1e-5)
+        # safe-set selection: the points the reference put into the QP at this call
+        sel, qsel = [], []
+        for jj in range(2):
+            p, q = lmpc_helper.select_points(ss, g["ss/Qfun0"], 2 - jj - 1, g["lmpc/x"][c], 44 / 2, 0)
+            sel.append(p), qsel.append(q)
+        np.testing.assert_array_equal(np.concatenate(sel, axis=1), g["lmpc/ss"][c])
+        np.testing.assert_array_equal(np.concatenate(qsel), g["lmpc/qfun"][c])
+        X, U = g["lmpc/X"][c], g["lmpc/U"][c]
+        lin_points, lin_input = np.concatenate((X[1:], X[-1:]), axis=0), np.vstack((U[1:], U[-1]))
+        ss[time_ss[1] + c + 1, :, 1] = g["lmpc/x"][c] + np.array([0, 0, 0, 0, L, 0])
+        us[time_ss[1] + c + 1, :, 1] = U[0]
