@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X: NLP solves/s (N=12, 6-state bicycle).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|lmpc]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident
 in HBM.  Default workload = BASELINE.json configs[1]: MPC-CBF NLP (control/control.py:476-607 of
 the reference), 1 obstacle, batch 256, N = 12 -- per GPU (weak scaling: the batch shards by problem,
 no data-path collective).  `--workload cfg3` = 1024 planner scenarios x 4 region QPs + region
 selection per GPU, followed by ONE all-gather of the winning trajectories (the only exchange step
-the path has); cfg4 = 16384 tracking NLPs, N = 20, 3 obstacles.
+the path has); cfg4 = 16384 tracking NLPs, N = 20, 3 obstacles; lmpc (not a
+BASELINE config) = 4096 learning-MPC QPs (control.py:610-730): the certified instances recorded from the
+reference's LMPC lap (tests/golden/racing_game.npz), tiled.
 
 Rank 0 prints ONE JSON line.  `value` counts every problem handed to the solver per second of the
 timed region, whole job (all GPUs); converged fraction and KKT bound are reported beside it.
@@ -36,6 +38,8 @@ def algorithmic_bytes(workload, N, n_obs):
     """doubles in + doubles out per solve, times 8."""
     if workload == "cfg3":
         return (11 * N + 18) * 8                                   # a1: 1200 B at N = 12
+    if workload == "lmpc":                                          # n_obs carries M here
+        return (8 + 54 * N + 7 * n_obs + 1 + 6 * (N + 1) + 2 * N + n_obs + 3) * 8   # 8912 B at N = 12, M = 44
     tgt = (N + 1) if workload == "cfg4" else 0                      # per-stage ey target
     d_in = 6 + 6 + 2 * n_obs * (N + 1) + n_obs + tgt
     d_out = 6 * (N + 1) + 2 * N + n_obs * (N + 1) + 3
@@ -47,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "lmpc"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scenario-filter", action="store_true",
@@ -81,7 +85,26 @@ def main():
         t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         return t.to(dtype) if dtype is not None else t
 
-    if wl in ("cfg2", "cfg4"):
+    if wl == "lmpc":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
+        ok = np.nonzero(g["lmpc_success"])[0]
+        batch = args.batch or 4096
+        idx = ok[(np.arange(batch) + 7 * rank) % len(ok)]
+        N, M = g["lmpc/A"].shape[1], g["lmpc/ss"].shape[2]
+        desc = abi.lmpc_desc(N=N, n_ss_max=M)
+        p = dict(x0=g["lmpc/x"][idx], u_old=g["lmpc/u_old"][idx], A=g["lmpc/A"][idx].reshape(batch, N, 36),
+                 B=g["lmpc/B"][idx].reshape(batch, N, 12), C=g["lmpc/C"][idx], ss=g["lmpc/ss"][idx], qfun=g["lmpc/qfun"][idx],
+                 n_ss=np.full(batch, M, dtype=np.int32))
+        n_obs = M
+        t_in = [to_dev(p[k]) for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun")] + [to_dev(p["n_ss"], torch.int32)]
+        ws = torch_api.LmpcWorkspace(desc, batch, dev)
+        units = batch
+
+        def step():
+            torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
+
+        name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, batch)
+    elif wl in ("cfg2", "cfg4"):
         if wl == "cfg2":
             batch = args.batch or 256
             p = synth.cfg2_mpccbf(batch, N=12, seed=2 + seed_shift, safe_start=not args.no_scenario_filter)
@@ -148,6 +171,8 @@ def main():
     for _ in range(min(50, max(5, args.steps))):
         if wl == "cfg3":
             torch_api.planner_solve_dev(desc, *t_in, ws=ws)
+        elif wl == "lmpc":
+            torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
         else:
             torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
         kms.append(L.crx_last_kernel_ms())
@@ -171,6 +196,10 @@ def main():
     nz = nx + nu
     flop_iter = N * (2 * nx * nx * nz + 2 * nx * nz * nz + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nu * nx * (nx + 1)) \
         + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
+    if wl == "lmpc":   # Cholesky of K_u (2N) and G (M), 7 + 2 carried right-hand sides, assembly of K_u and G
+        nu2, M = 2 * N, n_obs
+        flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + M ** 3 / 3 + 2 * 2 * M * M + 6 * M * M + 4 * (N - 1) * nu2 * nu2 / 2 \
+            + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
 
     traffic = None
@@ -185,15 +214,16 @@ def main():
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3}[wl], "batch_per_gpu": int(batch),
-                   "horizon": int(N), "n_obs": int(n_obs), "tol": desc.opts.tol,
+        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3, "lmpc": None}[wl], "batch_per_gpu": int(batch),
+                   "horizon": int(N), "n_obs": 0 if wl == "lmpc" else int(n_obs), "n_ss": int(n_obs) if wl == "lmpc" else 0,
+                   "tol": desc.opts.tol,
                    "scenario_filter": not args.no_scenario_filter,
                    "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
                    "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
                    "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
+                     "kernel": "crx_lmpc_kernel" if wl == "lmpc" else "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
                      "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
                      "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS},
     }
@@ -217,6 +247,9 @@ def cpu_baseline(wl, desc, p, batch):
     if wl == "cfg3":
         a = (p["x0"][:n], p["bez_s"][:n], p["bez_ey"][:n], p["ey_lb"][:n], p["ey_ub"][:n])
         fn = lambda: orc.planner_solve(desc, *a)  # noqa: E731
+    elif wl == "lmpc":
+        a = tuple(p[k][:n] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss"))
+        fn = lambda: orc.lmpc_solve(desc, *a)  # noqa: E731
     else:
         a = (p["x0"][:n], p["xt"][:n], p["obs_s"][:n], p["obs_ey"][:n], p["lap_off"][:n], p["n_obs"][:n])
         fn = lambda: orc.cbf_solve(desc, *a)  # noqa: E731
@@ -226,7 +259,7 @@ def cpu_baseline(wl, desc, p, batch):
         fn()
         reps += 1
         el = time.perf_counter() - t0
-        if el > 3.0 or reps >= 200:
+        if el > 8.0 or reps >= 400:
             break
     try:
         import casadi  # noqa: F401

@@ -112,3 +112,36 @@ def select_dev(desc, n_veh, X, obs_s, obs_ey, old_flag, ws=None):
     _call("crx_select_dev", C.byref(desc), C.c_int(S), _ptr(n_veh), _ptr(X), _ptr(obs_s), _ptr(obs_ey),
           _ptr(old_flag), _ptr(ws.flag), _ptr(ws.sel_cost), _ptr(ws.best_X), _stream())
     return ws
+
+
+class LmpcWorkspace:
+    def __init__(self, desc, batch, device):
+        N, M = desc.N, desc.n_ss_max
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.X = torch.empty((batch, N + 1, 6), **f64)
+        self.U = torch.empty((batch, N, 2), **f64)
+        self.lam = torch.empty((batch, M), **f64)
+        self.cost = torch.empty(batch, **f64)
+        self.kkt = torch.empty(batch, **f64)
+        self.status = torch.empty(batch, **i32)
+        self.iters = torch.empty(batch, **i32)
+
+
+def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None):
+    """crx_lmpc_solve_dev.  n_ss must satisfy 1 <= n_ss <= desc.n_ss_max (checked here on the host copy the
+    caller keeps; the kernel indexes LDS with it)."""
+    N, M, Bn = desc.N, desc.n_ss_max, x0.shape[0]
+    _chk(x0, torch.float64, (Bn, 6), "x0")
+    _chk(u_old, torch.float64, (Bn, 2), "u_old")
+    _chk(A, torch.float64, (Bn, N, 36), "A")
+    _chk(B, torch.float64, (Bn, N, 12), "B")
+    _chk(Cm, torch.float64, (Bn, N, 6), "C")
+    _chk(ss, torch.float64, (Bn, 6, M), "ss")
+    _chk(qfun, torch.float64, (Bn, M), "qfun")
+    _chk(n_ss, torch.int32, (Bn,), "n_ss")
+    ws = ws or LmpcWorkspace(desc, Bn, x0.device)
+    _call("crx_lmpc_solve_dev", C.byref(desc), C.c_int(Bn), _ptr(x0), _ptr(u_old), _ptr(A), _ptr(B), _ptr(Cm),
+          _ptr(ss), _ptr(qfun), _ptr(n_ss), _ptr(ws.X), _ptr(ws.U), _ptr(ws.lam), _ptr(ws.cost), _ptr(ws.status),
+          _ptr(ws.kkt), _ptr(ws.iters), _stream())
+    return ws
