@@ -37,6 +37,8 @@ struct crx_lmpc_kparams {
     const int32_t* n_ss;
     double *X, *U, *lambda, *cost, *kkt;
     int32_t *status, *iters;
+    double* trace;   // optional per-iteration phase cycles of ONE problem (diagnostics): trace[it][16]
+    int trace_problem, trace_rows;
 };
 
 struct crx_select_kparams {
@@ -55,6 +57,6 @@ hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
-size_t crx_lmpc_lds_bytes(int N);
+size_t crx_lmpc_lds_bytes(int N, int n_ss_max);
 #endif
 #endif

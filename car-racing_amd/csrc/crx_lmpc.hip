@@ -36,15 +36,14 @@
 template <int NMAX>
 struct LL {
     static constexpr int NU2 = 2 * NMAX + 6 /* inputs + initial-state relaxation */, LDK = NU2 + 1, KR = NU2 + 7;
-    static constexpr int MS = CRX_MAX_SS, LDG = MS + 1, GR = MS + 2;
+    static constexpr int MS = CRX_MAX_SS;
     static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS;
     // offsets in doubles
     static constexpr int A = 0, B = A + 36 * NMAX, C = B + 12 * NMAX, xf = C + 6 * NMAX;
     static constexpr int S = xf + 6 * (NMAX + 1);              // S[(k*6+c)*NU2 + a], k = 0..NMAX
     static constexpr int Hu = S + 6 * (NMAX + 1) * NU2;        // NU2 x NU2, row-major, stride NU2
     static constexpr int K = Hu + NU2 * NU2;                   // KR x LDK
-    static constexpr int G = K + KR * LDK;                     // GR x LDG
-    static constexpr int SS = G + GR * LDG;                    // [6][MS]
+    static constexpr int SS = K + KR * LDK;                    // [6][MS]
     static constexpr int qf = SS + 6 * MS, T = qf + MS;        // T[j*6+c]
     static constexpr int u = T + 6 * MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
     static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS, cl = rl + MS;
@@ -53,8 +52,9 @@ struct LL {
     static constexpr int t = ig + MS, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
     static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
     static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
-    static constexpr int END = Fph + LMAXF;
-    static constexpr size_t BYTES = (size_t)END * 8;
+    static constexpr int G = Fph + LMAXF;                      // (n_ss_max + 2) x ldg, sized at launch (last region)
+    static constexpr int ldg(int n_ss_max) { return (n_ss_max + 1) | 1; }   // odd stride: conflict-free row-per-lane access
+    static constexpr size_t bytes(int n_ss_max) { return (size_t)(G + (n_ss_max + 4) * ldg(n_ss_max)) * 8; }   // +2 rows: the blocked Cholesky reads (not uses) up to row n+2
 };
 
 struct LCtx {
@@ -79,6 +79,7 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
             int comp = q ? 5 : 0;
             double s = LDS(L::xf + 6 * k + comp);
             const int so = L::S + (k * 6 + comp) * L::NU2;
+#pragma unroll 4
             for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
             for (int a = x.nu2; a < x.nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
             cv = q == 0 ? kp.v_max - s : (q == 1 ? kp.ey_max - s : s + kp.ey_max);
@@ -106,6 +107,7 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
         for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + (x.N * 6 + c6) * L::NU2 + a), LDS(L::y + c6), s);
         if (a < x.nu2) s -= LDS(wo + 4 * i + 2 * cc) - LDS(wo + 4 * i + 2 * cc + 1);
         // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo)
+#pragma unroll 4
         for (int k = a < x.nu2 ? i + 1 : 1; k < x.N; k++) {
             s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a), LDS(L::w0 + k), s);
             s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s);
@@ -123,34 +125,70 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
 
 // left-looking Cholesky, in place, of the leading n x n block (lower triangle) of a row-major array
 // (stride LD); rows n..n+extra-1 are carried along, i.e. forward-substituted right-hand sides.
-// Lane i owns row i.  Returns 0 if a pivot is not positive.
-template <int LD>
-__device__ __forceinline__ int l_chol(double* sm, int base, int inv, int n, int extra, int lane) {
-    int ok = 1;
+// Lane i owns row i.  Blocked by 4 columns: the panel product against all finished columns is one long
+// loop of independent LDS reads (own row entry + 4 broadcast entries per k), the 4x4 diagonal block is
+// finished in registers with v_readlane broadcasts -- one LDS round trip per 4 columns instead of per
+// column.  Returns 0 if a pivot is not positive.
+__device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int n, int extra, int lane) {
     const int rows = n + extra;
     const int ri = base + lane * LD;
-    for (int j = 0; j < n; j++) {
-        double s = 0.0;
-        if (lane >= j && lane < rows) {
-            s = sm[ri + j];
-            const int rj = base + j * LD;
-#pragma unroll 4
-            for (int k = 0; k < j; k++) s = fma(-sm[ri + k], sm[rj + k], s);
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        const bool mine = lane >= j0 && lane < rows;
+        double s[4], l[4];
+        const int r0 = base + j0 * LD;
+#pragma unroll
+        for (int c = 0; c < 4; c++) s[c] = (mine && j0 + c < n) ? sm[ri + j0 + c] : 0.0;
+        if (mine) {
+#pragma unroll 2
+            for (int k = 0; k < j0; k++) {
+                const double a = sm[ri + k];
+#pragma unroll
+                for (int c = 0; c < 4; c++) s[c] = fma(-a, sm[r0 + c * LD + k], s[c]);   // rows j0+c <= n+2: inside the array
+            }
         }
-        const double d = lane_f64(s, j);
-        if (!(d > 0.0)) { ok = 0; break; }
-        const double rinv = frsqrt(d);
-        if (lane >= j && lane < rows) sm[ri + j] = lane == j ? d * rinv : s * rinv;
-        if (lane == 0) sm[inv + j] = rinv;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = j0 + c;
+            if (j < n) {
+#pragma unroll
+                for (int cc = 0; cc < c; cc++) s[c] = fma(-l[cc], lane_f64(l[cc], j), s[c]);
+                const double d = lane_f64(s[c], j);
+                if (!(d > 0.0)) return 0;
+                const double rinv = frsqrt(d);
+                l[c] = lane == j ? d * rinv : s[c] * rinv;
+                if (lane >= j && lane < rows) sm[ri + j] = l[c];
+                if (lane == 0) sm[inv + j] = rinv;
+            } else {
+                l[c] = 0.0;
+            }
+        }
         SYNC();
     }
-    return ok;
+    return 1;
 }
 
-// x <- L^-T x for `NR` right-hand sides held one entry per lane (lane i = entry i), L as above
-template <int LD, int NR>
-__device__ __forceinline__ void l_backsub(const double* sm, int base, int inv, int n, int lane, double* b) {
-    for (int j = n - 1; j >= 0; j--) {
+// x <- L^-T x for `NR` right-hand sides held one entry per lane (lane i = entry i), L as above.  The
+// LDS operands of four steps are fetched ahead of the dependent readlane/fma chain.
+template <int NR>
+__device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, int inv, int n, int lane, double* b) {
+    int j = n - 1;
+    for (; j >= 3; j -= 4) {
+        double rinv[4], lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rinv[q] = sm[inv + j - q];
+            lj[q] = lane < j - q ? sm[base + (j - q) * LD + lane] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double xj = lane_f64(b[r], j - q) * rinv[q];
+                if (lane == j - q) b[r] = xj;
+                b[r] = fma(-lj[q], xj, b[r]);
+            }
+    }
+    for (; j >= 0; j--) {
         const double rinv = sm[inv + j];
         const double lj = lane < j ? sm[base + j * LD + lane] : 0.0;
 #pragma unroll
@@ -173,7 +211,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     x.N = kp.N;
     x.nu2 = 2 * kp.N;
     x.M = kp.n_ss[pb];
-    const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max;
+    const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max, ldg = L::ldg(Mx);
     const crx_ipm_opts& o = kp.opts;
 
     // ---- load the problem (coalesced) --------------------------------------------------------------
@@ -320,10 +358,15 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         status = CRX_MAX_ITER;
         f = f0;
         for (it = 0;; it++) {
+            long long tk[14];
+            int tn = 0;
+#define TICK() do { if (kp.trace) tk[tn++] = clock64(); } while (0)
+            TICK();
             // ---- rows, gradient, equality residual ----
             l_rows<NMAX>(sm, x, kp);
             if (lane < nv) {
                 double s = LDS(L::g0u + lane);
+#pragma unroll 8
                 for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::u + b), s);
                 LDS(L::gu + lane) = s;
             }
@@ -332,15 +375,19 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 if (lane < 6) {
                     s = LDS(L::xf + 6 * N + lane);
                     const int so = L::S + (N * 6 + lane) * L::NU2;
+#pragma unroll 8
                     for (int a = 0; a < nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
+#pragma unroll 8
                     for (int j = 0; j < M; j++) s = fma(-LDS(L::SS + lane * L::MS + j), LDS(L::lam + j), s);
                 } else {
                     s = -1.0;
+#pragma unroll 8
                     for (int j = 0; j < M; j++) s += LDS(L::lam + j);
                 }
                 LDS(L::e + lane) = s;
             }
             SYNC();
+            TICK();   // 1
             // ---- error measure ----
             l_lagr<NMAX>(sm, x, kp, L::nu);
             double nus = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
@@ -372,6 +419,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             E0 = fmax(e_d, fmax(e_p, e_c));
             if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
             if (it >= o.max_iter) break;
+            TICK();   // 2
             // ---- barrier update ----
             for (;;) {
                 double e_cm = 0.0;
@@ -383,6 +431,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 } else
                     break;
             }
+            TICK();   // 3
             const double tau = fmax(o.tau_min, 1.0 - mu);
             // ---- Sigma (in dnu), omega = mu/t - Sigma rp (in wv); rhs = -(g + E'y - J'omega) ----
             for (int r = lane; r < m; r += WAVE) {
@@ -399,6 +448,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::w5 + lane) = LDS(L::dnu + r + 1) + LDS(L::dnu + r + 2);
             }
             SYNC();
+            TICK();   // 4
             // ---- K_u (lower triangle) + extra rows Phi (6) and rhs_u ----
             for (int en = lane; en < nv * (nv + 1) / 2; en += WAVE) {
                 int a = (int)((sqrt(8.0 * en + 1.0) - 1.0) * 0.5);
@@ -407,6 +457,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const int b = en - a * (a + 1) / 2;
                 double s = LDS(L::Hu + a * L::NU2 + b);
                 if (a == b && a < nu2) s += LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1)) + LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1) + 1);
+#pragma unroll 4
                 for (int k = a < nu2 ? (a >> 1) + 1 : 1; k < N; k++) {
                     s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a) * LDS(L::w0 + k), LDS(L::S + (k * 6 + 0) * L::NU2 + b), s);
                     s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a) * LDS(L::w5 + k), LDS(L::S + (k * 6 + 5) * L::NU2 + b), s);
@@ -418,7 +469,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::K + (nv + r) * L::LDK + j) = r < 6 ? LDS(L::S + (N * 6 + r) * L::NU2 + j) : -LDS(L::ru + j);
             }
             SYNC();
-            int ok = l_chol<L::LDK>(sm, L::K, L::ik, nv, 7, lane);
+            TICK();   // 5
+            int ok = l_chol(sm, L::K, L::LDK, L::ik, nv, 7, lane);
+            TICK();   // 6
             if (!ok) break;
             // ---- W~ and b_x ----
             if (lane < 27) {
@@ -427,6 +480,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     int r = 0, q = lane;
                     while (q > r) { q -= r + 1; r++; }   // lane -> (r, q), q <= r
                     const int ro = L::K + (nv + r) * L::LDK, qo = L::K + (nv + q) * L::LDK;
+#pragma unroll 8
                     for (int j = 0; j < nv; j++) s = fma(LDS(ro + j), LDS(qo + j), s);
                     LDS(L::Wt + 6 * r + q) = s;
                     LDS(L::Wt + 6 * q + r) = s;
@@ -434,6 +488,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     const int r = lane - 21;
                     s = LDS(L::e + r);
                     const int ro = L::K + (nv + r) * L::LDK, zo = L::K + (nv + 6) * L::LDK;
+#pragma unroll 8
                     for (int j = 0; j < nv; j++) s = fma(LDS(ro + j), LDS(zo + j), s);
                     LDS(L::bx + r) = s;
                 }
@@ -477,27 +532,37 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::cl + lane) = s;
             }
             SYNC();
+            TICK();   // 7
             // ---- G = D_lambda + T T' (lower triangle, lane i = row i) with extra rows cl and 1 ----
             if (lane < M) {
-                const int go = L::G + lane * L::LDG;
-                for (int j = 0; j <= lane; j++) {
-                    double s = 0.0;
+                const int go = L::G + lane * ldg;
+                const double dl = LDS(L::dnu + x.r_lam + lane);
+                for (int j0 = 0; j0 <= lane; j0 += 4) {   // rows past `lane` are fetched (neighbouring LDS words) but never stored
+                    double sv[4];
 #pragma unroll
-                    for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], LDS(L::T + 6 * j + c6), s);
-                    LDS(go + j) = s;
+                    for (int q = 0; q < 4; q++) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], LDS(L::T + 6 * (j0 + q) + c6), s);
+                        sv[q] = j0 + q == lane ? s + dl : s;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (j0 + q <= lane) LDS(go + j0 + q) = sv[q];
                 }
-                LDS(go + lane) += LDS(L::dnu + x.r_lam + lane);
-                LDS(L::G + M * L::LDG + lane) = LDS(L::cl + lane);
-                LDS(L::G + (M + 1) * L::LDG + lane) = 1.0;
+                LDS(L::G + M * ldg + lane) = LDS(L::cl + lane);
+                LDS(L::G + (M + 1) * ldg + lane) = 1.0;
             }
             SYNC();
-            ok = l_chol<L::LDG>(sm, L::G, L::ig, M, 2, lane);
+            TICK();   // 8
+            ok = l_chol(sm, L::G, ldg, L::ig, M, 2, lane);
+            TICK();   // 9
             if (!ok) break;
             {
                 double b2[2];
-                b2[0] = lane < M ? LDS(L::G + M * L::LDG + lane) : 0.0;
-                b2[1] = lane < M ? LDS(L::G + (M + 1) * L::LDG + lane) : 0.0;
-                l_backsub<L::LDG, 2>(sm, L::G, L::ig, M, lane, b2);
+                b2[0] = lane < M ? LDS(L::G + M * ldg + lane) : 0.0;
+                b2[1] = lane < M ? LDS(L::G + (M + 1) * ldg + lane) : 0.0;
+                l_backsub<2>(sm, L::G, ldg, L::ig, M, lane, b2);
                 const double s1 = wave_sum(lane < M ? b2[0] : 0.0), s2 = wave_sum(lane < M ? b2[1] : 0.0);
                 const double dy1 = (s1 + LDS(L::e + 6)) / s2;
                 const double dl = lane < M ? b2[0] - b2[1] * dy1 : 0.0;
@@ -526,10 +591,11 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nv + r) * L::LDK + lane), dyx[r], s);
                     b1[0] = s;
                 }
-                l_backsub<L::LDK, 1>(sm, L::K, L::ik, nv, lane, b1);
+                l_backsub<1>(sm, L::K, L::LDK, L::ik, nv, lane, b1);
                 if (lane < nv) LDS(L::du + lane) = b1[0];
             }
             SYNC();
+            TICK();   // 10
             // ---- row steps ----
             double rp_max = 0.0, rd_max = 0.0, Dphi = 0.0;
             for (int r = lane; r < m; r += WAVE) {
@@ -540,6 +606,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 } else if (r < x.r_lam) {
                     const int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
                     double s = 0.0;
+#pragma unroll 4
                     for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
                     for (int a = nu2; a < nv; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
                     jd = q == 2 ? s : -s;
@@ -563,6 +630,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const double d = LDS(L::du + lane);
                 gdv = LDS(L::gu + lane) * d;
                 double s = 0.0;
+#pragma unroll 8
                 for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::du + b), s);
                 qd = s * d;
             }
@@ -583,6 +651,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 theta_min = 1e-4 * fmax(1.0, theta);
                 theta_max = 1e4 * fmax(1.0, theta);
             }
+            TICK();   // 11
             // ---- filter line search (all rows linear: c(v + al dv) = c + al J dv) ----
             double al = a_p, fn = f;
             int acc = 0, ftype = 0;
@@ -621,6 +690,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 nf++;
             }
             if (!acc) break;
+            TICK();   // 12
             // ---- accept ----
             double numax = 0.0;
             for (int r = lane; r < m; r += WAVE) {
@@ -639,6 +709,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             f = fn;
             numax = wave_max(numax);
             SYNC();
+            TICK();   // 13
+            if (kp.trace && pb == kp.trace_problem && lane == 0 && total_it + it < kp.trace_rows) {
+                double* tr = kp.trace + (size_t)(total_it + it) * 16;
+                for (int q = 0; q < 13; q++) tr[q] = (double)(tk[q + 1] - tk[q]);
+                tr[13] = (double)(tk[13] - tk[0]);
+                tr[14] = mu;
+                tr[15] = al;
+            }
             if (numax > 1e12 && theta > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
         }
         total_it += it;
@@ -670,7 +748,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
 
 template <int NMAX>
 static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
-    const size_t bytes = LL<NMAX>::BYTES;
+    const size_t bytes = LL<NMAX>::bytes(kp.n_ss_max);
     hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(crx_lmpc_kernel<NMAX>, dim3(kp.batch), dim3(WAVE), bytes, st, kp);
@@ -682,5 +760,5 @@ hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     return kp.N <= 12 ? launch_l<12>(kp, st) : launch_l<CRX_LMPC_MAX_N>(kp, st);
 }
 
-size_t crx_lmpc_lds_bytes(int N) { return N <= 12 ? LL<12>::BYTES : LL<CRX_LMPC_MAX_N>::BYTES; }
-static_assert(LL<CRX_LMPC_MAX_N>::BYTES <= 160 * 1024, "LDS budget");
+size_t crx_lmpc_lds_bytes(int N, int n_ss_max) { return N <= 12 ? LL<12>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N>::bytes(n_ss_max); }
+static_assert(LL<CRX_LMPC_MAX_N>::bytes(CRX_MAX_SS) <= 160 * 1024, "LDS budget");
