@@ -22,8 +22,8 @@
  *     for every inequality (CasADi Opti passes all constraints as general g), monotone
  *     Fiacco-McCormick barrier update (eq. 7), fraction-to-the-boundary rule (eq. 15), primal-dual
  *     Newton step with inertia correction by W + delta_w*I (Alg. IC), multiplier safeguard (eq. 16),
- *     gradient-based constraint scaling (sec. 3.8), error measure E_mu (eq. 5); IPOPT's filter is
- *     replaced by an l1-merit backtracking line search and there is no restoration phase.
+ *     gradient-based constraint scaling (sec. 3.8), error measure E_mu (eq. 5), filter line search
+ *     (sec. 2.3) without second-order correction; there is no restoration phase.
  *     Because the dynamics are linear and x0 is fixed, states are eliminated (condensing) and the
  *     reduced Newton system is factorised by a DENSE Cholesky -- on purpose a different linear-algebra
  *     route from the HIP kernel's Riccati recursion, so that agreement between the two is evidence.
