@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "lmpc"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-prep", action="store_true",
+                    help="cfg3: start each step from the raw scenarios (crx_planner_prep on the device) instead of prepared QP arrays")
     ap.add_argument("--no-scenario-filter", action="store_true",
                     help="keep doomed / unsafe-start scenarios in the synthetic batch (DESIGN.md section 6)")
     args = ap.parse_args()
@@ -136,14 +138,24 @@ def main():
         sws = torch_api.SelectWorkspace(sdesc, n_scen, dev)
         gathered = torch.empty((world * n_scen, N + 1, 6), dtype=torch.float64, device=dev) if world > 1 else None
         units = batch
+        if args.device_prep:
+            w = p["raw"]
+            pdesc = abi.prep_desc(N, V, len(w["opt_s"]), w["track_width"], w["lap_length"])
+            t_raw = [to_dev(w["x"]), to_dev(w["x"]), to_dev(w["n_veh"], torch.int32), to_dev(w["veh_info"]), to_dev(w["max_dv"]),
+                     to_dev(w["obs_s"]), to_dev(w["obs_ey"]), to_dev(w["opt_s"]), to_dev(w["opt_ey"])]
+            pws = torch_api.PrepWorkspace(pdesc, n_scen, dev)
+            t_in = [pws.x0, pws.bez_s, pws.bez_ey, pws.ey_lb, pws.ey_ub]
 
         def step():
+            if args.device_prep:
+                torch_api.planner_prep_dev(pdesc, *t_raw, ws=pws)
             torch_api.planner_solve_dev(desc, *t_in, ws=ws)
             torch_api.select_dev(sdesc, t_sel[0], ws.X.view(n_scen, V + 1, N + 1, 6), t_sel[1], t_sel[2], t_sel[3], ws=sws)
             if world > 1:  # the path's only exchange: winners to every rank (RCCL all-gather over xGMI)
                 dist.all_gather_into_tensor(gathered, sws.best_X)
 
-        name = "overtake planner: %d scenarios x %d region QPs (overtake_traj_planner.py:248-379) + selection (:205-246), N=12, per GPU" % (n_scen, V + 1)
+        name = "overtake planner: %d scenarios x %d region QPs (overtake_traj_planner.py:248-379) + selection (:205-246), N=12, per GPU%s" % (
+            n_scen, V + 1, "; Bezier references and ey bounds built on the device from the raw scenarios" if args.device_prep else "")
 
     def sync_all():
         if world > 1:

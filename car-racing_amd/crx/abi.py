@@ -93,6 +93,23 @@ class LmpcDesc(C.Structure):
     ]
 
 
+class PrepDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("n_veh_max", C.c_int32),
+        ("n_opt", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("prediction_factor", C.c_double),
+        ("lookahead", C.c_double),
+        ("track_width", C.c_double),
+        ("lap_length", C.c_double),
+        ("veh_length", C.c_double),
+        ("veh_width", C.c_double),
+        ("safety_margin", C.c_double),
+        ("dt_ref", C.c_double),
+    ]
+
+
 class SelectDesc(C.Structure):
     _fields_ = [
         ("N", C.c_int32),
@@ -139,6 +156,12 @@ def lmpc_desc(N=12, n_ss_max=44, Q=(0.0,) * 6, R=(1.0, 0.25), dR=(4.0, 0.0), x_t
                     _arr(C.c_double, 6, x_track), v_max, ey_max, delta_max, a_max, w_x0, opts or default_opts())
 
 
+def prep_desc(N, n_veh_max, n_opt, track_width, lap_length, prediction_factor=0.5, veh_length=0.4, veh_width=0.2):
+    """planner_helper.py:51-53 and overtake_traj_planner.py:288,296 literals."""
+    return PrepDesc(int(N), int(n_veh_max), int(n_opt), 0, prediction_factor, 4.0, track_width, lap_length,
+                    veh_length, veh_width, 0.15, 0.1)
+
+
 def select_desc(N, n_veh_max, lap_length, veh_length=0.4, veh_width=0.2):
     """overtake_traj_planner.py:209,223,243 literals."""
     return SelectDesc(int(N), int(n_veh_max), veh_length, veh_width, lap_length, 10.0, 100.0, 100.0)
@@ -164,7 +187,7 @@ class Binding:
 
     def __init__(self, lib, prefix):
         self.lib, self.prefix = lib, prefix
-        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve"):
+        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve", "planner_prep"):
             if hasattr(lib, prefix + name):
                 getattr(lib, prefix + name).restype = C.c_int
         self._check = None
@@ -289,4 +312,22 @@ class Binding:
             _p(n_ss), _p(out["X"]), _p(out["U"]), _p(out["lam"]), _p(out["cost"]), _p(out["status"]),
             _p(out["kkt"]), _p(out["iters"]),
         )
+        return out
+
+    def planner_prep(self, desc, x_wrapped, x_raw, n_veh, veh_info, max_dv, obs_s, obs_ey, opt_s, opt_ey):
+        """crx_planner_prep: Bezier references + ey bounds of every region, in crx_planner_solve's layout."""
+        N, V, T = desc.N, desc.n_veh_max, desc.n_opt
+        n_veh = np.ascontiguousarray(n_veh, dtype=_I)
+        S = n_veh.shape[0]
+        R = V + 1
+        x_wrapped, x_raw = _in(x_wrapped, _D, (S, 6)), _in(x_raw, _D, (S, 6))
+        veh_info = _in(veh_info, _D, (S, V, 3))
+        max_dv = _in(max_dv, _D, (S,))
+        obs_s, obs_ey = _in(obs_s, _D, (S, V, N + 1)), _in(obs_ey, _D, (S, V, N + 1))
+        opt_s, opt_ey = _in(opt_s, _D, (T,)), _in(opt_ey, _D, (T,))
+        out = dict(x0=np.zeros((S * R, 6)), bez_s=np.zeros((S * R, N + 1)), bez_ey=np.zeros((S * R, N + 1)),
+                   ey_lb=np.zeros((S * R, N)), ey_ub=np.zeros(S * R))
+        self._call("planner_prep", C.byref(desc), C.c_int(S), _p(x_wrapped), _p(x_raw), _p(n_veh), _p(veh_info),
+                   _p(max_dv), _p(obs_s), _p(obs_ey), _p(opt_s), _p(opt_ey), _p(out["x0"]), _p(out["bez_s"]),
+                   _p(out["bez_ey"]), _p(out["ey_lb"]), _p(out["ey_ub"]))
         return out

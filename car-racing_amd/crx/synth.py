@@ -117,16 +117,12 @@ def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True):
     return p
 
 
-def cfg3_planner(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_SHAPE):
-    """Overtake-planner scenarios: ego + V surrounding vehicles in the front interest window
-    (planner_helper.py:231-236), constant-speed predictions; all V+1 region QPs per scenario
-    (overtake_traj_planner.py:182-197) and the selection inputs (:205-246).
-
-    Returns the crx_planner_solve arrays with batch = n_scen*(V+1) (scenario-major, region minor)
-    plus the per-scenario selection arrays."""
+def cfg3_raw(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_SHAPE):
+    """Raw overtake-planner scenarios, i.e. what OvertakeTrajPlanner.get_local_traj has in hand before
+    its host prep (overtake_traj_planner.py:66-92): ego + V surrounding vehicles in the front interest
+    window (planner_helper.py:231-236), constant-speed predictions.  veh_info rows (s, max ey, min ey)
+    are in ITERATION order (quirk Q4), predictions in the reference's partial ey order (quirk Q3)."""
     from planning import planner_helper as ph
-
-    from . import hostprep
 
     rng = np.random.default_rng(np.random.PCG64(seed))
     opt = np.genfromtxt(os.path.join(_ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
@@ -138,23 +134,40 @@ def cfg3_planner(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP
     dv = np.abs(x[:, 0, None] - v_o)
     s_o = x[:, 4, None] + rng.uniform(0.0, 1.0, (n_scen, V)) * (4.5 * 0.4 + 0.5 * dv)
     ey_o = _lanes(rng, (n_scen, V))
-    bez = np.zeros((n_scen, R, N + 1, 2))
     obs_s = np.zeros((n_scen, V, N + 1))
     obs_ey = np.zeros((n_scen, V, N + 1))
     for i in range(n_scen):
         order = ph.sort_by_ey(list(range(V)), lambda n: ey_o[i, n])
-        # veh_infos in ITERATION order (quirk Q4); predictions in SORTED order
-        vi = np.stack([s_o[i], ey_o[i], ey_o[i]], axis=1)
-        cp = ph.bezier_control_points(V, vi, dv[i].max(), 0.5, track_width, lap_length, 0.2, opt, x[i])
-        bez[i] = ph.bezier_polylines(cp, N)
         for k, n in enumerate(order):
             obs_s[i, k] = s_o[i, n] + 0.1 * j * v_o[i, n]
             obs_ey[i, k] = ey_o[i, n]
-    n_veh = np.full(n_scen, V, dtype=np.int32)
-    lb, ub = hostprep.planner_ey_bounds(x, obs_s, obs_ey, n_veh, track_width, lap_length, N)
+    return dict(
+        x=x, veh_info=np.stack([s_o, ey_o, ey_o], axis=2), max_dv=dv.max(axis=1), obs_s=obs_s, obs_ey=obs_ey,
+        n_veh=np.full(n_scen, V, dtype=np.int32), opt_s=np.ascontiguousarray(opt[:, 4]),
+        opt_ey=np.ascontiguousarray(opt[:, 5]), opt=opt, N=N, V=V, n_scen=n_scen, track_width=track_width,
+        lap_length=lap_length, old_flag=rng.integers(-1, R, n_scen).astype(np.int32),
+    )
+
+
+def cfg3_planner(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_SHAPE):
+    """cfg3_raw + the HOST prep of the mirror (planner_helper / hostprep): the crx_planner_solve arrays
+    with batch = n_scen*(V+1) (scenario-major, region minor) plus the per-scenario selection arrays
+    (overtake_traj_planner.py:182-197, :205-246).  crx_planner_prep produces the same arrays on the device."""
+    from planning import planner_helper as ph
+
+    from . import hostprep
+
+    w = cfg3_raw(n_scen, N, seed, V, track_width, lap_length)
+    R = V + 1
+    x = w["x"]
+    bez = np.zeros((n_scen, R, N + 1, 2))
+    for i in range(n_scen):
+        cp = ph.bezier_control_points(V, w["veh_info"][i], w["max_dv"][i], 0.5, track_width, lap_length, 0.2, w["opt"], x[i])
+        bez[i] = ph.bezier_polylines(cp, N)
+    lb, ub = hostprep.planner_ey_bounds(x, w["obs_s"], w["obs_ey"], w["n_veh"], track_width, lap_length, N)
     return dict(
         x0=np.repeat(x, R, axis=0), bez_s=bez[..., 0].reshape(n_scen * R, N + 1),
         bez_ey=bez[..., 1].reshape(n_scen * R, N + 1), ey_lb=lb.reshape(n_scen * R, N),
-        ey_ub=ub.reshape(n_scen * R), N=N, V=V, n_scen=n_scen, n_veh=n_veh, obs_s=obs_s, obs_ey=obs_ey,
-        old_flag=rng.integers(-1, R, n_scen).astype(np.int32), lap_length=lap_length,
+        ey_ub=ub.reshape(n_scen * R), N=N, V=V, n_scen=n_scen, n_veh=w["n_veh"], obs_s=w["obs_s"], obs_ey=w["obs_ey"],
+        old_flag=w["old_flag"], lap_length=lap_length, raw=w,
     )

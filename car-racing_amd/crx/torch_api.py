@@ -145,3 +145,34 @@ def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None):
           _ptr(ss), _ptr(qfun), _ptr(n_ss), _ptr(ws.X), _ptr(ws.U), _ptr(ws.lam), _ptr(ws.cost), _ptr(ws.status),
           _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws
+
+
+class PrepWorkspace:
+    """Outputs of planner_prep_dev = inputs of planner_solve_dev (same layout)."""
+
+    def __init__(self, desc, n_scen, device):
+        N, R = desc.N, desc.n_veh_max + 1
+        f64 = dict(dtype=torch.float64, device=device)
+        self.x0 = torch.empty((n_scen * R, 6), **f64)
+        self.bez_s = torch.empty((n_scen * R, N + 1), **f64)
+        self.bez_ey = torch.empty((n_scen * R, N + 1), **f64)
+        self.ey_lb = torch.empty((n_scen * R, N), **f64)
+        self.ey_ub = torch.empty((n_scen * R,), **f64)
+
+
+def planner_prep_dev(desc, x_wrapped, x_raw, n_veh, veh_info, max_dv, obs_s, obs_ey, opt_s, opt_ey, ws=None):
+    N, V, T, S = desc.N, desc.n_veh_max, desc.n_opt, x_wrapped.shape[0]
+    _chk(x_wrapped, torch.float64, (S, 6), "x_wrapped")
+    _chk(x_raw, torch.float64, (S, 6), "x_raw")
+    _chk(n_veh, torch.int32, (S,), "n_veh")
+    _chk(veh_info, torch.float64, (S, V, 3), "veh_info")
+    _chk(max_dv, torch.float64, (S,), "max_dv")
+    _chk(obs_s, torch.float64, (S, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (S, V, N + 1), "obs_ey")
+    _chk(opt_s, torch.float64, (T,), "opt_s")
+    _chk(opt_ey, torch.float64, (T,), "opt_ey")
+    ws = ws or PrepWorkspace(desc, S, x_wrapped.device)
+    _call("crx_planner_prep_dev", C.byref(desc), C.c_int(S), _ptr(x_wrapped), _ptr(x_raw), _ptr(n_veh), _ptr(veh_info),
+          _ptr(max_dv), _ptr(obs_s), _ptr(obs_ey), _ptr(opt_s), _ptr(opt_ey), _ptr(ws.x0), _ptr(ws.bez_s),
+          _ptr(ws.bez_ey), _ptr(ws.ey_lb), _ptr(ws.ey_ub), _stream())
+    return ws

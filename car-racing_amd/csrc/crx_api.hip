@@ -428,6 +428,94 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     return CRX_OK;
 }
 
+// ---- planner host prep on the device ---------------------------------------------------------------
+void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, double track_width, double lap_length) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->n_veh_max = n_veh_max; d->n_opt = n_opt;
+    d->prediction_factor = 0.5; d->lookahead = 4.0; d->track_width = track_width; d->lap_length = lap_length;
+    d->veh_length = 0.4; d->veh_width = 0.2; d->safety_margin = 0.15; d->dt_ref = 0.1;
+}
+
+static int fill_prep(crx_prep_kparams& pp, const crx_prep_desc* d, int n_scen) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 3 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [3,%d]", d->N, CRX_MAX_N);
+    if (d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [0,%d]", d->n_veh_max, CRX_MAX_OBS);
+    if (d->n_opt < 2) return fail(CRX_ERR_ARG, "n_opt < 2");
+    if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
+    if (!(d->lap_length > 0.0) || !(d->track_width > 0.0)) return fail(CRX_ERR_ARG, "lap_length and track_width must be positive");
+    memset(&pp, 0, sizeof(pp));
+    pp.N = d->N; pp.V = d->n_veh_max; pp.n_scen = n_scen; pp.n_opt = d->n_opt;
+    pp.prediction_factor = d->prediction_factor; pp.lookahead = d->lookahead; pp.track_width = d->track_width;
+    pp.lap_length = d->lap_length; pp.veh_length = d->veh_length; pp.veh_width = d->veh_width;
+    pp.safety_margin = d->safety_margin; pp.dt_ref = d->dt_ref;
+    return 0;
+}
+
+int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wrapped, const double* x_raw,
+                         const int32_t* n_veh, const double* veh_info, const double* max_dv, const double* obs_s,
+                         const double* obs_ey, const double* opt_s, const double* opt_ey, double* x0, double* bez_s,
+                         double* bez_ey, double* ey_lb, double* ey_ub, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    crx_prep_kparams pp;
+    if (int rc = fill_prep(pp, d, n_scen)) return rc;
+    if (n_scen == 0) return CRX_OK;
+    if (!x_wrapped || !x_raw || !n_veh || !max_dv || !opt_s || !opt_ey || !x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub ||
+        (d->n_veh_max > 0 && (!veh_info || !obs_s || !obs_ey)))
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    pp.x_wrapped = x_wrapped; pp.x_raw = x_raw; pp.n_veh = n_veh; pp.veh_info = veh_info; pp.max_dv = max_dv;
+    pp.obs_s = obs_s; pp.obs_ey = obs_ey; pp.opt_s = opt_s; pp.opt_ey = opt_ey;
+    pp.x0 = x0; pp.bez_s = bez_s; pp.bez_ey = bez_ey; pp.ey_lb = ey_lb; pp.ey_ub = ey_ub;
+    hipError_t e = crx_launch_prep(pp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "prep launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_planner_prep(const crx_prep_desc* d, int n_scen, const double* x_wrapped, const double* x_raw,
+                     const int32_t* n_veh, const double* veh_info, const double* max_dv, const double* obs_s,
+                     const double* obs_ey, const double* opt_s, const double* opt_ey, double* x0, double* bez_s,
+                     double* bez_ey, double* ey_lb, double* ey_ub) {
+    if (int rc = ensure_init()) return rc;
+    crx_prep_kparams chk;
+    if (int rc = fill_prep(chk, d, n_scen)) return rc;
+    if (n_scen == 0) return CRX_OK;
+    if (!x_wrapped || !x_raw || !n_veh || !max_dv || !opt_s || !opt_ey || !x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub ||
+        (d->n_veh_max > 0 && (!veh_info || !obs_s || !obs_ey)))
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    for (int i = 0; i < n_scen; i++)
+        if (n_veh[i] < 0 || n_veh[i] > d->n_veh_max) return fail(CRX_ERR_ARG, "n_veh[%d]=%d outside [0,%d]", i, n_veh[i], d->n_veh_max);
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t S = (size_t)n_scen, N = (size_t)d->N, V = (size_t)d->n_veh_max, R = V + 1, T = (size_t)d->n_opt;
+    const size_t n_vi = S * V * 3, n_ob = S * V * (N + 1), n_bz = S * R * (N + 1), n_lb = S * R * N;
+    if (int rc = g_in.ensure((S * 13 + n_vi + 2 * n_ob + 2 * T) * 8 + S * 4 + 12 * 256)) return rc;
+    if (int rc = g_out.ensure((S * R * 7 + 2 * n_bz + n_lb) * 8 + 8 * 256)) return rc;
+    Carver ci(g_in.p), co(g_out.p);
+    double* dxw = ci.take<double>(S * 6); double* dxr = ci.take<double>(S * 6); double* dmd = ci.take<double>(S);
+    double* dvi = ci.take<double>(n_vi + 1); double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1);
+    double* dts = ci.take<double>(T); double* dte = ci.take<double>(T); int32_t* dnv = ci.take<int32_t>(S);
+    double* dx0 = co.take<double>(S * R * 6); double* dbs = co.take<double>(n_bz); double* dbe = co.take<double>(n_bz);
+    double* dlb = co.take<double>(n_lb); double* dub = co.take<double>(S * R);
+    HIP_TRY(hipMemcpyAsync(dxw, x_wrapped, S * 48, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dxr, x_raw, S * 48, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dmd, max_dv, S * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dnv, n_veh, S * 4, hipMemcpyHostToDevice, g_stream));
+    if (V > 0) {
+        HIP_TRY(hipMemcpyAsync(dvi, veh_info, n_vi * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dts, opt_s, T * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dte, opt_ey, T * 8, hipMemcpyHostToDevice, g_stream));
+    if (int rc = crx_planner_prep_dev(d, n_scen, dxw, dxr, dnv, dvi, dmd, dos, doe, dts, dte, dx0, dbs, dbe, dlb, dub, g_stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(x0, dx0, S * R * 48, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(bez_s, dbs, n_bz * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(bez_ey, dbe, n_bz * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(ey_lb, dlb, n_lb * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(ey_ub, dub, S * R * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return CRX_OK;
+}
+
 // ---- learning-MPC QP ------------------------------------------------------------------------------
 void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max) {
     memset(d, 0, sizeof(*d));

@@ -51,11 +51,20 @@ struct crx_select_kparams {
     double *sel_cost, *best_X;
 };
 
+struct crx_prep_kparams {
+    int N, V, n_scen, n_opt;
+    double prediction_factor, lookahead, track_width, lap_length, veh_length, veh_width, safety_margin, dt_ref;
+    const double *x_wrapped, *x_raw, *veh_info, *max_dv, *obs_s, *obs_ey, *opt_s, *opt_ey;
+    const int32_t* n_veh;
+    double *x0, *bez_s, *bez_ey, *ey_lb, *ey_ub;
+};
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
 size_t crx_lmpc_lds_bytes(int N, int n_ss_max);
 #endif

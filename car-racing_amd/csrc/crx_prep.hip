@@ -1,0 +1,87 @@
+// crx_prep.hip -- planner host prep on the device: Bezier references and
+// per-stage ey bounds of every region of a scenario, written in the layout crx_solve_kernel<0> reads.
+// One wavefront per scenario, lanes over (region, sample).  Closed-form arithmetic, HBM-bound
+// (reads ~ (12 + 3V + 2V(N+1)) doubles, writes (V+1)(6 + 3N + 3) doubles per scenario).
+//
+// Restates (paths into /root/reference/car_racing):
+//   planning/planner_helper.py:43-135   get_bezier_control_points
+//   planning/planner_helper.py:138-153  get_bezier_curve, sampled at t = j/N (overtake_traj_planner.py:105-111)
+//   planning/overtake_traj_planner.py:277-324  ey bounds with the obstacle windows (quirks Q2, Q5)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "crx_kparams.h"
+#include "crx_wave.h"
+
+// scipy interp1d(kind="linear") (searchsorted-left, index clipped to [1,n-1], slope form), as used at
+// planner_helper.py:121-134
+__device__ __forceinline__ double prep_interp(const double* xs, const double* ys, int n, double x) {
+    int lo = 0, hi = n;   // first index with xs[i] >= x
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (xs[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    int i1 = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const int i0 = i1 - 1;
+    const double slope = (ys[i1] - ys[i0]) / (xs[i1] - xs[i0]);
+    return slope * (x - xs[i0]) + ys[i0];
+}
+
+__global__ void __launch_bounds__(WAVE) crx_prep_kernel(const crx_prep_kparams pp) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= pp.n_scen) return;
+    const int N = pp.N, V = pp.V, R = V + 1, nv = pp.n_veh[s];
+    const double* xw = pp.x_wrapped + (size_t)6 * s;
+    const double* vi = pp.veh_info + (size_t)3 * V * s;
+    const double L = pp.lap_length, vw = pp.veh_width, tw = pp.track_width;
+    // control points in s (:49-85)
+    const double s0 = xw[4];
+    double s3 = s0 + pp.prediction_factor * pp.max_dv[s] + pp.lookahead, span;
+    if (s0 > s3) { span = s3 + L - s0; s3 = s3 + L; } else { span = s3 - s0; }
+    const double s1 = span / 3.0 + s0, s2 = 2.0 * span / 3.0 + s0;
+    // end point rides the optimal trajectory (:121-134)
+    const double s_end = s3 >= L ? s3 - L : s3;
+    const double e3 = s_end <= pp.opt_s[0] ? pp.opt_ey[0] : prep_interp(pp.opt_s, pp.opt_ey, pp.n_opt, s_end);
+    const double e0 = xw[5];   // :95 overrides :87-94
+    for (int e = lane; e < R * (N + 1); e += WAVE) {
+        const int r = e / (N + 1), j = e - r * (N + 1);
+        const int rr = r > nv ? nv : r;   // regions beyond this scenario's vehicles repeat the last one (never selected)
+        double e12;
+        if (rr == 0) e12 = 0.8 * tw - (-vi[3 * rr + 1] - 0.5 * vw) * 0.2;                       // :98-104
+        else if (rr == nv) e12 = -0.8 * tw + (vi[3 * (rr - 1) + 1] - 0.5 * vw) * 0.2;           // :106-112
+        else e12 = 0.7 * (vi[3 * rr + 1] + 0.5 * vw) + 0.3 * (vi[3 * (rr - 1) + 1] - 0.5 * vw);   // :113-119
+        const double t = j * (1.0 / N), u = 1.0 - t;
+        const double b0 = pow(u, 3.0), b1 = 3.0 * t * (u * u), b2 = 3.0 * (t * t) * u, b3 = pow(t, 3.0);   // :139-146
+        const size_t o = ((size_t)s * R + r) * (N + 1) + j;
+        pp.bez_s[o] = s0 * b0 + s1 * b1 + s2 * b2 + s3 * b3;
+        pp.bez_ey[o] = e0 * b0 + e12 * b1 + e12 * b2 + e3 * b3;
+    }
+    // ey bounds (:277-324): both neighbours impose ey >= ey_obs + W + margin inside their s-window (quirk Q2)
+    const double ub = tw - 0.5 * vw, win = pp.veh_length + pp.safety_margin;
+    for (int e = lane; e < R * N; e += WAVE) {
+        const int r = e / N, k = e - r * N;
+        const double s_nom = xw[4] + (k * pp.dt_ref) * xw[0];                                   // :296 (wrapped copy, Q5)
+        double lb = -ub;
+        for (int side = 0; side < 2; side++) {
+            const int v = side == 0 ? r - 1 : r;                                                // sorted[r-1], sorted[r]
+            if (v < 0 || v >= nv) continue;
+            double os = pp.obs_s[((size_t)s * V + v) * (N + 1) + k];
+            while (os > L) os -= L;                                                             // :291-292
+            if (s_nom >= os - win && s_nom <= os + win)
+                lb = fmax(lb, pp.obs_ey[((size_t)s * V + v) * (N + 1) + k] + vw + pp.safety_margin);
+        }
+        pp.ey_lb[((size_t)s * R + r) * N + k] = lb;
+    }
+    for (int e = lane; e < R * 6; e += WAVE) {
+        const int r = e / 6, c = e - 6 * r;
+        pp.x0[((size_t)s * R + r) * 6 + c] = pp.x_raw[(size_t)6 * s + c];                      // :266 (raw state, Q5)
+    }
+    if (lane < R) pp.ey_ub[(size_t)s * R + lane] = ub;
+}
+
+hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st) {
+    if (pp.n_scen == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_prep_kernel, dim3(pp.n_scen), dim3(WAVE), 0, st, pp);
+    return hipGetLastError();
+}

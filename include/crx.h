@@ -151,6 +151,22 @@ typedef struct crx_select_desc {
     double w_switch;       /* 100 (:243) */
 } crx_select_desc;
 
+/* ---- planner host prep on the device (planner_helper.py:43-153, overtake_traj_planner.py:277-324) ---- */
+typedef struct crx_prep_desc {
+    int32_t N;             /* num_horizon_planner */
+    int32_t n_veh_max;     /* leading dimension V of the per-vehicle arrays; regions R = V + 1 */
+    int32_t n_opt;         /* rows of the optimal-trajectory table (data/optimal_traj/xcurv_*.csv) */
+    int32_t reserved0;
+    double prediction_factor; /* 0.5  racing_game_param.planning_prediction_factor (planner_helper.py:51-53) */
+    double lookahead;      /* 4.0  literal in the end point s3 = s0 + factor * max|dv| + 4 (:51-53) */
+    double track_width;    /* track.width */
+    double lap_length;
+    double veh_length;     /* 0.4 */
+    double veh_width;      /* 0.2 */
+    double safety_margin;  /* 0.15 (overtake_traj_planner.py:288) */
+    double dt_ref;         /* 0.1  literal time step of the window test (:296) */
+} crx_prep_desc;
+
 /* library management */
 int crx_version(void);
 /* device >= 0: HIP device ordinal.  There is no CPU back-end in this library: a missing device is
@@ -165,6 +181,7 @@ void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const
 void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B);
 void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length);
 void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max);
+void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, double track_width, double lap_length);
 
 /*
  * Planner region QPs.  One problem per (scenario, region).
@@ -224,6 +241,30 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
                          const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status,
                          double* kkt, int32_t* iters, int32_t* flag, double* sel_cost, double* best_X,
                          void* stream);
+
+/*
+ * Planner host prep on the device: per scenario, the cubic Bezier reference of
+ * every region (planner_helper.get_bezier_control_points :43-135 and get_bezier_curve :138-153, sampled
+ * as overtake_traj_planner.py:105-111) and the per-stage ey bounds with the obstacle windows
+ * (overtake_traj_planner.py:277-324, quirks Q2/Q5), written directly in the layout crx_planner_solve reads.
+ *   x_wrapped [S][6]   start-line-wrapped ego state (xcurv_ego: control points :49,95 and window test :296)
+ *   x_raw     [S][6]   ego.xcurv as stored on the vehicle (becomes x0 of every region, :266, quirk Q5)
+ *   n_veh     [S]      vehicles of interest, 0..V
+ *   veh_info  [S][V][3] rows (s, max ey over the prediction, min ey) in ITERATION order (quirk Q4, :87-92)
+ *   max_dv    [S]      agent_info.max_delta_v (planner_helper.py:177-201)
+ *   obs_s, obs_ey [S][V][N+1]  predictions of the SORTED vehicles
+ *   opt_s, opt_ey [n_opt]      columns 4 and 5 of the optimal-trajectory table (shared by all scenarios;
+ *                              precondition: the end point s3 lies inside the table, else the reference raises)
+ * outputs, S*(V+1) leading dimension, scenario-major: x0 [.][6], bez_s, bez_ey [.][N+1], ey_lb [.][N], ey_ub [.]
+ */
+int crx_planner_prep(const crx_prep_desc* d, int n_scen, const double* x_wrapped, const double* x_raw,
+                     const int32_t* n_veh, const double* veh_info, const double* max_dv, const double* obs_s,
+                     const double* obs_ey, const double* opt_s, const double* opt_ey, double* x0, double* bez_s,
+                     double* bez_ey, double* ey_lb, double* ey_ub);
+int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wrapped, const double* x_raw,
+                         const int32_t* n_veh, const double* veh_info, const double* max_dv, const double* obs_s,
+                         const double* obs_ey, const double* opt_s, const double* opt_ey, double* x0,
+                         double* bez_s, double* bez_ey, double* ey_lb, double* ey_ub, void* stream);
 
 /*
  * Learning-MPC QPs: control.lmpc (control.py:610-730) after its safe-set

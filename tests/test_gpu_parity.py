@@ -180,6 +180,62 @@ def test_golden_lmpc(gpu, orc, golden_racing_game):
     np.testing.assert_array_equal(r1["X"], rg["X"][3:9])
 
 
+def test_device_prep(gpu, golden_planner):
+    """crx_planner_prep (Bezier references + ey bounds on the device) against the host prep of the mirror
+    (planner_helper / hostprep, themselves pinned to the reference at 1e-13 by test_host_mirror) and
+    against the Bezier polylines the reference itself computed in the recorded scenarios."""
+    import os
+
+    import conftest
+    from crx import abi, hostprep, synth
+    from planning import planner_helper as ph
+
+    p = synth.cfg3_planner(256, N=12)
+    w = p["raw"]
+    d = abi.prep_desc(12, 3, len(w["opt_s"]), w["track_width"], w["lap_length"])
+    r = gpu.planner_prep(d, w["x"], w["x"], w["n_veh"], w["veh_info"], w["max_dv"], w["obs_s"], w["obs_ey"],
+                         w["opt_s"], w["opt_ey"])
+    # pow() in the Bernstein weights may differ from libm's by an ulp
+    np.testing.assert_allclose(r["bez_s"], p["bez_s"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(r["bez_ey"], p["bez_ey"], rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(r["ey_lb"], p["ey_lb"])
+    np.testing.assert_array_equal(r["ey_ub"], p["ey_ub"])
+    np.testing.assert_array_equal(r["x0"], p["x0"])
+    # ragged vehicle counts: regions 0..n_veh match the host prep of a scenario with only those vehicles
+    nv = (np.arange(256) % 4).astype(np.int32)
+    rr = gpu.planner_prep(d, w["x"], w["x"], nv, w["veh_info"], w["max_dv"], w["obs_s"], w["obs_ey"], w["opt_s"], w["opt_ey"])
+    lb, _ = hostprep.planner_ey_bounds(w["x"], w["obs_s"], w["obs_ey"], nv, w["track_width"], w["lap_length"], 12)
+    for i in range(0, 256, 7):
+        n = int(nv[i])
+        if n == 0:
+            continue
+        cp = ph.bezier_control_points(n, w["veh_info"][i, :n], w["max_dv"][i], 0.5, w["track_width"], w["lap_length"], 0.2, w["opt"], w["x"][i])
+        np.testing.assert_allclose(rr["bez_ey"].reshape(256, 4, 13)[i, :n + 1], ph.bezier_polylines(cp, 12)[:, :, 1], rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(rr["ey_lb"].reshape(256, 4, 12)[i, :n + 1], lb[i, :n + 1])
+    # the reference's own polylines
+    opt = np.genfromtxt(os.path.join(conftest.ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
+    for name in golden_planner.names:
+        c = golden_planner.case(name)
+        if not bool(c["overtake_flag"]):
+            continue
+        N = int(c["N"])
+        names = [str(x) for x in c["veh_names"]]
+        interest = [n for n, f in zip(names, c["veh_is_interest"]) if f]
+        xc = {n: c["veh_xcurv"][i] for i, n in enumerate(names)}
+        pred = {str(n): c["obs_pred"][i] for i, n in enumerate(c["sorted_vehicles"])}
+        V = len(interest)
+        vi = np.array([[xc[n][4], pred[n][5].max(), pred[n][5].min()] for n in interest])[None]
+        mdv = np.array([max(abs(c["x_raw"][0] - xc[n][0]) for n in interest)])
+        dg = abi.prep_desc(N, V, opt.shape[0], float(c["width"]), float(c["lap_length"]))
+        g = gpu.planner_prep(dg, c["x_wrapped"][None], c["x_raw"][None], np.array([V], np.int32), vi, mdv,
+                             c["obs_pred"][None, :, 4, :], c["obs_pred"][None, :, 5, :], opt[:, 4].copy(), opt[:, 5].copy())
+        np.testing.assert_allclose(g["bez_s"], c["bezier_xcurvs"][:, :, 0], rtol=0, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(g["bez_ey"], c["bezier_xcurvs"][:, :, 1], rtol=0, atol=1e-13, err_msg=name)
+        dd, args = helpers.planner_inputs(c, *[np.eye(6), np.zeros((6, 2))])
+        np.testing.assert_array_equal(g["ey_lb"], args[3])
+        np.testing.assert_array_equal(g["x0"], args[0])
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 
