@@ -414,6 +414,7 @@ static void ipm_solve(work_t* w, result_t* res) {
             double s = w->g[a];
             for (int j = 0; j < m; j++) s -= w->J[j][a] * w->nu[j];
             rd[a] = s;
+            (void)rd;
             if (fabs(s) > e_d) e_d = fabs(s);
         }
         e_d /= sd;
