@@ -60,6 +60,31 @@ struct DevBuf {
     }
 };
 DevBuf g_in, g_out;  // staging for the host-pointer entry points
+
+// pinned host mirrors of g_in / g_out: a host-pointer call gathers ALL its inputs into one pinned block
+// (one H2D copy), and scatters its outputs from one pinned block (one D2H copy) -- a batch-1 control step
+// is launch-latency bound, and a dozen separate small copies cost more than the solve itself
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 2 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CRX_ERR_HIP, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+PinBuf g_hin, g_hout;
 DevBuf g_trace;
 int g_trace_rows = 0, g_trace_problem = 0;
 
@@ -67,6 +92,51 @@ int ensure_init() {
     if (g_init) return 0;
     return fail(CRX_ERR_NOT_INIT, "crx_init() has not been called (or failed)");
 }
+
+// staging plan of one host-pointer call: in()/out() carve the device buffers and their pinned mirrors
+// at identical offsets; up() / down() move each block once
+struct Stage {
+    size_t oi = 0, oo = 0;
+    struct Back { void* host; size_t off, bytes; };
+    Back backs[16];
+    int nb = 0;
+    int reserve(size_t bytes_in, size_t bytes_out) {
+        bytes_in += 20 * 256; bytes_out += 20 * 256;   // alignment slack for up to 20 arrays each
+        if (int rc = g_in.ensure(bytes_in)) return rc;
+        if (int rc = g_hin.ensure(bytes_in)) return rc;
+        if (int rc = g_out.ensure(bytes_out)) return rc;
+        return g_hout.ensure(bytes_out);
+    }
+    template <typename T>
+    T* in(const T* src, size_t n) {   // src may be NULL (array not used by this call): zero-filled
+        oi = (oi + 255) & ~size_t(255);
+        T* dev = (T*)((char*)g_in.p + oi);
+        if (n) {
+            if (src) memcpy((char*)g_hin.p + oi, src, n * sizeof(T)); else memset((char*)g_hin.p + oi, 0, n * sizeof(T));
+        }
+        oi += n * sizeof(T);
+        return dev;
+    }
+    template <typename T>
+    T* out(T* host, size_t n) {       // host may be NULL (result not wanted)
+        oo = (oo + 255) & ~size_t(255);
+        T* dev = (T*)((char*)g_out.p + oo);
+        backs[nb++] = Back{(void*)host, oo, n * sizeof(T)};
+        oo += n * sizeof(T);
+        return dev;
+    }
+    int up(hipStream_t st) {
+        if (oi) HIP_TRY(hipMemcpyAsync(g_in.p, g_hin.p, oi, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    int down(hipStream_t st) {
+        if (oo) HIP_TRY(hipMemcpyAsync(g_hout.p, g_out.p, oo, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < nb; i++)
+            if (backs[i].host && backs[i].bytes) memcpy(backs[i].host, (char*)g_hout.p + backs[i].off, backs[i].bytes);
+        return 0;
+    }
+};
 
 // bump allocator over a DevBuf
 struct Carver {
@@ -176,7 +246,7 @@ int crx_init(int device) {
     HIP_TRY(hipSetDevice(device));
     if (g_init && g_device == device) return CRX_OK;
     if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-    g_in.release(); g_out.release();
+    g_in.release(); g_out.release(); g_hin.release(); g_hout.release();
     HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     g_device = device;
     g_init = true;
@@ -187,7 +257,7 @@ void crx_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) return;
     (void)hipSetDevice(g_device);
-    g_in.release(); g_out.release();
+    g_in.release(); g_out.release(); g_hin.release(); g_hout.release();
     if (g_stream) (void)hipStreamDestroy(g_stream);
     if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); }
     g_stream = nullptr; g_ev0 = g_ev1 = nullptr; g_ev_valid = false;
@@ -283,27 +353,15 @@ int crx_planner_solve(const crx_planner_desc* d, int batch, const double* x0, co
     const size_t B = (size_t)batch, N = (size_t)d->N;
     const size_t n_x0 = B * 6, n_bz = B * (N + 1), n_lb = B * N, n_ub = B;
     const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2;
-    if (int rc = g_in.ensure((n_x0 + 2 * n_bz + n_lb + n_ub) * 8 + 8 * 256)) return rc;
-    if (int rc = g_out.ensure((n_X + n_U + 2 * B) * 8 + 2 * B * 4 + 8 * 256)) return rc;
-    Carver ci(g_in.p), co(g_out.p);
-    double* dx0 = ci.take<double>(n_x0); double* dbs = ci.take<double>(n_bz); double* dbe = ci.take<double>(n_bz);
-    double* dlb = ci.take<double>(n_lb); double* dub = ci.take<double>(n_ub);
-    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dc = co.take<double>(B);
-    double* dk = co.take<double>(B); int32_t* ds = co.take<int32_t>(B); int32_t* di = co.take<int32_t>(B);
-    HIP_TRY(hipMemcpyAsync(dx0, x0, n_x0 * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dbs, bez_s, n_bz * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dbe, bez_ey, n_bz * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dlb, ey_lb, n_lb * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dub, ey_ub, n_ub * 8, hipMemcpyHostToDevice, g_stream));
+    Stage sg;
+    if (int rc = sg.reserve((n_x0 + 2 * n_bz + n_lb + n_ub) * 8, (n_X + n_U + 2 * B) * 8 + 2 * B * 4)) return rc;
+    double* dx0 = sg.in(x0, n_x0); double* dbs = sg.in(bez_s, n_bz); double* dbe = sg.in(bez_ey, n_bz);
+    double* dlb = sg.in(ey_lb, n_lb); double* dub = sg.in(ey_ub, n_ub);
+    double* dX = sg.out(X, n_X); double* dU = sg.out(U, n_U); double* dc = sg.out(cost, B);
+    double* dk = sg.out(kkt, B); int32_t* ds = sg.out(status, B); int32_t* di = sg.out(iters, B);
+    if (int rc = sg.up(g_stream)) return rc;
     if (int rc = crx_planner_solve_dev(d, batch, dx0, dbs, dbe, dlb, dub, dX, dU, dc, ds, dk, di, g_stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(cost, dc, B * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(kkt, dk, B * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(status, ds, B * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(iters, di, B * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return CRX_OK;
+    return sg.down(g_stream);
 }
 
 // ---- MPC-CBF ---------------------------------------------------------------------------------------
@@ -340,34 +398,16 @@ int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const doub
     HIP_TRY(hipSetDevice(g_device));
     const size_t n_x0 = B * 6, n_xt = d->per_stage_target ? B * (N + 1) * 6 : B * 6, n_ob = B * V * (N + 1), n_lo = B * V;
     const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2;
-    if (int rc = g_in.ensure((n_x0 + n_xt + 2 * n_ob + n_lo) * 8 + B * 4 + 8 * 256)) return rc;
-    if (int rc = g_out.ensure((n_X + n_U + n_ob + 2 * B) * 8 + 2 * B * 4 + 8 * 256)) return rc;
-    Carver ci(g_in.p), co(g_out.p);
-    double* dx0 = ci.take<double>(n_x0); double* dxt = ci.take<double>(n_xt);
-    double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1); double* dlo = ci.take<double>(n_lo + 1);
-    int32_t* dno = ci.take<int32_t>(B);
-    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dsg = co.take<double>(n_ob + 1);
-    double* dc = co.take<double>(B); double* dk = co.take<double>(B); int32_t* ds = co.take<int32_t>(B); int32_t* di = co.take<int32_t>(B);
-    HIP_TRY(hipMemcpyAsync(dx0, x0, n_x0 * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dxt, xt, n_xt * 8, hipMemcpyHostToDevice, g_stream));
-    if (V > 0) {
-        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(dlo, lap_off, n_lo * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(dno, n_obs, B * 4, hipMemcpyHostToDevice, g_stream));
-    } else {
-        HIP_TRY(hipMemsetAsync(dno, 0, B * 4, g_stream));
-    }
+    Stage sg;
+    if (int rc = sg.reserve((n_x0 + n_xt + 2 * n_ob + n_lo) * 8 + B * 4, (n_X + n_U + n_ob + 2 * B) * 8 + 2 * B * 4)) return rc;
+    double* dx0 = sg.in(x0, n_x0); double* dxt = sg.in(xt, n_xt);
+    double* dos = sg.in(obs_s, n_ob); double* doe = sg.in(obs_ey, n_ob); double* dlo = sg.in(lap_off, n_lo);
+    int32_t* dno = sg.in(V > 0 ? n_obs : (const int32_t*)nullptr, B);
+    double* dX = sg.out(X, n_X); double* dU = sg.out(U, n_U); double* dsg = sg.out(sigma, n_ob);
+    double* dc = sg.out(cost, B); double* dk = sg.out(kkt, B); int32_t* ds = sg.out(status, B); int32_t* di = sg.out(iters, B);
+    if (int rc = sg.up(g_stream)) return rc;
     if (int rc = crx_cbf_solve_dev(d, batch, dx0, dxt, dos, doe, dlo, dno, dX, dU, dsg, dc, ds, dk, di, g_stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
-    if (V > 0) HIP_TRY(hipMemcpyAsync(sigma, dsg, n_ob * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(cost, dc, B * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(kkt, dk, B * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(status, ds, B * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(iters, di, B * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return CRX_OK;
+    return sg.down(g_stream);
 }
 
 // ---- selection -------------------------------------------------------------------------------------
@@ -407,25 +447,14 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g_device));
     const size_t n_X = S * R * (N + 1) * 6, n_ob = S * V * (N + 1), n_bX = S * (N + 1) * 6;
-    if (int rc = g_in.ensure((n_X + 2 * n_ob) * 8 + 2 * S * 4 + 8 * 256)) return rc;
-    if (int rc = g_out.ensure((S * R + n_bX) * 8 + S * 4 + 8 * 256)) return rc;
-    Carver ci(g_in.p), co(g_out.p);
-    double* dX = ci.take<double>(n_X); double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1);
-    int32_t* dnv = ci.take<int32_t>(S); int32_t* dof = ci.take<int32_t>(S);
-    int32_t* dfl = co.take<int32_t>(S); double* dsc = co.take<double>(S * R); double* dbX = co.take<double>(n_bX);
-    HIP_TRY(hipMemcpyAsync(dX, X, n_X * 8, hipMemcpyHostToDevice, g_stream));
-    if (V > 0) {
-        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-    }
-    HIP_TRY(hipMemcpyAsync(dnv, n_veh, S * 4, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dof, old_flag, S * 4, hipMemcpyHostToDevice, g_stream));
+    Stage sg;
+    if (int rc = sg.reserve((n_X + 2 * n_ob) * 8 + 2 * S * 4, (S * R + n_bX) * 8 + S * 4)) return rc;
+    double* dX = sg.in(X, n_X); double* dos = sg.in(obs_s, n_ob); double* doe = sg.in(obs_ey, n_ob);
+    int32_t* dnv = sg.in(n_veh, S); int32_t* dof = sg.in(old_flag, S);
+    int32_t* dfl = sg.out(flag, S); double* dsc = sg.out(sel_cost, S * R); double* dbX = sg.out(best_X, n_bX);
+    if (int rc = sg.up(g_stream)) return rc;
     if (int rc = crx_select_dev(d, n_scen, dnv, dX, dos, doe, dof, dfl, dsc, dbX, g_stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(flag, dfl, S * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(sel_cost, dsc, S * R * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(best_X, dbX, n_bX * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return CRX_OK;
+    return sg.down(g_stream);
 }
 
 // ---- planner host prep on the device ---------------------------------------------------------------
@@ -487,33 +516,16 @@ int crx_planner_prep(const crx_prep_desc* d, int n_scen, const double* x_wrapped
     HIP_TRY(hipSetDevice(g_device));
     const size_t S = (size_t)n_scen, N = (size_t)d->N, V = (size_t)d->n_veh_max, R = V + 1, T = (size_t)d->n_opt;
     const size_t n_vi = S * V * 3, n_ob = S * V * (N + 1), n_bz = S * R * (N + 1), n_lb = S * R * N;
-    if (int rc = g_in.ensure((S * 13 + n_vi + 2 * n_ob + 2 * T) * 8 + S * 4 + 12 * 256)) return rc;
-    if (int rc = g_out.ensure((S * R * 7 + 2 * n_bz + n_lb) * 8 + 8 * 256)) return rc;
-    Carver ci(g_in.p), co(g_out.p);
-    double* dxw = ci.take<double>(S * 6); double* dxr = ci.take<double>(S * 6); double* dmd = ci.take<double>(S);
-    double* dvi = ci.take<double>(n_vi + 1); double* dos = ci.take<double>(n_ob + 1); double* doe = ci.take<double>(n_ob + 1);
-    double* dts = ci.take<double>(T); double* dte = ci.take<double>(T); int32_t* dnv = ci.take<int32_t>(S);
-    double* dx0 = co.take<double>(S * R * 6); double* dbs = co.take<double>(n_bz); double* dbe = co.take<double>(n_bz);
-    double* dlb = co.take<double>(n_lb); double* dub = co.take<double>(S * R);
-    HIP_TRY(hipMemcpyAsync(dxw, x_wrapped, S * 48, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dxr, x_raw, S * 48, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dmd, max_dv, S * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dnv, n_veh, S * 4, hipMemcpyHostToDevice, g_stream));
-    if (V > 0) {
-        HIP_TRY(hipMemcpyAsync(dvi, veh_info, n_vi * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(dos, obs_s, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(doe, obs_ey, n_ob * 8, hipMemcpyHostToDevice, g_stream));
-    }
-    HIP_TRY(hipMemcpyAsync(dts, opt_s, T * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dte, opt_ey, T * 8, hipMemcpyHostToDevice, g_stream));
+    Stage sg;
+    if (int rc = sg.reserve((S * 13 + n_vi + 2 * n_ob + 2 * T) * 8 + S * 4, (S * R * 7 + 2 * n_bz + n_lb) * 8)) return rc;
+    double* dxw = sg.in(x_wrapped, S * 6); double* dxr = sg.in(x_raw, S * 6); double* dmd = sg.in(max_dv, S);
+    double* dvi = sg.in(veh_info, n_vi); double* dos = sg.in(obs_s, n_ob); double* doe = sg.in(obs_ey, n_ob);
+    double* dts = sg.in(opt_s, T); double* dte = sg.in(opt_ey, T); int32_t* dnv = sg.in(n_veh, S);
+    double* dx0 = sg.out(x0, S * R * 6); double* dbs = sg.out(bez_s, n_bz); double* dbe = sg.out(bez_ey, n_bz);
+    double* dlb = sg.out(ey_lb, n_lb); double* dub = sg.out(ey_ub, S * R);
+    if (int rc = sg.up(g_stream)) return rc;
     if (int rc = crx_planner_prep_dev(d, n_scen, dxw, dxr, dnv, dvi, dmd, dos, doe, dts, dte, dx0, dbs, dbe, dlb, dub, g_stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(x0, dx0, S * R * 48, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(bez_s, dbs, n_bz * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(bez_ey, dbe, n_bz * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(ey_lb, dlb, n_lb * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(ey_ub, dub, S * R * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return CRX_OK;
+    return sg.down(g_stream);
 }
 
 // ---- learning-MPC QP ------------------------------------------------------------------------------
@@ -582,33 +594,16 @@ int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const do
     const size_t Bn = (size_t)batch, N = (size_t)d->N, M = (size_t)d->n_ss_max;
     const size_t n_A = Bn * N * 36, n_B = Bn * N * 12, n_C = Bn * N * 6, n_ss_ = Bn * 6 * M, n_q = Bn * M;
     const size_t n_X = Bn * (N + 1) * 6, n_U = Bn * N * 2;
-    if (int rc = g_in.ensure((Bn * 8 + n_A + n_B + n_C + n_ss_ + n_q) * 8 + Bn * 4 + 12 * 256)) return rc;
-    if (int rc = g_out.ensure((n_X + n_U + n_q + 2 * Bn) * 8 + 2 * Bn * 4 + 10 * 256)) return rc;
-    Carver ci(g_in.p), co(g_out.p);
-    double* dx0 = ci.take<double>(Bn * 6); double* duo = ci.take<double>(Bn * 2);
-    double* dA = ci.take<double>(n_A); double* dB = ci.take<double>(n_B); double* dC = ci.take<double>(n_C);
-    double* dss = ci.take<double>(n_ss_); double* dq = ci.take<double>(n_q); int32_t* dn = ci.take<int32_t>(Bn);
-    double* dX = co.take<double>(n_X); double* dU = co.take<double>(n_U); double* dl = co.take<double>(n_q);
-    double* dc = co.take<double>(Bn); double* dk = co.take<double>(Bn);
-    int32_t* ds = co.take<int32_t>(Bn); int32_t* di = co.take<int32_t>(Bn);
-    HIP_TRY(hipMemcpyAsync(dx0, x0, Bn * 48, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(duo, u_old, Bn * 16, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dA, A, n_A * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dB, B, n_B * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dC, C, n_C * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dss, ss, n_ss_ * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dq, qfun, n_q * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(dn, n_ss, Bn * 4, hipMemcpyHostToDevice, g_stream));
+    Stage sg;
+    if (int rc = sg.reserve((Bn * 8 + n_A + n_B + n_C + n_ss_ + n_q) * 8 + Bn * 4, (n_X + n_U + n_q + 2 * Bn) * 8 + 2 * Bn * 4)) return rc;
+    double* dx0 = sg.in(x0, Bn * 6); double* duo = sg.in(u_old, Bn * 2);
+    double* dA = sg.in(A, n_A); double* dB = sg.in(B, n_B); double* dC = sg.in(C, n_C);
+    double* dss = sg.in(ss, n_ss_); double* dq = sg.in(qfun, n_q); int32_t* dn = sg.in(n_ss, Bn);
+    double* dX = sg.out(X, n_X); double* dU = sg.out(U, n_U); double* dl = sg.out(lambda, n_q);
+    double* dc = sg.out(cost, Bn); double* dk = sg.out(kkt, Bn); int32_t* ds = sg.out(status, Bn); int32_t* di = sg.out(iters, Bn);
+    if (int rc = sg.up(g_stream)) return rc;
     if (int rc = crx_lmpc_solve_dev(d, batch, dx0, duo, dA, dB, dC, dss, dq, dn, dX, dU, dl, dc, ds, dk, di, g_stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(X, dX, n_X * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(U, dU, n_U * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(lambda, dl, n_q * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(cost, dc, Bn * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(kkt, dk, Bn * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(status, ds, Bn * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipMemcpyAsync(iters, di, Bn * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return CRX_OK;
+    return sg.down(g_stream);
 }
 
 // ---- fused planner step ------------------------------------------------------------------------------
@@ -633,11 +628,36 @@ int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n
     if (!d || !sd) return fail(CRX_ERR_ARG, "desc is NULL");
     if (sd->N != d->N) return fail(CRX_ERR_ARG, "planner and selection horizons differ");
     if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
-    const int R = sd->n_veh_max + 1;
-    // host staging: the two host entry points back to back (X makes one extra PCIe round trip; the
-    // device-resident variant above keeps it in HBM)
-    if (int rc = crx_planner_solve(d, n_scen * R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters)) return rc;
-    return crx_select(sd, n_scen, n_veh, X, obs_s, obs_ey, old_flag, flag, sel_cost, best_X);
+    if (int rc = ensure_init()) return rc;
+    crx_kparams chk;
+    if (int rc = fill_planner(chk, d, 0)) return rc;
+    if (sd->n_veh_max < 0 || sd->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (n_scen == 0) return CRX_OK;
+    if (!x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub || !n_veh || !old_flag || !X || !U || !cost || !status || !kkt || !iters ||
+        !flag || !sel_cost || !best_X || (sd->n_veh_max > 0 && (!obs_s || !obs_ey)))
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    const size_t S = (size_t)n_scen, N = (size_t)d->N, V = (size_t)sd->n_veh_max, R = V + 1, B = S * R;
+    for (size_t i = 0; i < S; i++)
+        if (n_veh[i] < 0 || n_veh[i] > (int)V) return fail(CRX_ERR_ARG, "n_veh[%zu]=%d outside [0,%zu]", i, n_veh[i], V);
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    // one staging round trip for the whole step; X stays on the device between the two kernels
+    const size_t n_x0 = B * 6, n_bz = B * (N + 1), n_lb = B * N, n_ob = S * V * (N + 1);
+    const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2, n_bX = S * (N + 1) * 6;
+    Stage sg;
+    if (int rc = sg.reserve((n_x0 + 2 * n_bz + n_lb + B + 2 * n_ob) * 8 + 2 * S * 4,
+                            (n_X + n_U + 2 * B + S * R + n_bX) * 8 + 2 * B * 4 + S * 4)) return rc;
+    double* dx0 = sg.in(x0, n_x0); double* dbs = sg.in(bez_s, n_bz); double* dbe = sg.in(bez_ey, n_bz);
+    double* dlb = sg.in(ey_lb, n_lb); double* dub = sg.in(ey_ub, B);
+    double* dos = sg.in(obs_s, n_ob); double* doe = sg.in(obs_ey, n_ob);
+    int32_t* dnv = sg.in(n_veh, S); int32_t* dof = sg.in(old_flag, S);
+    double* dX = sg.out(X, n_X); double* dU = sg.out(U, n_U); double* dc = sg.out(cost, B); double* dk = sg.out(kkt, B);
+    int32_t* ds = sg.out(status, B); int32_t* di = sg.out(iters, B);
+    int32_t* dfl = sg.out(flag, S); double* dsc = sg.out(sel_cost, S * R); double* dbX = sg.out(best_X, n_bX);
+    if (int rc = sg.up(g_stream)) return rc;
+    if (int rc = crx_planner_plan_dev(d, sd, n_scen, dx0, dbs, dbe, dlb, dub, dnv, dos, doe, dof, dX, dU, dc, ds, dk, di,
+                                      dfl, dsc, dbX, g_stream)) return rc;
+    return sg.down(g_stream);
 }
 
 }  // extern "C"
