@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.  `value` counts every problem handed to the solver 
 timed region, whole job (all GPUs); converged fraction and KKT bound are reported beside it.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -233,6 +234,8 @@ def main():
             + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
 
+    L.crx_debug_lds_bytes.restype = C.c_long
+    lds = int(L.crx_debug_lds_bytes(1 if wl == "lmpc" else 0, int(N), int(n_obs)))
     traffic = None
     try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, collected with rocprofv3 --pmc)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
@@ -257,7 +260,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "crx_lmpc_kernel" if wl == "lmpc" else "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
                      "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
-                     "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS},
+                     "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
+                     "lds_bytes_per_problem": lds, "resident_problems_per_cu": int((160 * 1024) // lds)},
     }
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, desc, p, batch)

@@ -286,6 +286,12 @@ int crx_trace_read(double* host, int rows) {
     return CRX_OK;
 }
 
+// diagnostics (not in crx.h): LDS bytes one problem occupies (= one single-wave workgroup), for the
+// "resident problems per CU" figure of bench.py.  kind 0: crx_solve_kernel (N, n_obs_max); 1: crx_lmpc_kernel (N, n_ss_max)
+long crx_debug_lds_bytes(int kind, int N, int n) {
+    return kind == 0 ? (long)crx_solve_lds_bytes(N, n) : (long)crx_lmpc_lds_bytes(N, n);
+}
+
 double crx_last_kernel_ms(void) {
     if (!g_ev_valid) return -1.0;
     float ms = 0.f;

@@ -506,12 +506,13 @@ static void ipm_solve(work_t* w, result_t* res) {
         memcpy(w->dv, w->rhs, sizeof(double) * n);
         chol_solve(n, w->H, w->dv);
         double a_p = 1.0, a_d = 1.0, theta = 0.0, Dphi = 0.0, curv = 0.0;
+        int jblock = -1;
         for (int j = 0; j < m; j++) {
             double s = rp[j];
             for (int a = 0; a < n; a++) s += w->J[j][a] * w->dv[a];
             w->dt[j] = s;
             w->dnu[j] = (mu - w->t[j] * w->nu[j] - w->nu[j] * s) / w->t[j];
-            if (s < 0.0) a_p = fmin(a_p, -tau * w->t[j] / s);
+            if (s < 0.0 && -tau * w->t[j] / s < a_p) { a_p = -tau * w->t[j] / s; jblock = j; }
             if (w->dnu[j] < 0.0) a_d = fmin(a_d, -tau * w->nu[j] / w->dnu[j]);
             theta += fabs(rp[j]);
             Dphi -= mu * s / w->t[j];
@@ -554,6 +555,9 @@ static void ipm_solve(work_t* w, result_t* res) {
             if (acc) break;
             al *= 0.5;
         }
+        if (g_verbose > 1 && jblock >= 0)
+            fprintf(stderr, "      blocking row %d kind %d k %d i %d: t %.3e dt %.3e c %.3e nu %.3e\n", jblock, w->row[jblock].kind,
+                    w->row[jblock].k, w->row[jblock].i, w->t[jblock], w->dt[jblock], w->c[jblock], w->nu[jblock]);
         if (g_verbose) fprintf(stderr, "      a_p %.3e a_d %.3e alpha %.3e acc %d ftype %d theta %.2e Dphi %.2e curv %.2e dw %.1e\n", a_p, a_d, al, acc, ftype, theta, Dphi, curv, dw);
         if (acc && !ftype && nf < MAXF) {
             Fth[nf] = (1.0 - 1e-5) * theta;
