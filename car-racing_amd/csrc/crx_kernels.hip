@@ -32,7 +32,7 @@
 #include "crx_kparams.h"
 #include "crx_wave.h"
 
-#define MAXF 16 /* filter entries (reset at every barrier update; 16 were never reached in testing) */
+#define MAXF 12 /* filter entries (reset at every barrier update; when full, further entries are dropped) */
 
 // a^p for small p >= 0.  The exponent is wave-uniform (the CBF degree and degree-1, degree-2), so the
 // switch is a scalar branch; the generic loop costs ~40 cycles of branch overhead per factor.
@@ -70,6 +70,11 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 // Row slots inside a stage k: 0..3 input box (d lo, d hi, a lo, a hi); 4..7 box of x_{k+1} (vx lo,
 // vx hi, ey lo, ey hi); 8+o: sigma_{k+1}^o >= 0; 8+NOBS+o: CBF row (k,o).  Rows N*NR+o: sigma_0^o.
 // ------------------------------------------------------------------------------------------------
+#define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
+#define RIV_NEG (1 << 30)
+#define RIV_IDX(pk) ((pk) & 0xFFFF)
+#define RIV_SGN(pk) (((pk) & RIV_SIMPLE) ? (((pk) & RIV_NEG) ? -1.0 : 1.0) : 0.0)
+
 template <int NOBS, int NMAX>
 struct Lay {
     static constexpr int NX = 6 + NOBS, NU = 2 + NOBS, NZ = NX + NU, NR = 8 + 2 * NOBS;
@@ -81,27 +86,25 @@ struct Lay {
     static constexpr int dZ = Z + NV;                // Newton step
     static constexpr int xr = dZ + NV;               // [NMAX+1][6] tracking references
     static constexpr int wc = xr + (NMAX + 1) * 6;   // [NMAX] coupling weight on (ey_{k+1}-ey_k)^2
-    static constexpr int obs_s = wc + NMAX;          // [NO][NMAX+1]
-    static constexpr int obs_e = obs_s + NO * (NMAX + 1);
-    static constexpr int rt = obs_e + NO * (NMAX + 1);  // rows: slack, multiplier, value, steps, ...
+    static constexpr int obs_s = wc + NMAX;          // [NOBS][NMAX+1]   (CBF-only arrays have size 0 in the planner instantiation)
+    static constexpr int obs_e = obs_s + NOBS * (NMAX + 1);
+    static constexpr int rt = obs_e + NOBS * (NMAX + 1);  // rows: slack, multiplier, value, steps, ...
     static constexpr int rnu = rt + MR;
     static constexpr int rc = rnu + MR;
     static constexpr int rdt = rc + MR;
-    static constexpr int rdnu = rdt + MR;
-    static constexpr int rtt = rdnu + MR;            // trial slack
+    static constexpr int rtt = rdt + MR;             // trial slack / 1/t (dnu is recomputed at accept: -w + Sigma (rp - dt))
     static constexpr int rsig = rtt + MR;            // Sigma = nu/t
     static constexpr int rw = rsig + MR;             // w = nu - mu/t + Sigma*(c - t)
     static constexpr int rsc = rw + MR;              // row scale (0 = row absent)
-    static constexpr int rsg = rsc + MR;             // simple rows: sign of the Jacobian entry
-    static constexpr int rb = rsg + MR;              // simple rows: bound
+    static constexpr int rb = rsc + MR;              // simple rows: bound (their sign lives in the riv table)
     static constexpr int G = rb + MR;                // [NMAX][NO][8] CBF derivatives at the iterate
-    static constexpr int Hd = G + NMAX * NO * 8;     // [NV] stage Hessian diagonal
+    static constexpr int Hd = G + NMAX * NOBS * 8;   // [NV] stage Hessian diagonal
     static constexpr int hg = Hd + NV;               // [NV] Newton gradient
     static constexpr int ga = hg + NV;               // [NV] Lagrangian gradient / reduced form
     static constexpr int Jc = ga + NV;               // [NMAX][NO][NZ] CBF Jacobians (scaled)
-    static constexpr int kS = Jc + NMAX * NO * NZ;   // [NMAX] "next" CBF curvature on s_{k+1}
-    static constexpr int kE = kS + NMAX;             //          ... on ey_{k+1}
-    static constexpr int P = kE + NMAX;              // Riccati work
+    static constexpr int kS = Jc + NMAX * NOBS * NZ; // [NMAX] "next" CBF curvature on s_{k+1}
+    static constexpr int kE = kS + (NOBS ? NMAX : 0);   //        ... on ey_{k+1}
+    static constexpr int P = kE + (NOBS ? NMAX : 0); // Riccati work
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
     static constexpr int H = T + NX * NZ;
@@ -114,13 +117,16 @@ struct Lay {
     static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 12.. lap_off
     static constexpr int END_D = cst + 16;
     // int tables (stored after the doubles)
-    static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ
-    static constexpr int vlo = riv + MR;             // [NV]  row index of the lower-bound row of a coordinate (-1 none)
-    static constexpr int vhi = vlo + NV;             // [NV]  ... upper-bound row
-    static constexpr int triH = vhi + NV;            // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
+    static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
+    static constexpr int triH = riv + MR;            // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
     static constexpr int updP = triH + (NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2);  // [64] packed (i << 8 | j) lane map of the Riccati update
     static constexpr int END_I = updP + 64;
-    static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)((END_I + 1) & ~1) * 4;
+    // int16 tables (stored after the ints; viewed through SH())
+    static constexpr int vlo = 0;                    // [NV]  row index of the lower-bound row of a coordinate (-1 none)
+    static constexpr int vhi = vlo + NV;             // [NV]  ... upper-bound row
+    static constexpr int END_S = vhi + NV;
+    static constexpr int SH_OFF = (END_I + 1) & ~1;  // in ints, from si
+    static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)SH_OFF * 4 + (size_t)((END_S + 3) & ~3) * 2;
 };
 
 // problem context kept in registers (all wave-uniform)
@@ -232,7 +238,8 @@ __device__ __forceinline__ void eval_rows(double* sm, const int* si, const Ctx& 
     using L = Lay<NOBS, NMAX>;
     for (int j = c.lane; j < c.m; j += WAVE) {
         const double sc = LD(L::rsc + j);
-        double v = LD(L::rsg + j) * (LD(L::Z + si[L::riv + j]) - LD(L::rb + j));
+        const int pk = si[L::riv + j];
+        double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
         if (NOBS && j < c.N * L::NR) {
             const int k = j / L::NR, r = j - k * L::NR;
             if (r >= 8 + NOBS && sc != 0.0) v = sc * cbf_value<NOBS, NMAX>(sm, c, k, r - 8 - NOBS, 0.0);
@@ -289,7 +296,8 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         double g = w2 * (LD(L::Z + e) - ref);
         g += (k == N && a == 4) ? c.lin_sN : 0.0;
         g += sig_on ? c.wsig : 0.0;
-        const int rl = si[L::vlo + e], rh = si[L::vhi + e];
+        const short* sh = (const short*)(si + L::SH_OFF);
+        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
         const double nl = LD(L::rnu + (rl >= 0 ? rl : 0)), nh = LD(L::rnu + (rh >= 0 ? rh : 0));
         g -= (rl >= 0) ? nl : 0.0;
         g += (rh >= 0) ? nh : 0.0;
@@ -367,7 +375,8 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         double h = (isx || isu) ? 2.0 * LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
         // absent obstacle: pin its sigma_0 (state copy at k = 0) and sigma_{k+1} (input copy)
         h += ((iss0 && k == 0 && o >= c.nobs) || (iss1 && o >= c.nobs)) ? 1.0 : 0.0;
-        const int rl = si[L::vlo + e], rh = si[L::vhi + e];
+        const short* sh = (const short*)(si + L::SH_OFF);
+        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
         h += ((rl >= 0) ? LD(L::rsig + il) : 0.0) + ((rh >= 0) ? LD(L::rsig + ih) : 0.0);
         g += ((rl >= 0) ? LD(L::rw + il) : 0.0) - ((rh >= 0) ? LD(L::rw + ih) : 0.0);
@@ -396,8 +405,10 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
                 ke -= nd * LD(L::G + (k * L::NO + o) * 8 + 5);
             }
         }
-        LD(L::kS + k) = ks;
-        LD(L::kE + k) = ke;
+        if (NOBS) {
+            LD(L::kS + k) = ks;
+            LD(L::kE + k) = ke;
+        }
     }
     SYNC();
 }
@@ -416,8 +427,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         double v = 0.0;
         if (i == j) {
             v = LD(L::Hd + N * NZ + i);
-            if (i == 4) v += LD(L::kS + N - 1);
-            if (i == 5) v += LD(L::kE + N - 1) + 2.0 * LD(L::wc + N - 1);
+            if (i == 4) v += NOBS ? LD(L::kS + N - 1) : 0.0;
+            if (i == 5) v += (NOBS ? LD(L::kE + N - 1) : 0.0) + 2.0 * LD(L::wc + N - 1);
         }
         LD(L::P + e) = v;
     }
@@ -553,8 +564,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             const int i = pk >> 8, j = pk & 255;   // feedback lanes: column j, i = 0 (unused)
             const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
-            const double exS = (k >= 1) ? LD(L::kS + km) : 0.0;
-            const double exE = (k >= 1) ? LD(L::kE + km) + 2.0 * LD(L::wc + km) : 0.0;
+            const double exS = (NOBS && k >= 1) ? LD(L::kS + km) : 0.0;
+            const double exE = (k >= 1) ? (NOBS ? LD(L::kE + km) : 0.0) + 2.0 * LD(L::wc + km) : 0.0;
             // straight-line body with selects; only the two store regions are predicated
             const bool gcol = j >= NX;             // gradient column
             double yi[NU], yj[NU];
@@ -701,7 +712,8 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         } else if (a == NX + 2 + (i - 6)) v = 1.0;
         LD(L::M + e) = v;
     }
-    for (int e = lane; e < (N + 1) * NZ; e += WAVE) { LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0; si[L::vlo + e] = -1; si[L::vhi + e] = -1; }
+    short* sh = (short*)(si + L::SH_OFF);
+    for (int e = lane; e < (N + 1) * NZ; e += WAVE) { LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0; sh[L::vlo + e] = -1; sh[L::vhi + e] = -1; }
     if (lane < 16) {
         double v = 0.0;
         if (lane < 6) v = kp.wq[lane];
@@ -810,17 +822,16 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             }
         }
         if (simple && on != 0.0) {
-            if (sg > 0.0) si[L::vlo + iv] = j; else si[L::vhi + iv] = j;
+            if (sg > 0.0) sh[L::vlo + iv] = (short)j; else sh[L::vhi + iv] = (short)j;
         }
         if (on == 0.0 || !simple) { sg = 0.0; bd = 0.0; iv = 0; }
-        si[L::riv + j] = iv;
-        LD(L::rsg + j) = sg;
+        si[L::riv + j] = iv | (sg != 0.0 ? RIV_SIMPLE : 0) | (sg < 0.0 ? RIV_NEG : 0);
         LD(L::rb + j) = bd;
         LD(L::rsc + j) = on;
         LD(L::rnu + j) = on;       // multiplier start 1 (0 for absent rows)
         LD(L::rt + j) = 1.0;
         LD(L::rc + j) = 1.0;
-        LD(L::rdt + j) = 0.0; LD(L::rdnu + j) = 0.0; LD(L::rsig + j) = 0.0; LD(L::rw + j) = 0.0; LD(L::rtt + j) = 1.0;
+        LD(L::rdt + j) = 0.0; LD(L::rsig + j) = 0.0; LD(L::rw + j) = 0.0; LD(L::rtt + j) = 1.0;
     }
     SYNC();
     // starting point: u = 0, sigma = 0, x by roll-out
@@ -864,11 +875,12 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     (void)dual_infeasibility<NOBS, NMAX>(sm, c);  // ga <- reduced cost gradient (inputs, sigma_0)
     for (int j = lane; j < m; j += WAVE) {
         double nu = LD(L::rtt + j);
-        if (nu != 0.0 && LD(L::rsg + j) != 0.0) {
-            const int iv = si[L::riv + j];
+        const int pk = si[L::riv + j];
+        if (nu != 0.0 && (pk & RIV_SIMPLE)) {
+            const int iv = RIV_IDX(pk);
             const int kk = iv / NZ, a = iv - kk * NZ;
             if (a >= NX || (kk == 0 && a >= 6)) {          // input or sigma_0 coordinate
-                const double gg = LD(L::rsg + j) * LD(L::ga + iv);
+                const double gg = RIV_SGN(pk) * LD(L::ga + iv);
                 if (gg > 1.0) nu = gg;
             }
         }
@@ -952,7 +964,8 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             const bool on = sc != 0.0;
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
             // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
-            double jd = LD(L::rsg + j) * LD(L::dZ + si[L::riv + j]);
+            const int pk = si[L::riv + j];
+            double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
             if (NOBS && j < N * NR) {
                 const int k = j / NR, r = j - k * NR;
                 if (r >= 8 + NOBS) {
@@ -968,7 +981,6 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             // dnu = (mu - t nu - nu dt)/t = mu/t - nu - Sigma dt = -w + Sigma (rp - dt)
             const double dnu = on ? (-LD(L::rw + j) + LD(L::rsig + j) * (rp - dt)) : 0.0;
             LD(L::rdt + j) = dt;
-            LD(L::rdnu + j) = dnu;
             const double dtr = dt * rti;                       // dt / t
             rp_max = fmax(rp_max, -dtr);
             rd_max = fmax(rd_max, on ? -dnu * frcp(nu) : 0.0);
@@ -1051,7 +1063,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (LD(L::rsc + j) == 0.0) continue;
             const double tn = LD(L::rtt + j);
             const double mut = mu * frcp(tn);
-            double nn = LD(L::rnu + j) + a_d * LD(L::rdnu + j);
+            const double rp = LD(L::rc + j) - LD(L::rt + j);   // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
+            const double dnu = -LD(L::rw + j) + LD(L::rsig + j) * (rp - LD(L::rdt + j));
+            double nn = LD(L::rnu + j) + a_d * dnu;
             nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
             LD(L::rt + j) = tn;
             LD(L::rnu + j) = nn;
