@@ -100,8 +100,9 @@ struct Lay {
     static constexpr int G = rb + MR;                // [NMAX][NO][8] CBF derivatives at the iterate
     static constexpr int Hd = G + NMAX * NOBS * 8;   // [NV] stage Hessian diagonal
     static constexpr int hg = Hd + NV;               // [NV] Newton gradient
-    static constexpr int ga = hg + NV;               // [NV] Lagrangian gradient / reduced form
-    static constexpr int Jc = ga + NV;               // [NMAX][NO][NZ] CBF Jacobians (scaled)
+    static constexpr int ga = hg;                    // Lagrangian gradient / reduced form: SAME storage -- assemble_newton turns ga[e]
+                                                     // into hg[e] in place, and nothing reads ga again before first_order rebuilds it
+    static constexpr int Jc = hg + NV;               // [NMAX][NO][NZ] CBF Jacobians (scaled)
     static constexpr int kS = Jc + NMAX * NOBS * NZ; // [NMAX] "next" CBF curvature on s_{k+1}
     static constexpr int kE = kS + (NOBS ? NMAX : 0);   //        ... on ey_{k+1}
     static constexpr int P = kE + (NOBS ? NMAX : 0); // Riccati work
@@ -742,9 +743,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     SYNC();
     int infeas0 = 0;
     if (kp.mode == 0) {
-        // planner front-end (overtake_traj_planner.py:266-334); bez arrays staged in hg/ga scratch
+        // planner front-end (overtake_traj_planner.py:266-334); bez arrays staged in hg/Hd scratch
         double* bs = sm + L::hg;
-        double* be = sm + L::ga;
+        double* be = sm + L::Hd;
         for (int j = lane; j <= N; j += WAVE) {
             bs[j] = kp.bez_s[(size_t)b * (N + 1) + j];
             be[j] = kp.bez_ey[(size_t)b * (N + 1) + j];
@@ -765,7 +766,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         const double e0 = LD(L::Z + 5);
         if (e0 < kp.ey_lb[(size_t)b * N] - kp.opts.tol || e0 > kp.ey_ub[b] + kp.opts.tol) infeas0 = 1;
     } else {
-        c.nobs = kp.n_obs ? kp.n_obs[b] : NOBS;
+        c.nobs = kp.n_obs ? min(max(kp.n_obs[b], 0), min(NOBS, kp.n_obs_max)) : NOBS;   // clamp: device-resident counts cannot be validated on the host
         for (int e = lane; e < (N + 1) * 6; e += WAVE)
             LD(L::xr + e) = kp.per_stage_target ? kp.xt[(size_t)b * (N + 1) * 6 + e] : kp.xt[(size_t)b * 6 + (e % 6)];
         for (int j = lane; j < N; j += WAVE) LD(L::wc + j) = 0.0;
@@ -1096,7 +1097,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // reference fall-back trajectory (overtake_traj_planner.py:365-374)
         const double s0 = kp.x0[(size_t)b * 6 + 4], vx0 = kp.x0[(size_t)b * 6];
         double* bs = sm + L::hg;
-        double* be = sm + L::ga;
+        double* be = sm + L::Hd;
         for (int j = lane; j <= N; j += WAVE) {
             bs[j] = kp.bez_s[(size_t)b * (N + 1) + j];
             be[j] = kp.bez_ey[(size_t)b * (N + 1) + j];
@@ -1134,7 +1135,8 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
 __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kparams sp) {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= sp.n_scen) return;
-    const int N = sp.N, V = sp.V, R = V + 1, nv = sp.n_veh[s];
+    const int N = sp.N, V = sp.V, R = V + 1;
+    const int nv = min(max(sp.n_veh[s], 0), V);   // the *_dev entry points cannot validate device-resident counts: clamp
     const double r2 = sp.veh_length * sp.veh_length + sp.veh_width * sp.veh_width;
     double best_c = INFINITY;
     int best = 0;
@@ -1177,9 +1179,13 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     return hipGetLastError();
 }
 
+// horizon classes: 12 and CRX_MAX_N for every obstacle count, plus 20 for the 3-obstacle instantiation
+// (BASELINE config 4: N = 20)
 template <int NOBS>
 static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
-    return kp.N <= 12 ? launch_t<NOBS, 12>(kp, st) : launch_t<NOBS, CRX_MAX_N>(kp, st);
+    if (kp.N <= 12) return launch_t<NOBS, 12>(kp, st);
+    if (NOBS == 3 && kp.N <= 20) return launch_t<3, 20>(kp, st);
+    return launch_t<NOBS, CRX_MAX_N>(kp, st);
 }
 
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st) {
@@ -1199,7 +1205,7 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
         case 0: return small ? Lay<0, 12>::BYTES : Lay<0, CRX_MAX_N>::BYTES;
         case 1: return small ? Lay<1, 12>::BYTES : Lay<1, CRX_MAX_N>::BYTES;
         case 2: return small ? Lay<2, 12>::BYTES : Lay<2, CRX_MAX_N>::BYTES;
-        default: return small ? Lay<3, 12>::BYTES : Lay<3, CRX_MAX_N>::BYTES;
+        default: return small ? Lay<3, 12>::BYTES : (N <= 20 ? Lay<3, 20>::BYTES : Lay<3, CRX_MAX_N>::BYTES);
     }
 }
 

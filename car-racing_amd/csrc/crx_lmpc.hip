@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     x.lane = threadIdx.x;
     x.N = kp.N;
     x.nu2 = 2 * kp.N;
-    x.M = kp.n_ss[pb];
+    x.M = min(max(kp.n_ss[pb], 1), kp.n_ss_max);   // device-resident counts cannot be validated on the host: clamp (M indexes LDS)
     const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max, ldg = L::ldg(Mx);
     const crx_ipm_opts& o = kp.opts;
 

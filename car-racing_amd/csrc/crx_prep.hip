@@ -31,7 +31,8 @@ __device__ __forceinline__ double prep_interp(const double* xs, const double* ys
 __global__ void __launch_bounds__(WAVE) crx_prep_kernel(const crx_prep_kparams pp) {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= pp.n_scen) return;
-    const int N = pp.N, V = pp.V, R = V + 1, nv = pp.n_veh[s];
+    const int N = pp.N, V = pp.V, R = V + 1;
+    const int nv = min(max(pp.n_veh[s], 0), V);   // device-resident counts cannot be validated on the host: clamp
     const double* xw = pp.x_wrapped + (size_t)6 * s;
     const double* vi = pp.veh_info + (size_t)3 * V * s;
     const double L = pp.lap_length, vw = pp.veh_width, tw = pp.track_width;
