@@ -110,6 +110,18 @@ class PrepDesc(C.Structure):
     ]
 
 
+class PlantDesc(C.Structure):
+    _fields_ = [
+        ("n_sub", C.c_int32),
+        ("n_seg", C.c_int32),
+        ("dt_sub", C.c_double),
+        ("lap_length", C.c_double),
+        ("m", C.c_double), ("lf", C.c_double), ("lr", C.c_double), ("Iz", C.c_double),
+        ("Df", C.c_double), ("Cf", C.c_double), ("Bf", C.c_double),
+        ("Dr", C.c_double), ("Cr", C.c_double), ("Br", C.c_double),
+    ]
+
+
 class SelectDesc(C.Structure):
     _fields_ = [
         ("N", C.c_int32),
@@ -162,6 +174,15 @@ def prep_desc(N, n_veh_max, n_opt, track_width, lap_length, prediction_factor=0.
                     veh_length, veh_width, 0.15, 0.1)
 
 
+def plant_desc(n_seg, lap_length, timestep=0.1, dt_sub=0.001):
+    """BicycleDynamicsParam defaults (utils/base.py:686-697) and the sub-step loop of base.py:899-905."""
+    n_sub = 0
+    while (n_sub + 1) * dt_sub <= timestep:
+        n_sub += 1
+    D = 0.8 * 1.98 * 9.81 / 2.0
+    return PlantDesc(n_sub, int(n_seg), dt_sub, lap_length, 1.98, 0.125, 0.125, 0.024, D, 1.25, 1.0, D, 1.25, 1.0)
+
+
 def select_desc(N, n_veh_max, lap_length, veh_length=0.4, veh_width=0.2):
     """overtake_traj_planner.py:209,223,243 literals."""
     return SelectDesc(int(N), int(n_veh_max), veh_length, veh_width, lap_length, 10.0, 100.0, 100.0)
@@ -187,7 +208,7 @@ class Binding:
 
     def __init__(self, lib, prefix):
         self.lib, self.prefix = lib, prefix
-        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve", "planner_prep"):
+        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve", "planner_prep", "plant_step"):
             if hasattr(lib, prefix + name):
                 getattr(lib, prefix + name).restype = C.c_int
         self._check = None
@@ -330,4 +351,15 @@ class Binding:
         self._call("planner_prep", C.byref(desc), C.c_int(S), _p(x_wrapped), _p(x_raw), _p(n_veh), _p(veh_info),
                    _p(max_dv), _p(obs_s), _p(obs_ey), _p(opt_s), _p(opt_ey), _p(out["x0"]), _p(out["bez_s"]),
                    _p(out["bez_ey"]), _p(out["ey_lb"]), _p(out["ey_ub"]))
+        return out
+
+    def plant_step(self, desc, track, xglob, xcurv, u):
+        """crx_plant_step: one control step of the zero-noise plant for a batch of vehicles."""
+        xglob = np.ascontiguousarray(xglob, dtype=_D)
+        Bn = xglob.shape[0]
+        track = _in(track, _D, (desc.n_seg, 6))
+        xglob, xcurv, u = _in(xglob, _D, (Bn, 6)), _in(xcurv, _D, (Bn, 6)), _in(u, _D, (Bn, 2))
+        out = dict(xglob=np.zeros((Bn, 6)), xcurv=np.zeros((Bn, 6)))
+        self._call("plant_step", C.byref(desc), C.c_int(Bn), _p(track), _p(xglob), _p(xcurv), _p(u), _p(out["xglob"]),
+                   _p(out["xcurv"]))
         return out

@@ -176,3 +176,17 @@ def planner_prep_dev(desc, x_wrapped, x_raw, n_veh, veh_info, max_dv, obs_s, obs
           _ptr(max_dv), _ptr(obs_s), _ptr(obs_ey), _ptr(opt_s), _ptr(opt_ey), _ptr(ws.x0), _ptr(ws.bez_s),
           _ptr(ws.bez_ey), _ptr(ws.ey_lb), _ptr(ws.ey_ub), _stream())
     return ws
+
+
+def plant_step_dev(desc, track, xglob, xcurv, u, xglob_next=None, xcurv_next=None):
+    """crx_plant_step_dev; returns (xglob_next, xcurv_next) (allocated unless given)."""
+    Bn = xglob.shape[0]
+    _chk(track, torch.float64, (desc.n_seg, 6), "track")
+    _chk(xglob, torch.float64, (Bn, 6), "xglob")
+    _chk(xcurv, torch.float64, (Bn, 6), "xcurv")
+    _chk(u, torch.float64, (Bn, 2), "u")
+    xglob_next = torch.empty_like(xglob) if xglob_next is None else xglob_next
+    xcurv_next = torch.empty_like(xcurv) if xcurv_next is None else xcurv_next
+    _call("crx_plant_step_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
+          _ptr(xglob_next), _ptr(xcurv_next), _stream())
+    return xglob_next, xcurv_next

@@ -463,6 +463,55 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     return sg.down(g_stream);
 }
 
+// ---- plant ----------------------------------------------------------------------------------------
+void crx_plant_desc_default(crx_plant_desc* d, int n_seg, double lap_length) {
+    memset(d, 0, sizeof(*d));
+    d->n_sub = 100; d->n_seg = n_seg; d->dt_sub = 0.001; d->lap_length = lap_length;
+    d->m = 1.98; d->lf = 0.125; d->lr = 0.125; d->Iz = 0.024;
+    d->Df = 0.8 * 1.98 * 9.81 / 2.0; d->Cf = 1.25; d->Bf = 1.0;
+    d->Dr = 0.8 * 1.98 * 9.81 / 2.0; d->Cr = 1.25; d->Br = 1.0;
+}
+
+static int check_plant(const crx_plant_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->n_sub < 0 || d->n_seg < 1 || d->n_seg > 64) return fail(CRX_ERR_ARG, "n_sub < 0 or n_seg outside [1,64]");
+    if (!(d->lap_length > 0.0) || !(d->m > 0.0) || !(d->Iz > 0.0)) return fail(CRX_ERR_ARG, "lap_length, m, Iz must be positive");
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    return 0;
+}
+
+int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                       const double* u, double* xglob_next, double* xcurv_next, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_plant(d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_plant_kparams pk;
+    pk.d = *d; pk.batch = batch; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
+    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next;
+    hipError_t e = crx_launch_plant(pk, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "plant launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                   const double* u, double* xglob_next, double* xcurv_next) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_plant(d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t B = (size_t)batch, T = (size_t)d->n_seg * 6;
+    Stage sg;
+    if (int rc = sg.reserve((T + B * 14) * 8, B * 12 * 8)) return rc;
+    double* dtr = sg.in(track, T); double* dg = sg.in(xglob, B * 6); double* dc = sg.in(xcurv, B * 6); double* du = sg.in(u, B * 2);
+    double* dgn = sg.out(xglob_next, B * 6); double* dcn = sg.out(xcurv_next, B * 6);
+    if (int rc = sg.up(g_stream)) return rc;
+    if (int rc = crx_plant_step_dev(d, batch, dtr, dg, dc, du, dgn, dcn, g_stream)) return rc;
+    return sg.down(g_stream);
+}
+
 // ---- planner host prep on the device ---------------------------------------------------------------
 void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, double track_width, double lap_length) {
     memset(d, 0, sizeof(*d));

@@ -59,11 +59,19 @@ struct crx_prep_kparams {
     double *x0, *bez_s, *bez_ey, *ey_lb, *ey_ub;
 };
 
+struct crx_plant_kparams {
+    crx_plant_desc d;
+    int batch;
+    const double *track, *xglob, *xcurv, *u;
+    double *xglob_next, *xcurv_next;
+};
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
 size_t crx_lmpc_lds_bytes(int N, int n_ss_max);

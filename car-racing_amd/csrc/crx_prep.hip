@@ -86,3 +86,67 @@ hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st) {
     hipLaunchKernelGGL(crx_prep_kernel, dim3(pp.n_scen), dim3(WAVE), 0, st, pp);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Plant: one thread per vehicle, n_sub Euler sub-steps.  Restates
+//   system/vehicle_dynamics.py:4-49          one Euler step, global + curvilinear
+//   utils/racing_env.py:225-246              curvature lookup (first matching segment, inclusive ends)
+//   utils/base.py:897-942                    DynamicBicycleModel.forward_dynamics, zero noise
+// Compute-bound on transcendentals (2 atan2, 2 atan, 6 sin/cos per sub-step); HBM traffic 14+12 doubles
+// per vehicle per control step.
+// ------------------------------------------------------------------------------------------------
+#define CRX_PLANT_MAX_SEG 64
+
+__global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams pk) {
+    __shared__ double seg_lo[CRX_PLANT_MAX_SEG], seg_hi[CRX_PLANT_MAX_SEG], seg_cv[CRX_PLANT_MAX_SEG];
+    const crx_plant_desc& d = pk.d;
+    for (int i = threadIdx.x; i < d.n_seg; i += blockDim.x) {
+        seg_lo[i] = pk.track[6 * i + 3];
+        seg_hi[i] = pk.track[6 * i + 3] + pk.track[6 * i + 4];
+        seg_cv[i] = pk.track[6 * i + 5];
+    }
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= pk.batch) return;
+    double vx = pk.xcurv[6 * b], vy = pk.xcurv[6 * b + 1], wz = pk.xcurv[6 * b + 2];
+    double epsi = pk.xcurv[6 * b + 3], s = pk.xcurv[6 * b + 4], ey = pk.xcurv[6 * b + 5];
+    double psi = pk.xglob[6 * b + 3], X = pk.xglob[6 * b + 4], Y = pk.xglob[6 * b + 5];
+    const double delta = pk.u[2 * b], acc = pk.u[2 * b + 1], dt = d.dt_sub;
+    const double sd = sin(delta), cd = cos(delta);
+    for (int it = 0; it < d.n_sub; it++) {
+        // curvature at s (wrapped into one lap), first segment with lo <= s <= hi
+        double sw = s;
+        while (sw > d.lap_length) sw -= d.lap_length;
+        while (sw < 0.0) sw += d.lap_length;
+        double curv = 0.0;
+        for (int i = 0; i < d.n_seg; i++)
+            if (sw >= seg_lo[i] && sw <= seg_hi[i]) { curv = seg_cv[i]; break; }
+        // tyre slip angles and lateral forces (the reference uses lf for the rear axle too, :25)
+        const double slip_f = delta - atan2(vy + d.lf * wz, vx);
+        const double slip_r = -atan2(vy - d.lf * wz, vx);
+        const double Fyf = 2 * d.Df * sin(d.Cf * atan(d.Bf * slip_f));
+        const double Fyr = 2 * d.Dr * sin(d.Cr * atan(d.Br * slip_r));
+        const double dvx = acc - 1 / d.m * Fyf * sd + wz * vy;
+        const double dvy = 1 / d.m * (Fyf * cd + Fyr) - wz * vx;
+        const double dwz = 1 / d.Iz * (d.lf * Fyf * cd - d.lr * Fyr);
+        const double ce = cos(epsi), se = sin(epsi), cp = cos(psi), sp = sin(psi);
+        const double v_long = (vx * ce - vy * se) / (1 - curv * ey);
+        const double psi_n = psi + dt * wz;
+        const double X_n = X + dt * (vx * cp - vy * sp), Y_n = Y + dt * (vx * sp + vy * cp);
+        const double epsi_n = epsi + dt * (wz - v_long * curv);
+        const double s_n = s + dt * v_long;
+        const double ey_n = ey + dt * (vx * se + vy * ce);
+        const double vx_n = vx + dt * dvx, vy_n = vy + dt * dvy, wz_n = wz + dt * dwz;
+        vx = vx_n; vy = vy_n; wz = wz_n; epsi = epsi_n; s = s_n; ey = ey_n; psi = psi_n; X = X_n; Y = Y_n;
+    }
+    double* g = pk.xglob_next + 6 * (size_t)b;
+    double* c = pk.xcurv_next + 6 * (size_t)b;
+    g[0] = vx; g[1] = vy; g[2] = wz; g[3] = psi; g[4] = X; g[5] = Y;
+    c[0] = vx; c[1] = vy; c[2] = wz; c[3] = epsi; c[4] = s; c[5] = ey;
+}
+
+hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st) {
+    if (pk.batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_plant_kernel, dim3((pk.batch + 255) / 256), dim3(256), 0, st, pk);
+    return hipGetLastError();
+}

@@ -167,6 +167,17 @@ typedef struct crx_prep_desc {
     double dt_ref;         /* 0.1  literal time step of the window test (:296) */
 } crx_prep_desc;
 
+/* ---- plant of the simulator (system/vehicle_dynamics.py:4-49, utils/base.py:897-942) ------------------ */
+typedef struct crx_plant_desc {
+    int32_t n_sub;         /* 100: explicit Euler sub-steps per control step (`while (i+1)*0.001 <= timestep`, base.py:905) */
+    int32_t n_seg;         /* rows of the track table point_and_tangent (racing_env.py:17-120) */
+    double dt_sub;         /* 0.001 (base.py:899) */
+    double lap_length;
+    double m, lf, lr, Iz;  /* BicycleDynamicsParam (base.py:686-697): 1.98, 0.125, 0.125, 0.024 */
+    double Df, Cf, Bf;     /* front Pacejka: 0.8*m*g/2, 1.25, 1.0 */
+    double Dr, Cr, Br;     /* rear  Pacejka */
+} crx_plant_desc;
+
 /* library management */
 int crx_version(void);
 /* device >= 0: HIP device ordinal.  There is no CPU back-end in this library: a missing device is
@@ -181,6 +192,7 @@ void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const
 void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B);
 void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length);
 void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max);
+void crx_plant_desc_default(crx_plant_desc* d, int n_seg, double lap_length);
 void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, double track_width, double lap_length);
 
 /*
@@ -265,6 +277,19 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
                          const int32_t* n_veh, const double* veh_info, const double* max_dv, const double* obs_s,
                          const double* obs_ey, const double* opt_s, const double* opt_ey, double* x0,
                          double* bez_s, double* bez_ey, double* ey_lb, double* ey_ub, void* stream);
+
+/*
+ * One control step of the plant for a batch of vehicles: n_sub explicit Euler
+ * sub-steps of the dynamic bicycle with Pacejka tyres (system/vehicle_dynamics.py:4-49) in global and
+ * curvilinear coordinates, the curvature looked up from the track table at every sub-step
+ * (racing_env.py:225-246), exactly DynamicBicycleModel.forward_dynamics with zero noise (base.py:897-942;
+ * the bounded process noise :930-939 is host RNG and stays with the caller).
+ *   track [n_seg][6] rows (x, y, psi, s_start, length, curvature);  xglob, xcurv [batch][6];  u [batch][2]
+ */
+int crx_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                   const double* u, double* xglob_next, double* xcurv_next);
+int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
+                       const double* xcurv, const double* u, double* xglob_next, double* xcurv_next, void* stream);
 
 /*
  * Learning-MPC QPs: control.lmpc (control.py:610-730) after its safe-set

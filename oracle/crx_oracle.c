@@ -780,3 +780,47 @@ int crx_oracle_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh
     }
     return CRX_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Plant: DynamicBicycleModel.forward_dynamics with zero noise
+ * (utils/base.py:897-942) = n_sub explicit Euler sub-steps of system/vehicle_dynamics.py:4-49 with the
+ * curvature looked up per sub-step (utils/racing_env.py:225-246: s wrapped into one lap, first segment
+ * with lo <= s <= hi).  Pinned by tests/golden/harness.npz (single steps and a PID closed loop recorded
+ * from the reference).
+ * ---------------------------------------------------------------------------------------------- */
+int crx_oracle_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
+                          const double* xcurv, const double* u, double* xglob_next, double* xcurv_next) {
+    if (!d || batch < 0 || d->n_seg < 1) return CRX_ERR_ARG;
+    for (int b = 0; b < batch; b++) {
+        double vx = xcurv[6 * b], vy = xcurv[6 * b + 1], wz = xcurv[6 * b + 2];
+        double epsi = xcurv[6 * b + 3], s = xcurv[6 * b + 4], ey = xcurv[6 * b + 5];
+        double psi = xglob[6 * b + 3], X = xglob[6 * b + 4], Y = xglob[6 * b + 5];
+        const double delta = u[2 * b], acc = u[2 * b + 1], dt = d->dt_sub;
+        for (int it = 0; it < d->n_sub; it++) {
+            double sw = s, curv = 0.0;
+            while (sw > d->lap_length) sw -= d->lap_length;
+            while (sw < 0.0) sw += d->lap_length;
+            for (int i = 0; i < d->n_seg; i++)
+                if (sw >= track[6 * i + 3] && sw <= track[6 * i + 3] + track[6 * i + 4]) { curv = track[6 * i + 5]; break; }
+            const double slip_f = delta - atan2(vy + d->lf * wz, vx);          /* :24 */
+            const double slip_r = -atan2(vy - d->lf * wz, vx);                 /* :25 (lf, as the reference) */
+            const double Fyf = 2 * d->Df * sin(d->Cf * atan(d->Bf * slip_f));  /* :27 */
+            const double Fyr = 2 * d->Dr * sin(d->Cr * atan(d->Br * slip_r));  /* :28 */
+            const double dvx = acc - 1 / d->m * Fyf * sin(delta) + wz * vy;    /* :31 */
+            const double dvy = 1 / d->m * (Fyf * cos(delta) + Fyr) - wz * vx;  /* :32 */
+            const double dwz = 1 / d->Iz * (d->lf * Fyf * cos(delta) - d->lr * Fyr); /* :33 */
+            const double v_long = (vx * cos(epsi) - vy * sin(epsi)) / (1 - curv * ey);
+            const double n_psi = psi + dt * wz;
+            const double n_X = X + dt * (vx * cos(psi) - vy * sin(psi)), n_Y = Y + dt * (vx * sin(psi) + vy * cos(psi));
+            const double n_epsi = epsi + dt * (wz - v_long * curv), n_s = s + dt * v_long;
+            const double n_ey = ey + dt * (vx * sin(epsi) + vy * cos(epsi));
+            const double n_vx = vx + dt * dvx, n_vy = vy + dt * dvy, n_wz = wz + dt * dwz;
+            vx = n_vx; vy = n_vy; wz = n_wz; epsi = n_epsi; s = n_s; ey = n_ey; psi = n_psi; X = n_X; Y = n_Y;
+        }
+        double* g = xglob_next + 6 * (size_t)b;
+        double* c = xcurv_next + 6 * (size_t)b;
+        g[0] = vx; g[1] = vy; g[2] = wz; g[3] = psi; g[4] = X; g[5] = Y;
+        c[0] = vx; c[1] = vy; c[2] = wz; c[3] = epsi; c[4] = s; c[5] = ey;
+    }
+    return CRX_OK;
+}

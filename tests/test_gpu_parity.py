@@ -236,6 +236,42 @@ def test_device_prep(gpu, golden_planner):
         np.testing.assert_array_equal(g["x0"], args[0])
 
 
+def test_plant_step(gpu, orc):
+    """crx_plant_step (one thread per vehicle, 100 Euler sub-steps) vs the CPU restatement (pinned to the
+    reference at 0 ulp by test_oracle_golden) over a lap's worth of states, and in a 60-step closed loop."""
+    import os
+
+    import conftest
+    from control import control
+    from crx import abi
+    from utils import racing_env
+
+    spec = np.genfromtxt(os.path.join(conftest.ROOT, "data/track_layout/l_shape.csv"), delimiter=",")
+    track = racing_env.ClosedTrack(spec, track_width=1.0)
+    tab = track.point_and_tangent
+    d = abi.plant_desc(tab.shape[0], track.lap_length)
+    rng = np.random.default_rng(11)
+    B = 4096
+    xc = np.stack([rng.uniform(0.3, 2.0, B), rng.normal(0, 0.05, B), rng.normal(0, 0.3, B), rng.uniform(-0.2, 0.2, B),
+                   rng.uniform(-1.0, 2.2 * track.lap_length, B), rng.uniform(-0.8, 0.8, B)], axis=1)
+    xg = np.stack([xc[:, 0], xc[:, 1], xc[:, 2], rng.uniform(-3, 3, B), rng.uniform(-5, 5, B), rng.uniform(-5, 5, B)], axis=1)
+    u = np.stack([rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)], axis=1)
+    rg, ro = gpu.plant_step(d, tab, xg, xc, u), orc.plant_step(d, tab, xg, xc, u)
+    # device sin/cos/atan differ from glibc's in the last place; 100 sub-steps accumulate ~1e-14
+    np.testing.assert_allclose(rg["xcurv"], ro["xcurv"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rg["xglob"], ro["xglob"], rtol=0, atol=1e-12)
+    # closed loop under PID, 60 steps (crosses two corners)
+    g = (np.zeros((1, 6)), np.zeros((1, 6)))
+    o = (np.zeros((1, 6)), np.zeros((1, 6)))
+    for k in range(60):
+        ug = control.pid(g[1][0], np.array([0.8, 0, 0, 0, 0, 0.0]))[None]
+        uo = control.pid(o[1][0], np.array([0.8, 0, 0, 0, 0, 0.0]))[None]
+        r = gpu.plant_step(d, tab, g[0], g[1], ug); g = (r["xglob"], r["xcurv"])
+        r = orc.plant_step(d, tab, o[0], o[1], uo); o = (r["xglob"], r["xcurv"])
+    np.testing.assert_allclose(g[1], o[1], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(g[0], o[0], rtol=0, atol=1e-10)
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 

@@ -147,3 +147,34 @@ def test_lmpc_qps(orc, golden_racing_game, linalg):
     # the first instance HiGHS proved infeasible (the reference pins its terminal slack to zero): reported, not hidden
     first_bad = int(g["lmpc_first_uncertified"])
     assert r["status"][first_bad] == 2
+
+
+def test_plant_step(orc):
+    """The plant restatement (system/vehicle_dynamics.py:4-49 under the sub-step loop of
+    utils/base.py:897-942) against the reference: 40 recorded single Euler steps and the 30-step PID
+    closed loop on l_shape (tests/golden/harness.npz)."""
+    import os
+
+    import conftest
+    from control import control
+    from crx import abi
+    from utils import racing_env
+
+    H = np.load(os.path.join(conftest.GOLDEN, "harness.npz"))
+    for i in range(H["plant/u"].shape[0]):
+        d = abi.plant_desc(1, 1e9, timestep=0.001)          # one sub-step, one segment carrying the recorded curvature
+        tr = np.array([[0, 0, 0, -1e9, 3e9, H["plant/curv"][i]]])
+        r = orc.plant_step(d, tr, H["plant/xglob"][i:i + 1], H["plant/xcurv"][i:i + 1], H["plant/u"][i:i + 1])
+        np.testing.assert_allclose(r["xglob"][0], H["plant/xglob_next"][i], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(r["xcurv"][0], H["plant/xcurv_next"][i], rtol=0, atol=1e-15)
+    spec = np.genfromtxt(os.path.join(conftest.ROOT, "data/track_layout/l_shape.csv"), delimiter=",")
+    track = racing_env.ClosedTrack(spec, track_width=0.8)
+    d = abi.plant_desc(track.point_and_tangent.shape[0], track.lap_length)
+    assert d.n_sub == 100
+    xg, xc = np.zeros((1, 6)), np.zeros((1, 6))
+    for k in range(H["pid/xcurv_log"].shape[0]):
+        u = control.pid(xc[0], np.array([0.8, 0, 0, 0, 0, 0.0]))
+        r = orc.plant_step(d, track.point_and_tangent, xg, xc, u[None])
+        xg, xc = r["xglob"], r["xcurv"]
+        np.testing.assert_allclose(xc[0], H["pid/xcurv_log"][k], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(xg[0], H["pid/xglob_log"][k], rtol=0, atol=1e-13)
