@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "lmpc"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "lmpc", "races"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-prep", action="store_true",
@@ -88,7 +88,24 @@ def main():
         t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         return t.to(dtype) if dtype is not None else t
 
-    if wl == "lmpc":
+    races = None
+    if wl == "races":
+        # B closed-loop MPC-CBF races, one control step of all of them per bench step
+        from crx import montecarlo
+        from utils import racing_env
+        track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+        batch = args.batch or 4096
+        rng = np.random.default_rng(50 + rank)
+        s0 = np.sort(rng.uniform(3.0, 17.0, (batch, 2)), axis=1)
+        s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
+        races = montecarlo.MpccbfRaces(track.point_and_tangent, track.lap_length, track.width, A, B, np.zeros((batch, 6)),
+                                       np.zeros((batch, 6)), s0, rng.uniform(0.1, 0.4, (batch, 2)),
+                                       rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (batch, 2)), vt=0.8, N=10, device=dev)
+        desc, ws, N, n_obs, units = races.desc, races.ws, 10, 2, batch
+        p = None
+        step = races.step
+        name = "closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per step (predictions, window filter, NLP N=10 with 2 scripted cars, plant)" % batch
+    elif wl == "lmpc":
         g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
         ok = np.nonzero(g["lmpc_success"])[0]
         batch = args.batch or 4096
@@ -186,6 +203,8 @@ def main():
             torch_api.planner_solve_dev(desc, *t_in, ws=ws)
         elif wl == "lmpc":
             torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
+        elif wl == "races":
+            torch_api.cbf_solve_dev(desc, races.xc, races.xt, *races_last_inputs(races), ws=ws)
         else:
             torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
         kms.append(L.crx_last_kernel_ms())
@@ -201,7 +220,9 @@ def main():
     # ONE control step as the reference's class surface issues it: host arrays in, host arrays out, the batch
     # one step sees (1 NLP / 1 QP, or the V+1 region QPs + selection of one planner call) -- PCIe-inclusive
     hb = crx.binding()
-    if wl == "cfg3":
+    if wl == "races":
+        one = lambda: None  # noqa: E731  (the class-surface step of this scenario is the cfg2-type call)
+    elif wl == "cfg3":
         R1 = V + 1
         a1 = tuple(p[k][:R1] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")) + tuple(p[k][:1] for k in ("n_veh", "obs_s", "obs_ey", "old_flag"))
         one = lambda: hb.planner_plan(desc, sdesc, *a1)  # noqa: E731
@@ -248,7 +269,7 @@ def main():
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3, "lmpc": None}[wl], "batch_per_gpu": int(batch),
+        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3, "lmpc": None, "races": None}[wl], "batch_per_gpu": int(batch),
                    "horizon": int(N), "n_obs": 0 if wl == "lmpc" else int(n_obs), "n_ss": int(n_obs) if wl == "lmpc" else 0,
                    "tol": desc.opts.tol,
                    "scenario_filter": not args.no_scenario_filter,
@@ -263,12 +284,25 @@ def main():
                      "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
                      "lds_bytes_per_problem": lds, "resident_problems_per_cu": int((160 * 1024) // lds)},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and wl != "races":
         out["cpu_baseline"] = cpu_baseline(wl, desc, p, batch)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def races_last_inputs(r):
+    """Obstacle arrays of the current control step of a MpccbfRaces object (for the kernel-time probe)."""
+    import torch
+
+    N, Lp = r.N, r.lap_length
+    tt = r.t + r.jdt
+    obs_s = r.v[:, :, None] * tt[None, None, :] + r.s0[:, :, None]
+    obs_e = r.ey[:, :, None] + 0.0 * tt[None, None, :]
+    nce = torch.trunc(r.xc[:, 4:5] / Lp)
+    nco = torch.trunc(obs_s[:, :, 0] / Lp)
+    return obs_s.contiguous(), obs_e.contiguous(), ((nce - nco) * Lp).contiguous(), torch.full((r.batch,), r.V, dtype=torch.int32, device=r.xc.device)
 
 
 def cpu_baseline(wl, desc, p, batch):

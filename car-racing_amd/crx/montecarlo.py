@@ -1,0 +1,95 @@
+"""Batched closed-loop races, device-resident from the first step to the last.
+
+`mpccbf_races` is the simulation loop of the reference's MPC-CBF racing scenario
+(tests/auto_mpccbf_test.py:9-46 -> racing/offboard.py:114-131 -> utils/base.py:780-794) for B independent
+races at once: per control step, obstacle predictions of the scripted cars (utils/base.py:879-886), the
+window filter and lap offsets of control.mpccbf (control/control.py:499-523,538-540), ONE
+crx_cbf_solve_dev over all races, ONE crx_plant_step_dev, lap bookkeeping (utils/base.py:795-819).
+Nothing returns to the host inside the loop; torch is used for device memory and the element-wise
+glue only, the two solves are libcrx kernels.
+
+The reference runs such sweeps one race at a time (car_racing/tests/overtake_planner_test.py
+--multi-tests); this is the same experiment with the race index as the batch dimension.
+"""
+import numpy as np
+import torch
+
+from . import abi, torch_api
+
+_LAP_TRUNC = torch.trunc
+
+
+class MpccbfRaces:
+    """State of B races on the device; step() advances all of them by one control step."""
+
+    def __init__(self, track_table, lap_length, track_width, A, B, xcurv0, xglob0, car_s0, car_v, car_ey,
+                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None):
+        dev = torch.device(device if device is not None else "cuda")
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.xc = torch.as_tensor(np.ascontiguousarray(xcurv0), **f64).clone()
+        self.xg = torch.as_tensor(np.ascontiguousarray(xglob0), **f64).clone()
+        self.s0, self.v, self.ey = (torch.as_tensor(np.ascontiguousarray(a), **f64) for a in (car_s0, car_v, car_ey))
+        Bn, V = self.s0.shape
+        if V > abi.CRX_MAX_OBS:
+            raise ValueError("at most %d scripted cars" % abi.CRX_MAX_OBS)
+        self.N, self.V, self.batch, self.lap_length, self.timestep = N, V, Bn, lap_length, timestep
+        self.tab = torch.as_tensor(np.ascontiguousarray(track_table), **f64)
+        self.desc = abi.cbf_desc(N, V, A, B, alpha=alpha, margin=0.2, ey_max=track_width)
+        self.pdesc = abi.plant_desc(self.tab.shape[0], lap_length, timestep=timestep)
+        self.xt = torch.tensor([vt, 0, 0, 0, 0, eyt], **f64).repeat(Bn, 1).contiguous()
+        self.ws = torch_api.CbfWorkspace(self.desc, Bn, dev)
+        self.jdt = torch.arange(N + 1, **f64) * timestep
+        self.laps = torch.zeros(Bn, dtype=torch.int32, device=dev)
+        self.ar = torch.arange(V, device=dev)
+        self.t = 0.0   # every vehicle's own clock, advanced by `+= timestep` like the reference's (base.py:889,941)
+        self.u = None
+
+    def step(self):
+        N, L, xc = self.N, self.lap_length, self.xc
+        # predictions from the cars' clock (quirk Q6), unwrapped in s
+        tt = self.t + self.jdt                                                       # [N+1]
+        obs_s = self.v[:, :, None] * tt[None, None, :] + self.s0[:, :, None]         # [B,V,N+1]
+        obs_e = self.ey[:, :, None] + 0.0 * tt[None, None, :]
+        # window filter and lap offsets (control.py:499-523,538-540); int() truncates toward zero
+        margin = 2.0 * xc[:, 0:1]
+        nce = _LAP_TRUNC(xc[:, 4:5] / L)
+        dist_ego = xc[:, 4:5] - nce * L
+        nco = _LAP_TRUNC(obs_s[:, :, 0] / L)
+        dist_obs = obs_s[:, :, 0] - nco * L
+        keep = (dist_ego > dist_obs - margin) & (dist_ego < dist_obs + margin)       # [B,V]
+        lap_off = (nce - nco) * L
+        # kept obstacles to the front, in vehicle order (stable), the rest zero-padded
+        order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices
+        n_obs = keep.sum(dim=1).to(torch.int32)
+        live = (self.ar[None, :] < n_obs[:, None])
+        ps = torch.gather(obs_s, 1, order[:, :, None].expand(-1, -1, N + 1)) * live[:, :, None]
+        pe = torch.gather(obs_e, 1, order[:, :, None].expand(-1, -1, N + 1)) * live[:, :, None]
+        po = torch.gather(lap_off, 1, order) * live
+        torch_api.cbf_solve_dev(self.desc, xc, self.xt, ps.contiguous(), pe.contiguous(), po.contiguous(), n_obs.contiguous(),
+                                ws=self.ws)
+        self.u = self.ws.U[:, 0, :].contiguous()
+        self.xg, xc = torch_api.plant_step_dev(self.pdesc, self.tab, self.xg, xc, self.u)
+        # lap bookkeeping: s wrapped in place once it exceeds the lap length (base.py:795-819)
+        crossed = xc[:, 4] > L
+        xc[:, 4] = torch.where(crossed, xc[:, 4] - L, xc[:, 4])
+        self.laps += crossed.to(torch.int32)
+        self.xc = xc
+        self.t += self.timestep
+
+
+def mpccbf_races(track_table, lap_length, track_width, A, B, xcurv0, xglob0, car_s0, car_v, car_ey, steps,
+                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None, log_every=1):
+    """xcurv0, xglob0 [B,6]; car_s0, car_v, car_ey [B,V] with V <= 3: scripted cars s(t) = v t + s0, ey(t) = ey
+    (NoDynamicsModel, utils/base.py:847-890).  Returns host arrays: xcurv [T+1,B,6] (T = steps/log_every), u [T,B,2],
+    status [T,B], laps [B]."""
+    r = MpccbfRaces(track_table, lap_length, track_width, A, B, xcurv0, xglob0, car_s0, car_v, car_ey, vt=vt, eyt=eyt,
+                    N=N, alpha=alpha, timestep=timestep, device=device)
+    log_x, log_u, log_st = [r.xc.clone()], [], []
+    for k in range(steps):
+        r.step()
+        if (k + 1) % log_every == 0:
+            log_x.append(r.xc.clone())
+            log_u.append(r.u)
+            log_st.append(r.ws.status.clone())
+    return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(),
+                status=torch.stack(log_st).cpu().numpy(), laps=r.laps.cpu().numpy())

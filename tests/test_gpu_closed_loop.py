@@ -261,3 +261,76 @@ def test_racing_game(capsys):
         dey = e3[1:len(c) + 1, 5] - c[:, 5]
         assert ds[0] < 0 < ds[-1], (car.name, ds[0], ds[-1])
         assert ((ds / 0.4) ** 6 + (dey / 0.2) ** 6).min() >= 1.0, car.name
+
+
+def test_batched_closed_loop_races(AB):
+    """crx.montecarlo.mpccbf_races: the MPC-CBF racing loop with the race index as the batch dimension,
+    device-resident (prediction -> window filter -> crx_cbf_solve_dev -> crx_plant_step_dev -> lap wrap).
+    64 copies of the reference's tests/auto_mpccbf_test.py scenario must reproduce the reference's own
+    closed loop (closed_loop_mpccbf.npz) and each other; a randomised sweep must stay finite, mostly
+    converged and contact-free."""
+    from crx import montecarlo
+
+    A, B = AB
+    track = _track(1.0)
+    tab, L = track.point_and_tangent, track.lap_length
+    ref = np.load(conftest.GOLDEN + "/closed_loop_mpccbf.npz")
+    steps = int(ref["steps"])
+    n = 64
+    z = np.zeros((n, 6))
+    r = montecarlo.mpccbf_races(tab, L, track.width, A, B, z, z, np.tile([4.0, 10.0], (n, 1)), np.tile([0.2, 0.2], (n, 1)),
+                                np.tile([0.1, -0.1], (n, 1)), steps, vt=0.8, N=10, alpha=0.8)
+    e = r["xcurv"][1:, 0]
+    assert e.shape == (steps, 6) and np.isfinite(r["xcurv"]).all()
+    np.testing.assert_array_equal(r["xcurv"][:, 1:], r["xcurv"][:, :1].repeat(n - 1, axis=1))   # identical races, identical bits
+    n_ok = int(np.nonzero(~ref["solve_success"][1:])[0][0]) + 1
+    np.testing.assert_allclose(e[:n_ok], ref["ego_xcurv"][:n_ok], atol=1e-3)
+    np.testing.assert_allclose(e[:, [0, 4, 5]], ref["ego_xcurv"][:, [0, 4, 5]], atol=5e-2)      # the whole 40 s, as the class-surface test
+    # randomised sweep: cars ahead of the ego at random gaps, speeds and lanes
+    rng = np.random.default_rng(5)
+    m = 512
+    s0 = np.sort(rng.uniform(3.0, 17.0, (m, 2)), axis=1)
+    s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
+    v = rng.uniform(0.1, 0.4, (m, 2))
+    ey = rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (m, 2))
+    rr = montecarlo.mpccbf_races(tab, L, track.width, A, B, np.zeros((m, 6)), np.zeros((m, 6)), s0, v, ey, 300, vt=0.8)
+    x = rr["xcurv"]
+    assert np.isfinite(x).all()
+    assert (rr["status"] == 0).mean() >= 0.97
+    assert np.abs(x[:, :, 5]).max() <= 1.2 * track.width
+    assert (rr["laps"] >= 1).mean() >= 0.5          # 30 s at vt = 0.8 is more than a lap unless a car blocks the way
+    # the same races one at a time through the mirrored class surface (MPCCBFRacing -> control.mpccbf -> host prep
+    # -> crx_cbf_solve, DynamicBicycleModel.forward_dynamics in numpy): the batched loop must retrace them.
+    # (No safety property is asserted on random placements: the reference's CBF rows are soft, and its one-sided
+    # lap correction -- quirk Q1, control.py:539-542 -- lets the ego drive through a car at the start line; both
+    # paths reproduce that.)
+    import sympy as sp
+
+    from racing import offboard
+    from utils import base
+
+    t_symbol = sp.symbols("t")
+    for b in (3, 127, 458):
+        ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+        ego.set_zero_noise()
+        ego.set_state_curvilinear(np.zeros((6,)))
+        ego.set_state_global(np.zeros((6,)))
+        ego.start_logging()
+        ego.set_ctrl_policy(offboard.MPCCBFRacing(base.MPCCBFRacingParam(vt=0.8), ego.system_param))
+        ego.ctrl_policy.set_timestep(0.1)
+        ego.set_track(track)
+        ego.ctrl_policy.set_track(track)
+        simulator = offboard.CarRacingSim()
+        simulator.set_timestep(0.1)
+        simulator.set_track(track)
+        simulator.add_vehicle(ego)
+        ego.ctrl_policy.set_racing_sim(simulator)
+        for c in range(2):
+            car = offboard.NoDynamicsModel(name="car%d" % (c + 1), param=base.CarParam())
+            car.set_track(track)
+            car.set_state_curvilinear_func(t_symbol, float(v[b, c]) * t_symbol + float(s0[b, c]), float(ey[b, c]) + 0.0 * t_symbol)
+            car.start_logging()
+            simulator.add_vehicle(car)
+        simulator.sim(sim_time=12.0)
+        one = np.array(ego.xcurv_log)
+        np.testing.assert_allclose(x[1:one.shape[0] + 1, b], one, atol=1e-3, err_msg="race %d" % b)
