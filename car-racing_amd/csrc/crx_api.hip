@@ -86,6 +86,7 @@ struct PinBuf {
 };
 PinBuf g_hin, g_hout;
 DevBuf g_trace;
+int g_poison = 0;
 int g_trace_rows = 0, g_trace_problem = 0;
 
 int ensure_init() {
@@ -212,6 +213,7 @@ int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
 int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
     crx_kparams kq = kp;
     if (g_trace_rows != 0) { kq.trace = (double*)g_trace.p; kq.trace_problem = g_trace_problem; kq.trace_rows = g_trace_rows; }
+    kq.poison = g_poison;
     size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
     if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
     timing_begin(st);
@@ -285,6 +287,10 @@ int crx_trace_read(double* host, int rows) {
     HIP_TRY(hipMemcpy(host, g_trace.p, (size_t)rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return CRX_OK;
 }
+
+// diagnostics (not in crx.h): make the solver kernels fill their LDS slice with NaN before set-up, so that a read
+// of LDS the kernel did not write shows up as a changed result (tests/test_gpu_parity.py::test_no_stale_lds_reads)
+void crx_debug_poison_lds(int enable) { g_poison = enable != 0; }
 
 // diagnostics (not in crx.h): LDS bytes one problem occupies (= one single-wave workgroup), for the
 // "resident problems per CU" figure of bench.py.  kind 0: crx_solve_kernel (N, n_obs_max); 1: crx_lmpc_kernel (N, n_ss_max)
@@ -626,6 +632,7 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
     kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
     kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
     if (g_trace_rows > 0) { kp.trace = (double*)g_trace.p; kp.trace_problem = g_trace_problem; kp.trace_rows = g_trace_rows; }
+    kp.poison = g_poison;
     timing_begin((hipStream_t)stream);
     hipError_t e = crx_launch_lmpc(kp, (hipStream_t)stream);
     timing_end((hipStream_t)stream);

@@ -279,9 +279,11 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
                 J[5] -= d * c.om * gec;
                 J[6 + o] += d * c.om;
                 J[L::NX + 2 + o] -= d;
-            } else {
+            } else {   // absent obstacle: its rows carry zero weights, but 0 * (stale LDS) must not become NaN
 #pragma unroll
                 for (int a = 0; a < L::NZ; a++) J[a] = 0.0;
+#pragma unroll
+                for (int a = 0; a < 8; a++) G[a] = 0.0;
             }
         }
         SYNC();
@@ -697,6 +699,10 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     int* si = (int*)(sm + L::END_D);
     const int b = blockIdx.x, lane = threadIdx.x, N = kp.N;
     if (b >= kp.batch) return;
+    if (kp.poison) {   // diagnostics (crx_debug_poison_lds): any read of LDS this kernel did not write turns into NaN
+        for (int e = lane; e < (int)(L::BYTES / 8); e += WAVE) sm[e] = __longlong_as_double(0x7ff8dead0000beefLL);
+        SYNC();
+    }
     Ctx c;
     c.N = N; c.lane = lane; c.m = N * NR + NOBS; c.nobs = 0;
     const int m = c.m;

@@ -26,6 +26,7 @@ struct crx_kparams {
     // optional per-iteration trace of ONE problem (diagnostics): trace[it][8]
     double* trace;
     int trace_problem, trace_rows;
+    int poison;   // diagnostics: fill the LDS slice with NaN before set-up (catches reads of stale LDS)
 };
 
 struct crx_lmpc_kparams {
@@ -39,6 +40,7 @@ struct crx_lmpc_kparams {
     int32_t *status, *iters;
     double* trace;   // optional per-iteration phase cycles of ONE problem (diagnostics): trace[it][16]
     int trace_problem, trace_rows;
+    int poison;      // diagnostics: fill the LDS slice with NaN before set-up
 };
 
 struct crx_select_kparams {

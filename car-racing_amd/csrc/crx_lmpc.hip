@@ -213,6 +213,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     x.M = min(max(kp.n_ss[pb], 1), kp.n_ss_max);   // device-resident counts cannot be validated on the host: clamp (M indexes LDS)
     const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max, ldg = L::ldg(Mx);
     const crx_ipm_opts& o = kp.opts;
+    if (kp.poison) {   // diagnostics (crx_debug_poison_lds)
+        for (int e = lane; e < (int)(L::bytes(Mx) / 8); e += WAVE) sm[e] = __longlong_as_double(0x7ff8dead0000beefLL);
+        SYNC();
+    }
 
     // ---- load the problem (coalesced) --------------------------------------------------------------
     for (int i = lane; i < 36 * N; i += WAVE) LDS(L::A + i) = kp.A[(size_t)36 * N * pb + i];

@@ -272,6 +272,42 @@ def test_plant_step(gpu, orc):
     np.testing.assert_allclose(g[0], o[0], rtol=0, atol=1e-10)
 
 
+def test_no_stale_lds_reads(gpu, AB, golden_racing_game):
+    """Every solver kernel with its LDS slice pre-filled with NaN (hidden crx_debug_poison_lds): results must be
+    bit-identical to the unpoisoned run.  Catches `0 * (LDS the kernel never wrote)`, which is harmless after any
+    kernel left finite data behind and nondeterministic on a fresh device."""
+    import crx
+    from crx import abi, synth
+
+    A, B = AB
+    L = crx.lib()
+    p2 = synth.cfg2_mpccbf(96, N=12, n_obs=2)
+    n2 = (np.arange(96) % 3).astype(np.int32)                       # 0, 1, 2 obstacles present out of 2 slots
+    d2 = abi.cbf_desc(12, 2, A, B, alpha=p2["alpha"], margin=p2["margin"])
+    a2 = (p2["x0"], p2["xt"], p2["obs_s"], p2["obs_ey"], p2["lap_off"], n2)
+    p4 = synth.cfg4_tracking_cbf(64, N=20)
+    n4 = (np.arange(64) % 4).astype(np.int32)
+    d4 = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    a4 = (p4["x0"], p4["xt"], p4["obs_s"], p4["obs_ey"], p4["lap_off"], n4)
+    p3 = synth.cfg3_planner(32, N=12)
+    d3 = abi.planner_desc(12, A, B)
+    a3 = (p3["x0"], p3["bez_s"], p3["bez_ey"], p3["ey_lb"], p3["ey_ub"])
+    dl, al = helpers.lmpc_inputs(golden_racing_game)                # includes instances that take the second attempt
+
+    def run():
+        return (gpu.cbf_solve(d2, *a2), gpu.cbf_solve(d4, *a4), gpu.planner_solve(d3, *a3), gpu.lmpc_solve(dl, *al))
+
+    clean = run()
+    L.crx_debug_poison_lds(1)
+    try:
+        dirty = run()
+    finally:
+        L.crx_debug_poison_lds(0)
+    for rc, rd in zip(clean, dirty):
+        for k in ("X", "U", "status", "iters", "kkt"):
+            np.testing.assert_array_equal(rc[k], rd[k], err_msg=k)
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 
