@@ -308,6 +308,65 @@ def test_no_stale_lds_reads(gpu, AB, golden_racing_game):
             np.testing.assert_array_equal(rc[k], rd[k], err_msg=k)
 
 
+def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
+    """Differential fuzz over the descriptor space (horizons 3..24 incl. odd ones, 0..3 obstacle slots with ragged
+    counts, CBF degree 2/4/6, alpha, margins, weights, per-stage targets; LMPC with ragged safe-set sizes and
+    horizons): kernel vs oracle, same verdict and same trajectory wherever both converge."""
+    from crx import abi, synth
+
+    A, B = AB
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for trial in range(14):
+        N = int(rng.integers(3, 25))
+        V = int(rng.integers(0, 4))
+        nb = 48
+        if V == 0:
+            p = synth.cfg2_mpccbf(nb, N=N, seed=100 + trial, n_obs=1)
+            d = abi.cbf_desc(N, 0, A, B, Q=tuple(rng.uniform(0, 30, 6)), R=tuple(rng.uniform(0.05, 1.0, 2)), ey_max=float(rng.uniform(0.7, 1.2)))
+            args = (p["x0"], p["xt"], np.zeros((nb, 0, N + 1)), np.zeros((nb, 0, N + 1)), np.zeros((nb, 0)), np.zeros(nb, np.int32))
+        else:
+            per_stage = bool(rng.integers(0, 2))
+            p = synth.cfg4_tracking_cbf(nb, N=N, seed=100 + trial, n_obs=V) if per_stage else synth.cfg2_mpccbf(nb, N=N, seed=100 + trial, n_obs=V)
+            d = abi.cbf_desc(N, V, A, B, alpha=float(rng.uniform(0.3, 1.0)), margin=float(rng.uniform(0.05, 0.3)),
+                             degree=int(rng.choice([2, 4, 6])), per_stage_target=per_stage,
+                             Q=(10.0, 0, 0, float(rng.uniform(1, 8)), 0, float(rng.uniform(10, 60))))
+            n = rng.integers(0, V + 1, nb).astype(np.int32)
+            args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], n)
+        rg, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+        agree = ((rg["status"] == 0) == (ro["status"] == 0)).mean()
+        assert agree >= 0.9, (trial, N, V, agree)
+        both = (rg["status"] == 0) & (ro["status"] == 0)
+        if both.any():
+            dX = np.abs(rg["X"][both] - ro["X"][both])
+            assert dX[..., [0, 4, 5]].max() <= XW and dX.max() <= XALL, (trial, N, V, dX.max())
+            checked += int(both.sum())
+    assert checked >= 300
+    # planner QPs at every horizon class
+    for N in (3, 7, 12, 13, 19, 24):
+        p = synth.cfg3_planner(16, N=N, seed=N)
+        d = abi.planner_desc(N, A, B)
+        args = (p["x0"], p["bez_s"], p["bez_ey"], p["ey_lb"], p["ey_ub"])
+        rg, ro = gpu.planner_solve(d, *args), orc.planner_solve(d, *args)
+        assert ((rg["status"] == 0) == (ro["status"] == 0)).all(), N
+        _cmp("planner N=%d" % N, rg, ro, need_same_status=False)
+    # learning-MPC QPs: ragged safe-set sizes (first n points of each recorded hull) and shorter horizons
+    g = golden_racing_game
+    ok = np.nonzero(g["lmpc_success"])[0][:24]
+    for N in (12, 9, 5):
+        M = g["lmpc/ss"].shape[2]
+        d = abi.lmpc_desc(N=N, n_ss_max=M)
+        n_ss = rng.integers(8, M + 1, len(ok)).astype(np.int32)
+        args = (g["lmpc/x"][ok], g["lmpc/u_old"][ok], g["lmpc/A"][ok][:, :N], g["lmpc/B"][ok][:, :N], g["lmpc/C"][ok][:, :N],
+                g["lmpc/ss"][ok], g["lmpc/qfun"][ok], n_ss)
+        rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
+        assert (rg["status"] == ro["status"]).mean() >= 0.9, (N, rg["status"], ro["status"])
+        both = (rg["status"] == ro["status"]) & (ro["status"] != 1)
+        assert both.sum() >= 12
+        assert np.abs(rg["X"][both] - ro["X"][both]).max() <= 1e-5, N
+        assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 
