@@ -204,7 +204,7 @@ def main():
         elif wl == "lmpc":
             torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
         elif wl == "races":
-            torch_api.cbf_solve_dev(desc, races.xc, races.xt, *races_last_inputs(races), ws=ws)
+            torch_api.cbf_solve_dev(desc, races.xc, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=ws)
         else:
             torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
         kms.append(L.crx_last_kernel_ms())
@@ -290,19 +290,6 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-
-
-def races_last_inputs(r):
-    """Obstacle arrays of the current control step of a MpccbfRaces object (for the kernel-time probe)."""
-    import torch
-
-    N, Lp = r.N, r.lap_length
-    tt = r.t + r.jdt
-    obs_s = r.v[:, :, None] * tt[None, None, :] + r.s0[:, :, None]
-    obs_e = r.ey[:, :, None] + 0.0 * tt[None, None, :]
-    nce = torch.trunc(r.xc[:, 4:5] / Lp)
-    nco = torch.trunc(obs_s[:, :, 0] / Lp)
-    return obs_s.contiguous(), obs_e.contiguous(), ((nce - nco) * Lp).contiguous(), torch.full((r.batch,), r.V, dtype=torch.int32, device=r.xc.device)
 
 
 def cpu_baseline(wl, desc, p, batch):

@@ -3,10 +3,9 @@
 `mpccbf_races` is the simulation loop of the reference's MPC-CBF racing scenario
 (tests/auto_mpccbf_test.py:9-46 -> racing/offboard.py:114-131 -> utils/base.py:780-794) for B independent
 races at once: per control step, obstacle predictions of the scripted cars (utils/base.py:879-886), the
-window filter and lap offsets of control.mpccbf (control/control.py:499-523,538-540), ONE
-crx_cbf_solve_dev over all races, ONE crx_plant_step_dev, lap bookkeeping (utils/base.py:795-819).
-Nothing returns to the host inside the loop; torch is used for device memory and the element-wise
-glue only, the two solves are libcrx kernels.
+window filter and lap offsets of control.mpccbf (control/control.py:499-523,538-540), crx_cbf_prep_dev), ONE crx_cbf_solve_dev over all races, ONE crx_plant_step_wrap_dev incl. the lap
+bookkeeping (utils/base.py:795-819).  Three libcrx launches per control step, nothing returns to the host
+inside the loop; torch only owns the device memory.
 
 The reference runs such sweeps one race at a time (car_racing/tests/overtake_planner_test.py
 --multi-tests); this is the same experiment with the race index as the batch dimension.
@@ -41,16 +40,34 @@ class MpccbfRaces:
         self.jdt = torch.arange(N + 1, **f64) * timestep
         self.laps = torch.zeros(Bn, dtype=torch.int32, device=dev)
         self.ar = torch.arange(V, device=dev)
+        self.obs_s = torch.empty((Bn, V, N + 1), **f64)
+        self.obs_e = torch.empty((Bn, V, N + 1), **f64)
+        self.lap_off = torch.empty((Bn, V), **f64)
+        self.n_obs = torch.empty((Bn,), dtype=torch.int32, device=dev)
+        self.xg_next, self.xc_next = torch.empty_like(self.xg), torch.empty_like(self.xc)
         self.t = 0.0   # every vehicle's own clock, advanced by `+= timestep` like the reference's (base.py:889,941)
         self.u = None
 
     def step(self):
+        """One control step of every race: three libcrx launches, nothing else."""
+        N = self.N
+        torch_api.cbf_prep_dev(N, self.lap_length, self.t, self.timestep, self.xc, self.s0, self.v, self.ey,
+                               self.obs_s, self.obs_e, self.lap_off, self.n_obs)
+        torch_api.cbf_solve_dev(self.desc, self.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.ws)
+        # the plant reads u_0 of every race straight out of the solver's U [B][N][2]
+        torch_api.plant_step_wrap_dev(self.pdesc, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps)
+        self.xg, self.xg_next = self.xg_next, self.xg
+        self.xc, self.xc_next = self.xc_next, self.xc
+        self.u = self.ws.U[:, 0, :]
+        self.t += self.timestep
+
+    def step_glue(self):
+        """The same control step with the prediction / window filter / packing / lap wrap written as element-wise
+        torch ops (the first version; kept as an independent restatement for the tests)."""
         N, L, xc = self.N, self.lap_length, self.xc
-        # predictions from the cars' clock (quirk Q6), unwrapped in s
         tt = self.t + self.jdt                                                       # [N+1]
         obs_s = self.v[:, :, None] * tt[None, None, :] + self.s0[:, :, None]         # [B,V,N+1]
         obs_e = self.ey[:, :, None] + 0.0 * tt[None, None, :]
-        # window filter and lap offsets (control.py:499-523,538-540); int() truncates toward zero
         margin = 2.0 * xc[:, 0:1]
         nce = _LAP_TRUNC(xc[:, 4:5] / L)
         dist_ego = xc[:, 4:5] - nce * L
@@ -58,7 +75,6 @@ class MpccbfRaces:
         dist_obs = obs_s[:, :, 0] - nco * L
         keep = (dist_ego > dist_obs - margin) & (dist_ego < dist_obs + margin)       # [B,V]
         lap_off = (nce - nco) * L
-        # kept obstacles to the front, in vehicle order (stable), the rest zero-padded
         order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices
         n_obs = keep.sum(dim=1).to(torch.int32)
         live = (self.ar[None, :] < n_obs[:, None])
@@ -69,7 +85,6 @@ class MpccbfRaces:
                                 ws=self.ws)
         self.u = self.ws.U[:, 0, :].contiguous()
         self.xg, xc = torch_api.plant_step_dev(self.pdesc, self.tab, self.xg, xc, self.u)
-        # lap bookkeeping: s wrapped in place once it exceeds the lap length (base.py:795-819)
         crossed = xc[:, 4] > L
         xc[:, 4] = torch.where(crossed, xc[:, 4] - L, xc[:, 4])
         self.laps += crossed.to(torch.int32)
@@ -78,7 +93,7 @@ class MpccbfRaces:
 
 
 def mpccbf_races(track_table, lap_length, track_width, A, B, xcurv0, xglob0, car_s0, car_v, car_ey, steps,
-                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None, log_every=1):
+                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None, log_every=1, glue=False):
     """xcurv0, xglob0 [B,6]; car_s0, car_v, car_ey [B,V] with V <= 3: scripted cars s(t) = v t + s0, ey(t) = ey
     (NoDynamicsModel, utils/base.py:847-890).  Returns host arrays: xcurv [T+1,B,6] (T = steps/log_every), u [T,B,2],
     status [T,B], laps [B]."""
@@ -86,10 +101,10 @@ def mpccbf_races(track_table, lap_length, track_width, A, B, xcurv0, xglob0, car
                     N=N, alpha=alpha, timestep=timestep, device=device)
     log_x, log_u, log_st = [r.xc.clone()], [], []
     for k in range(steps):
-        r.step()
+        (r.step_glue if glue else r.step)()
         if (k + 1) % log_every == 0:
             log_x.append(r.xc.clone())
-            log_u.append(r.u)
+            log_u.append(r.u.clone())
             log_st.append(r.ws.status.clone())
     return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(),
                 status=torch.stack(log_st).cpu().numpy(), laps=r.laps.cpu().numpy())

@@ -190,3 +190,33 @@ def plant_step_dev(desc, track, xglob, xcurv, u, xglob_next=None, xcurv_next=Non
     _call("crx_plant_step_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
           _ptr(xglob_next), _ptr(xcurv_next), _stream())
     return xglob_next, xcurv_next
+
+
+def cbf_prep_dev(N, lap_length, t, dt, xcurv, car_s0, car_v, car_ey, obs_s, obs_ey, lap_off, n_obs, safety_time=2.0):
+    """crx_cbf_prep_dev: obstacle inputs of cbf_solve_dev for scripted cars, written into the given tensors."""
+    Bn, V = car_s0.shape
+    _chk(xcurv, torch.float64, (Bn, 6), "xcurv")
+    for name, a in (("car_s0", car_s0), ("car_v", car_v), ("car_ey", car_ey), ("lap_off", lap_off)):
+        _chk(a, torch.float64, (Bn, V), name)
+    _chk(obs_s, torch.float64, (Bn, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (Bn, V, N + 1), "obs_ey")
+    _chk(n_obs, torch.int32, (Bn,), "n_obs")
+    _call("crx_cbf_prep_dev", C.c_int(N), C.c_int(V), C.c_double(lap_length), C.c_double(t), C.c_double(dt),
+          C.c_double(safety_time), C.c_int(Bn), _ptr(xcurv), _ptr(car_s0), _ptr(car_v), _ptr(car_ey), _ptr(obs_s),
+          _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _stream())
+
+
+def plant_step_wrap_dev(desc, track, xglob, xcurv, u, u_stride, xglob_next, xcurv_next, laps):
+    """crx_plant_step_wrap_dev: plant step + lap bookkeeping; `u` may be a strided view's base tensor (u_stride doubles
+    between vehicles, e.g. the U output of cbf_solve_dev with u_stride = 2 N)."""
+    Bn = xglob.shape[0]
+    _chk(track, torch.float64, (desc.n_seg, 6), "track")
+    _chk(xglob, torch.float64, (Bn, 6), "xglob")
+    _chk(xcurv, torch.float64, (Bn, 6), "xcurv")
+    _chk(xglob_next, torch.float64, (Bn, 6), "xglob_next")
+    _chk(xcurv_next, torch.float64, (Bn, 6), "xcurv_next")
+    _chk(laps, torch.int32, (Bn,), "laps")
+    if not u.is_cuda or u.dtype != torch.float64 or not u.is_contiguous() or u.numel() < (Bn - 1) * u_stride + 2:
+        raise ValueError("u: expected a contiguous cuda float64 tensor holding %d inputs at stride %d" % (Bn, u_stride))
+    _call("crx_plant_step_wrap_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
+          C.c_int(u_stride), _ptr(xglob_next), _ptr(xcurv_next), _ptr(laps), _stream())

@@ -493,10 +493,41 @@ int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, 
     if (batch == 0) return CRX_OK;
     if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
     crx_plant_kparams pk;
-    pk.d = *d; pk.batch = batch; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
-    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next;
+    pk.d = *d; pk.batch = batch; pk.u_stride = 2; pk.wrap = 0; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
+    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = nullptr;
     hipError_t e = crx_launch_plant(pk, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "plant launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_plant_step_wrap_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                            const double* u, int u_stride, double* xglob_next, double* xcurv_next, int32_t* laps, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_plant(d, batch)) return rc;
+    if (u_stride < 2) return fail(CRX_ERR_ARG, "u_stride < 2");
+    if (batch == 0) return CRX_OK;
+    if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_plant_kparams pk;
+    pk.d = *d; pk.batch = batch; pk.u_stride = u_stride; pk.wrap = 1; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
+    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = laps;
+    hipError_t e = crx_launch_plant(pk, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "plant launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_cbf_prep_dev(int N, int V, double lap_length, double t, double dt, double safety_time, int batch,
+                     const double* xcurv, const double* car_s0, const double* car_v, const double* car_ey,
+                     double* obs_s, double* obs_ey, double* lap_off, int32_t* n_obs, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (N < 1 || N > CRX_MAX_N || V < 1 || V > CRX_MAX_OBS || batch < 0 || !(lap_length > 0.0)) return fail(CRX_ERR_ARG, "bad cbf prep dimensions");
+    if (batch == 0) return CRX_OK;
+    if (!xcurv || !car_s0 || !car_v || !car_ey || !obs_s || !obs_ey || !lap_off || !n_obs) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_cbfprep_kparams cp;
+    cp.N = N; cp.V = V; cp.batch = batch; cp.lap_length = lap_length; cp.t = t; cp.dt = dt; cp.safety_time = safety_time;
+    cp.xcurv = xcurv; cp.car_s0 = car_s0; cp.car_v = car_v; cp.car_ey = car_ey;
+    cp.obs_s = obs_s; cp.obs_ey = obs_ey; cp.lap_off = lap_off; cp.n_obs = n_obs;
+    hipError_t e = crx_launch_cbfprep(cp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "cbf prep launch: %s", hipGetErrorString(e));
     return CRX_OK;
 }
 

@@ -63,9 +63,18 @@ struct crx_prep_kparams {
 
 struct crx_plant_kparams {
     crx_plant_desc d;
-    int batch;
+    int batch, u_stride, wrap;
     const double *track, *xglob, *xcurv, *u;
     double *xglob_next, *xcurv_next;
+    int32_t* laps;
+};
+
+struct crx_cbfprep_kparams {
+    int N, V, batch;
+    double lap_length, t, dt, safety_time;
+    const double *xcurv, *car_s0, *car_v, *car_ey;
+    double *obs_s, *obs_ey, *lap_off;
+    int32_t* n_obs;
 };
 
 #ifdef __HIPCC__
@@ -73,6 +82,7 @@ struct crx_plant_kparams {
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);

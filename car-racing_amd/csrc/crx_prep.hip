@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams 
     double vx = pk.xcurv[6 * b], vy = pk.xcurv[6 * b + 1], wz = pk.xcurv[6 * b + 2];
     double epsi = pk.xcurv[6 * b + 3], s = pk.xcurv[6 * b + 4], ey = pk.xcurv[6 * b + 5];
     double psi = pk.xglob[6 * b + 3], X = pk.xglob[6 * b + 4], Y = pk.xglob[6 * b + 5];
-    const double delta = pk.u[2 * b], acc = pk.u[2 * b + 1], dt = d.dt_sub;
+    const double delta = pk.u[(size_t)pk.u_stride * b], acc = pk.u[(size_t)pk.u_stride * b + 1], dt = d.dt_sub;
     const double sd = sin(delta), cd = cos(delta);
     for (int it = 0; it < d.n_sub; it++) {
         // curvature at s (wrapped into one lap), first segment with lo <= s <= hi
@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams 
         const double vx_n = vx + dt * dvx, vy_n = vy + dt * dvy, wz_n = wz + dt * dwz;
         vx = vx_n; vy = vy_n; wz = wz_n; epsi = epsi_n; s = s_n; ey = ey_n; psi = psi_n; X = X_n; Y = Y_n;
     }
+    if (pk.wrap && s > d.lap_length) {   // ModelBase.update_memory (base.py:795-819)
+        s -= d.lap_length;
+        if (pk.laps) pk.laps[b] += 1;
+    }
     double* g = pk.xglob_next + 6 * (size_t)b;
     double* c = pk.xcurv_next + 6 * (size_t)b;
     g[0] = vx; g[1] = vy; g[2] = wz; g[3] = psi; g[4] = X; g[5] = Y;
@@ -148,5 +152,48 @@ __global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams 
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st) {
     if (pk.batch == 0) return hipSuccess;
     hipLaunchKernelGGL(crx_plant_kernel, dim3((pk.batch + 255) / 256), dim3(256), 0, st, pk);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Obstacle arrays of control.mpccbf for scripted cars (see crx_cbf_prep_dev in include/crx.h): one thread
+// per race.  int() of the reference truncates toward zero (control.py:500,519).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) crx_cbfprep_kernel(const crx_cbfprep_kparams cp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= cp.batch) return;
+    const int N = cp.N, V = cp.V;
+    const double L = cp.lap_length, vx = cp.xcurv[6 * (size_t)b], se = cp.xcurv[6 * (size_t)b + 4];
+    const double margin = cp.safety_time * vx;
+    const double nce = trunc(se / L), dist_ego = se - nce * L;
+    int n = 0;
+    for (int v = 0; v < V; v++) {
+        const double s0 = cp.car_s0[(size_t)b * V + v], sv = cp.car_v[(size_t)b * V + v], ey = cp.car_ey[(size_t)b * V + v];
+        const double s_now = sv * (cp.t + 0 * cp.dt) + s0;
+        const double nco = trunc(s_now / L), dist_obs = s_now - nco * L;
+        if (dist_ego > dist_obs - margin && dist_ego < dist_obs + margin) {
+            double* os = cp.obs_s + ((size_t)b * V + n) * (N + 1);
+            double* oe = cp.obs_ey + ((size_t)b * V + n) * (N + 1);
+            for (int j = 0; j <= N; j++) {
+                const double tj = cp.t + j * cp.dt;
+                os[j] = sv * tj + s0;
+                oe[j] = ey + 0.0 * tj;
+            }
+            cp.lap_off[(size_t)b * V + n] = (nce - nco) * L;
+            n++;
+        }
+    }
+    for (int v = n; v < V; v++) {
+        double* os = cp.obs_s + ((size_t)b * V + v) * (N + 1);
+        double* oe = cp.obs_ey + ((size_t)b * V + v) * (N + 1);
+        for (int j = 0; j <= N; j++) { os[j] = 0.0; oe[j] = 0.0; }
+        cp.lap_off[(size_t)b * V + v] = 0.0;
+    }
+    cp.n_obs[b] = n;
+}
+
+hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st) {
+    if (cp.batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_cbfprep_kernel, dim3((cp.batch + 255) / 256), dim3(256), 0, st, cp);
     return hipGetLastError();
 }

@@ -285,11 +285,30 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
  * (racing_env.py:225-246), exactly DynamicBicycleModel.forward_dynamics with zero noise (base.py:897-942;
  * the bounded process noise :930-939 is host RNG and stays with the caller).
  *   track [n_seg][6] rows (x, y, psi, s_start, length, curvature);  xglob, xcurv [batch][6];  u [batch][2]
+ * crx_plant_step_wrap_dev additionally applies the lap bookkeeping of ModelBase.update_memory (base.py:795-819):
+ * s > lap_length -> s -= lap_length, laps[b] += 1 (laps may be NULL).  u_stride = doubles between the inputs of
+ * consecutive vehicles (2 for a packed array, 2N to read u_0 straight out of a crx_cbf_solve U array).
  */
+int crx_plant_step_wrap_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
+                            const double* xcurv, const double* u, int u_stride, double* xglob_next, double* xcurv_next,
+                            int32_t* laps, void* stream);
 int crx_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
                    const double* u, double* xglob_next, double* xcurv_next);
 int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
                        const double* xcurv, const double* u, double* xglob_next, double* xcurv_next, void* stream);
+
+/*
+ * Obstacle arrays of control.mpccbf for scripted cars, built on the device (used by device-resident race loops):
+ * predictions s_o(t + j dt) = v_o (t + j dt) + s0_o, ey_o constant, j = 0..N, from the cars' clock t
+ * (NoDynamicsModel.get_trajectory_nsteps, utils/base.py:879-886, quirk Q6); window filter
+ * dist_obs - 2 vx < dist_ego < dist_obs + 2 vx on the lap-folded positions and lap offsets
+ * (num_cycle_ego - num_cycle_obs) * lap_length (control/control.py:499-523, 538-540); kept cars packed to the
+ * front in vehicle order, the rest zero.  Outputs are exactly the obstacle inputs of crx_cbf_solve.
+ *   xcurv [batch][6];  car_s0, car_v, car_ey [batch][V];  obs_s, obs_ey [batch][V][N+1];  lap_off [batch][V];  n_obs [batch]
+ */
+int crx_cbf_prep_dev(int N, int V, double lap_length, double t, double dt, double safety_time, int batch,
+                     const double* xcurv, const double* car_s0, const double* car_v, const double* car_ey,
+                     double* obs_s, double* obs_ey, double* lap_off, int32_t* n_obs, void* stream);
 
 /*
  * Learning-MPC QPs: control.lmpc (control.py:610-730) after its safe-set

@@ -282,6 +282,12 @@ def test_batched_closed_loop_races(AB):
                                 np.tile([0.1, -0.1], (n, 1)), steps, vt=0.8, N=10, alpha=0.8)
     e = r["xcurv"][1:, 0]
     assert e.shape == (steps, 6) and np.isfinite(r["xcurv"]).all()
+    # the three-launch loop (crx_cbf_prep_dev -> crx_cbf_solve_dev -> crx_plant_step_wrap_dev) against its independent
+    # restatement with element-wise torch ops for the glue
+    rt = montecarlo.mpccbf_races(tab, L, track.width, A, B, z[:4], z[:4], np.tile([4.0, 10.0], (4, 1)), np.tile([0.2, 0.2], (4, 1)),
+                                 np.tile([0.1, -0.1], (4, 1)), steps, vt=0.8, N=10, alpha=0.8, glue=True)
+    np.testing.assert_allclose(rt["xcurv"][:, 0], r["xcurv"][:, 0], atol=1e-9)
+    np.testing.assert_array_equal(rt["laps"], r["laps"][:4])
     np.testing.assert_array_equal(r["xcurv"][:, 1:], r["xcurv"][:, :1].repeat(n - 1, axis=1))   # identical races, identical bits
     n_ok = int(np.nonzero(~ref["solve_success"][1:])[0][0]) + 1
     np.testing.assert_allclose(e[:n_ok], ref["ego_xcurv"][:n_ok], atol=1e-3)
