@@ -276,7 +276,7 @@ def main():
                    "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
                    "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
                    "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99)),
-                   "p50_host_call_one_control_step_ms": float(np.median(hlat))},
+                   "p50_host_call_one_control_step_ms": None if wl == "races" else float(np.median(hlat))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "crx_lmpc_kernel" if wl == "lmpc" else "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
