@@ -69,3 +69,11 @@ def planner_plan(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs
 
 def lmpc_solve(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss=None):
     return binding().lmpc_solve(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss)
+
+
+def path_solve(desc, opt, bez, lb, ub, e0, eN):
+    return binding().path_solve(desc, opt, bez, lb, ub, e0, eN)
+
+
+def plant_step(desc, track, xglob, xcurv, u):
+    return binding().plant_step(desc, track, xglob, xcurv, u)

@@ -110,6 +110,10 @@ class PrepDesc(C.Structure):
     ]
 
 
+class PathDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("reserved0", C.c_int32), ("alpha", C.c_double), ("w_rate", C.c_double), ("opts", IpmOpts)]
+
+
 class PlantDesc(C.Structure):
     _fields_ = [
         ("n_sub", C.c_int32),
@@ -174,6 +178,11 @@ def prep_desc(N, n_veh_max, n_opt, track_width, lap_length, prediction_factor=0.
                     veh_length, veh_width, 0.15, 0.1)
 
 
+def path_desc(N, alpha, w_rate=100.0, opts=None):
+    """overtake_path_planner.py:246-253 literals."""
+    return PathDesc(int(N), 0, float(alpha), float(w_rate), opts or default_opts())
+
+
 def plant_desc(n_seg, lap_length, timestep=0.1, dt_sub=0.001):
     """BicycleDynamicsParam defaults (utils/base.py:686-697) and the sub-step loop of base.py:899-905."""
     n_sub = 0
@@ -208,7 +217,7 @@ class Binding:
 
     def __init__(self, lib, prefix):
         self.lib, self.prefix = lib, prefix
-        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve", "planner_prep", "plant_step"):
+        for name in ("planner_solve", "cbf_solve", "select", "lmpc_solve", "planner_prep", "plant_step", "path_solve"):
             if hasattr(lib, prefix + name):
                 getattr(lib, prefix + name).restype = C.c_int
         self._check = None
@@ -362,4 +371,17 @@ class Binding:
         out = dict(xglob=np.zeros((Bn, 6)), xcurv=np.zeros((Bn, 6)))
         self._call("plant_step", C.byref(desc), C.c_int(Bn), _p(track), _p(xglob), _p(xcurv), _p(u), _p(out["xglob"]),
                    _p(out["xcurv"]))
+        return out
+
+    def path_solve(self, desc, opt, bez, lb, ub, e0, eN):
+        """crx_path_solve: the 1-D QPs of the overtake path planner, one per candidate region."""
+        N = desc.N
+        e0 = np.ascontiguousarray(e0, dtype=_D)
+        Bn = e0.shape[0]
+        opt, bez, lb, ub = (_in(a, _D, (Bn, N + 1)) for a in (opt, bez, lb, ub))
+        e0, eN = _in(e0, _D, (Bn,)), _in(eN, _D, (Bn,))
+        out = dict(E=np.zeros((Bn, N + 1)), cost=np.zeros(Bn), status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn),
+                   iters=np.zeros(Bn, dtype=_I))
+        self._call("path_solve", C.byref(desc), C.c_int(Bn), _p(opt), _p(bez), _p(lb), _p(ub), _p(e0), _p(eN), _p(out["E"]),
+                   _p(out["cost"]), _p(out["status"]), _p(out["kkt"]), _p(out["iters"]))
         return out

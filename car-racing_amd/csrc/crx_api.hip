@@ -469,6 +469,61 @@ int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const
     return sg.down(g_stream);
 }
 
+// ---- overtake path planner QP -----------------------------------------------------------------------
+void crx_path_desc_default(crx_path_desc* d, int N, double alpha) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->alpha = alpha; d->w_rate = 100.0;
+    crx_ipm_opts_default(&d->opts);
+}
+
+static int fill_path(crx_path_kparams& pp, const crx_path_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 2 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [2,%d]", d->N, CRX_MAX_N);
+    if (!(d->alpha >= 0.0 && d->alpha <= 1.0) || !(d->w_rate >= 0.0)) return fail(CRX_ERR_ARG, "alpha outside [0,1] or w_rate < 0");
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (int rc = check_opts(d->opts)) return rc;
+    memset(&pp, 0, sizeof(pp));
+    pp.N = d->N; pp.batch = batch; pp.alpha = d->alpha; pp.w_rate = d->w_rate; pp.opts = d->opts;
+    return 0;
+}
+
+int crx_path_solve_dev(const crx_path_desc* d, int batch, const double* opt, const double* bez, const double* lb,
+                       const double* ub, const double* e0, const double* eN, double* E, double* cost, int32_t* status,
+                       double* kkt, int32_t* iters, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    crx_path_kparams pp;
+    if (int rc = fill_path(pp, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!opt || !bez || !lb || !ub || !e0 || !eN || !E || !cost || !status || !kkt || !iters) return fail(CRX_ERR_ARG, "NULL array argument");
+    pp.opt = opt; pp.bez = bez; pp.lb = lb; pp.ub = ub; pp.e0 = e0; pp.eN = eN;
+    pp.E = E; pp.cost = cost; pp.status = status; pp.kkt = kkt; pp.iters = iters;
+    hipError_t e = crx_launch_path(pp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "path launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_path_solve(const crx_path_desc* d, int batch, const double* opt, const double* bez, const double* lb,
+                   const double* ub, const double* e0, const double* eN, double* E, double* cost, int32_t* status,
+                   double* kkt, int32_t* iters) {
+    if (int rc = ensure_init()) return rc;
+    crx_path_kparams chk;
+    if (int rc = fill_path(chk, d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!opt || !bez || !lb || !ub || !e0 || !eN || !E || !cost || !status || !kkt || !iters) return fail(CRX_ERR_ARG, "NULL array argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t B = (size_t)batch, n1 = B * (size_t)(d->N + 1);
+    Stage sg;
+    if (int rc = sg.reserve((4 * n1 + 2 * B) * 8, (n1 + 2 * B) * 8 + 2 * B * 4)) return rc;
+    double* dop = sg.in(opt, n1); double* dbz = sg.in(bez, n1); double* dlb = sg.in(lb, n1); double* dub = sg.in(ub, n1);
+    double* d0 = sg.in(e0, B); double* dN = sg.in(eN, B);
+    double* dE = sg.out(E, n1); double* dc = sg.out(cost, B); double* dk = sg.out(kkt, B);
+    int32_t* ds = sg.out(status, B); int32_t* di = sg.out(iters, B);
+    if (int rc = sg.up(g_stream)) return rc;
+    if (int rc = crx_path_solve_dev(d, batch, dop, dbz, dlb, dub, d0, dN, dE, dc, ds, dk, di, g_stream)) return rc;
+    return sg.down(g_stream);
+}
+
 // ---- plant ----------------------------------------------------------------------------------------
 void crx_plant_desc_default(crx_plant_desc* d, int n_seg, double lap_length) {
     memset(d, 0, sizeof(*d));

@@ -61,6 +61,15 @@ struct crx_prep_kparams {
     double *x0, *bez_s, *bez_ey, *ey_lb, *ey_ub;
 };
 
+struct crx_path_kparams {
+    int N, batch;
+    double alpha, w_rate;
+    crx_ipm_opts opts;
+    const double *opt, *bez, *lb, *ub, *e0, *eN;
+    double *E, *cost, *kkt;
+    int32_t *status, *iters;
+};
+
 struct crx_plant_kparams {
     crx_plant_desc d;
     int batch, u_stride, wrap;
@@ -82,6 +91,7 @@ struct crx_cbfprep_kparams {
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);
 hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);

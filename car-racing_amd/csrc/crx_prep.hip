@@ -197,3 +197,161 @@ hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st) {
     hipLaunchKernelGGL(crx_cbfprep_kernel, dim3((cp.batch + 255) / 256), dim3(256), 0, st, cp);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Overtake PATH planner QP (planning/overtake_path_planner.py:199-318): one
+// 1-D QP per wavefront, lane i = interior offset ey_{i+1}.  Same interior-point iteration as the other
+// kernels; the Newton matrix (tridiagonal cost + barrier diagonal) is factorised dense with the shared
+// row-per-lane Cholesky (n <= 23).  HBM: 4(N+1)+2 doubles in, N+1+3 out per problem.
+// ------------------------------------------------------------------------------------------------
+#define PATH_NV (CRX_MAX_N)
+#define PATH_LD (CRX_MAX_N + 1)
+
+__global__ void __launch_bounds__(WAVE) crx_path_kernel(const crx_path_kparams pp) {
+    __shared__ double sh[(PATH_NV + 4) * PATH_LD + 3 * PATH_NV + 32];   // +3 rows: the blocked Cholesky reads (not uses) past the last row
+    double* Km = sh;
+    constexpr int IK = (PATH_NV + 4) * PATH_LD;
+    double *v = sh + IK + PATH_NV, *dv = v + PATH_NV, *Fth = dv + PATH_NV, *Fph = Fth + 16;
+    const int b = blockIdx.x, lane = threadIdx.x, N = pp.N, n = N - 1;
+    if (b >= pp.batch) return;
+    const crx_ipm_opts& o = pp.opts;
+    const double *op = pp.opt + (size_t)(N + 1) * b, *bz = pp.bez + (size_t)(N + 1) * b;
+    const double *lo = pp.lb + (size_t)(N + 1) * b, *hi = pp.ub + (size_t)(N + 1) * b;
+    const double a0 = pp.e0[b], aN = pp.eN[b], w1 = 1.0 - pp.alpha, w2 = pp.alpha, wr = pp.w_rate;
+    double* Eb = pp.E + (size_t)(N + 1) * b;
+    const bool mine = lane < n;
+    const int j = mine ? lane + 1 : 1;
+    const double lj = lo[j], hj = hi[j], oj = op[j], bj = bz[j];
+    // infeasible by inspection: an end point outside its own box, or an empty box
+    int bad = (mine && lj > hj) ? 1 : 0;
+    if (lane == 0) bad |= !(a0 >= lo[0] - o.tol && a0 <= hi[0] + o.tol && aN >= lo[N] - o.tol && aN <= hi[N] + o.tol);
+    bad = wave_max((double)bad) > 0.0;
+    if (bad) {
+        if (mine) Eb[j] = fmin(fmax(bj, fmin(lj, hj)), fmax(lj, hj));
+        if (lane == 0) { Eb[0] = a0; Eb[N] = aN; pp.cost[b] = INFINITY; pp.status[b] = CRX_INFEASIBLE; pp.kkt[b] = INFINITY; pp.iters[b] = 0; }
+        return;
+    }
+    const bool hasL = mine && lj > -INFINITY, hasU = mine && hj < INFINITY;
+    const double Hd = 2.0 * (w1 + w2) + 4.0 * wr;
+    double g0 = mine ? -2.0 * (w1 * oj + w2 * bj) : 0.0;
+    if (mine && lane == 0) g0 -= 2.0 * wr * a0;
+    if (mine && lane == n - 1) g0 -= 2.0 * wr * aN;
+    double f0 = mine ? w1 * oj * oj + w2 * bj * bj : 0.0;
+    f0 = wave_sum(f0) + w1 * (a0 - op[0]) * (a0 - op[0]) + w2 * (a0 - bz[0]) * (a0 - bz[0]) + w1 * (aN - op[N]) * (aN - op[N]) +
+         w2 * (aN - bz[N]) * (aN - bz[N]) + wr * a0 * a0 + wr * aN * aN;
+    const int m = (int)wave_sum((hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0));
+    // per-lane row state: lower row c = v - lo, upper row c = hi - v
+    double vi = 0.0, tL = hasL ? fmax(fabs(-lj), o.slack_push) : 1.0, tU = hasU ? fmax(fabs(hj), o.slack_push) : 1.0, nL = hasL ? 1.0 : 0.0,
+           nU = hasU ? 1.0 : 0.0;
+    if (mine) v[lane] = 0.0;
+    SYNC();
+    double mu = o.mu_init, theta_min = 0.0, theta_max = INFINITY, E0 = INFINITY, f = f0;
+    int nf = 0, st = CRX_MAX_ITER, it = 0;
+    for (it = 0;; it++) {
+        const double vm = (mine && lane > 0) ? v[lane - 1] : 0.0, vp = (mine && lane + 1 < n) ? v[lane + 1] : 0.0;
+        const double g = mine ? Hd * vi - 2.0 * wr * vm - 2.0 * wr * vp + g0 : 0.0;
+        const double cL = vi - lj, cU = hj - vi;
+        const double rpL = hasL ? cL - tL : 0.0, rpU = hasU ? cU - tU : 0.0;
+        const double nus = wave_sum(nL + nU);
+        const double sd = m ? fmax(100.0, nus / m) / 100.0 : 1.0;
+        const double e_d = wave_max(mine ? fabs(g - nL + nU) : 0.0) / sd;
+        const double e_p = wave_max(fmax(fabs(rpL), fabs(rpU)));
+        const double e_c = wave_max(fmax(hasL ? tL * nL : 0.0, hasU ? tU * nU : 0.0)) / sd;
+        const double theta = wave_sum(fabs(rpL) + fabs(rpU));
+        E0 = fmax(e_d, fmax(e_p, e_c));
+        if (E0 <= o.tol) { st = CRX_CONVERGED; break; }
+        if (it >= o.max_iter) break;
+        for (;;) {
+            const double e_cm = wave_max(fmax(hasL ? fabs(tL * nL - mu) : 0.0, hasU ? fabs(tU * nU - mu) : 0.0)) / sd;
+            if (fmax(e_d, fmax(e_p, e_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+                mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                nf = 0;
+            } else
+                break;
+        }
+        const double tau = fmax(o.tau_min, 1.0 - mu);
+        // Newton matrix (lower triangle, row per lane) with the right-hand side as the extra row
+        const double sgL = hasL ? nL / tL : 0.0, sgU = hasU ? nU / tU : 0.0;
+        const double rhs = mine ? -g + (hasL ? mu / tL - sgL * rpL : 0.0) - (hasU ? mu / tU - sgU * rpU : 0.0) : 0.0;
+        if (mine) {
+            for (int q = 0; q < lane; q++) Km[lane * PATH_LD + q] = (q == lane - 1) ? -2.0 * wr : 0.0;
+            Km[lane * PATH_LD + lane] = Hd + sgL + sgU;
+            Km[n * PATH_LD + lane] = rhs;
+        }
+        SYNC();
+        if (!l_chol(sh, 0, PATH_LD, IK, n, 1, lane)) break;
+        double bb[1];
+        bb[0] = mine ? Km[n * PATH_LD + lane] : 0.0;
+        l_backsub<1>(sh, 0, PATH_LD, IK, n, lane, bb);
+        const double d = mine ? bb[0] : 0.0;
+        if (mine) dv[lane] = d;
+        SYNC();
+        const double dtL = hasL ? rpL + d : 0.0, dtU = hasU ? rpU - d : 0.0;
+        const double dnL = hasL ? (mu - tL * nL - nL * dtL) / tL : 0.0, dnU = hasU ? (mu - tU * nU - nU * dtU) / tU : 0.0;
+        double a_p = 1.0, a_d = 1.0;
+        if (dtL < 0.0) a_p = fmin(a_p, -tau * tL / dtL);
+        if (dtU < 0.0) a_p = fmin(a_p, -tau * tU / dtU);
+        if (dnL < 0.0) a_d = fmin(a_d, -tau * nL / dnL);
+        if (dnU < 0.0) a_d = fmin(a_d, -tau * nU / dnU);
+        a_p = wave_min(a_p);
+        a_d = wave_min(a_d);
+        const double dm = (mine && lane > 0) ? dv[lane - 1] : 0.0, dp = (mine && lane + 1 < n) ? dv[lane + 1] : 0.0;
+        const double gdv = wave_sum(g * d), qd = wave_sum(mine ? d * (Hd * d - 2.0 * wr * dm - 2.0 * wr * dp) : 0.0);
+        const double Dphi = gdv - mu * wave_sum((hasL ? dtL / tL : 0.0) + (hasU ? dtU / tU : 0.0));
+        LogAcc l0;
+        if (hasL) l0.mul(tL);
+        if (hasU) l0.mul(tU);
+        const double phi0 = f - mu * l0.wave_total();
+        if (it == 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+        double al = a_p, fn = f, tLn = tL, tUn = tU;
+        int acc = 0, ftype = 0;
+        for (int ls = 0; ls < 40; ls++) {
+            fn = f + al * (gdv + 0.5 * al * qd);
+            const double vt = vi + al * d;
+            tLn = hasL ? fmax(tL + al * dtL, vt - lj) : 1.0;
+            tUn = hasU ? fmax(tU + al * dtU, hj - vt) : 1.0;
+            const double thn = wave_sum((hasL ? fabs(vt - lj - tLn) : 0.0) + (hasU ? fabs(hj - vt - tUn) : 0.0));
+            LogAcc la;
+            if (hasL) la.mul(tLn);
+            if (hasU) la.mul(tUn);
+            const double phin = fn - mu * la.wave_total();
+            int okf = (thn <= theta_max) && (phin == phin);
+            for (int i = 0; i < nf && okf; i++)
+                if (!(thn < Fth[i] || phin < Fph[i])) okf = 0;
+            if (okf) {
+                const int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                if (theta <= theta_min && sw) {
+                    if (phin <= phi0 + 1e-8 * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
+                    acc = 1;
+                }
+            }
+            if (acc) break;
+            al *= 0.5;
+        }
+        if (acc && !ftype && nf < 16) {
+            if (lane == 0) { Fth[nf] = (1.0 - 1e-5) * theta; Fph[nf] = phi0 - 1e-8 * theta; }
+            nf++;
+        }
+        if (!acc) break;
+        vi += al * d;
+        f = fn;
+        tL = tLn; tU = tUn;
+        if (hasL) nL = fmin(fmax(nL + a_d * dnL, mu / (1e10 * tL)), 1e10 * mu / tL);
+        if (hasU) nU = fmin(fmax(nU + a_d * dnU, mu / (1e10 * tU)), 1e10 * mu / tU);
+        if (mine) v[lane] = vi;
+        SYNC();
+    }
+    if (mine) Eb[j] = vi;
+    if (lane == 0) {
+        Eb[0] = a0; Eb[N] = aN;
+        pp.cost[b] = st == CRX_CONVERGED ? f : INFINITY;
+        pp.status[b] = st; pp.kkt[b] = E0; pp.iters[b] = it;
+    }
+}
+
+hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st) {
+    if (pp.batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_path_kernel, dim3(pp.batch), dim3(WAVE), 0, st, pp);
+    return hipGetLastError();
+}

@@ -83,4 +83,85 @@ __device__ __forceinline__ double frsqrt(double x) {
     r = r * fma(-0.5 * x * r, r, 1.5);
     return r;
 }
+
+// ------------------------------------------------------------------------------------------------
+// dense factorisations in LDS, one matrix row per lane (crx_lmpc.hip, crx_path kernel in crx_prep.hip)
+// ------------------------------------------------------------------------------------------------
+// left-looking Cholesky, in place, of the leading n x n block (lower triangle) of a row-major array
+// (stride LD); rows n..n+extra-1 are carried along, i.e. forward-substituted right-hand sides.
+// Lane i owns row i.  Blocked by 4 columns: the panel product against all finished columns is one long
+// loop of independent LDS reads (own row entry + 4 broadcast entries per k), the 4x4 diagonal block is
+// finished in registers with v_readlane broadcasts -- one LDS round trip per 4 columns instead of per
+// column.  Returns 0 if a pivot is not positive.
+__device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int n, int extra, int lane) {
+    const int rows = n + extra;
+    const int ri = base + lane * LD;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        const bool mine = lane >= j0 && lane < rows;
+        double s[4], l[4];
+        const int r0 = base + j0 * LD;
+#pragma unroll
+        for (int c = 0; c < 4; c++) s[c] = (mine && j0 + c < n) ? sm[ri + j0 + c] : 0.0;
+        if (mine) {
+#pragma unroll 2
+            for (int k = 0; k < j0; k++) {
+                const double a = sm[ri + k];
+#pragma unroll
+                for (int c = 0; c < 4; c++) s[c] = fma(-a, sm[r0 + c * LD + k], s[c]);   // rows j0+c <= n+2: inside the array
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = j0 + c;
+            if (j < n) {
+#pragma unroll
+                for (int cc = 0; cc < c; cc++) s[c] = fma(-l[cc], lane_f64(l[cc], j), s[c]);
+                const double d = lane_f64(s[c], j);
+                if (!(d > 0.0)) return 0;
+                const double rinv = frsqrt(d);
+                l[c] = lane == j ? d * rinv : s[c] * rinv;
+                if (lane >= j && lane < rows) sm[ri + j] = l[c];
+                if (lane == 0) sm[inv + j] = rinv;
+            } else {
+                l[c] = 0.0;
+            }
+        }
+        SYNC();
+    }
+    return 1;
+}
+
+// x <- L^-T x for `NR` right-hand sides held one entry per lane (lane i = entry i), L as above.  The
+// LDS operands of four steps are fetched ahead of the dependent readlane/fma chain.
+template <int NR>
+__device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, int inv, int n, int lane, double* b) {
+    int j = n - 1;
+    for (; j >= 3; j -= 4) {
+        double rinv[4], lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rinv[q] = sm[inv + j - q];
+            lj[q] = lane < j - q ? sm[base + (j - q) * LD + lane] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double xj = lane_f64(b[r], j - q) * rinv[q];
+                if (lane == j - q) b[r] = xj;
+                b[r] = fma(-lj[q], xj, b[r]);
+            }
+    }
+    for (; j >= 0; j--) {
+        const double rinv = sm[inv + j];
+        const double lj = lane < j ? sm[base + j * LD + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const double xj = lane_f64(b[r], j) * rinv;
+            if (lane == j) b[r] = xj;
+            b[r] = fma(-lj, xj, b[r]);
+        }
+    }
+}
+
 #endif

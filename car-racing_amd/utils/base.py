@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from control import control, lmpc_helper
-from planning import overtake_traj_planner
+from planning import overtake_path_planner, overtake_traj_planner
 from system import vehicle_dynamics
 from utils import racing_env
 from utils.constants import U_DIM, X_DIM
@@ -179,11 +179,15 @@ class LMPCRacingGame(ControlBase):
     crx_cbf_solve) run on the GPU; safe-set bookkeeping and the local model regression stay on the
     host (control/lmpc_helper.py)."""
 
-    def __init__(self, lmpc_param, racing_game_param=None, system_param=None):
+    def __init__(self, lmpc_param, racing_game_param=None, system_param=None, path_planner=False):
         ControlBase.__init__(self)
-        self.path_planner = False
+        # the reference hard-codes False (:414); the keyword lets a user pick its OvertakePathPlanner (:415-416)
+        self.path_planner = path_planner
         self.lmpc_param, self.racing_game_param, self.system_param = lmpc_param, racing_game_param, system_param
-        self.overtake_planner = overtake_traj_planner.OvertakeTrajPlanner(racing_game_param)
+        if self.path_planner:
+            self.overtake_planner = overtake_path_planner.OvertakePathPlanner(racing_game_param)
+        else:
+            self.overtake_planner = overtake_traj_planner.OvertakeTrajPlanner(racing_game_param)
         self.x_pred = self.u_pred = None
         self.lin_points = self.lin_input = None
         self.ss_point_selected_tot = self.Qfun_selected_tot = None
@@ -248,9 +252,13 @@ class LMPCRacingGame(ControlBase):
             ego.lmpc_prediction.append(self._prediction_xglob(self.x_pred))
             ego.mpc_cbf_prediction.append(None)
         else:
-            (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
-             all_traj_xglob) = pl.get_local_traj(x, self.time, vehicles_interest, matrix_Atv, matrix_Btv, matrix_Ctv,
-                                                 self.old_ey, self.old_direction_flag)
+            if self.path_planner:
+                (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
+                 all_traj_xglob) = pl.get_local_path(x, self.time, vehicles_interest)
+            else:
+                (traj_xcurv, traj_xglob, direction_flag, sorted_vehicles, bezier_xglob, solve_time, all_bezier_xglob,
+                 all_traj_xglob) = pl.get_local_traj(x, self.time, vehicles_interest, matrix_Atv, matrix_Btv, matrix_Ctv,
+                                                     self.old_ey, self.old_direction_flag)
             self.old_ey, self.old_direction_flag = traj_xcurv[-1, 5], direction_flag
             ego.local_trajs.append(traj_xglob)
             ego.vehicles_interest.append(vehicles_interest)

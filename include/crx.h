@@ -178,6 +178,15 @@ typedef struct crx_plant_desc {
     double Dr, Cr, Br;     /* rear  Pacejka */
 } crx_plant_desc;
 
+/* ---- overtake PATH planner QP (planning/overtake_path_planner.py:199-318) ------------------------------- */
+typedef struct crx_path_desc {
+    int32_t N;             /* num_horizon_planner: N+1 lateral offsets per candidate path */
+    int32_t reserved0;
+    double alpha;          /* racing_game_param.alpha: weight of the Bezier reference; 1 - alpha on the optimal line (:248-250) */
+    double w_rate;         /* 100: weight on (ey_j - ey_{j-1})^2 (:252-253) */
+    crx_ipm_opts opts;
+} crx_path_desc;
+
 /* library management */
 int crx_version(void);
 /* device >= 0: HIP device ordinal.  There is no CPU back-end in this library: a missing device is
@@ -192,6 +201,7 @@ void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const
 void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A, const double* B);
 void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length);
 void crx_lmpc_desc_default(crx_lmpc_desc* d, int N, int n_ss_max);
+void crx_path_desc_default(crx_path_desc* d, int N, double alpha);
 void crx_plant_desc_default(crx_plant_desc* d, int n_seg, double lap_length);
 void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, double track_width, double lap_length);
 
@@ -296,6 +306,23 @@ int crx_plant_step(const crx_plant_desc* d, int batch, const double* track, cons
                    const double* u, double* xglob_next, double* xcurv_next);
 int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
                        const double* xcurv, const double* u, double* xglob_next, double* xcurv_next, void* stream);
+
+/*
+ * Overtake PATH planner: one 1-D QP per candidate region
+ * (overtake_path_planner.py:199-318).  Variables ey_0..ey_N along fixed s samples;
+ *   cost  sum_j (1-alpha)(ey_j - opt_j)^2 + alpha (ey_j - bez_j)^2  +  w_rate sum_{j>=1} (ey_j - ey_{j-1})^2      (:246-253)
+ *   ey_0 = e0 (:258), ey_N = eN (:261), lb_j <= ey_j <= ub_j (track box :263-264 and the neighbours' side rows :265-297,
+ *   merged by the caller; a row the reference skips is +-inf)
+ *   opt, bez, lb, ub [batch][N+1];  e0, eN [batch];  E [batch][N+1];  cost [batch] (inf unless converged, :311)
+ * status CRX_INFEASIBLE: an end point violates its own box or lb_j > ub_j somewhere (the reference then keeps IPOPT's
+ * debug iterate, :310; here E holds the end points joined by the box-clipped Bezier reference).
+ */
+int crx_path_solve(const crx_path_desc* d, int batch, const double* opt, const double* bez, const double* lb,
+                   const double* ub, const double* e0, const double* eN, double* E, double* cost, int32_t* status,
+                   double* kkt, int32_t* iters);
+int crx_path_solve_dev(const crx_path_desc* d, int batch, const double* opt, const double* bez, const double* lb,
+                       const double* ub, const double* e0, const double* eN, double* E, double* cost, int32_t* status,
+                       double* kkt, int32_t* iters, void* stream);
 
 /*
  * Obstacle arrays of control.mpccbf for scripted cars, built on the device (used by device-resident race loops):

@@ -582,3 +582,182 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
     }
     return CRX_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Overtake PATH planner QP (planning/overtake_path_planner.py:199-318):
+ * N+1 lateral offsets, end points fixed (:258,:261), box rows (:263-297 merged by the caller), cost
+ * (1-alpha)(ey-opt)^2 + alpha(ey-bez)^2 + 100 (ey_j - ey_{j-1})^2 (:246-253).  Same interior-point
+ * iteration as above on the N-1 interior offsets; the (tridiagonal + diagonal) Newton matrix is
+ * factorised dense.
+ * ---------------------------------------------------------------------------------------------- */
+static double path_f(int n, const double* Hd, const double* g0, double f0, double wr, const double* v) {
+    double s = f0;
+    for (int i = 0; i < n; i++) {
+        double q = Hd[i] * v[i];
+        if (i > 0) q -= 2.0 * wr * v[i - 1];
+        if (i + 1 < n) q -= 2.0 * wr * v[i + 1];
+        s += v[i] * (0.5 * q + g0[i]);
+    }
+    return s;
+}
+
+int crx_oracle_path_solve(const crx_path_desc* d, int batch, const double* opt, const double* bez, const double* lb,
+                          const double* ub, const double* e0, const double* eN, double* E, double* cost, int32_t* status,
+                          double* kkt, int32_t* iters) {
+    if (!d || d->N < 2 || d->N > CRX_MAX_N || batch < 0) return CRX_ERR_ARG;
+    const int N = d->N, n = N - 1;
+    const crx_ipm_opts* o = &d->opts;
+    const double w1 = 1.0 - d->alpha, w2 = d->alpha, wr = d->w_rate, smax = 100.0, eta = 1e-8, ksig = 1e10;
+    for (int b = 0; b < batch; b++) {
+        const double *op = opt + (size_t)(N + 1) * b, *bz = bez + (size_t)(N + 1) * b, *lo = lb + (size_t)(N + 1) * b,
+                     *hi = ub + (size_t)(N + 1) * b;
+        double* Eb = E + (size_t)(N + 1) * b;
+        const double a0 = e0[b], aN = eN[b];
+        int bad = !(a0 >= lo[0] - o->tol && a0 <= hi[0] + o->tol && aN >= lo[N] - o->tol && aN <= hi[N] + o->tol);
+        for (int j = 1; j < N; j++)
+            if (lo[j] > hi[j]) bad = 1;
+        if (bad) {
+            Eb[0] = a0; Eb[N] = aN;
+            for (int j = 1; j < N; j++) Eb[j] = fmin(fmax(bz[j], fmin(lo[j], hi[j])), fmax(lo[j], hi[j]));
+            cost[b] = HUGE_VAL; status[b] = CRX_INFEASIBLE; kkt[b] = HUGE_VAL; iters[b] = 0;
+            continue;
+        }
+        /* f(v) = 1/2 v'Hv + g0'v + f0 over v = ey_1..ey_{N-1}; rows: v_i - lo >= 0 (if finite), hi - v_i >= 0 (if finite) */
+        double Hd[CRX_MAX_N], g0[CRX_MAX_N], v[CRX_MAX_N], f0 = 0.0;
+        f0 = w1 * (a0 - op[0]) * (a0 - op[0]) + w2 * (a0 - bz[0]) * (a0 - bz[0]) + w1 * (aN - op[N]) * (aN - op[N]) +
+             w2 * (aN - bz[N]) * (aN - bz[N]);
+        for (int i = 0; i < n; i++) {
+            const int j = i + 1;
+            Hd[i] = 2.0 * (w1 + w2) + 4.0 * wr;
+            g0[i] = -2.0 * (w1 * op[j] + w2 * bz[j]);
+            f0 += w1 * op[j] * op[j] + w2 * bz[j] * bz[j];
+            v[i] = 0.0;
+        }
+        g0[0] -= 2.0 * wr * a0; g0[n - 1] -= 2.0 * wr * aN;
+        f0 += wr * a0 * a0 + wr * aN * aN;
+        int ri[2 * CRX_MAX_N], m = 0;
+        double rs[2 * CRX_MAX_N], rb[2 * CRX_MAX_N], t[2 * CRX_MAX_N], nu[2 * CRX_MAX_N], dt[2 * CRX_MAX_N], dnu[2 * CRX_MAX_N];
+        for (int i = 0; i < n; i++) {
+            if (lo[i + 1] > -HUGE_VAL) { ri[m] = i; rs[m] = 1.0; rb[m] = -lo[i + 1]; m++; }
+            if (hi[i + 1] < HUGE_VAL) { ri[m] = i; rs[m] = -1.0; rb[m] = hi[i + 1]; m++; }
+        }
+#define PF(vv, out) (out) = path_f(n, Hd, g0, f0, wr, (vv))
+        for (int j = 0; j < m; j++) { t[j] = fmax(fabs(rb[j]), o->slack_push); nu[j] = 1.0; }
+        double mu = o->mu_init, theta_min = 0.0, theta_max = HUGE_VAL, Fth[16], Fph[16], E0 = HUGE_VAL, f;
+        int nf = 0, st = CRX_MAX_ITER, it = 0;
+        PF(v, f);
+        for (it = 0;; it++) {
+            double g[CRX_MAX_N], c[2 * CRX_MAX_N], rp[2 * CRX_MAX_N], K[CRX_MAX_N][CRX_MAX_N], rhs[CRX_MAX_N], dv[CRX_MAX_N];
+            for (int i = 0; i < n; i++) {
+                double q = Hd[i] * v[i] + g0[i];
+                if (i > 0) q -= 2.0 * wr * v[i - 1];
+                if (i + 1 < n) q -= 2.0 * wr * v[i + 1];
+                g[i] = q;
+            }
+            double nus = 0.0, e_d = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
+            double rd[CRX_MAX_N];
+            for (int i = 0; i < n; i++) rd[i] = g[i];
+            for (int j = 0; j < m; j++) {
+                c[j] = rs[j] * v[ri[j]] + rb[j];
+                rp[j] = c[j] - t[j];
+                rd[ri[j]] -= rs[j] * nu[j];
+                nus += nu[j];
+                e_p = fmax(e_p, fabs(rp[j])); theta += fabs(rp[j]); e_c = fmax(e_c, t[j] * nu[j]);
+            }
+            for (int i = 0; i < n; i++) e_d = fmax(e_d, fabs(rd[i]));
+            const double sd = m ? fmax(smax, nus / m) / smax : 1.0;
+            e_d /= sd; e_c /= sd;
+            E0 = fmax(e_d, fmax(e_p, e_c));
+            if (E0 <= o->tol) { st = CRX_CONVERGED; break; }
+            if (it >= o->max_iter) break;
+            for (;;) {
+                double e_cm = 0.0;
+                for (int j = 0; j < m; j++) e_cm = fmax(e_cm, fabs(t[j] * nu[j] - mu));
+                e_cm /= sd;
+                if (fmax(e_d, fmax(e_p, e_cm)) <= o->kappa_eps * mu && mu > o->tol / 10.0) {
+                    mu = fmax(o->tol / 10.0, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
+                    nf = 0;
+                } else break;
+            }
+            const double tau = fmax(o->tau_min, 1.0 - mu);
+            for (int i = 0; i < n; i++) {
+                for (int q = 0; q < n; q++) K[i][q] = 0.0;
+                K[i][i] = Hd[i];
+                if (i > 0) K[i][i - 1] = -2.0 * wr;
+                rhs[i] = -g[i];
+            }
+            for (int j = 0; j < m; j++) {
+                const double sg = nu[j] / t[j];
+                K[ri[j]][ri[j]] += sg;
+                rhs[ri[j]] += rs[j] * (mu / t[j] - sg * rp[j]);
+            }
+            int okc = 1;
+            for (int j = 0; j < n && okc; j++) {   /* dense Cholesky, lower */
+                double dd = K[j][j];
+                for (int k = 0; k < j; k++) dd -= K[j][k] * K[j][k];
+                if (!(dd > 0.0)) { okc = 0; break; }
+                dd = sqrt(dd); K[j][j] = dd;
+                for (int i = j + 1; i < n; i++) {
+                    double s = K[i][j];
+                    for (int k = 0; k < j; k++) s -= K[i][k] * K[j][k];
+                    K[i][j] = s / dd;
+                }
+            }
+            if (!okc) break;
+            for (int i = 0; i < n; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= K[i][k] * dv[k]; dv[i] = s / K[i][i]; }
+            for (int i = n - 1; i >= 0; i--) { double s = dv[i]; for (int k = i + 1; k < n; k++) s -= K[k][i] * dv[k]; dv[i] = s / K[i][i]; }
+            double a_p = 1.0, a_d = 1.0, Dphi = 0.0;
+            for (int j = 0; j < m; j++) {
+                const double s = rp[j] + rs[j] * dv[ri[j]];
+                dt[j] = s;
+                dnu[j] = (mu - t[j] * nu[j] - nu[j] * s) / t[j];
+                if (s < 0.0) a_p = fmin(a_p, -tau * t[j] / s);
+                if (dnu[j] < 0.0) a_d = fmin(a_d, -tau * nu[j] / dnu[j]);
+                Dphi -= mu * s / t[j];
+            }
+            for (int i = 0; i < n; i++) Dphi += g[i] * dv[i];
+            double phi0 = f;
+            for (int j = 0; j < m; j++) phi0 -= mu * log(t[j]);
+            if (it == 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+            double al = a_p, fn = f, vt[CRX_MAX_N], tt[2 * CRX_MAX_N];
+            int acc = 0, ftype = 0;
+            for (int ls = 0; ls < 40; ls++) {
+                for (int i = 0; i < n; i++) vt[i] = v[i] + al * dv[i];
+                PF(vt, fn);
+                double phin = fn, thn = 0.0;
+                for (int j = 0; j < m; j++) {
+                    const double cj = rs[j] * vt[ri[j]] + rb[j];
+                    double tn = t[j] + al * dt[j];
+                    if (cj > tn) tn = cj;
+                    tt[j] = tn; phin -= mu * log(tn); thn += fabs(cj - tn);
+                }
+                int okf = (thn <= theta_max) && (phin == phin);
+                for (int i = 0; i < nf && okf; i++)
+                    if (!(thn < Fth[i] || phin < Fph[i])) okf = 0;
+                if (okf) {
+                    const int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                    if (theta <= theta_min && sw) {
+                        if (phin <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                    } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) acc = 1;
+                }
+                if (acc) break;
+                al *= 0.5;
+            }
+            if (acc && !ftype && nf < 16) { Fth[nf] = (1.0 - 1e-5) * theta; Fph[nf] = phi0 - 1e-8 * theta; nf++; }
+            if (!acc) break;
+            for (int i = 0; i < n; i++) v[i] = vt[i];
+            f = fn;
+            for (int j = 0; j < m; j++) {
+                double nn = nu[j] + a_d * dnu[j];
+                nn = fmin(fmax(nn, mu / (ksig * tt[j])), ksig * mu / tt[j]);
+                t[j] = tt[j]; nu[j] = nn;
+            }
+        }
+#undef PF
+        Eb[0] = a0; Eb[N] = aN;
+        for (int i = 0; i < n; i++) Eb[i + 1] = v[i];
+        cost[b] = st == CRX_CONVERGED ? f : HUGE_VAL;
+        status[b] = st; kkt[b] = E0; iters[b] = it;
+    }
+    return CRX_OK;
+}

@@ -53,3 +53,8 @@ def golden_planner():
 @pytest.fixture(scope="session")
 def golden_racing_game():
     return np.load(os.path.join(GOLDEN, "racing_game.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_path():
+    return Golden(os.path.join(GOLDEN, "path_planner.npz"))

@@ -384,6 +384,74 @@ def gen_planner():
     np.savez_compressed(os.path.join(OUT, "planner.npz"), **out)
 
 
+def path_case(x0, cars, N=10, alpha=0.8, width=1.0, time=0.0):
+    """OvertakePathPlanner.get_local_path (planning/overtake_path_planner.py:37-183) on scripted cars."""
+    from planning import overtake_path_planner as opp
+
+    track = make_track(width)
+    par = base.RacingGameParam(timestep=0.1, num_horizon_planner=N, num_horizon_ctrl=N, alpha=alpha)
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+    ego.set_state_curvilinear(np.array(x0, float)); ego.set_state_global(np.zeros(6)); ego.set_track(track); ego.set_timestep(0.1)
+    vehicles = {"ego": ego}
+    for i, (s0, v, ey) in enumerate(cars):
+        c = offboard.NoDynamicsModel(name="car%d" % (i + 1), param=base.CarParam())
+        c.set_track(track); c.set_timestep(0.1)
+        c.set_state_curvilinear_func(T, v * T + s0, ey + 0.0 * T)
+        c.time = time
+        c.xcurv, c.xglob = c.get_estimation(time)
+        vehicles[c.name] = c
+    pl = opp.OvertakePathPlanner(par)
+    pl.vehicles, pl.agent_name, pl.track, pl.opti_traj_xcurv = vehicles, "ego", track, OPTI_XCURV
+    x = np.array(x0, float)
+    flag, interest = pl.get_overtake_flag(x)
+    names = [n for n in vehicles if n != "ego"]
+    res = dict(x=x, N=N, alpha=alpha, width=width, lap_length=track.lap_length, overtake_flag=bool(flag), time=time,
+               cars=np.array(cars, float).reshape(-1, 3), veh_names=np.array(names),
+               veh_xcurv=np.array([vehicles[n].xcurv for n in names]).reshape(len(names), 6),
+               veh_is_interest=np.array([n in interest for n in names]))
+    if not flag:
+        return res
+    del RECORDS[:]
+    (traj, traj_glob, dflag, sorted_veh, bez_glob, solve_time, all_bez_glob, all_traj_glob) = pl.get_local_path(x, time, interest)
+    recs = list(RECORDS)
+    V = len(sorted_veh)
+    assert len(recs) == V + 1
+    if os.environ.get("CRX_GOLDEN_DEBUG"):
+        for r in recs:
+            print("   region:", {k: v for k, v in r[2].items() if k in ("success", "reason", "lp_status", "ipm_status", "ipm_iters", "stationarity", "ineq_violation", "eq_violation", "min_multiplier", "const_violation", "polished")})
+    res.update(sorted_vehicles=np.array(sorted_veh), direction_flag=int(dflag), traj_xcurv=np.array(traj, float),
+               traj_xglob=np.array(traj_glob, float), region_success=np.array([r[2]["success"] for r in recs]),
+               region_E=np.array([r[1][:N + 1] for r in recs]), region_cert=np.array([cert_fields(r[2]) for r in recs]),
+               region_lp_status=np.array([r[2].get("lp_status", -1) for r in recs]),
+               all_bezier_xglob=np.array(all_bez_glob, float))
+    return res
+
+
+def gen_path():
+    cases = {
+        "one_car_ahead": dict(x0=[1.2, 0.0, 0.0, 0.0, 5.0, 0.1], cars=[(6.0, 0.7, -0.1)]),
+        "one_car_left": dict(x0=[1.3, 0.0, 0.0, 0.02, 8.0, -0.2], cars=[(8.9, 0.6, 0.4)]),
+        "two_cars": dict(x0=[1.3, 0.0, 0.0, 0.0, 5.0, 0.0], cars=[(5.9, 0.7, -0.5), (6.4, 0.72, -0.2)]),
+        "three_cars": dict(x0=[1.4, 0.01, 0.0, 0.0, 10.0, 0.1], cars=[(10.7, 0.7, -0.5), (11.2, 0.72, 0.0), (11.6, 0.74, 0.5)]),
+        "wide_track": dict(x0=[1.2, 0.0, 0.0, 0.0, 3.0, 0.0], cars=[(4.2, 0.6, 0.2)], width=2.0),
+        "wide_two": dict(x0=[1.3, 0.0, 0.0, 0.0, 12.0, -0.3], cars=[(12.9, 0.7, 0.9), (13.3, 0.6, -0.9)], width=2.0, N=12),
+        "alpha05": dict(x0=[1.0, 0.0, 0.0, 0.0, 12.0, 0.3], cars=[(12.6, 0.9, -0.2)], alpha=0.5, width=1.6),
+        "no_interest": dict(x0=[1.0, 0.0, 0.0, 0.0, 2.0, 0.0], cars=[(9.0, 0.7, 0.0)]),
+    }
+    out = {}
+    for name, kw in cases.items():
+        r = path_case(**kw)
+        if r["overtake_flag"]:
+            print("path %-14s V %d flag %d region_success %s lp %s" % (name, len(r["sorted_vehicles"]), r["direction_flag"],
+                                                                       r["region_success"], r["region_lp_status"]))
+        else:
+            print("path %-14s no vehicle of interest" % name)
+        for k, v in r.items():
+            out[name + "/" + k] = v
+    out["names"] = np.array(sorted(cases))
+    np.savez_compressed(os.path.join(OUT, "path_planner.npz"), **out)
+
+
 def gen_harness():
     """Solver-free host code: track geometry, plant step, vehicle predictions, PID closed loop."""
     from system import vehicle_dynamics as vd
@@ -587,6 +655,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["mpccbf", "planner", "harness"]
     if "racing_game" in which:
         gen_racing_game()
+    if "path" in which:
+        gen_path()
     if "closed_loop" in which:
         gen_closed_loop()
     if "harness" in which:

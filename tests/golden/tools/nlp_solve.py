@@ -50,6 +50,16 @@ def kkt_certificate(opti, z, nu=None, act_tol=1e-7):
         lam_fit, *_ = np.linalg.lstsq(rows[nz].T, gf, rcond=None)
         lam = np.zeros(rows.shape[0])
         lam[nz] = lam_fit
+        if len(act) and lam[len(ce):].min() < -1e-9:
+            # linearly dependent active rows (e.g. a bound on a variable that an equality already fixes) leave the
+            # multipliers non-unique: look for a sign-feasible choice before calling the point non-stationary
+            from scipy.optimize import lsq_linear
+
+            lo = np.concatenate([np.full(len(ce), -np.inf), np.zeros(len(act))])[nz]
+            fit = lsq_linear(rows[nz].T, gf, bounds=(lo, np.full(len(nz), np.inf)), tol=1e-14, max_iter=2000)
+            if np.abs(gf - rows[nz].T @ fit.x).max() <= 1e-9 * max(1.0, np.abs(gf).max()):
+                lam = np.zeros(rows.shape[0])
+                lam[nz] = fit.x
         stat = gf - rows.T @ lam
         nu = np.zeros(len(ci))
         if len(act):

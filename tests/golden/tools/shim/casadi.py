@@ -19,7 +19,7 @@ The recorded problem + certified solution become the committed fixtures in tests
 """
 import numpy as np
 
-__all__ = ["Opti", "mtimes", "MX", "vertcat", "horzcat"]
+__all__ = ["Opti", "mtimes", "MX", "vertcat", "horzcat", "inf"]
 
 
 class Node:
@@ -215,6 +215,13 @@ class MX:
     def __le__(self, o):
         return self._cmp(o, "ge", -1)
 
+    # CasADi's Opti treats strict inequalities as non-strict (overtake_path_planner.py:280,297 use < and >)
+    def __gt__(self, o):
+        return self._cmp(o, "ge", +1)
+
+    def __lt__(self, o):
+        return self._cmp(o, "ge", -1)
+
     __hash__ = None
 
 
@@ -368,3 +375,4 @@ class Opti:
 
     def value(self, e):  # opti.debug.value(...)
         return self._last.value(e)
+inf = float("inf")  # casadi exports it; overtake_path_planner.py:316 relies on `from casadi import *`

@@ -51,3 +51,35 @@ def lmpc_inputs(g, idx=None):
     d = abi.lmpc_desc(N=g["lmpc/A"].shape[1], n_ss_max=g["lmpc/ss"].shape[2], ey_max=float(g["lmpc/lap_width"][0]))
     return d, (g["lmpc/x"][sl], g["lmpc/u_old"][sl], g["lmpc/A"][sl], g["lmpc/B"][sl], g["lmpc/C"][sl],
                g["lmpc/ss"][sl], g["lmpc/qfun"][sl])
+
+
+def path_inputs(c):
+    """crx_path_solve inputs of a recorded OvertakePathPlanner scenario (tests/golden/path_planner.npz), through the
+    PRODUCT's host prep (planning/overtake_path_planner.path_qp_inputs)."""
+    import os
+
+    import conftest
+    from planning import overtake_path_planner as opp
+    from planning import planner_helper as ph
+
+    opt = np.genfromtxt(os.path.join(conftest.ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
+    N = int(c["N"])
+    names = [str(x) for x in c["veh_names"]]
+    interest = [n for n, f in zip(names, c["veh_is_interest"]) if f]
+    xc = {n: c["veh_xcurv"][i] for i, n in enumerate(names)}
+    cars = {n: c["cars"][i] for i, n in enumerate(names)}
+    order = ph.sort_by_ey(interest, lambda n: xc[n][5])
+    assert order == [str(x) for x in c["sorted_vehicles"]]
+    x = c["x"]
+    info = ph.AgentInfo()
+    vx = np.array([xc[n][0] for n in order]); s = np.array([xc[n][4] for n in order])
+    dv = np.abs(x[0] - vx)
+    L = float(c["lap_length"])
+    s = np.where(s <= 20, s + L, s)
+    info.min_vx, info.max_vx, info.min_delta_v, info.max_delta_v = vx.min(), vx.max(), dv.min(), dv.max()
+    info.min_s, info.max_s = hostprep.wrap_above(s.min(), L), hostprep.wrap_above(s.max(), L)
+    obs_infos = np.array([[xc[n][4], cars[n][2], cars[n][2]] for n in order])       # scripted cars: ey constant
+    cps = ph.bezier_control_points(len(order), obs_infos, info.max_delta_v, 0.5, float(c["width"]), L, 0.2, opt, x)
+    bez = ph.bezier_polylines(cps, N)
+    qp = opp.path_qp_inputs(x[4], x[5], obs_infos, info, cps, bez, opt[:, 4], opt[:, 5], N, float(c["width"]), L, 4.5, 0.5, 0.4, 0.2)
+    return abi.path_desc(N, float(c["alpha"])), qp

@@ -340,3 +340,47 @@ def test_batched_closed_loop_races(AB):
         simulator.sim(sim_time=12.0)
         one = np.array(ego.xcurv_log)
         np.testing.assert_allclose(x[1:one.shape[0] + 1, b], one, atol=1e-3, err_msg="race %d" % b)
+
+
+def test_overtake_path_step(golden_path):
+    """OvertakePathPlanner.get_local_path (planning/overtake_path_planner.py:37-183) through the mirror on the
+    scenarios recorded from the reference: same region selection, same target trajectory, same Bezier lines."""
+    import sympy as sp
+
+    from planning import overtake_path_planner
+    from racing import offboard
+    from utils import base
+
+    opt = np.genfromtxt(conftest.ROOT + "/data/optimal_traj/xcurv_l_shape.csv", delimiter=",")
+    t = sp.symbols("t")
+    checked = 0
+    for name in golden_path.names:
+        g = golden_path.case(name)
+        N = int(g["N"])
+        track = _track(float(g["width"]))
+        par = base.RacingGameParam(timestep=0.1, num_horizon_planner=N, num_horizon_ctrl=N, alpha=float(g["alpha"]))
+        ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
+        ego.set_state_curvilinear(g["x"].copy()); ego.set_state_global(np.zeros(6))
+        ego.set_track(track); ego.set_timestep(0.1)
+        vehicles = {"ego": ego}
+        for vn, (s0, v, ey) in zip(g["veh_names"], g["cars"]):
+            c = offboard.NoDynamicsModel(name=str(vn), param=base.CarParam())
+            c.set_track(track); c.set_timestep(0.1)
+            c.set_state_curvilinear_func(t, float(v) * t + float(s0), float(ey) + 0.0 * t)
+            vehicles[c.name] = c
+        pl = overtake_path_planner.OvertakePathPlanner(par)
+        pl.vehicles, pl.agent_name, pl.track, pl.opti_traj_xcurv = vehicles, "ego", track, opt
+        x = g["x"].copy()
+        flag, interest = pl.get_overtake_flag(x)
+        assert flag == bool(g["overtake_flag"]), name
+        if not flag:
+            continue
+        traj, traj_glob, dflag, sorted_veh, bez_glob, solve_time, all_bez, all_traj = pl.get_local_path(x, float(g["time"]), interest)
+        assert sorted_veh == [str(v) for v in g["sorted_vehicles"]]
+        assert dflag == int(g["direction_flag"]), name
+        np.testing.assert_allclose(all_bez, g["all_bezier_xglob"], atol=1e-9, err_msg=name)
+        if g["region_success"][dflag]:       # otherwise the reference returns IPOPT's debug iterate of an infeasible QP
+            np.testing.assert_allclose(traj, g["traj_xcurv"], atol=5e-6, err_msg=name)
+            np.testing.assert_allclose(traj_glob, g["traj_xglob"], atol=5e-6, err_msg=name)
+        checked += 1
+    assert checked >= 6

@@ -367,6 +367,37 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
 
 
+def test_path_planner_qps(gpu, orc):
+    """crx_path_solve (overtake PATH planner, overtake_path_planner.py:199-318) vs the oracle: random references and
+    boxes incl. one-sided / missing bounds, active side rows, infeasible boxes and end points, every horizon."""
+    from crx import abi
+
+    rng = np.random.default_rng(77)
+    for N in (2, 3, 10, 12, 17, 24):
+        Bn = 96
+        opt, bez = rng.uniform(-0.4, 0.4, (Bn, N + 1)), rng.uniform(-0.9, 0.9, (Bn, N + 1))
+        lb, ub = np.full((Bn, N + 1), -1.0), np.full((Bn, N + 1), 1.0)
+        side = rng.integers(0, 5, Bn)
+        for b in range(Bn):
+            j0 = int(rng.integers(0, N)); j1 = int(rng.integers(j0, N + 1))
+            if side[b] == 1: ub[b, j0:j1 + 1] = rng.uniform(-0.6, 0.3)
+            if side[b] == 2: lb[b, j0:j1 + 1] = rng.uniform(-0.3, 0.6)
+            if side[b] == 3: lb[b, :] = -np.inf
+            if side[b] == 4: lb[b, j0] = 0.5; ub[b, j0] = 0.3          # empty box
+        e0, eN = rng.uniform(-0.5, 0.5, Bn), rng.uniform(-0.5, 0.5, Bn)
+        e0[:4] = 1.3                                                   # end point outside its box
+        d = abi.path_desc(N, float(rng.uniform(0.5, 1.0)))
+        rg, ro = gpu.path_solve(d, opt, bez, lb, ub, e0, eN), orc.path_solve(d, opt, bez, lb, ub, e0, eN)
+        np.testing.assert_array_equal(rg["status"], ro["status"])
+        ok = ro["status"] == 0
+        assert ok.sum() >= Bn // 3 and (ro["status"] == 2).sum() >= 4
+        np.testing.assert_allclose(rg["E"][ok], ro["E"][ok], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(rg["cost"][ok], ro["cost"][ok], rtol=1e-9)
+        np.testing.assert_array_equal(rg["E"][~ok], ro["E"][~ok])
+        assert np.isinf(rg["cost"][~ok]).all()
+        assert rg["kkt"][ok].max() <= 1e-8
+
+
 def test_edge_cases(gpu, orc, AB):
     from crx import abi, synth
 

@@ -178,3 +178,24 @@ def test_plant_step(orc):
         xg, xc = r["xglob"], r["xcurv"]
         np.testing.assert_allclose(xc[0], H["pid/xcurv_log"][k], rtol=0, atol=1e-13)
         np.testing.assert_allclose(xg[0], H["pid/xglob_log"][k], rtol=0, atol=1e-13)
+
+
+def test_path_planner_regions(orc, golden_path):
+    """OvertakePathPlanner QPs (overtake_path_planner.py:199-318) as the reference built them (recorded through the
+    CasADi stand-in, certified): every region's verdict and solution, and the selection the reference made."""
+    seen_ok = seen_bad = 0
+    for name in golden_path.names:
+        c = golden_path.case(name)
+        if not bool(c["overtake_flag"]):
+            continue
+        d, qp = helpers.path_inputs(c)
+        r = orc.path_solve(d, *qp)
+        ok = c["region_success"]
+        assert ((r["status"] == 0) == ok).all(), (name, r["status"], ok)
+        np.testing.assert_allclose(r["E"][ok], c["region_E"][ok], rtol=0, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(r["cost"][ok], c["region_cert"][ok, 0], rtol=1e-8, err_msg=name)
+        assert np.isinf(r["cost"][~ok]).all()
+        costs = [float(v) for v in r["cost"]]
+        assert costs.index(min(costs)) == int(c["direction_flag"]), name
+        seen_ok += int(ok.sum()); seen_bad += int((~ok).sum())
+    assert seen_ok >= 8 and seen_bad >= 4
