@@ -353,16 +353,17 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
     # learning-MPC QPs: ragged safe-set sizes (first n points of each recorded hull) and shorter horizons
     g = golden_racing_game
     ok = np.nonzero(g["lmpc_success"])[0][:24]
-    for N in (12, 9, 5):
+    for N in (12, 9, 5, 14, 16):      # 14 and 16 (the second horizon class of the kernel): last stage model repeated
         M = g["lmpc/ss"].shape[2]
         d = abi.lmpc_desc(N=N, n_ss_max=M)
         n_ss = rng.integers(8, M + 1, len(ok)).astype(np.int32)
-        args = (g["lmpc/x"][ok], g["lmpc/u_old"][ok], g["lmpc/A"][ok][:, :N], g["lmpc/B"][ok][:, :N], g["lmpc/C"][ok][:, :N],
+        idx = np.minimum(np.arange(N), g["lmpc/A"].shape[1] - 1)
+        args = (g["lmpc/x"][ok], g["lmpc/u_old"][ok], g["lmpc/A"][ok][:, idx], g["lmpc/B"][ok][:, idx], g["lmpc/C"][ok][:, idx],
                 g["lmpc/ss"][ok], g["lmpc/qfun"][ok], n_ss)
         rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
         assert (rg["status"] == ro["status"]).mean() >= 0.9, (N, rg["status"], ro["status"])
         both = (rg["status"] == ro["status"]) & (ro["status"] != 1)
-        assert both.sum() >= 12
+        assert both.sum() >= (12 if N <= 12 else 4), (N, ro["status"])
         assert np.abs(rg["X"][both] - ro["X"][both]).max() <= 1e-5, N
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
 
