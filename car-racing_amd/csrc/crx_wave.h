@@ -6,7 +6,16 @@
 #include <math.h>
 
 #define WAVE 64
+// Every kernel that uses SYNC() runs ONE wavefront per workgroup.  Lanes of a wave execute in lockstep and the LDS
+// unit serves a wave's operations in issue order, so cross-lane exchange through LDS needs no s_barrier and no
+// s_waitcnt -- only that the compiler keeps the program order of the LDS accesses.  A wavefront-scope fence is
+// exactly that (LLVM's AMDGPU memory model emits no instruction for it); measured against __syncthreads():
+// identical results, fewer stall cycles.  CRX_SYNC_BARRIER restores the barrier for A/B runs.
+#ifdef CRX_SYNC_BARRIER
 #define SYNC() __syncthreads()
+#else
+#define SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // (1) wave primitives: DPP butterflies inside each 16-lane row, then the four row totals are read
