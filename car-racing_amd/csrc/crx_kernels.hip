@@ -288,7 +288,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         }
         SYNC();
     }
-    for (int e = c.lane; e < (N + 1) * L::NZ; e += WAVE) {
+    for (int e = c.lane; e < N * L::NZ + L::NX; e += WAVE) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
         // selects instead of branches: every divergent region costs ~30 cycles on a lone wave
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         LD(L::rw + j) = on ? (nu - mu * rti + sig * (LD(L::rc + j) - t)) : 0.0;
     }
     SYNC();
-    for (int e = c.lane; e < (N + 1) * L::NZ; e += WAVE) {
+    for (int e = c.lane; e < N * L::NZ + L::NX; e += WAVE) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
         const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
@@ -1065,7 +1065,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         if (!acc) break;
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
-        for (int e = lane; e < (N + 1) * NZ; e += WAVE) LD(L::Z + e) += al * LD(L::dZ + e);
+        for (int e = lane; e < N * NZ + NX; e += WAVE) LD(L::Z + e) += al * LD(L::dZ + e);
         for (int j = lane; j < m; j += WAVE) {
             if (LD(L::rsc + j) == 0.0) continue;
             const double tn = LD(L::rtt + j);
