@@ -203,26 +203,33 @@ __device__ __forceinline__ double cost_value(const double* sm, const Ctx& c, dou
     return wave_sum(acc) + c.cconst;
 }
 
-// exact directional derivative of the cost along dZ
+// The cost is exactly quadratic along a step: f(Z + al dZ) = f + al (g'dZ) + al^2 (1/2 dZ'H dZ).  Returns the
+// directional derivative g'dZ and the curvature term qq = 1/2 dZ'H dZ in one pass, so that a line-search
+// trial costs no evaluation loop at all.
 template <int NOBS, int NMAX>
-__device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c) {
+__device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c, double& qq) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N;
-    double acc = 0.0;
+    double acc = 0.0, q = 0.0;
     for (int e = c.lane; e < (N + 1) * 6; e += WAVE) {
         const int k = e / 6, i = e - k * 6;
-        const double dv = LD(L::dZ + k * L::NZ + i);
-        acc += 2.0 * LD(L::cst + i) * (LD(L::Z + k * L::NZ + i) - LD(L::xr + e)) * dv;
+        const double dv = LD(L::dZ + k * L::NZ + i), w = LD(L::cst + i);
+        acc += 2.0 * w * (LD(L::Z + k * L::NZ + i) - LD(L::xr + e)) * dv;
+        q += w * dv * dv;
         if (k == N && i == 4) acc += c.lin_sN * dv;
     }
     for (int e = c.lane; e < N * 2; e += WAVE) {
         const int k = e >> 1, i = e & 1;
-        acc += 2.0 * LD(L::cst + 6 + i) * LD(L::Z + k * L::NZ + L::NX + i) * LD(L::dZ + k * L::NZ + L::NX + i);
+        const double dv = LD(L::dZ + k * L::NZ + L::NX + i), w = LD(L::cst + 6 + i);
+        acc += 2.0 * w * LD(L::Z + k * L::NZ + L::NX + i) * dv;
+        q += w * dv * dv;
     }
     for (int k = c.lane; k < N; k += WAVE) {
         const double de = LD(L::Z + (k + 1) * L::NZ + 5) - LD(L::Z + k * L::NZ + 5);
         const double dd = LD(L::dZ + (k + 1) * L::NZ + 5) - LD(L::dZ + k * L::NZ + 5);
-        acc += 2.0 * LD(L::wc + k) * de * dd;
+        const double w = LD(L::wc + k);
+        acc += 2.0 * w * de * dd;
+        q += w * dd * dd;
     }
     if (NOBS) {
         for (int e = c.lane; e < (N + 1) * NOBS; e += WAVE) {
@@ -230,6 +237,7 @@ __device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c) {
             if (o < c.nobs) acc += c.wsig * LD(L::dZ + k * L::NZ + 6 + o);
         }
     }
+    qq = wave_sum(q);
     return wave_sum(acc);
 }
 
@@ -998,7 +1006,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
         const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
         const double a_d = (rd_max > tau) ? tau / rd_max : 1.0;
-        Dphi = wave_sum(Dphi) + cost_dir<NOBS, NMAX>(sm, c);
+        double cost_qq;
+        const double cost_d = cost_dir<NOBS, NMAX>(sm, c, cost_qq);
+        Dphi = wave_sum(Dphi) + cost_d;
         const double phi0 = f - mu * lg0.wave_total();
         if (it == 0) {
             theta_min = 1e-4 * fmax(1.0, theta);
@@ -1012,7 +1022,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         const bool sw_try = (theta <= theta_min) && (Dphi < 0.0);
         const double sw_lhs = sw_try ? pow(-Dphi, 2.3) : 0.0, sw_rhs = sw_try ? pow(theta, 1.1) : 0.0;
         for (int ls = 0; ls < 40; ls++) {
-            fn = cost_value<NOBS, NMAX>(sm, c, al);
+            fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
             for (int j = lane; j < m; j += WAVE) {
