@@ -1076,27 +1076,35 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
         for (int e = lane; e < N * NZ + NX; e += WAVE) LD(L::Z + e) += al * LD(L::dZ + e);
+        SYNC();
+        f = fn;
+        // one pass over the rows: multiplier update (from the pre-step row state), new slack, row value at the new
+        // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
+        double numax = 0.0, th = 0.0;
         for (int j = lane; j < m; j += WAVE) {
-            if (LD(L::rsc + j) == 0.0) continue;
+            const double sc = LD(L::rsc + j);
+            const bool on = sc != 0.0;
             const double tn = LD(L::rtt + j);
             const double mut = mu * frcp(tn);
             const double rp = LD(L::rc + j) - LD(L::rt + j);   // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
             const double dnu = -LD(L::rw + j) + LD(L::rsig + j) * (rp - LD(L::rdt + j));
             double nn = LD(L::rnu + j) + a_d * dnu;
             nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
-            LD(L::rt + j) = tn;
-            LD(L::rnu + j) = nn;
+            const int pk = si[L::riv + j];
+            double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
+            if (NOBS && j < N * NR) {
+                const int k = j / NR, r = j - k * NR;
+                if (r >= 8 + NOBS && on) v = sc * cbf_value<NOBS, NMAX>(sm, c, k, r - 8 - NOBS, 0.0);
+            }
+            if (on) {
+                LD(L::rt + j) = tn;
+                LD(L::rnu + j) = nn;
+                numax = fmax(numax, nn);
+                th = fmax(th, fabs(v - tn));
+            }
+            LD(L::rc + j) = on ? v : 1.0;
         }
         SYNC();
-        f = fn;
-        eval_rows<NOBS, NMAX>(sm, si, c);
-        SYNC();
-        double numax = 0.0, th = 0.0;
-        for (int j = lane; j < m; j += WAVE) {
-            if (LD(L::rsc + j) == 0.0) continue;
-            numax = fmax(numax, LD(L::rnu + j));
-            th = fmax(th, fabs(LD(L::rc + j) - LD(L::rt + j)));
-        }
         numax = wave_max(numax); th = wave_max(th);
         first_order<NOBS, NMAX>(sm, si, c);
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
