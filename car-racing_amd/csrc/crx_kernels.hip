@@ -915,18 +915,23 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+    // row statistics of the current iterate: sum nu, max |c - t|, max and min of t*nu over the present rows.  Computed
+    // here for the start point and afterwards inside the accept pass, which touches every row anyway.
+    double nus = 0.0, e_p = 0.0, cmax = 0.0, cmin = INFINITY;
+    for (int j = lane; j < m; j += WAVE) {
+        const bool on = LD(L::rsc + j) != 0.0;
+        const double t = LD(L::rt + j), nu = LD(L::rnu + j);
+        nus += nu;
+        e_p = fmax(e_p, on ? fabs(LD(L::rc + j) - t) : 0.0);
+        cmax = fmax(cmax, on ? t * nu : 0.0);
+        cmin = fmin(cmin, on ? t * nu : INFINITY);
+    }
+    nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
+
     for (it = 0;; it++) {
         long long tc0 = clock64();
         // ---- KKT error -----------------------------------------------------------------------------
-        double nus = 0.0, e_p = 0.0, e_c = 0.0;
-        for (int j = lane; j < m; j += WAVE) {
-            const double on = (LD(L::rsc + j) != 0.0) ? 1.0 : 0.0;
-            const double t = LD(L::rt + j), nu = LD(L::rnu + j);
-            nus += nu;
-            e_p = fmax(e_p, on * fabs(LD(L::rc + j) - t));
-            e_c = fmax(e_c, on * t * nu);
-        }
-        nus = wave_sum(nus); e_p = wave_max(e_p); e_c = wave_max(e_c);
+        double e_c = cmax;
         const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
         long long tc1 = clock64();
         const double e_d = dual_infeasibility<NOBS, NMAX>(sm, c) / sd;
@@ -937,10 +942,8 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         if (it >= o.max_iter) break;
         // ---- barrier update ------------------------------------------------------------------------
         for (;;) {
-            double e_cm = 0.0;
-            for (int j = lane; j < m; j += WAVE)
-                if (LD(L::rsc + j) != 0.0) e_cm = fmax(e_cm, fabs(LD(L::rt + j) * LD(L::rnu + j) - mu));
-            e_cm = wave_max(e_cm) / sd;
+            // max_j |t_j nu_j - mu| from the extremes of t*nu: no pass over the rows
+            const double e_cm = fmax(cmax - mu, mu - cmin) / sd;
             const double Emu = fmax(e_d, fmax(e_p, e_cm));
             if (Emu <= o.kappa_eps * mu && mu > o.tol / 10.0) {
                 mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, o.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, o.theta_mu)));
@@ -1081,6 +1084,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // one pass over the rows: multiplier update (from the pre-step row state), new slack, row value at the new
         // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
         double numax = 0.0, th = 0.0;
+        nus = 0.0; cmax = 0.0; cmin = INFINITY;
         for (int j = lane; j < m; j += WAVE) {
             const double sc = LD(L::rsc + j);
             const bool on = sc != 0.0;
@@ -1101,11 +1105,16 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                 LD(L::rnu + j) = nn;
                 numax = fmax(numax, nn);
                 th = fmax(th, fabs(v - tn));
+                nus += nn;
+                cmax = fmax(cmax, tn * nn);
+                cmin = fmin(cmin, tn * nn);
             }
             LD(L::rc + j) = on ? v : 1.0;
         }
         SYNC();
         numax = wave_max(numax); th = wave_max(th);
+        nus = wave_sum(nus); cmax = wave_max(cmax); cmin = wave_min(cmin);
+        e_p = th;
         first_order<NOBS, NMAX>(sm, si, c);
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
             kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (clock64() - tc8));   // slot 8: KKT rows + accept/first-order
