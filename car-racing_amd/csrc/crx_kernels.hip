@@ -446,6 +446,20 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     if (lane < NX) LD(L::pv + lane) = LD(L::hg + N * NZ + lane);
     SYNC();
     bool ok = true;
+    // lane maps of the H and update phases do not depend on the stage: decode them once (a table read inside the
+    // stage loop is one more dependent LDS round trip per phase)
+    constexpr bool FULL = NZ * NZ <= WAVE;
+    constexpr int NTRI = FULL ? NZ * NZ : NZ * (NZ + 1) / 2;
+    constexpr int HCNT = (NTRI + WAVE - 1) / WAVE;
+    int hr[HCNT], ha[HCNT];
+#pragma unroll
+    for (int q = 0; q < HCNT; q++) {
+        const int e0 = lane + q * WAVE;
+        const int e = e0 < NTRI ? e0 : 0;
+        if (FULL) { hr[q] = e / NZ; ha[q] = e - hr[q] * NZ; }
+        else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
+    }
+    const int upk = si[L::updP + lane];
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = clock64();
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
@@ -491,19 +505,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // The body is branch-free (selects): every divergent region costs ~30 cycles of exec-mask
         // traffic on a lone wave.
         const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
-        constexpr bool FULL = NZ * NZ <= WAVE;
-        constexpr int NTRI = FULL ? NZ * NZ : NZ * (NZ + 1) / 2;
-        constexpr int HCNT = (NTRI + WAVE - 1) / WAVE;
         double hs[HCNT];
-        int hr[HCNT], ha[HCNT];
 #pragma unroll
         for (int q = 0; q < HCNT; q++) {
-            const int e0 = lane + q * WAVE;
-            const int e = e0 < NTRI ? e0 : 0;
-            int r, a;
-            if (FULL) { r = e / NZ; a = e - r * NZ; }
-            else { const int pk = si[L::triH + e]; r = pk >> 8; a = pk & 255; }
-            hr[q] = r; ha[q] = a;
+            const int r = hr[q], a = ha[q];
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < NX; i++) s += LD(L::M + i * NZ + r) * LD(L::T + i * NZ + a);
@@ -571,8 +576,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // (T and hv are done), so they are overwritten in place.
         {
             constexpr int NP = NX * (NX + 1) / 2 + NX;
-            const int pk = si[L::updP + lane];
-            const int i = pk >> 8, j = pk & 255;   // feedback lanes: column j, i = 0 (unused)
+            const int i = upk >> 8, j = upk & 255;   // feedback lanes: column j, i = 0 (unused)
             const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
             const double exS = (NOBS && k >= 1) ? LD(L::kS + km) : 0.0;
