@@ -342,11 +342,14 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     if (lane < L::NX) LD(cur + lane) = LD(L::ga + N * L::NZ + lane);
     if (lane < L::NZ) LD(L::ga + N * L::NZ + lane) = 0.0;
     SYNC();
+    double mcol[L::NX];   // column `lane` of the (stage-invariant) model matrix, kept in registers across the sweep
+#pragma unroll
+    for (int i = 0; i < L::NX; i++) mcol[i] = LD(L::M + i * L::NZ + (lane < L::NZ ? lane : 0));
     for (int k = N - 1; k >= 0; k--) {
         if (lane < L::NZ) {
             double tot = LD(L::ga + k * L::NZ + lane);
 #pragma unroll
-            for (int i = 0; i < L::NX; i++) tot += LD(L::M + i * L::NZ + lane) * LD(cur + i);
+            for (int i = 0; i < L::NX; i++) tot += mcol[i] * LD(cur + i);
             if (lane >= L::NX) emax = fmax(emax, fabs(tot));
             const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
             LD(L::ga + k * L::NZ + lane) = keep ? tot : 0.0;
@@ -460,22 +463,34 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
     }
     const int upk = si[L::updP + lane];
+    // the entries of the model matrix each lane multiplies with in the T and H phases, in registers
+    constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
+    double mT[TCNT][6], mH[HCNT][NX];
+#pragma unroll
+    for (int q = 0; q < TCNT; q++) {
+        const int cc = (lane + q * WAVE) & 7;
+        const int a = cc < 6 ? cc : NX + (cc - 6);
+#pragma unroll
+        for (int j = 0; j < 6; j++) mT[q][j] = LD(L::M + j * NZ + a);
+    }
+#pragma unroll
+    for (int q = 0; q < HCNT; q++)
+#pragma unroll
+        for (int i = 0; i < NX; i++) mH[q][i] = LD(L::M + i * NZ + hr[q]);
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = clock64();
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
         // dot products of length 6); the sigma_k columns of T are zero and the sigma_{k+1} columns
         // are copies of P's sigma columns (M = [A 0 B 0; 0 0 0 I]).
         {
-            constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
             double ts[TCNT];
 #pragma unroll
             for (int q = 0; q < TCNT; q++) {
                 const int e = lane + q * WAVE;
-                const int i = (e >> 3) < NX ? (e >> 3) : 0, cc = e & 7;
-                const int a = cc < 6 ? cc : NX + (cc - 6);
+                const int i = (e >> 3) < NX ? (e >> 3) : 0;
                 double s = 0.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) s += LD(L::P + i * NX + j) * LD(L::M + j * NZ + a);
+                for (int j = 0; j < 6; j++) s += LD(L::P + i * NX + j) * mT[q][j];
                 ts[q] = s;
             }
 #pragma unroll
@@ -511,7 +526,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             const int r = hr[q], a = ha[q];
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; i++) s += LD(L::M + i * NZ + r) * LD(L::T + i * NZ + a);
+            for (int i = 0; i < NX; i++) s += mH[q][i] * LD(L::T + i * NZ + a);
             const double dg = LD(L::Hd + k * NZ + r) + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
             s += (r == a) ? dg : 0.0;
             if (NOBS) {
@@ -680,6 +695,9 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
     const int N = c.N, lane = c.lane;
+    double mrow[NZ];      // row `lane` of the model matrix, in registers across the sweep
+#pragma unroll
+    for (int j = 0; j < NZ; j++) mrow[j] = LD(L::M + (lane < NX ? lane : 0) * NZ + j);
     for (int k = 0; k < N; k++) {
         if (lane < NU) {
             double s = LD(L::kf + k * NU + lane);
@@ -691,7 +709,7 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
         if (lane < NX) {
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < NZ; j++) s += LD(L::M + lane * NZ + j) * LD(L::dZ + k * NZ + j);
+            for (int j = 0; j < NZ; j++) s += mrow[j] * LD(L::dZ + k * NZ + j);
             LD(L::dZ + (k + 1) * NZ + lane) = s;
         }
         SYNC();
