@@ -70,6 +70,10 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 // Row slots inside a stage k: 0..3 input box (d lo, d hi, a lo, a hi); 4..7 box of x_{k+1} (vx lo,
 // vx hi, ey lo, ey hi); 8+o: sigma_{k+1}^o >= 0; 8+NOBS+o: CBF row (k,o).  Rows N*NR+o: sigma_0^o.
 // ------------------------------------------------------------------------------------------------
+// all rows of a problem, pass by pass, fully unrolled: the LDS loads of every pass are issued before the first
+// dependent use instead of one pass paying its latency after the other (RP = passes the instantiation can need)
+#define ROWS(j, lane_, m_) _Pragma("unroll") for (int q_ = 0; q_ < (L::MR + WAVE - 1) / WAVE; q_++) if (const int j = (lane_) + q_ * WAVE; j < (m_))
+
 #define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
 #define RIV_NEG (1 << 30)
 #define RIV_IDX(pk) ((pk) & 0xFFFF)
@@ -371,7 +375,7 @@ template <int NOBS, int NMAX>
 __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const Ctx& c, double mu) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N;
-    for (int j = c.lane; j < c.m; j += WAVE) {
+    ROWS(j, c.lane, c.m) {
         const double t = LD(L::rt + j), nu = LD(L::rnu + j);
         const double rti = frcp(t);
         const double sig = nu * rti;
@@ -999,7 +1003,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
         double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
         LogAcc lg0;
-        for (int j = lane; j < m; j += WAVE) {
+        ROWS(j, lane, m) {
             const double sc = LD(L::rsc + j);
             const bool on = sc != 0.0;
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
@@ -1050,7 +1054,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
-            for (int j = lane; j < m; j += WAVE) {
+            ROWS(j, lane, m) {
                 const double sc = LD(L::rsc + j);
                 const double t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
                 double cn = cj + al * (dt - (cj - t));         // linear rows: exact
@@ -1107,7 +1111,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
         double numax = 0.0, th = 0.0;
         nus = 0.0; cmax = 0.0; cmin = INFINITY;
-        for (int j = lane; j < m; j += WAVE) {
+        ROWS(j, lane, m) {
             const double sc = LD(L::rsc + j);
             const bool on = sc != 0.0;
             const double tn = LD(L::rtt + j);
