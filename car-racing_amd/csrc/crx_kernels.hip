@@ -74,6 +74,8 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 // dependent use instead of one pass paying its latency after the other (RP = passes the instantiation can need)
 #define ROWS(j, lane_, m_) _Pragma("unroll") for (int q_ = 0; q_ < (L::MR + WAVE - 1) / WAVE; q_++) if (const int j = (lane_) + q_ * WAVE; j < (m_))
 
+#define COORDS(e, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (L::NV + WAVE - 1) / WAVE; q_++) if (const int e = (lane_) + q_ * WAVE; e < (n_))
+
 #define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
 #define RIV_NEG (1 << 30)
 #define RIV_IDX(pk) ((pk) & 0xFFFF)
@@ -300,7 +302,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         }
         SYNC();
     }
-    for (int e = c.lane; e < N * L::NZ + L::NX; e += WAVE) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
+    COORDS(e, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
         // selects instead of branches: every divergent region costs ~30 cycles on a lone wave
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
@@ -385,7 +387,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         LD(L::rw + j) = on ? (nu - mu * rti + sig * (LD(L::rc + j) - t)) : 0.0;
     }
     SYNC();
-    for (int e = c.lane; e < N * L::NZ + L::NX; e += WAVE) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
+    COORDS(e, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
         const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
@@ -1104,7 +1106,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         if (!acc) break;
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
-        for (int e = lane; e < N * NZ + NX; e += WAVE) LD(L::Z + e) += al * LD(L::dZ + e);
+        COORDS(e, lane, N * NZ + NX) LD(L::Z + e) += al * LD(L::dZ + e);
         SYNC();
         f = fn;
         // one pass over the rows: multiplier update (from the pre-step row state), new slack, row value at the new
