@@ -287,12 +287,16 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
                 G[4] = qq * p2sn * c.rLs * c.rLs; G[5] = qq * p2en * c.rWs * c.rWs;
                 G[6] = qq * p2sc * c.rLs * c.rLs; G[7] = qq * p2ec * c.rWs * c.rWs;
                 const double d = LD(L::rsc + k * L::NR + 8 + NOBS + o);
+                // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
 #pragma unroll
-                for (int a = 0; a < L::NZ; a++) J[a] = d * (gsn * LD(L::M + 4 * L::NZ + a) + gen * LD(L::M + 5 * L::NZ + a));
-                J[4] -= d * c.om * gsc;
-                J[5] -= d * c.om * gec;
-                J[6 + o] += d * c.om;
-                J[L::NX + 2 + o] -= d;
+                for (int a = 0; a < L::NZ; a++) {
+                    double v = d * (gsn * LD(L::M + 4 * L::NZ + a) + gen * LD(L::M + 5 * L::NZ + a));
+                    if (a == 4) v -= d * c.om * gsc;
+                    if (a == 5) v -= d * c.om * gec;
+                    v += (a == 6 + o) ? d * c.om : 0.0;
+                    v -= (a == L::NX + 2 + o) ? d : 0.0;
+                    J[a] = v;
+                }
             } else {   // absent obstacle: its rows carry zero weights, but 0 * (stale LDS) must not become NaN
 #pragma unroll
                 for (int a = 0; a < L::NZ; a++) J[a] = 0.0;
