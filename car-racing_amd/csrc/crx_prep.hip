@@ -1,5 +1,11 @@
-// crx_prep.hip -- planner host prep on the device: Bezier references and
-// per-stage ey bounds of every region of a scenario, written in the layout crx_solve_kernel<0> reads.
+// crx_prep.hip -- the small kernels around the solvers:
+//   crx_prep_kernel     planner host prep: Bezier references and per-stage ey bounds of every region of a scenario
+//   crx_plant_kernel    one control step of the plant for a batch of vehicles
+//   crx_cbfprep_kernel  obstacle arrays of control.mpccbf for scripted cars
+//   crx_path_kernel     the 1-D QPs of the overtake PATH planner
+//
+// crx_prep_kernel: Bezier references and per-stage ey bounds of every region of a scenario, written in the layout
+// crx_solve_kernel<0> reads.
 // One wavefront per scenario, lanes over (region, sample).  Closed-form arithmetic, HBM-bound
 // (reads ~ (12 + 3V + 2V(N+1)) doubles, writes (V+1)(6 + 3N + 3) doubles per scenario).
 //
