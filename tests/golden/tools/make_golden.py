@@ -517,10 +517,12 @@ def gen_harness():
     print("harness fixture written:", len(out), "arrays")
 
 
-def gen_closed_loop(steps=int(os.environ.get("CRX_GOLDEN_STEPS", "150"))):
+def gen_closed_loop(steps=int(os.environ.get("CRX_GOLDEN_STEPS", "150")), layout=os.environ.get("CRX_GOLDEN_TRACK", "l_shape")):
     """The scenario of the reference's tests/auto_mpccbf_test.py:9-46 (zero noise), first `steps`
-    control steps, every NLP solved by the certified golden solver."""
-    track = make_track(1.0)
+    control steps, every NLP solved by the certified golden solver.  CRX_GOLDEN_TRACK selects another
+    layout of data/track_layout (car_racing/tests/mpccbf_test.py --track-layout)."""
+    track = (make_track(1.0) if layout == "l_shape" else
+             racing_env.ClosedTrack(np.genfromtxt("data/track_layout/%s.csv" % layout, delimiter=","), track_width=1.0))
     ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
     ego.set_zero_noise()
     ego.set_state_curvilinear(np.zeros((6,))); ego.set_state_global(np.zeros((6,))); ego.start_logging()
@@ -536,7 +538,7 @@ def gen_closed_loop(steps=int(os.environ.get("CRX_GOLDEN_STEPS", "150"))):
     sim.sim(sim_time=steps * 0.1)
     ok = np.array([r[2]["success"] for r in RECORDS])
     nobs = np.array([(r[0].nvar - 86) // 11 for r in RECORDS])
-    np.savez_compressed(os.path.join(OUT, "closed_loop_mpccbf.npz"), steps=steps,
+    np.savez_compressed(os.path.join(OUT, "closed_loop_mpccbf.npz" if layout == "l_shape" else "closed_loop_mpccbf_%s.npz" % layout), steps=steps,
                         ego_xcurv=np.array(ego.xcurv_log), ego_xglob=np.array(ego.xglob_log),
                         ego_u=np.array([r[1][66:68] for r in RECORDS]), solve_success=ok, n_obs=nobs,
                         car1_xcurv=np.array(car1.xcurv_log), car2_xcurv=np.array(car2.xcurv_log))
