@@ -257,6 +257,7 @@ def main():
 
     L.crx_debug_lds_bytes.restype = C.c_long
     lds = int(L.crx_debug_lds_bytes(1 if wl == "lmpc" else 0, int(N), int(n_obs)))
+    resident = int(L.crx_debug_resident_per_cu(1 if wl == "lmpc" else 0, int(N), int(n_obs)))   # runtime: min(LDS, registers)
     traffic = None
     try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, collected with rocprofv3 --pmc)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
@@ -282,7 +283,7 @@ def main():
                      "kernel": "crx_lmpc_kernel" if wl == "lmpc" else "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
                      "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
                      "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
-                     "lds_bytes_per_problem": lds, "resident_problems_per_cu": int((160 * 1024) // lds)},
+                     "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // lds)},
     }
     if rank == 0 and not args.no_cpu_baseline and wl != "races":
         out["cpu_baseline"] = cpu_baseline(wl, desc, p, batch)

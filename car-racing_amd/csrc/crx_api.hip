@@ -298,6 +298,12 @@ long crx_debug_lds_bytes(int kind, int N, int n) {
     return kind == 0 ? (long)crx_solve_lds_bytes(N, n) : (long)crx_lmpc_lds_bytes(N, n);
 }
 
+// diagnostics (not in crx.h): problems resident per CU as the runtime computes it (LDS AND registers); needs a GPU
+int crx_debug_resident_per_cu(int kind, int N, int n) {
+    if (ensure_init() != CRX_OK) return -1;
+    return kind == 0 ? crx_solve_resident_per_cu(N, n) : crx_lmpc_resident_per_cu(N, n);
+}
+
 double crx_last_kernel_ms(void) {
     if (!g_ev_valid) return -1.0;
     float ms = 0.f;

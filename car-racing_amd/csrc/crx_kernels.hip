@@ -145,6 +145,14 @@ struct Ctx {
 
 #define LD(off) sm[(off)]
 
+// phase clocks of the crx_trace_enable diagnostics.  s_memtime shares lgkmcnt with the LDS and returns out of order, so
+// every clock read in a sweep turns the partial waits around it into full drains: compiled in only by `make TRACE=1`
+#ifdef CRX_PHASE_CLOCKS
+#define CLK() clock64()
+#else
+#define CLK() 0LL
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // (4) phases
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +496,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
         for (int i = 0; i < NX; i++) mH[q][i] = LD(L::M + i * NZ + hr[q]);
     for (int k = N - 1; k >= 0; k--) {
-        long long q0 = clock64();
+        long long q0 = CLK();
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
         // dot products of length 6); the sigma_k columns of T are zero and the sigma_{k+1} columns
         // are copies of P's sigma columns (M = [A 0 B 0; 0 0 0 I]).
@@ -522,7 +530,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
         }
         SYNC();
-        long long q1 = clock64();
+        long long q1 = CLK();
         // H = M'T + stage terms, lower triangle only (NZ(NZ+1)/2 <= 105 entries), mirrored on store;
         // hv = M'p + hg.  All sums of a lane are formed before any store so that the LDS reads of
         // both of its entries are in flight together.
@@ -567,7 +575,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         }
         if (lane < NZ) LD(L::hv + lane) = hvs;
         SYNC();
-        long long q2 = clock64();
+        long long q2 = CLK();
         // every lane factorises Huu = L D L' itself (NU <= 5, broadcast LDS reads); unit-lower L,
         // reciprocal pivots: no square roots and one division per pivot on the dependent chain
         double Lf[NU][NU], Dp[NU], rD[NU];
@@ -592,7 +600,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
         }
         if (!ok) break;  // uniform: every lane computed the same pivots
-        long long q3 = clock64();
+        long long q3 = CLK();
         // Factorised update (block-Cholesky form): Y = L^{-1} Hux, P_new = Hxx - Y' D^{-1} Y,
         // K = -L^{-T} D^{-1} Y; column NX is the gradient column (p_new, kff).  P_new is formed from
         // the SAME factor for (i,j) and (j,i): symmetric positive semi-definite by construction.
@@ -644,7 +652,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
         }
         SYNC();
-        long long q4 = clock64();
+        long long q4 = CLK();
         if (tsub) { tsub[0] += q1 - q0; tsub[1] += q2 - q1; tsub[2] += q3 - q2; tsub[3] += q4 - q3; }
     }
     if (!ok) { SYNC(); return false; }
@@ -731,6 +739,9 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
 // ------------------------------------------------------------------------------------------------
 // (5) the solver kernel
 // ------------------------------------------------------------------------------------------------
+// (No amdgpu_waves_per_eu budget: capping the instantiations at the register count their LDS footprint would
+// allow -- 168 VGPRs for <0,12>, 256 for <1,12>/<2,12> -- was measured 3-20 % SLOWER: spills, and the scheduler stops
+// clustering the LDS loads.  Residency is therefore min(LDS, 512 / VGPRs per SIMD); crx_debug_resident_per_cu asks the runtime.)
 template <int NOBS, int NMAX>
 __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     using L = Lay<NOBS, NMAX>;
@@ -961,13 +972,13 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
 
     for (it = 0;; it++) {
-        long long tc0 = clock64();
+        long long tc0 = CLK();
         // ---- KKT error -----------------------------------------------------------------------------
         double e_c = cmax;
         const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
-        long long tc1 = clock64();
+        long long tc1 = CLK();
         const double e_d = dual_infeasibility<NOBS, NMAX>(sm, c) / sd;
-        long long tc2 = clock64();
+        long long tc2 = CLK();
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (E0 <= o.tol) { status = 0; break; }
@@ -985,9 +996,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         }
         const double tau = fmax(o.tau_min, 1.0 - mu);
         // ---- Newton step ---------------------------------------------------------------------------
-        long long tc3 = clock64();
+        long long tc3 = CLK();
         assemble_newton<NOBS, NMAX>(sm, si, c, mu);
-        long long tc4 = clock64();
+        long long tc4 = CLK();
         double dw = 0.0;
         long long tsub[4] = {0, 0, 0, 0};
         bool ok = riccati_backward<NOBS, NMAX>(sm, si, c, 0.0, tsub);
@@ -1002,9 +1013,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (!ok) break;
             dw_last = dw;
         }
-        long long tc5 = clock64();
+        long long tc5 = CLK();
         riccati_forward<NOBS, NMAX>(sm, c);
-        long long tc6 = clock64();
+        long long tc6 = CLK();
         // ---- row steps, step lengths, merit pieces ---------------------------------------------------
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
         double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
@@ -1049,7 +1060,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             theta_min = 1e-4 * fmax(1.0, theta);
             theta_max = 1e4 * fmax(1.0, theta);
         }
-        long long tc7 = clock64();
+        long long tc7 = CLK();
         // ---- filter line search ----------------------------------------------------------------------
         double al = a_p, fn = f;
         int acc = 0, ftype = 0;
@@ -1094,7 +1105,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (acc) break;
             al *= 0.5;
         }
-        long long tc8 = clock64();
+        long long tc8 = CLK();
         tph[0] = tc1 - tc0; tph[1] = tc2 - tc1; tph[2] = tc3 - tc2; tph[3] = tc4 - tc3; tph[4] = tc5 - tc4;
         tph[5] = tc6 - tc5; tph[6] = tc7 - tc6; tph[7] = tc8 - tc7;
         if (kp.trace_rows < 0) { tph[0] = tsub[0]; tph[1] = tsub[1]; tph[2] = tsub[2]; tph[3] = tsub[3]; }
@@ -1149,7 +1160,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         e_p = th;
         first_order<NOBS, NMAX>(sm, si, c);
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
-            kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (clock64() - tc8));   // slot 8: KKT rows + accept/first-order
+            kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (CLK() - tc8));   // slot 8: KKT rows + accept/first-order
         if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
     }
     if (infeas0) status = 2;
@@ -1271,6 +1282,31 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
         case 1: return small ? Lay<1, 12>::BYTES : Lay<1, CRX_MAX_N>::BYTES;
         case 2: return small ? Lay<2, 12>::BYTES : Lay<2, CRX_MAX_N>::BYTES;
         default: return small ? Lay<3, 12>::BYTES : (N <= 20 ? Lay<3, 20>::BYTES : Lay<3, CRX_MAX_N>::BYTES);
+    }
+}
+
+// resident single-wave workgroups per CU of the instantiation that would run (N, nobs_template): the runtime's
+// answer, i.e. min over the LDS and the register file
+template <int NOBS, int NMAX>
+static int occ_t() {
+    int n = 0;
+    const size_t bytes = Lay<NOBS, NMAX>::BYTES;
+    if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX>, WAVE, bytes) != hipSuccess) return -1;
+    return n;
+}
+template <int NOBS>
+static int occ_n(int N) {
+    if (N <= 12) return occ_t<NOBS, 12>();
+    if (NOBS == 3 && N <= 20) return occ_t<3, 20>();
+    return occ_t<NOBS, CRX_MAX_N>();
+}
+int crx_solve_resident_per_cu(int N, int nobs_template) {
+    switch (nobs_template) {
+        case 0: return occ_n<0>(N);
+        case 1: return occ_n<1>(N);
+        case 2: return occ_n<2>(N);
+        default: return occ_n<3>(N);
     }
 }
 

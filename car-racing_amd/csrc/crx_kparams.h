@@ -91,11 +91,13 @@ struct crx_cbfprep_kparams {
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
+int crx_solve_resident_per_cu(int N, int nobs_template);
 hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);
 hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
 size_t crx_lmpc_lds_bytes(int N, int n_ss_max);
+int crx_lmpc_resident_per_cu(int N, int n_ss_max);
 #endif
 #endif

@@ -285,9 +285,13 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         status = CRX_MAX_ITER;
         f = f0;
         for (it = 0;; it++) {
-            long long tk[14];
-            int tn = 0;
+            long long tk[14] = {};
+            [[maybe_unused]] int tn = 0;
+#ifdef CRX_PHASE_CLOCKS   /* `make TRACE=1`; see crx_kernels.hip */
 #define TICK() do { if (kp.trace) tk[tn++] = clock64(); } while (0)
+#else
+#define TICK() do { } while (0)
+#endif
             TICK();
             // ---- rows, gradient, equality residual ----
             l_rows<NMAX>(sm, x, kp);
@@ -686,6 +690,16 @@ hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     if (kp.batch == 0) return hipSuccess;
     return kp.N <= 12 ? launch_l<12>(kp, st) : launch_l<CRX_LMPC_MAX_N>(kp, st);
 }
+
+template <int NMAX>
+static int occ_l(int n_ss_max) {
+    int n = 0;
+    const size_t bytes = LL<NMAX>::bytes(n_ss_max);
+    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX>, WAVE, bytes) != hipSuccess) return -1;
+    return n;
+}
+int crx_lmpc_resident_per_cu(int N, int n_ss_max) { return N <= 12 ? occ_l<12>(n_ss_max) : occ_l<CRX_LMPC_MAX_N>(n_ss_max); }
 
 size_t crx_lmpc_lds_bytes(int N, int n_ss_max) { return N <= 12 ? LL<12>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N>::bytes(n_ss_max); }
 static_assert(LL<CRX_LMPC_MAX_N>::bytes(CRX_MAX_SS) <= 160 * 1024, "LDS budget");

@@ -1,3 +1,4 @@
+# phase clocks need a library built with `make -C car-racing_amd/csrc clean all TRACE=1` (compiled out by default)
 """Diagnostics: per-phase shader cycles of one learning-MPC solve (hidden crx_trace_* entry points)."""
 import os, sys, ctypes as C, time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,5 @@
-"""Diagnostics: per-phase shader cycles of one crx_solve_kernel problem (hidden crx_trace_* entry points).
+"""(phase clocks need a library built with `make -C car-racing_amd/csrc clean all TRACE=1`; the default build compiles them out)
+Diagnostics: per-phase shader cycles of one crx_solve_kernel problem (hidden crx_trace_* entry points).
 usage: gpu_solve_trace.py [cfg2|cfg3|cfg4]"""
 import os, sys, ctypes as C
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
