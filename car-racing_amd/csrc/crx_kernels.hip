@@ -114,15 +114,15 @@ struct Lay {
     static constexpr int P = kE + (NOBS ? NMAX : 0); // Riccati work
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
-    static constexpr int H = T + NX * NZ;
-    static constexpr int hv = H + NZ * NZ;
-    static constexpr int Kk = hv + NZ;               // [NMAX][NU][NX]
+    static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
+    static constexpr int H = T + NX * NZ;            // [NZ][HS]
+    static constexpr int Kk = H + NZ * HS;           // [NMAX][NU][NX]
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
-    static constexpr int lam = kf + NMAX * NU;       // [NZ]
-    static constexpr int Fth = lam + NZ;
+    static constexpr int Fth = kf + NMAX * NU;
     static constexpr int Fph = Fth + MAXF;
     static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 12.. lap_off
-    static constexpr int END_D = cst + 16;
+    static constexpr int dmy = cst + 16;             // sink of the address-predicated stores (lanes without an entry write here)
+    static constexpr int END_D = dmy + 2;
     // int tables (stored after the doubles)
     static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
     static constexpr int triH = riv + MR;            // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
@@ -355,28 +355,29 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N, lane = c.lane;
     double emax = 0.0;
-    // costates ping-pong between lam and hv (free outside the Riccati sweep): one sync per stage
-    int cur = L::lam, nxt = L::hv;
-    if (lane < L::NX) LD(cur + lane) = LD(L::ga + N * L::NZ + lane);
-    if (lane < L::NZ) LD(L::ga + N * L::NZ + lane) = 0.0;
-    SYNC();
+    // The costate recursion lives in registers: lane i < NX carries lam[i], the NX values a stage needs are broadcast
+    // with v_readlane (scalar operands of the FMAs) -- no LDS round trip on the dependent chain (it was one per
+    // stage, ~350 cycles of 12); ga[k] does not depend on the chain, so its loads run ahead.
     double mcol[L::NX];   // column `lane` of the (stage-invariant) model matrix, kept in registers across the sweep
 #pragma unroll
     for (int i = 0; i < L::NX; i++) mcol[i] = LD(L::M + i * L::NZ + (lane < L::NZ ? lane : 0));
+    const int la = lane < L::NZ ? lane : 0;
+    double tot = LD(L::ga + N * L::NZ + la);        // lam_N = the terminal gradient (lanes < NX)
+    double gk = LD(L::ga + (N - 1) * L::NZ + la);
+    if (lane < L::NZ) LD(L::ga + N * L::NZ + lane) = 0.0;
     for (int k = N - 1; k >= 0; k--) {
-        if (lane < L::NZ) {
-            double tot = LD(L::ga + k * L::NZ + lane);
+        const double gn = LD(L::ga + (k >= 1 ? k - 1 : 0) * L::NZ + la);   // next stage's gradient, in flight during this one
+        double t = gk;
 #pragma unroll
-            for (int i = 0; i < L::NX; i++) tot += mcol[i] * LD(cur + i);
-            if (lane >= L::NX) emax = fmax(emax, fabs(tot));
-            const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
-            LD(L::ga + k * L::NZ + lane) = keep ? tot : 0.0;
-            if (lane < L::NX) LD(nxt + lane) = tot;
-        }
-        SYNC();
-        const int tmp = cur; cur = nxt; nxt = tmp;
+        for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+        tot = t;
+        if (lane >= L::NX && lane < L::NZ) emax = fmax(emax, fabs(tot));
+        const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
+        if (lane < L::NZ) LD(L::ga + k * L::NZ + lane) = keep ? tot : 0.0;
+        gk = gn;
     }
-    if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(LD(cur + lane)));
+    SYNC();
+    if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(tot));
     return wave_max(emax);
 }
 
@@ -451,7 +452,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 template <int NOBS, int NMAX>
 __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, const Ctx& c, double dw, long long* tsub = nullptr) {
     using L = Lay<NOBS, NMAX>;
-    constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
+    constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
     const int N = c.N, lane = c.lane;
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
     for (int e = lane; e < NX * NX; e += WAVE) {
@@ -467,27 +468,37 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     if (lane < NX) LD(L::pv + lane) = LD(L::hg + N * NZ + lane);
     SYNC();
     bool ok = true;
-    // lane maps of the H and update phases do not depend on the stage: decode them once (a table read inside the
-    // stage loop is one more dependent LDS round trip per phase)
+    // The sweep is straight-line code: every lane-dependent decision (which entry a lane owns, where it goes) is
+    // decoded ONCE here into addresses; lanes without an entry store to the sink L::dmy instead of being masked off.
+    // A predicated region costs ~30 cycles of exec-mask traffic, and -- worse -- the compiler sinks the LDS loads of
+    // values only such a region uses into it, which turned the update phase into three serialized LDS round trips.
     constexpr bool FULL = NZ * NZ <= WAVE;
     constexpr int NTRI = FULL ? NZ * NZ : NZ * (NZ + 1) / 2;
     constexpr int HCNT = (NTRI + WAVE - 1) / WAVE;
-    int hr[HCNT], ha[HCNT];
+    int hr[HCNT], ha[HCNT], hst[HCNT], hst2[HCNT];
 #pragma unroll
     for (int q = 0; q < HCNT; q++) {
         const int e0 = lane + q * WAVE;
         const int e = e0 < NTRI ? e0 : 0;
         if (FULL) { hr[q] = e / NZ; ha[q] = e - hr[q] * NZ; }
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
+        hst[q] = e0 < NTRI ? L::H + hr[q] * HS + ha[q] : L::dmy;
+        hst2[q] = (!FULL && e0 < NTRI) ? L::H + ha[q] * HS + hr[q] : L::dmy;
     }
-    const int upk = si[L::updP + lane];
+    const int lz = lane < NZ ? lane : 0;
+    const int hvst = lane < NZ ? L::H + lane * HS + NZ : L::dmy;
     // the entries of the model matrix each lane multiplies with in the T and H phases, in registers
     constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
     double mT[TCNT][6], mH[HCNT][NX];
+    int tld[TCNT], tst[TCNT];
 #pragma unroll
     for (int q = 0; q < TCNT; q++) {
-        const int cc = (lane + q * WAVE) & 7;
+        const int e = lane + q * WAVE;
+        const int cc = e & 7;
         const int a = cc < 6 ? cc : NX + (cc - 6);
+        const int i = (e >> 3) < NX ? (e >> 3) : 0;
+        tld[q] = L::P + i * NX;
+        tst[q] = e < NX * 8 ? L::T + i * NZ + a : L::dmy;
 #pragma unroll
         for (int j = 0; j < 6; j++) mT[q][j] = LD(L::M + j * NZ + a);
     }
@@ -495,165 +506,151 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     for (int q = 0; q < HCNT; q++)
 #pragma unroll
         for (int i = 0; i < NX; i++) mH[q][i] = LD(L::M + i * NZ + hr[q]);
+    // sigma columns of T (NOBS > 0): sigma_k -> 0, sigma_{k+1} -> P[:, 6+o]
+    static_assert(NX * 2 * NOBS <= WAVE, "one pass");
+    int t2ld = L::P, t2st = L::dmy;
+    bool t2nxt = false;
+    if (NOBS) {
+        const bool v2 = lane < NX * 2 * NOBS;
+        const int e2 = v2 ? lane : 0;
+        const int i2 = e2 / (2 * L::NO), cc = e2 - i2 * (2 * L::NO);
+        t2nxt = cc >= NOBS;
+        const int o = t2nxt ? cc - NOBS : cc;
+        t2ld = L::P + i2 * NX + 6 + o;
+        t2st = v2 ? L::T + i2 * NZ + (t2nxt ? NX + 2 + o : 6 + o) : L::dmy;
+    }
+    // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
+    // [NP, NP+NX+1) one feedback column each (<= 64 lanes for NX <= 9)
+    constexpr int NP = NX * (NX + 1) / 2 + NX;
+    const int upk = si[L::updP + lane];
+    const int ui = upk >> 8, uj = upk & 255;     // feedback lanes: column uj, ui = 0 (unused)
+    const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
+    const bool gcol = uj >= NX;                   // gradient column = column NZ of H
+    const int ujj = gcol ? NZ : uj;
+    const int yiA = L::H + NX * HS + ui, yjA = L::H + NX * HS + ujj, s0A = L::H + ui * HS + ujj;
+    const int pst1 = isP ? (gcol ? L::pv + ui : L::P + ui * NX + uj) : L::dmy;
+    const int pst2 = isP ? (gcol ? L::pv + ui : L::P + uj * NX + ui) : L::dmy;
+    const int kstr = isK ? (gcol ? 1 : NX) : 0, kstep = isK ? (gcol ? NU : NU * NX) : 0;
+    int kst = isK ? (gcol ? L::kf : L::Kk + uj) + (N - 1) * kstep : L::dmy;
+    const bool exSl = isP && !gcol && ui == uj && ui == 4, exEl = isP && !gcol && ui == uj && ui == 5;
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
         // dot products of length 6); the sigma_k columns of T are zero and the sigma_{k+1} columns
         // are copies of P's sigma columns (M = [A 0 B 0; 0 0 0 I]).
         {
-            double ts[TCNT];
+            double pl[TCNT][6];
+#pragma unroll
+            for (int q = 0; q < TCNT; q++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) pl[q][j] = LD(tld[q] + j);
+            const double p2 = NOBS ? LD(t2ld) : 0.0;
 #pragma unroll
             for (int q = 0; q < TCNT; q++) {
-                const int e = lane + q * WAVE;
-                const int i = (e >> 3) < NX ? (e >> 3) : 0;
-                double s = 0.0;
+                double t = 0.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) s += LD(L::P + i * NX + j) * mT[q][j];
-                ts[q] = s;
+                for (int j = 0; j < 6; j++) t += pl[q][j] * mT[q][j];
+                LD(tst[q]) = t;
             }
-#pragma unroll
-            for (int q = 0; q < TCNT; q++) {
-                const int e = lane + q * WAVE;
-                if (e < NX * 8) {
-                    const int i = e >> 3, cc = e & 7;
-                    LD(L::T + i * NZ + (cc < 6 ? cc : NX + (cc - 6))) = ts[q];
-                }
-            }
-            if (NOBS) {
-                // remaining columns: sigma_k -> 0, sigma_{k+1} -> P[:, 6+o]
-                for (int e2 = lane; e2 < NX * 2 * NOBS; e2 += WAVE) {
-                    const int i = e2 / (2 * NOBS), cc = e2 - i * (2 * NOBS);
-                    const bool nxt = cc >= NOBS;
-                    const int o = nxt ? cc - NOBS : cc;
-                    LD(L::T + i * NZ + (nxt ? NX + 2 + o : 6 + o)) = nxt ? LD(L::P + i * NX + 6 + o) : 0.0;
-                }
-            }
+            if (NOBS) LD(t2st) = t2nxt ? p2 : 0.0;
         }
         SYNC();
         long long q1 = CLK();
         // H = M'T + stage terms, lower triangle only (NZ(NZ+1)/2 <= 105 entries), mirrored on store;
-        // hv = M'p + hg.  All sums of a lane are formed before any store so that the LDS reads of
-        // both of its entries are in flight together.
-        // NZ*NZ <= 64 (no obstacle): one lane per entry of the full matrix, no mirroring needed.
-        // The body is branch-free (selects): every divergent region costs ~30 cycles of exec-mask
-        // traffic on a lone wave.
-        const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
-        double hs[HCNT];
+        // hv = M'p + hg, stored as column NZ of H.  NZ*NZ <= 64 (no obstacle): one lane per entry of the
+        // full matrix, no mirroring needed.
+        {
+            const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
+            double hs[HCNT];
 #pragma unroll
-        for (int q = 0; q < HCNT; q++) {
-            const int r = hr[q], a = ha[q];
-            double s = 0.0;
+            for (int q = 0; q < HCNT; q++) {
+                const int r = hr[q], a = ha[q];
+                double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; i++) s += mH[q][i] * LD(L::T + i * NZ + a);
-            const double dg = LD(L::Hd + k * NZ + r) + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
-            s += (r == a) ? dg : 0.0;
-            if (NOBS) {
+                for (int i = 0; i < NX; i++) t += mH[q][i] * LD(L::T + i * NZ + a);
+                const double dg = LD(L::Hd + k * NZ + r) + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
+                t += (r == a) ? dg : 0.0;
+                if (NOBS) {
 #pragma unroll
-                for (int o = 0; o < NOBS; o++) {
-                    const double* J = sm + L::Jc + (k * L::NO + o) * NZ;
-                    s += LD(L::rsig + k * L::NR + 8 + NOBS + o) * J[r] * J[a];
+                    for (int o = 0; o < NOBS; o++) {
+                        const double* J = sm + L::Jc + (k * L::NO + o) * NZ;
+                        t += LD(L::rsig + k * L::NR + 8 + NOBS + o) * J[r] * J[a];
+                    }
+                } else {
+                    // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
+                    const double m5a = LD(L::M + 5 * NZ + a), m5r = LD(L::M + 5 * NZ + r);
+                    t -= kc * (((r == 5) ? m5a : 0.0) + ((a == 5) ? m5r : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
                 }
-            } else {
-                // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
-                const double m5a = LD(L::M + 5 * NZ + a), m5r = LD(L::M + 5 * NZ + r);
-                s -= kc * (((r == 5) ? m5a : 0.0) + ((a == 5) ? m5r : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
+                hs[q] = t;
             }
-            hs[q] = s;
-        }
-        double hvs = 0.0;
-        if (lane < NZ) {
-            hvs = LD(L::hg + k * NZ + lane);
+            double hvs = LD(L::hg + k * NZ + lz);
 #pragma unroll
-            for (int i = 0; i < NX; i++) hvs += LD(L::M + i * NZ + lane) * LD(L::pv + i);
-        }
+            for (int i = 0; i < NX; i++) hvs += LD(L::M + i * NZ + lz) * LD(L::pv + i);
 #pragma unroll
-        for (int q = 0; q < HCNT; q++) {
-            if (lane + q * WAVE < NTRI) {
-                LD(L::H + hr[q] * NZ + ha[q]) = hs[q];
-                if (!FULL) LD(L::H + ha[q] * NZ + hr[q]) = hs[q];
+            for (int q = 0; q < HCNT; q++) {
+                LD(hst[q]) = hs[q];
+                if (!FULL) LD(hst2[q]) = hs[q];
             }
+            LD(hvst) = hvs;
         }
-        if (lane < NZ) LD(L::hv + lane) = hvs;
         SYNC();
         long long q2 = CLK();
-        // every lane factorises Huu = L D L' itself (NU <= 5, broadcast LDS reads); unit-lower L,
-        // reciprocal pivots: no square roots and one division per pivot on the dependent chain
-        double Lf[NU][NU], Dp[NU], rD[NU];
-#pragma unroll
-        for (int a = 0; a < NU; a++)
-#pragma unroll
-            for (int b = 0; b <= a; b++) Lf[a][b] = LD(L::H + (NX + a) * NZ + NX + b);
-#pragma unroll
-        for (int j = 0; j < NU; j++) {
-            double d = Lf[j][j];
-#pragma unroll
-            for (int q = 0; q < j; q++) d -= Lf[j][q] * Lf[j][q] * Dp[q];
-            if (!(d > 0.0)) ok = false;
-            Dp[j] = d;
-            rD[j] = frcp(d);
-#pragma unroll
-            for (int i = j + 1; i < NU; i++) {
-                double t = Lf[i][j];
-#pragma unroll
-                for (int q = 0; q < j; q++) t -= Lf[i][q] * Lf[j][q] * Dp[q];
-                Lf[i][j] = t * rD[j];
-            }
-        }
-        if (!ok) break;  // uniform: every lane computed the same pivots
-        long long q3 = CLK();
-        // Factorised update (block-Cholesky form): Y = L^{-1} Hux, P_new = Hxx - Y' D^{-1} Y,
-        // K = -L^{-T} D^{-1} Y; column NX is the gradient column (p_new, kff).  P_new is formed from
-        // the SAME factor for (i,j) and (j,i): symmetric positive semi-definite by construction.
-        // Lane map (<= 64 for NX <= 9): [0, NP) the upper triangle of P_new incl. the gradient column
-        // (i <= j <= NX), [NP, NP+NX+1) one feedback column each.  P/pv are not read in this phase
-        // (T and hv are done), so they are overwritten in place.
+        // Huu = L D L' (every lane factorises it itself: NU <= 5, broadcast LDS reads; unit-lower L, reciprocal
+        // pivots) and the factorised update (block-Cholesky form) in ONE LDS round trip: Y = L^{-1} Hux,
+        // P_new = Hxx - Y' D^{-1} Y, K = -L^{-T} D^{-1} Y; column NX of the lane map is the gradient column
+        // (p_new, kff).  P_new is formed from the SAME factor for (i,j) and (j,i): symmetric positive semi-definite
+        // by construction.  P/pv are not read in this phase (T and hv are done), so they are overwritten in place.
         {
-            constexpr int NP = NX * (NX + 1) / 2 + NX;
-            const int i = upk >> 8, j = upk & 255;   // feedback lanes: column j, i = 0 (unused)
-            const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
-            const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
-            const double exS = (NOBS && k >= 1) ? LD(L::kS + km) : 0.0;
-            const double exE = (k >= 1) ? (NOBS ? LD(L::kE + km) : 0.0) + 2.0 * LD(L::wc + km) : 0.0;
-            // straight-line body with selects; only the two store regions are predicated
-            const bool gcol = j >= NX;             // gradient column
-            double yi[NU], yj[NU];
+            double Lf[NU][NU], Dp[NU], rD[NU], yi[NU], yj[NU];
 #pragma unroll
-            for (int a = 0; a < NU; a++) {
-                yi[a] = LD(L::H + (NX + a) * NZ + i);
-                const double hj = LD(L::H + (NX + a) * NZ + (gcol ? 0 : j)), gj = LD(L::hv + NX + a);
-                yj[a] = gcol ? gj : hj;
+            for (int a = 0; a < NU; a++)
+#pragma unroll
+                for (int b2 = 0; b2 <= a; b2++) Lf[a][b2] = LD(L::H + (NX + a) * HS + NX + b2);
+#pragma unroll
+            for (int a = 0; a < NU; a++) { yi[a] = LD(yiA + a * HS); yj[a] = LD(yjA + a * HS); }
+            double t = LD(s0A);
+            const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
+            const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
+            const double exS = k >= 1 ? kSv : 0.0, exE = k >= 1 ? kEv + 2.0 * wcv : 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; j++) {
+                double d = Lf[j][j];
+#pragma unroll
+                for (int q = 0; q < j; q++) d -= Lf[j][q] * Lf[j][q] * Dp[q];
+                if (!(d > 0.0)) ok = false;
+                Dp[j] = d;
+                rD[j] = frcp(d);
+#pragma unroll
+                for (int i = j + 1; i < NU; i++) {
+                    double u = Lf[i][j];
+#pragma unroll
+                    for (int q = 0; q < j; q++) u -= Lf[i][q] * Lf[j][q] * Dp[q];
+                    Lf[i][j] = u * rD[j];
+                }
             }
-            const double hij = LD(L::H + i * NZ + (gcol ? 0 : j)), gi = LD(L::hv + i);
-            double s = gcol ? gi : hij;
 #pragma unroll
             for (int a = 1; a < NU; a++) {
 #pragma unroll
                 for (int q = 0; q < a; q++) { yi[a] -= Lf[a][q] * yi[q]; yj[a] -= Lf[a][q] * yj[q]; }
             }
 #pragma unroll
-            for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; s -= yi[a] * yj[a]; }
-            s += (!gcol && i == j) ? ((i == 4) ? exS : ((i == 5) ? exE : 0.0)) : 0.0;
-            if (isP) {
-                const int a1 = gcol ? L::pv + i : L::P + i * NX + j;
-                const int a2 = gcol ? L::pv + i : L::P + j * NX + i;
-                LD(a1) = s;
-                LD(a2) = s;
+            for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; t -= yi[a] * yj[a]; }
+            t += exSl ? exS : (exEl ? exE : 0.0);
+            LD(pst1) = t;
+            LD(pst2) = t;
+#pragma unroll
+            for (int a = NU - 2; a >= 0; a--) {
+#pragma unroll
+                for (int q = a + 1; q < NU; q++) yj[a] -= Lf[q][a] * yj[q];
             }
-            if (isK) {
 #pragma unroll
-                for (int a = NU - 2; a >= 0; a--) {
-#pragma unroll
-                    for (int q = a + 1; q < NU; q++) yj[a] -= Lf[q][a] * yj[q];
-                }
-                const int base = gcol ? L::kf + k * NU : L::Kk + k * NU * NX + j;
-                const int stride = gcol ? 1 : NX;
-#pragma unroll
-                for (int a = 0; a < NU; a++) LD(base + a * stride) = -yj[a];
-            }
+            for (int a = 0; a < NU; a++) LD(kst + a * kstr) = -yj[a];
+            kst -= kstep;
         }
+        if (!ok) break;  // uniform: every lane computed the same pivots (the entries just stored are discarded with the sweep)
         SYNC();
         long long q4 = CLK();
-        if (tsub) { tsub[0] += q1 - q0; tsub[1] += q2 - q1; tsub[2] += q3 - q2; tsub[3] += q4 - q3; }
+        if (tsub) { tsub[0] += q1 - q0; tsub[1] += q2 - q1; tsub[3] += q4 - q2; }
     }
     if (!ok) { SYNC(); return false; }
     // free initial components sigma_0: minimise 1/2 d'P d + p'd over them (x_0 is fixed)
@@ -705,9 +702,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     return ok;
 }
 
-// forward sweep: du = K dx + kff, dx_{k+1} = M [dx; du]; fills dZ for every stage.  (Fusing the two
-// steps into one LDS round trip by recomputing du on every lane was measured slower: 41 LDS reads per
-// lane instead of 7+10.)
+// forward sweep: du = K dx + kff, dx_{k+1} = M [dx; du]; fills dZ for every stage.  The recursion lives in registers:
+// lane j < NX carries dx_k[j], lane NX + a computes du_a; both are broadcast with v_readlane, the gains of the next
+// stage are loaded while this one computes, LDS only receives the result (it was two dependent LDS round trips per
+// stage).  Same operations in the same order as the LDS version: identical bits.
 template <int NOBS, int NMAX>
 __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
@@ -716,23 +714,35 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     double mrow[NZ];      // row `lane` of the model matrix, in registers across the sweep
 #pragma unroll
     for (int j = 0; j < NZ; j++) mrow[j] = LD(L::M + (lane < NX ? lane : 0) * NZ + j);
+    const bool isu = lane >= NX && lane < NZ;
+    const int ua = isu ? lane - NX : 0;
+    double zx = LD(L::dZ + (lane < NX ? lane : 0));   // dx_0: zero but for the free sigma_0 (riccati_backward)
+    double kr[NX], kfa;
+#pragma unroll
+    for (int j = 0; j < NX; j++) kr[j] = LD(L::Kk + ua * NX + j);
+    kfa = LD(L::kf + ua);
     for (int k = 0; k < N; k++) {
-        if (lane < NU) {
-            double s = LD(L::kf + k * NU + lane);
+        double krn[NX], kfn;                           // next stage's feedback row: off the dependent chain
+        const int kn = k + 1 < N ? k + 1 : k;
 #pragma unroll
-            for (int j = 0; j < NX; j++) s += LD(L::Kk + (k * NU + lane) * NX + j) * LD(L::dZ + k * NZ + j);
-            LD(L::dZ + k * NZ + NX + lane) = s;
-        }
-        SYNC();
-        if (lane < NX) {
-            double s = 0.0;
+        for (int j = 0; j < NX; j++) krn[j] = LD(L::Kk + (kn * NU + ua) * NX + j);
+        kfn = LD(L::kf + kn * NU + ua);
+        double xs[NX], du = kfa, xn = 0.0;
 #pragma unroll
-            for (int j = 0; j < NZ; j++) s += mrow[j] * LD(L::dZ + k * NZ + j);
-            LD(L::dZ + (k + 1) * NZ + lane) = s;
-        }
-        SYNC();
+        for (int j = 0; j < NX; j++) xs[j] = lane_f64(zx, j);
+#pragma unroll
+        for (int j = 0; j < NX; j++) du += kr[j] * xs[j];
+#pragma unroll
+        for (int j = 0; j < NX; j++) xn += mrow[j] * xs[j];
+#pragma unroll
+        for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
+        if (lane < NZ) LD(L::dZ + k * NZ + lane) = isu ? du : zx;
+        zx = xn;
+#pragma unroll
+        for (int j = 0; j < NX; j++) kr[j] = krn[j];
+        kfa = kfn;
     }
-    if (lane >= NX && lane < NZ) LD(L::dZ + N * NZ + lane) = 0.0;
+    if (lane < NZ) LD(L::dZ + N * NZ + lane) = lane < NX ? zx : 0.0;
     SYNC();
 }
 
