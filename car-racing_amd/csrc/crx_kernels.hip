@@ -70,11 +70,18 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 // Row slots inside a stage k: 0..3 input box (d lo, d hi, a lo, a hi); 4..7 box of x_{k+1} (vx lo,
 // vx hi, ey lo, ey hi); 8+o: sigma_{k+1}^o >= 0; 8+NOBS+o: CBF row (k,o).  Rows N*NR+o: sigma_0^o.
 // ------------------------------------------------------------------------------------------------
-// all rows of a problem, pass by pass, fully unrolled: the LDS loads of every pass are issued before the first
-// dependent use instead of one pass paying its latency after the other (RP = passes the instantiation can need)
-#define ROWS(j, lane_, m_) _Pragma("unroll") for (int q_ = 0; q_ < (L::MR + WAVE - 1) / WAVE; q_++) if (const int j = (lane_) + q_ * WAVE; j < (m_))
+// All rows of a problem, pass by pass, fully unrolled and STRAIGHT-LINE: a lane past the last row recomputes row 0
+// (jv = false).  Its stores of pure functions of other arrays rewrite row 0 with the value lane 0 wrote; read-modify-
+// write stores and stores that depend on jv go to the sink (SINK), sums and products are masked with jv, maxima need
+// nothing.  No predicated region: the LDS loads of every pass are in flight together, and the compiler cannot sink
+// loads into a branch (each such region was one more serialized LDS round trip).
+#define ROWS(j, jv, lane_, m_) _Pragma("unroll") for (int q_ = 0; q_ < (L::MR + WAVE - 1) / WAVE; q_++) \
+    if (const bool jv = (lane_) + q_ * WAVE < (m_); true) if (const int j = jv ? (lane_) + q_ * WAVE : 0; true)
 
-#define COORDS(e, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (L::NV + WAVE - 1) / WAVE; q_++) if (const int e = (lane_) + q_ * WAVE; e < (n_))
+#define COORDS(e, ev, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (L::NV + WAVE - 1) / WAVE; q_++) \
+    if (const bool ev = (lane_) + q_ * WAVE < (n_); true) if (const int e = ev ? (lane_) + q_ * WAVE : 0; true)
+
+#define SINK(cond, off) ((cond) ? (off) : L::dmy)
 
 #define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
 #define RIV_NEG (1 << 30)
@@ -225,31 +232,22 @@ __device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c, doubl
     using L = Lay<NOBS, NMAX>;
     const int N = c.N;
     double acc = 0.0, q = 0.0;
-    for (int e = c.lane; e < (N + 1) * 6; e += WAVE) {
-        const int k = e / 6, i = e - k * 6;
-        const double dv = LD(L::dZ + k * L::NZ + i), w = LD(L::cst + i);
-        acc += 2.0 * w * (LD(L::Z + k * L::NZ + i) - LD(L::xr + e)) * dv;
-        q += w * dv * dv;
-        if (k == N && i == 4) acc += c.lin_sN * dv;
-    }
-    for (int e = c.lane; e < N * 2; e += WAVE) {
-        const int k = e >> 1, i = e & 1;
-        const double dv = LD(L::dZ + k * L::NZ + L::NX + i), w = LD(L::cst + 6 + i);
-        acc += 2.0 * w * LD(L::Z + k * L::NZ + L::NX + i) * dv;
-        q += w * dv * dv;
-    }
-    for (int k = c.lane; k < N; k += WAVE) {
-        const double de = LD(L::Z + (k + 1) * L::NZ + 5) - LD(L::Z + k * L::NZ + 5);
-        const double dd = LD(L::dZ + (k + 1) * L::NZ + 5) - LD(L::dZ + k * L::NZ + 5);
-        const double w = LD(L::wc + k);
-        acc += 2.0 * w * de * dd;
-        q += w * dd * dd;
-    }
-    if (NOBS) {
-        for (int e = c.lane; e < (N + 1) * NOBS; e += WAVE) {
-            const int k = e / L::NO, o = e - k * L::NO;
-            if (o < c.nobs) acc += c.wsig * LD(L::dZ + k * L::NZ + 6 + o);
-        }
+    // one straight-line pass over the stage coordinates (the four loops of cost_value, by coordinate kind)
+    COORDS(e, ev, c.lane, N * L::NZ + L::NX) {
+        const int k = e / L::NZ, a = e - k * L::NZ;
+        const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX;
+        const bool cpl = a == 5 && k >= 1;                                   // (ey_k - ey_{k-1})^2, weight wc[k-1]
+        const double dv = LD(L::dZ + e), z = LD(L::Z + e);
+        const double w = (isx || isu) ? LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
+        const double ref = isx ? LD(L::xr + k * 6 + (isx ? a : 0)) : 0.0;
+        const int ep = cpl ? e - L::NZ : e;
+        const double de = z - LD(L::Z + ep), dd = dv - LD(L::dZ + ep);
+        const double wk = cpl ? LD(L::wc + (cpl ? k - 1 : 0)) : 0.0;
+        double t = 2.0 * (w * (z - ref) * dv + wk * de * dd);
+        t += (k == N && a == 4) ? c.lin_sN * dv : 0.0;
+        if (NOBS) t += (iss0 && a - 6 < c.nobs) ? c.wsig * dv : 0.0;
+        acc += ev ? t : 0.0;
+        q += ev ? w * dv * dv + wk * dd * dd : 0.0;
     }
     qq = wave_sum(q);
     return wave_sum(acc);
@@ -278,43 +276,46 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
     using L = Lay<NOBS, NMAX>;
     const int N = c.N;
     if (NOBS) {
-        for (int e = c.lane; e < N * NOBS; e += WAVE) {
-            const int k = e / NOBS, o = e - k * NOBS;
+#pragma unroll
+        for (int q_ = 0; q_ < (NMAX * NOBS + WAVE - 1) / WAVE; q_++) {
+            const int e0 = c.lane + q_ * WAVE;
+            const int e = e0 < N * NOBS ? e0 : 0;          // lanes past the table recompute entry 0 (same values)
+            const int k = e / L::NO, o = e - k * L::NO;
             double* G = sm + L::G + (k * L::NO + o) * 8;
             double* J = sm + L::Jc + (k * L::NO + o) * L::NZ;
-            if (o < c.nobs) {
-                double dsc, dec, dsn, den;
-                cbf_dist<NOBS, NMAX>(sm, c, k, o, 0.0, dsc, dec, dsn, den);
-                const int q = c.degree;
-                const double qd = (double)q, qq = (double)(q * (q - 1));
-                const double p2sn = ipow_d(dsn, q - 2), p2en = ipow_d(den, q - 2);
-                const double p2sc = ipow_d(dsc, q - 2), p2ec = ipow_d(dec, q - 2);
-                const double gsn = qd * p2sn * dsn * c.rLs, gen = qd * p2en * den * c.rWs;
-                const double gsc = qd * p2sc * dsc * c.rLs, gec = qd * p2ec * dec * c.rWs;
-                G[0] = gsn; G[1] = gen; G[2] = gsc; G[3] = gec;
-                G[4] = qq * p2sn * c.rLs * c.rLs; G[5] = qq * p2en * c.rWs * c.rWs;
-                G[6] = qq * p2sc * c.rLs * c.rLs; G[7] = qq * p2ec * c.rWs * c.rWs;
-                const double d = LD(L::rsc + k * L::NR + 8 + NOBS + o);
-                // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
+            // absent obstacle (o >= nobs): its data may be anything; every product below is discarded by a select, so
+            // that 0 * (stale LDS) never becomes NaN in G / J
+            const bool here = o < c.nobs;
+            double dsc, dec, dsn, den;
+            cbf_dist<NOBS, NMAX>(sm, c, k, o, 0.0, dsc, dec, dsn, den);
+            const int q = c.degree;
+            const double qd = (double)q, qq = (double)(q * (q - 1));
+            const double p2sn = ipow_d(dsn, q - 2), p2en = ipow_d(den, q - 2);
+            const double p2sc = ipow_d(dsc, q - 2), p2ec = ipow_d(dec, q - 2);
+            const double gsn = qd * p2sn * dsn * c.rLs, gen = qd * p2en * den * c.rWs;
+            const double gsc = qd * p2sc * dsc * c.rLs, gec = qd * p2ec * dec * c.rWs;
+            const double d = LD(L::rsc + k * L::NR + 8 + NOBS + o);
+            double m4[L::NZ], m5[L::NZ];
 #pragma unroll
-                for (int a = 0; a < L::NZ; a++) {
-                    double v = d * (gsn * LD(L::M + 4 * L::NZ + a) + gen * LD(L::M + 5 * L::NZ + a));
-                    if (a == 4) v -= d * c.om * gsc;
-                    if (a == 5) v -= d * c.om * gec;
-                    v += (a == 6 + o) ? d * c.om : 0.0;
-                    v -= (a == L::NX + 2 + o) ? d : 0.0;
-                    J[a] = v;
-                }
-            } else {   // absent obstacle: its rows carry zero weights, but 0 * (stale LDS) must not become NaN
+            for (int a = 0; a < L::NZ; a++) { m4[a] = LD(L::M + 4 * L::NZ + a); m5[a] = LD(L::M + 5 * L::NZ + a); }
+            G[0] = here ? gsn : 0.0; G[1] = here ? gen : 0.0; G[2] = here ? gsc : 0.0; G[3] = here ? gec : 0.0;
+            G[4] = here ? qq * p2sn * c.rLs * c.rLs : 0.0; G[5] = here ? qq * p2en * c.rWs * c.rWs : 0.0;
+            G[6] = here ? qq * p2sc * c.rLs * c.rLs : 0.0; G[7] = here ? qq * p2ec * c.rWs * c.rWs : 0.0;
+            // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
 #pragma unroll
-                for (int a = 0; a < L::NZ; a++) J[a] = 0.0;
-#pragma unroll
-                for (int a = 0; a < 8; a++) G[a] = 0.0;
+            for (int a = 0; a < L::NZ; a++) {
+                double v = d * (gsn * m4[a] + gen * m5[a]);
+                if (a == 4) v -= d * c.om * gsc;
+                if (a == 5) v -= d * c.om * gec;
+                v += (a == 6 + o) ? d * c.om : 0.0;
+                v -= (a == L::NX + 2 + o) ? d : 0.0;
+                J[a] = here ? v : 0.0;
             }
         }
         SYNC();
     }
-    COORDS(e, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
+    COORDS(e, ev, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
+        (void)ev;
         // selects instead of branches: every divergent region costs ~30 cycles on a lone wave
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
@@ -390,7 +391,8 @@ template <int NOBS, int NMAX>
 __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const Ctx& c, double mu) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N;
-    ROWS(j, c.lane, c.m) {
+    ROWS(j, jv, c.lane, c.m) {
+        (void)jv;
         const double t = LD(L::rt + j), nu = LD(L::rnu + j);
         const double rti = frcp(t);
         const double sig = nu * rti;
@@ -400,7 +402,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         LD(L::rw + j) = on ? (nu - mu * rti + sig * (LD(L::rc + j) - t)) : 0.0;
     }
     SYNC();
-    COORDS(e, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
+    COORDS(e, ev, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
         const int k = e / L::NZ, a = e - k * L::NZ;
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
         const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
@@ -423,25 +425,22 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
                 h += (k < N && (a == 4 || a == 5)) ? cur : 0.0;
             }
         }
-        if (k == N && a >= L::NX) { h = 0.0; g = 0.0; }
-        LD(L::Hd + e) = h;
-        LD(L::hg + e) = g;
+        const bool tail = k == N && a >= L::NX;
+        LD(L::Hd + e) = tail ? 0.0 : h;
+        LD(SINK(ev, L::hg + e)) = tail ? 0.0 : g;      // in place over ga: read-modify-write
     }
-    for (int k = c.lane; k < N; k += WAVE) {
+    if (NOBS) {
+        const int k = c.lane < N ? c.lane : 0;          // N <= 24 < WAVE: one pass; lanes past N recompute stage 0
         double ks = 0.0, ke = 0.0;
-        if (NOBS) {
 #pragma unroll
-            for (int o = 0; o < NOBS; o++) {
-                const int j = k * L::NR + 8 + NOBS + o;
-                const double nd = LD(L::rnu + j) * LD(L::rsc + j);
-                ks -= nd * LD(L::G + (k * L::NO + o) * 8 + 4);
-                ke -= nd * LD(L::G + (k * L::NO + o) * 8 + 5);
-            }
+        for (int o = 0; o < NOBS; o++) {
+            const int j = k * L::NR + 8 + NOBS + o;
+            const double nd = LD(L::rnu + j) * LD(L::rsc + j);
+            ks -= nd * LD(L::G + (k * L::NO + o) * 8 + 4);
+            ke -= nd * LD(L::G + (k * L::NO + o) * 8 + 5);
         }
-        if (NOBS) {
-            LD(L::kS + k) = ks;
-            LD(L::kE + k) = ke;
-        }
+        LD(L::kS + k) = ks;
+        LD(L::kE + k) = ke;
     }
     SYNC();
 }
@@ -749,9 +748,10 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
 // ------------------------------------------------------------------------------------------------
 // (5) the solver kernel
 // ------------------------------------------------------------------------------------------------
-// (No amdgpu_waves_per_eu budget: capping the instantiations at the register count their LDS footprint would
-// allow -- 168 VGPRs for <0,12>, 256 for <1,12>/<2,12> -- was measured 3-20 % SLOWER: spills, and the scheduler stops
-// clustering the LDS loads.  Residency is therefore min(LDS, 512 / VGPRs per SIMD); crx_debug_resident_per_cu asks the runtime.)
+// (No amdgpu_waves_per_eu budget.  Capping an instantiation at the register count its LDS footprint would admit --
+// 168 VGPRs for <0,12>, 256 for <2,12> -- buys a resident wave per SIMD but costs spills inside the interior-point loop:
+// measured -4 % on cfg3 and -2 % on cfg2 at the BASELINE batches, +1 % / +7 % only for batches of 16k planner QPs /
+// 16k two-car races.  Residency is therefore min(LDS, 512 / VGPRs per SIMD); crx_debug_resident_per_cu asks the runtime.)
 template <int NOBS, int NMAX>
 __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     using L = Lay<NOBS, NMAX>;
@@ -1009,20 +1009,19 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         long long tc3 = CLK();
         assemble_newton<NOBS, NMAX>(sm, si, c, mu);
         long long tc4 = CLK();
+        // inertia correction: retry the sweep with a growing regularisation dw until every pivot is positive (one call
+        // site: the sweep is inlined once)
         double dw = 0.0;
         long long tsub[4] = {0, 0, 0, 0};
-        bool ok = riccati_backward<NOBS, NMAX>(sm, si, c, 0.0, tsub);
-        if (!ok) {
-            dw = dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0);
-            for (;;) {
-                ok = riccati_backward<NOBS, NMAX>(sm, si, c, dw);
-                if (ok) break;
-                dw *= dw_last == 0.0 ? 100.0 : 8.0;
-                if (dw > 1e40) break;
-            }
-            if (!ok) break;
-            dw_last = dw;
+        bool ok;
+        for (int tries = 0;; tries++) {
+            ok = riccati_backward<NOBS, NMAX>(sm, si, c, dw, tsub);
+            if (ok) break;
+            dw = tries == 0 ? (dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0)) : dw * (dw_last == 0.0 ? 100.0 : 8.0);
+            if (dw > 1e40) break;
         }
+        if (!ok) break;
+        if (dw != 0.0) dw_last = dw;
         long long tc5 = CLK();
         riccati_forward<NOBS, NMAX>(sm, c);
         long long tc6 = CLK();
@@ -1030,21 +1029,22 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
         double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
         LogAcc lg0;
-        ROWS(j, lane, m) {
+        ROWS(j, jv, lane, m) {
             const double sc = LD(L::rsc + j);
-            const bool on = sc != 0.0;
+            const bool on = sc != 0.0, cnt = jv && on;
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
             // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
             const int pk = si[L::riv + j];
             double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
-            if (NOBS && j < N * NR) {
-                const int k = j / NR, r = j - k * NR;
-                if (r >= 8 + NOBS) {
-                    const double* J = sm + L::Jc + (k * L::NO + (r - 8 - NOBS)) * NZ;
-                    jd = 0.0;
+            if (NOBS) {   // CBF rows: the full Jacobian row (every lane forms the dot product of a clamped row; selected below)
+                const int k0 = j / NR, r = j - k0 * NR;
+                const bool iscbf = j < N * NR && r >= 8 + NOBS;
+                const int k = iscbf ? k0 : 0, ob = iscbf ? r - 8 - NOBS : 0;
+                const double* J = sm + L::Jc + (k * L::NO + ob) * NZ;
+                double jc = 0.0;
 #pragma unroll
-                    for (int a = 0; a < NZ; a++) jd += J[a] * LD(L::dZ + k * NZ + a);
-                }
+                for (int a = 0; a < NZ; a++) jc += J[a] * LD(L::dZ + k * NZ + a);
+                jd = iscbf ? jc : jd;
             }
             const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j);
             const double rp = LD(L::rc + j) - t;
@@ -1055,9 +1055,9 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             const double dtr = dt * rti;                       // dt / t
             rp_max = fmax(rp_max, -dtr);
             rd_max = fmax(rd_max, on ? -dnu * frcp(nu) : 0.0);
-            theta += on ? fabs(rp) : 0.0;
-            Dphi -= on ? mu * dtr : 0.0;
-            lg0.mul(t);
+            theta += cnt ? fabs(rp) : 0.0;
+            Dphi -= cnt ? mu * dtr : 0.0;
+            lg0.mul(jv ? t : 1.0);
         }
         rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
         const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
@@ -1081,29 +1081,33 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
-            ROWS(j, lane, m) {
+            ROWS(j, jv, lane, m) {
                 const double sc = LD(L::rsc + j);
                 const double t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
                 double cn = cj + al * (dt - (cj - t));         // linear rows: exact
-                if (NOBS && j < N * NR) {
-                    const int k = j / NR, r = j - k * NR;
-                    if (r >= 8 + NOBS && sc != 0.0) cn = sc * cbf_value<NOBS, NMAX>(sm, c, k, r - 8 - NOBS, al);
+                if (NOBS) {   // CBF rows: evaluated (every lane evaluates a clamped row; selected below)
+                    const int k0 = j / NR, r = j - k0 * NR;
+                    const bool iscbf = j < N * NR && r >= 8 + NOBS && sc != 0.0;
+                    const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, iscbf ? k0 : 0, iscbf ? r - 8 - NOBS : 0, al);
+                    cn = iscbf ? cv : cn;
                 }
                 double tn = t + al * dt;
-                if (cn > tn) tn = cn;                          // slack reset
-                if (sc == 0.0) { tn = 1.0; cn = 1.0; }
+                tn = (cn > tn) ? cn : tn;                      // slack reset
+                const bool off = sc == 0.0;
+                tn = off ? 1.0 : tn;
+                cn = off ? 1.0 : cn;
                 LD(L::rtt + j) = tn;
-                lg.mul(tn);
-                thn += fabs(cn - tn);
+                lg.mul(jv ? tn : 1.0);
+                thn += jv ? fabs(cn - tn) : 0.0;
             }
             const double phin = fn - mu * lg.wave_total();
             thn = wave_sum(thn);
             int okf = (thn <= theta_max) && (phin == phin);
-            {
-                int bad = 0;
-                for (int i = lane; i < nf; i += WAVE)
-                    if (!(thn < LD(L::Fth + i) || phin < LD(L::Fph + i))) bad = 1;
-                if (__any(bad)) okf = 0;
+            {   // filter (nf <= MAXF < WAVE entries: one pass, lanes past nf read entry 0 and are masked)
+                const bool iv = lane < nf;
+                const int i = iv ? lane : 0;
+                const double fth = LD(L::Fth + i), fph = LD(L::Fph + i);
+                if (__any(iv && !(thn < fth || phin < fph))) okf = 0;
             }
             if (okf) {
                 if (sw_try && al * sw_lhs > sw_rhs) {
@@ -1131,16 +1135,19 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         if (!acc) break;
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
-        COORDS(e, lane, N * NZ + NX) LD(L::Z + e) += al * LD(L::dZ + e);
+        COORDS(e, ev, lane, N * NZ + NX) {
+            const double zn = LD(L::Z + e) + al * LD(L::dZ + e);
+            LD(SINK(ev, L::Z + e)) = zn;                // read-modify-write
+        }
         SYNC();
         f = fn;
         // one pass over the rows: multiplier update (from the pre-step row state), new slack, row value at the new
         // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
         double numax = 0.0, th = 0.0;
         nus = 0.0; cmax = 0.0; cmin = INFINITY;
-        ROWS(j, lane, m) {
+        ROWS(j, jv, lane, m) {
             const double sc = LD(L::rsc + j);
-            const bool on = sc != 0.0;
+            const bool on = sc != 0.0, cnt = jv && on;
             const double tn = LD(L::rtt + j);
             const double mut = mu * frcp(tn);
             const double rp = LD(L::rc + j) - LD(L::rt + j);   // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
@@ -1149,19 +1156,19 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
             const int pk = si[L::riv + j];
             double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
-            if (NOBS && j < N * NR) {
-                const int k = j / NR, r = j - k * NR;
-                if (r >= 8 + NOBS && on) v = sc * cbf_value<NOBS, NMAX>(sm, c, k, r - 8 - NOBS, 0.0);
+            if (NOBS) {
+                const int k0 = j / NR, r = j - k0 * NR;
+                const bool iscbf = j < N * NR && r >= 8 + NOBS && on;
+                const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, iscbf ? k0 : 0, iscbf ? r - 8 - NOBS : 0, 0.0);
+                v = iscbf ? cv : v;
             }
-            if (on) {
-                LD(L::rt + j) = tn;
-                LD(L::rnu + j) = nn;
-                numax = fmax(numax, nn);
-                th = fmax(th, fabs(v - tn));
-                nus += nn;
-                cmax = fmax(cmax, tn * nn);
-                cmin = fmin(cmin, tn * nn);
-            }
+            LD(SINK(cnt, L::rt + j)) = tn;
+            LD(SINK(cnt, L::rnu + j)) = nn;             // read-modify-write
+            numax = fmax(numax, cnt ? nn : 0.0);        // cnt, not on: a lane past the last row re-reads row 0 AFTER its update
+            th = fmax(th, cnt ? fabs(v - tn) : 0.0);
+            nus += cnt ? nn : 0.0;
+            cmax = fmax(cmax, cnt ? tn * nn : 0.0);
+            cmin = fmin(cmin, cnt ? tn * nn : INFINITY);
             LD(L::rc + j) = on ? v : 1.0;
         }
         SYNC();
