@@ -82,6 +82,8 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
     if (const bool ev = (lane_) + q_ * WAVE < (n_); true) if (const int e = ev ? (lane_) + q_ * WAVE : 0; true)
 
 #define SINK(cond, off) ((cond) ? (off) : L::dmy)
+// nothing moves across: placed after the loads of a phase so that they are issued back to back
+#define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
 
 #define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
 #define RIV_NEG (1 << 30)
@@ -544,6 +546,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
                 for (int j = 0; j < 6; j++) pl[q][j] = LD(tld[q] + j);
             const double p2 = NOBS ? LD(t2ld) : 0.0;
+            LOADS_DONE();
 #pragma unroll
             for (int q = 0; q < TCNT; q++) {
                 double t = 0.0;
@@ -559,32 +562,54 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // hv = M'p + hg, stored as column NZ of H.  NZ*NZ <= 64 (no obstacle): one lane per entry of the
         // full matrix, no mirroring needed.
         {
+            // every operand of the phase is loaded first (LOADS_DONE pins that order: left alone, the scheduler trickles
+            // the loads out between the FMAs and the two chains pay the LDS latency one after the other)
             const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
+            double tc[HCNT][NX], hd[HCNT], jr[HCNT][L::NO], ja[HCNT][L::NO], rs[L::NO], m5a[HCNT], m5r[HCNT];
+#pragma unroll
+            for (int q = 0; q < HCNT; q++) {
+#pragma unroll
+                for (int i = 0; i < NX; i++) tc[q][i] = LD(L::T + i * NZ + ha[q]);
+                hd[q] = LD(L::Hd + k * NZ + hr[q]);
+                if (NOBS) {
+#pragma unroll
+                    for (int o = 0; o < NOBS; o++) {
+                        jr[q][o] = LD(L::Jc + (k * L::NO + o) * NZ + hr[q]);
+                        ja[q][o] = LD(L::Jc + (k * L::NO + o) * NZ + ha[q]);
+                    }
+                } else {
+                    m5a[q] = LD(L::M + 5 * NZ + ha[q]);
+                    m5r[q] = LD(L::M + 5 * NZ + hr[q]);
+                }
+            }
+            if (NOBS) {
+#pragma unroll
+                for (int o = 0; o < NOBS; o++) rs[o] = LD(L::rsig + k * L::NR + 8 + NOBS + o);
+            }
+            double hvs = LD(L::hg + k * NZ + lz), mz[NX], pvv[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) { mz[i] = LD(L::M + i * NZ + lz); pvv[i] = LD(L::pv + i); }
+            LOADS_DONE();
             double hs[HCNT];
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
                 const int r = hr[q], a = ha[q];
                 double t = 0.0;
 #pragma unroll
-                for (int i = 0; i < NX; i++) t += mH[q][i] * LD(L::T + i * NZ + a);
-                const double dg = LD(L::Hd + k * NZ + r) + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
+                for (int i = 0; i < NX; i++) t += mH[q][i] * tc[q][i];
+                const double dg = hd[q] + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
                 t += (r == a) ? dg : 0.0;
                 if (NOBS) {
 #pragma unroll
-                    for (int o = 0; o < NOBS; o++) {
-                        const double* J = sm + L::Jc + (k * L::NO + o) * NZ;
-                        t += LD(L::rsig + k * L::NR + 8 + NOBS + o) * J[r] * J[a];
-                    }
+                    for (int o = 0; o < NOBS; o++) t += rs[o] * jr[q][o] * ja[q][o];
                 } else {
                     // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
-                    const double m5a = LD(L::M + 5 * NZ + a), m5r = LD(L::M + 5 * NZ + r);
-                    t -= kc * (((r == 5) ? m5a : 0.0) + ((a == 5) ? m5r : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
+                    t -= kc * (((r == 5) ? m5a[q] : 0.0) + ((a == 5) ? m5r[q] : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
                 }
                 hs[q] = t;
             }
-            double hvs = LD(L::hg + k * NZ + lz);
 #pragma unroll
-            for (int i = 0; i < NX; i++) hvs += LD(L::M + i * NZ + lz) * LD(L::pv + i);
+            for (int i = 0; i < NX; i++) hvs += mz[i] * pvv[i];
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
                 LD(hst[q]) = hs[q];
@@ -610,6 +635,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             double t = LD(s0A);
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
             const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
+            LOADS_DONE();
             const double exS = k >= 1 ? kSv : 0.0, exE = k >= 1 ? kEv + 2.0 * wcv : 0.0;
 #pragma unroll
             for (int j = 0; j < NU; j++) {
@@ -1076,7 +1102,10 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         int acc = 0, ftype = 0;
         // switching condition al * (-Dphi)^2.3 > theta^1.1 (only consulted when theta <= theta_min)
         const bool sw_try = (theta <= theta_min) && (Dphi < 0.0);
-        const double sw_lhs = sw_try ? pow(-Dphi, 2.3) : 0.0, sw_rhs = sw_try ? pow(theta, 1.1) : 0.0;
+        // ... compared in the log2 domain: log2(al) + 2.3 log2(-Dphi) > 1.1 log2(theta), with log2_fast (double exponent +
+        // v_log_f32 of the mantissa, ~1e-7 absolute).  Two pow() calls were ~2.6 k cycles of this iteration and kept ~50
+        // VGPRs of polynomial constants alive; the test is a heuristic threshold, a tie within 1e-7 may fall either way.
+        const double sw_gap = sw_try ? 2.3 * log2_fast(-Dphi) - 1.1 * log2_fast(theta) : 0.0;
         for (int ls = 0; ls < 40; ls++) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
@@ -1110,7 +1139,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                 if (__any(iv && !(thn < fth || phin < fph))) okf = 0;
             }
             if (okf) {
-                if (sw_try && al * sw_lhs > sw_rhs) {
+                if (sw_try && log2_fast(al) + sw_gap > 0.0) {
                     if (phin <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
                 } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {
                     acc = 1;

@@ -76,6 +76,14 @@ struct LogAcc {
     }
 };
 
+// log2(x), x >= 0, to ~1e-7 absolute over the whole double range: exponent from frexp, mantissa through the
+// single-precision hardware log (v_log_f32).  log2_fast(0) = -inf.
+__device__ __forceinline__ double log2_fast(double x) {
+    int e;
+    const double m = frexp(x, &e);
+    return (double)e + (double)__builtin_amdgcn_logf((float)m);
+}
+
 // 1/x to ~1 ulp: hardware estimate (v_rcp_f64) + two Newton steps; ~5 dependent ops instead of the
 // ~10 of an IEEE division.  x must be finite, normal and non-zero (true for pivots and slacks).
 __device__ __forceinline__ double frcp(double x) {
