@@ -367,16 +367,16 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     const int la = lane < L::NZ ? lane : 0;
     double tot = LD(L::ga + N * L::NZ + la);        // lam_N = the terminal gradient (lanes < NX)
     double gk = LD(L::ga + (N - 1) * L::NZ + la);
-    if (lane < L::NZ) LD(L::ga + N * L::NZ + lane) = 0.0;
+    LD(SINK(lane < L::NZ, L::ga + N * L::NZ + lane)) = 0.0;
     for (int k = N - 1; k >= 0; k--) {
         const double gn = LD(L::ga + (k >= 1 ? k - 1 : 0) * L::NZ + la);   // next stage's gradient, in flight during this one
         double t = gk;
 #pragma unroll
         for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
         tot = t;
-        if (lane >= L::NX && lane < L::NZ) emax = fmax(emax, fabs(tot));
+        emax = fmax(emax, (lane >= L::NX && lane < L::NZ) ? fabs(tot) : 0.0);
         const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
-        if (lane < L::NZ) LD(L::ga + k * L::NZ + lane) = keep ? tot : 0.0;
+        LD(SINK(lane < L::NZ, L::ga + k * L::NZ + lane)) = keep ? tot : 0.0;
         gk = gn;
     }
     SYNC();
@@ -761,13 +761,13 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
         for (int j = 0; j < NX; j++) xn += mrow[j] * xs[j];
 #pragma unroll
         for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
-        if (lane < NZ) LD(L::dZ + k * NZ + lane) = isu ? du : zx;
+        LD(SINK(lane < NZ, L::dZ + k * NZ + lane)) = isu ? du : zx;
         zx = xn;
 #pragma unroll
         for (int j = 0; j < NX; j++) kr[j] = krn[j];
         kfa = kfn;
     }
-    if (lane < NZ) LD(L::dZ + N * NZ + lane) = lane < NX ? zx : 0.0;
+    LD(SINK(lane < NZ, L::dZ + N * NZ + lane)) = lane < NX ? zx : 0.0;
     SYNC();
 }
 
