@@ -194,7 +194,7 @@ int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
     if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
     if (d->N < 3 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [3,%d]", d->N, CRX_MAX_N);
     if (d->n_obs_max < 0 || d->n_obs_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_obs_max=%d outside [0,%d]", d->n_obs_max, CRX_MAX_OBS);
-    if (d->degree < 2 || (d->degree & 1)) return fail(CRX_ERR_ARG, "degree must be even and >= 2");
+    if (d->degree < 2 || d->degree > 8 || (d->degree & 1)) return fail(CRX_ERR_ARG, "degree must be 2, 4, 6 or 8");
     if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
     if (!(d->alpha > 0.0 && d->alpha <= 1.0)) return fail(CRX_ERR_ARG, "alpha outside (0,1]");
     if (int rc = check_opts(d->opts)) return rc;

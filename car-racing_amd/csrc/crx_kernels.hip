@@ -34,24 +34,18 @@
 
 #define MAXF 12 /* filter entries (reset at every barrier update; when full, further entries are dropped) */
 
-// a^p for small p >= 0.  The exponent is wave-uniform (the CBF degree and degree-1, degree-2), so the
-// switch is a scalar branch; the generic loop costs ~40 cycles of branch overhead per factor.
+// a^p for p in 0..8, straight-line: p is wave-uniform (the CBF degree 2/4/6/8, degree-1, degree-2), so every select
+// below is a scalar-condition v_cndmask.  (A switch on p is a chain of scalar branches -- ~40 cycles and, worse, a
+// basic-block boundary per factor inside the row passes.)
 __device__ __forceinline__ double ipow_d(double a, int p) {
     const double a2 = a * a;
-    switch (p) {
-        case 0: return 1.0;
-        case 1: return a;
-        case 2: return a2;
-        case 3: return a2 * a;
-        case 4: return a2 * a2;
-        case 5: return a2 * a2 * a;
-        case 6: return a2 * a2 * a2;
-        default: {
-            double r = a2 * a2 * a2;
-            for (int i = 6; i < p; i++) r *= a;
-            return r;
-        }
-    }
+    const int h = p >> 1;
+    double r = (p & 1) ? a : 1.0;
+    r = h >= 1 ? r * a2 : r;
+    r = h >= 2 ? r * a2 : r;
+    r = h >= 3 ? r * a2 : r;
+    r = h >= 4 ? r * a2 : r;
+    return r;
 }
 
 // scipy interp1d(kind="linear") (searchsorted-left, index clipped to [1,n-1], slope form)

@@ -104,7 +104,7 @@ typedef struct crx_cbf_desc {
     int32_t N;             /* num_horizon (utils/base.py:281) / num_horizon_ctrl (:390) */
     int32_t n_obs_max;     /* leading dimension of the obstacle arrays, <= CRX_MAX_OBS */
     int32_t per_stage_target; /* 0: xt is [batch][6] (mpccbf); 1: xt is [batch][N+1][6] (mpc_multi_agents :373-382) */
-    int32_t degree;        /* 6, must be even, (control.py:528 / :312) */
+    int32_t degree;        /* 6 (control.py:528 / :312); accepted: 2, 4, 6, 8 */
     double A[36];
     double B[12];
     double Q[6];           /* diag(matrix_Q)  (utils/base.py:277 / :384) */
