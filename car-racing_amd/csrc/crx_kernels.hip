@@ -40,11 +40,11 @@
 __device__ __forceinline__ double ipow_d(double a, int p) {
     const double a2 = a * a;
     const int h = p >> 1;
-    double r = (p & 1) ? a : 1.0;
-    r = h >= 1 ? r * a2 : r;
-    r = h >= 2 ? r * a2 : r;
-    r = h >= 3 ? r * a2 : r;
-    r = h >= 4 ? r * a2 : r;
+    double r = sel(p & 1, a, 1.0);
+    r = sel(h >= 1, r * a2, r);
+    r = sel(h >= 2, r * a2, r);
+    r = sel(h >= 3, r * a2, r);
+    r = sel(h >= 4, r * a2, r);
     return r;
 }
 
@@ -75,7 +75,7 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 #define COORDS(e, ev, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (L::NV + WAVE - 1) / WAVE; q_++) \
     if (const bool ev = (lane_) + q_ * WAVE < (n_); true) if (const int e = ev ? (lane_) + q_ * WAVE : 0; true)
 
-#define SINK(cond, off) ((cond) ? (off) : L::dmy)
+#define SINK(cond, off) seli((cond), (off), L::dmy)
 // nothing moves across: placed after the loads of a phase so that they are issued back to back
 #define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
 
@@ -234,16 +234,16 @@ __device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c, doubl
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX;
         const bool cpl = a == 5 && k >= 1;                                   // (ey_k - ey_{k-1})^2, weight wc[k-1]
         const double dv = LD(L::dZ + e), z = LD(L::Z + e);
-        const double w = (isx || isu) ? LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
-        const double ref = isx ? LD(L::xr + k * 6 + (isx ? a : 0)) : 0.0;
-        const int ep = cpl ? e - L::NZ : e;
+        const double w = sel(isx || isu, LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))), 0.0);
+        const double ref = sel(isx, LD(L::xr + k * 6 + (isx ? a : 0)), 0.0);
+        const int ep = seli(cpl, e - L::NZ, e);
         const double de = z - LD(L::Z + ep), dd = dv - LD(L::dZ + ep);
-        const double wk = cpl ? LD(L::wc + (cpl ? k - 1 : 0)) : 0.0;
+        const double wk = sel(cpl, LD(L::wc + seli(cpl, k - 1, 0)), 0.0);
         double t = 2.0 * (w * (z - ref) * dv + wk * de * dd);
-        t += (k == N && a == 4) ? c.lin_sN * dv : 0.0;
-        if (NOBS) t += (iss0 && a - 6 < c.nobs) ? c.wsig * dv : 0.0;
-        acc += ev ? t : 0.0;
-        q += ev ? w * dv * dv + wk * dd * dd : 0.0;
+        t += sel(k == N && a == 4, c.lin_sN * dv, 0.0);
+        if (NOBS) t += sel(iss0 && a - 6 < c.nobs, c.wsig * dv, 0.0);
+        acc += sel(ev, t, 0.0);
+        q += sel(ev, w * dv * dv + wk * dd * dd, 0.0);
     }
     qq = wave_sum(q);
     return wave_sum(acc);
@@ -294,18 +294,18 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
             double m4[L::NZ], m5[L::NZ];
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) { m4[a] = LD(L::M + 4 * L::NZ + a); m5[a] = LD(L::M + 5 * L::NZ + a); }
-            G[0] = here ? gsn : 0.0; G[1] = here ? gen : 0.0; G[2] = here ? gsc : 0.0; G[3] = here ? gec : 0.0;
-            G[4] = here ? qq * p2sn * c.rLs * c.rLs : 0.0; G[5] = here ? qq * p2en * c.rWs * c.rWs : 0.0;
-            G[6] = here ? qq * p2sc * c.rLs * c.rLs : 0.0; G[7] = here ? qq * p2ec * c.rWs * c.rWs : 0.0;
+            G[0] = sel(here, gsn, 0.0); G[1] = sel(here, gen, 0.0); G[2] = sel(here, gsc, 0.0); G[3] = sel(here, gec, 0.0);
+            G[4] = sel(here, qq * p2sn * c.rLs * c.rLs, 0.0); G[5] = sel(here, qq * p2en * c.rWs * c.rWs, 0.0);
+            G[6] = sel(here, qq * p2sc * c.rLs * c.rLs, 0.0); G[7] = sel(here, qq * p2ec * c.rWs * c.rWs, 0.0);
             // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) {
                 double v = d * (gsn * m4[a] + gen * m5[a]);
                 if (a == 4) v -= d * c.om * gsc;
                 if (a == 5) v -= d * c.om * gec;
-                v += (a == 6 + o) ? d * c.om : 0.0;
-                v -= (a == L::NX + 2 + o) ? d : 0.0;
-                J[a] = here ? v : 0.0;
+                v += sel(a == 6 + o, d * c.om, 0.0);
+                v -= sel(a == L::NX + 2 + o, d, 0.0);
+                J[a] = sel(here, v, 0.0);
             }
         }
         SYNC();
@@ -317,24 +317,30 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
         const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
         const bool sig_on = (o < c.nobs) && ((iss0 && k == 0) || (iss1 && k < N));
-        const double w2 = (isx || isu) ? 2.0 * LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
-        const double ref = isx ? LD(L::xr + k * 6 + (isx ? a : 0)) : 0.0;
+        // every load is unconditional on a clamped index and selected afterwards: `cond ? LD(..) : 0` compiles to a
+        // branch around the load (LDS loads are not speculated), i.e. one more serialized LDS round trip each
+        const double cw = LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))), xrv = LD(L::xr + k * 6 + (isx ? a : 0));
+        const double w2 = sel(isx || isu, 2.0 * cw, 0.0);
+        const double ref = sel(isx, xrv, 0.0);
         double g = w2 * (LD(L::Z + e) - ref);
         g += (k == N && a == 4) ? c.lin_sN : 0.0;
         g += sig_on ? c.wsig : 0.0;
         const short* sh = (const short*)(si + L::SH_OFF);
         const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
         const double nl = LD(L::rnu + (rl >= 0 ? rl : 0)), nh = LD(L::rnu + (rh >= 0 ? rh : 0));
-        g -= (rl >= 0) ? nl : 0.0;
-        g += (rh >= 0) ? nh : 0.0;
+        g -= sel(rl >= 0, nl, 0.0);
+        g += sel(rh >= 0, nh, 0.0);
         const int kk = k < N ? k : N - 1;                      // stage terms exist for k < N only
         if (NOBS == 0) {
             const double de = LD(L::Z + (kk + 1) * L::NZ + 5) - LD(L::Z + kk * L::NZ + 5);
-            g += (k < N) ? 2.0 * LD(L::wc + kk) * de * (LD(L::M + 5 * L::NZ + a) - (a == 5 ? 1.0 : 0.0)) : 0.0;
+            const double wck = LD(L::wc + kk), m5 = LD(L::M + 5 * L::NZ + a);
+            g += sel(k < N, 2.0 * wck * de * (m5 - (a == 5 ? 1.0 : 0.0)), 0.0);
         } else {
 #pragma unroll
-            for (int ob = 0; ob < NOBS; ob++)
-                g -= (k < N) ? LD(L::rnu + kk * L::NR + 8 + NOBS + ob) * LD(L::Jc + (kk * L::NO + ob) * L::NZ + a) : 0.0;
+            for (int ob = 0; ob < NOBS; ob++) {
+                const double nuv = LD(L::rnu + kk * L::NR + 8 + NOBS + ob), jv2 = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a);
+                g -= sel(k < N, nuv * jv2, 0.0);
+            }
         }
         g = (k == N && a >= L::NX) ? 0.0 : g;
         LD(L::ga + e) = g;
@@ -368,9 +374,9 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
 #pragma unroll
         for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
         tot = t;
-        emax = fmax(emax, (lane >= L::NX && lane < L::NZ) ? fabs(tot) : 0.0);
+        emax = fmax(emax, sel(lane >= L::NX && lane < L::NZ, fabs(tot), 0.0));
         const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
-        LD(SINK(lane < L::NZ, L::ga + k * L::NZ + lane)) = keep ? tot : 0.0;
+        LD(SINK(lane < L::NZ, L::ga + k * L::NZ + lane)) = sel(keep, tot, 0.0);
         gk = gn;
     }
     SYNC();
@@ -394,8 +400,9 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         const double sig = nu * rti;
         const bool on = LD(L::rsc + j) != 0.0;
         LD(L::rtt + j) = rti;                       // 1/t for the row-step pass (rtt is free until the line search)
-        LD(L::rsig + j) = on ? sig : 0.0;
-        LD(L::rw + j) = on ? (nu - mu * rti + sig * (LD(L::rc + j) - t)) : 0.0;
+        LD(L::rsig + j) = sel(on, sig, 0.0);
+        const double cj = LD(L::rc + j);
+        LD(L::rw + j) = sel(on, nu - mu * rti + sig * (cj - t), 0.0);
     }
     SYNC();
     COORDS(e, ev, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
@@ -403,27 +410,30 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         const bool isx = a < 6, isu = a >= L::NX && a < L::NX + 2, iss0 = a >= 6 && a < L::NX, iss1 = a >= L::NX + 2;
         const int o = iss0 ? a - 6 : (iss1 ? a - L::NX - 2 : 0);
         double g = LD(L::ga + e);
-        double h = (isx || isu) ? 2.0 * LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0))) : 0.0;
+        const double cw = LD(L::cst + (isx ? a : (isu ? 6 + a - L::NX : 0)));
+        double h = sel(isx || isu, 2.0 * cw, 0.0);
         // absent obstacle: pin its sigma_0 (state copy at k = 0) and sigma_{k+1} (input copy)
         h += ((iss0 && k == 0 && o >= c.nobs) || (iss1 && o >= c.nobs)) ? 1.0 : 0.0;
         const short* sh = (const short*)(si + L::SH_OFF);
         const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
-        h += ((rl >= 0) ? LD(L::rsig + il) : 0.0) + ((rh >= 0) ? LD(L::rsig + ih) : 0.0);
-        g += ((rl >= 0) ? LD(L::rw + il) : 0.0) - ((rh >= 0) ? LD(L::rw + ih) : 0.0);
+        const double sgl = LD(L::rsig + il), sgh = LD(L::rsig + ih), wl = LD(L::rw + il), wh = LD(L::rw + ih);
+        h += sel(rl >= 0, sgl, 0.0) + sel(rh >= 0, sgh, 0.0);
+        g += sel(rl >= 0, wl, 0.0) - sel(rh >= 0, wh, 0.0);
         if (NOBS) {
             const int kk = k < N ? k : N - 1;
 #pragma unroll
             for (int ob = 0; ob < NOBS; ob++) {
                 const int j = kk * L::NR + 8 + NOBS + ob;
-                g += (k < N) ? LD(L::Jc + (kk * L::NO + ob) * L::NZ + a) * LD(L::rw + j) : 0.0;
+                const double jca = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a), rwj = LD(L::rw + j);
+                g += sel(k < N, jca * rwj, 0.0);
                 const double cur = LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (kk * L::NO + ob) * 8 + (a == 4 ? 6 : 7));
-                h += (k < N && (a == 4 || a == 5)) ? cur : 0.0;
+                h += sel(k < N && (a == 4 || a == 5), cur, 0.0);
             }
         }
         const bool tail = k == N && a >= L::NX;
-        LD(L::Hd + e) = tail ? 0.0 : h;
-        LD(SINK(ev, L::hg + e)) = tail ? 0.0 : g;      // in place over ga: read-modify-write
+        LD(L::Hd + e) = sel(tail, 0.0, h);
+        LD(SINK(ev, L::hg + e)) = sel(tail, 0.0, g);   // in place over ga: read-modify-write
     }
     if (NOBS) {
         const int k = c.lane < N ? c.lane : 0;          // N <= 24 < WAVE: one pass; lanes past N recompute stage 0
@@ -450,17 +460,19 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
     const int N = c.N, lane = c.lane;
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
-    for (int e = lane; e < NX * NX; e += WAVE) {
-        const int i = e / NX, j = e - i * NX;
-        double v = 0.0;
-        if (i == j) {
-            v = LD(L::Hd + N * NZ + i);
-            if (i == 4) v += NOBS ? LD(L::kS + N - 1) : 0.0;
-            if (i == 5) v += (NOBS ? LD(L::kE + N - 1) : 0.0) + 2.0 * LD(L::wc + N - 1);
+    {
+        const double kSn = NOBS ? LD(L::kS + N - 1) : 0.0, kEn = (NOBS ? LD(L::kE + N - 1) : 0.0) + 2.0 * LD(L::wc + N - 1);
+#pragma unroll
+        for (int q_ = 0; q_ < (NX * NX + WAVE - 1) / WAVE; q_++) {
+            const int e0 = lane + q_ * WAVE;
+            const int e = e0 < NX * NX ? e0 : 0;            // lanes past the matrix recompute entry 0
+            const int i = e / NX, j = e - i * NX;
+            const double hd = LD(L::Hd + N * NZ + i);
+            LD(L::P + e) = sel(i == j, hd + sel(i == 4, kSn, sel(i == 5, kEn, 0.0)), 0.0);
         }
-        LD(L::P + e) = v;
+        const double hgN = LD(L::hg + N * NZ + (lane < NX ? lane : 0));
+        LD(SINK(lane < NX, L::pv + lane)) = hgN;
     }
-    if (lane < NX) LD(L::pv + lane) = LD(L::hg + N * NZ + lane);
     SYNC();
     bool ok = true;
     // The sweep is straight-line code: every lane-dependent decision (which entry a lane owns, where it goes) is
@@ -477,11 +489,11 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const int e = e0 < NTRI ? e0 : 0;
         if (FULL) { hr[q] = e / NZ; ha[q] = e - hr[q] * NZ; }
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
-        hst[q] = e0 < NTRI ? L::H + hr[q] * HS + ha[q] : L::dmy;
-        hst2[q] = (!FULL && e0 < NTRI) ? L::H + ha[q] * HS + hr[q] : L::dmy;
+        hst[q] = SINK(e0 < NTRI, L::H + hr[q] * HS + ha[q]);
+        hst2[q] = SINK(!FULL && e0 < NTRI, L::H + ha[q] * HS + hr[q]);
     }
     const int lz = lane < NZ ? lane : 0;
-    const int hvst = lane < NZ ? L::H + lane * HS + NZ : L::dmy;
+    const int hvst = SINK(lane < NZ, L::H + lane * HS + NZ);
     // the entries of the model matrix each lane multiplies with in the T and H phases, in registers
     constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
     double mT[TCNT][6], mH[HCNT][NX];
@@ -493,7 +505,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const int a = cc < 6 ? cc : NX + (cc - 6);
         const int i = (e >> 3) < NX ? (e >> 3) : 0;
         tld[q] = L::P + i * NX;
-        tst[q] = e < NX * 8 ? L::T + i * NZ + a : L::dmy;
+        tst[q] = SINK(e < NX * 8, L::T + i * NZ + a);
 #pragma unroll
         for (int j = 0; j < 6; j++) mT[q][j] = LD(L::M + j * NZ + a);
     }
@@ -512,7 +524,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         t2nxt = cc >= NOBS;
         const int o = t2nxt ? cc - NOBS : cc;
         t2ld = L::P + i2 * NX + 6 + o;
-        t2st = v2 ? L::T + i2 * NZ + (t2nxt ? NX + 2 + o : 6 + o) : L::dmy;
+        t2st = SINK(v2, L::T + i2 * NZ + seli(t2nxt, NX + 2 + o, 6 + o));
     }
     // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
     // [NP, NP+NX+1) one feedback column each (<= 64 lanes for NX <= 9)
@@ -523,10 +535,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     const bool gcol = uj >= NX;                   // gradient column = column NZ of H
     const int ujj = gcol ? NZ : uj;
     const int yiA = L::H + NX * HS + ui, yjA = L::H + NX * HS + ujj, s0A = L::H + ui * HS + ujj;
-    const int pst1 = isP ? (gcol ? L::pv + ui : L::P + ui * NX + uj) : L::dmy;
-    const int pst2 = isP ? (gcol ? L::pv + ui : L::P + uj * NX + ui) : L::dmy;
-    const int kstr = isK ? (gcol ? 1 : NX) : 0, kstep = isK ? (gcol ? NU : NU * NX) : 0;
-    int kst = isK ? (gcol ? L::kf : L::Kk + uj) + (N - 1) * kstep : L::dmy;
+    const int pst1 = SINK(isP, seli(gcol, L::pv + ui, L::P + ui * NX + uj));
+    const int pst2 = SINK(isP, seli(gcol, L::pv + ui, L::P + uj * NX + ui));
+    const int kstr = seli(isK, seli(gcol, 1, NX), 0), kstep = seli(isK, seli(gcol, NU, NU * NX), 0);
+    int kst = SINK(isK, seli(gcol, L::kf, L::Kk + uj) + (N - 1) * kstep);
     const bool exSl = isP && !gcol && ui == uj && ui == 4, exEl = isP && !gcol && ui == uj && ui == 5;
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
@@ -548,7 +560,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 for (int j = 0; j < 6; j++) t += pl[q][j] * mT[q][j];
                 LD(tst[q]) = t;
             }
-            if (NOBS) LD(t2st) = t2nxt ? p2 : 0.0;
+            if (NOBS) LD(t2st) = sel(t2nxt, p2, 0.0);
         }
         SYNC();
         long long q1 = CLK();
@@ -591,14 +603,14 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 double t = 0.0;
 #pragma unroll
                 for (int i = 0; i < NX; i++) t += mH[q][i] * tc[q][i];
-                const double dg = hd[q] + ((r >= NX || (k == 0 && r >= 6)) ? dw : 0.0);
-                t += (r == a) ? dg : 0.0;
+                const double dg = hd[q] + sel(r >= NX || (k == 0 && r >= 6), dw, 0.0);
+                t += sel(r == a, dg, 0.0);
                 if (NOBS) {
 #pragma unroll
                     for (int o = 0; o < NOBS; o++) t += rs[o] * jr[q][o] * ja[q][o];
                 } else {
                     // kC (m_e - e_ey)(m_e - e_ey)' with the m_e m_e' part already inside P[5][5]
-                    t -= kc * (((r == 5) ? m5a[q] : 0.0) + ((a == 5) ? m5r[q] : 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
+                    t -= kc * (sel(r == 5, m5a[q], 0.0) + sel(a == 5, m5r[q], 0.0) - ((r == 5 && a == 5) ? 1.0 : 0.0));
                 }
                 hs[q] = t;
             }
@@ -630,7 +642,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
             const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
             LOADS_DONE();
-            const double exS = k >= 1 ? kSv : 0.0, exE = k >= 1 ? kEv + 2.0 * wcv : 0.0;
+            const double exS = sel(k >= 1, kSv, 0.0), exE = sel(k >= 1, kEv + 2.0 * wcv, 0.0);
 #pragma unroll
             for (int j = 0; j < NU; j++) {
                 double d = Lf[j][j];
@@ -654,7 +666,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
 #pragma unroll
             for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; t -= yi[a] * yj[a]; }
-            t += exSl ? exS : (exEl ? exE : 0.0);
+            t += sel(exSl, exS, sel(exEl, exE, 0.0));
             LD(pst1) = t;
             LD(pst2) = t;
 #pragma unroll
@@ -755,13 +767,13 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
         for (int j = 0; j < NX; j++) xn += mrow[j] * xs[j];
 #pragma unroll
         for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
-        LD(SINK(lane < NZ, L::dZ + k * NZ + lane)) = isu ? du : zx;
+        LD(SINK(lane < NZ, L::dZ + k * NZ + lane)) = sel(isu, du, zx);
         zx = xn;
 #pragma unroll
         for (int j = 0; j < NX; j++) kr[j] = krn[j];
         kfa = kfn;
     }
-    LD(SINK(lane < NZ, L::dZ + N * NZ + lane)) = lane < NX ? zx : 0.0;
+    LD(SINK(lane < NZ, L::dZ + N * NZ + lane)) = sel(lane < NX, zx, 0.0);
     SYNC();
 }
 
@@ -1059,25 +1071,26 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (NOBS) {   // CBF rows: the full Jacobian row (every lane forms the dot product of a clamped row; selected below)
                 const int k0 = j / NR, r = j - k0 * NR;
                 const bool iscbf = j < N * NR && r >= 8 + NOBS;
-                const int k = iscbf ? k0 : 0, ob = iscbf ? r - 8 - NOBS : 0;
+                const int k = seli(iscbf, k0, 0), ob = seli(iscbf, r - 8 - NOBS, 0);
                 const double* J = sm + L::Jc + (k * L::NO + ob) * NZ;
                 double jc = 0.0;
 #pragma unroll
                 for (int a = 0; a < NZ; a++) jc += J[a] * LD(L::dZ + k * NZ + a);
-                jd = iscbf ? jc : jd;
+                jd = sel(iscbf, jc, jd);
             }
             const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j);
             const double rp = LD(L::rc + j) - t;
-            const double dt = on ? jd + rp : 0.0;
+            const double dt = sel(on, jd + rp, 0.0);
             // dnu = (mu - t nu - nu dt)/t = mu/t - nu - Sigma dt = -w + Sigma (rp - dt)
-            const double dnu = on ? (-LD(L::rw + j) + LD(L::rsig + j) * (rp - dt)) : 0.0;
+            const double rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
+            const double dnu = sel(on, -rwj + rsj * (rp - dt), 0.0);
             LD(L::rdt + j) = dt;
             const double dtr = dt * rti;                       // dt / t
             rp_max = fmax(rp_max, -dtr);
-            rd_max = fmax(rd_max, on ? -dnu * frcp(nu) : 0.0);
-            theta += cnt ? fabs(rp) : 0.0;
-            Dphi -= cnt ? mu * dtr : 0.0;
-            lg0.mul(jv ? t : 1.0);
+            rd_max = fmax(rd_max, sel(on, -dnu * frcp(nu), 0.0));
+            theta += sel(cnt, fabs(rp), 0.0);
+            Dphi -= sel(cnt, mu * dtr, 0.0);
+            lg0.mul(sel(jv, t, 1.0));
         }
         rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
         const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
@@ -1111,17 +1124,17 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
                 if (NOBS) {   // CBF rows: evaluated (every lane evaluates a clamped row; selected below)
                     const int k0 = j / NR, r = j - k0 * NR;
                     const bool iscbf = j < N * NR && r >= 8 + NOBS && sc != 0.0;
-                    const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, iscbf ? k0 : 0, iscbf ? r - 8 - NOBS : 0, al);
-                    cn = iscbf ? cv : cn;
+                    const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, seli(iscbf, k0, 0), seli(iscbf, r - 8 - NOBS, 0), al);
+                    cn = sel(iscbf, cv, cn);
                 }
                 double tn = t + al * dt;
-                tn = (cn > tn) ? cn : tn;                      // slack reset
+                tn = sel(cn > tn, cn, tn);                     // slack reset
                 const bool off = sc == 0.0;
-                tn = off ? 1.0 : tn;
-                cn = off ? 1.0 : cn;
+                tn = sel(off, 1.0, tn);
+                cn = sel(off, 1.0, cn);
                 LD(L::rtt + j) = tn;
-                lg.mul(jv ? tn : 1.0);
-                thn += jv ? fabs(cn - tn) : 0.0;
+                lg.mul(sel(jv, tn, 1.0));
+                thn += sel(jv, fabs(cn - tn), 0.0);
             }
             const double phin = fn - mu * lg.wave_total();
             thn = wave_sum(thn);
@@ -1182,17 +1195,17 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (NOBS) {
                 const int k0 = j / NR, r = j - k0 * NR;
                 const bool iscbf = j < N * NR && r >= 8 + NOBS && on;
-                const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, iscbf ? k0 : 0, iscbf ? r - 8 - NOBS : 0, 0.0);
-                v = iscbf ? cv : v;
+                const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, seli(iscbf, k0, 0), seli(iscbf, r - 8 - NOBS, 0), 0.0);
+                v = sel(iscbf, cv, v);
             }
             LD(SINK(cnt, L::rt + j)) = tn;
             LD(SINK(cnt, L::rnu + j)) = nn;             // read-modify-write
-            numax = fmax(numax, cnt ? nn : 0.0);        // cnt, not on: a lane past the last row re-reads row 0 AFTER its update
-            th = fmax(th, cnt ? fabs(v - tn) : 0.0);
-            nus += cnt ? nn : 0.0;
-            cmax = fmax(cmax, cnt ? tn * nn : 0.0);
-            cmin = fmin(cmin, cnt ? tn * nn : INFINITY);
-            LD(L::rc + j) = on ? v : 1.0;
+            numax = fmax(numax, sel(cnt, nn, 0.0));     // cnt, not on: a lane past the last row re-reads row 0 AFTER its update
+            th = fmax(th, sel(cnt, fabs(v - tn), 0.0));
+            nus += sel(cnt, nn, 0.0);
+            cmax = fmax(cmax, sel(cnt, tn * nn, 0.0));
+            cmin = fmin(cmin, sel(cnt, tn * nn, INFINITY));
+            LD(L::rc + j) = sel(on, v, 1.0);
         }
         SYNC();
         numax = wave_max(numax); th = wave_max(th);

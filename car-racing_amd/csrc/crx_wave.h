@@ -76,6 +76,12 @@ struct LogAcc {
     }
 };
 
+// select with BOTH operands evaluated first (function arguments).  `c ? expr : 0.0` with arithmetic or a load in an arm
+// is emitted as control flow, and the optimiser then sinks the arm's loads into it: a predicated region (exec-mask
+// traffic) plus one more serialized LDS round trip.  sel()/seli() keep it a v_cndmask.
+__device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ int seli(bool c, int a, int b) { return c ? a : b; }
+
 // log2(x), x >= 0, to ~1e-7 absolute over the whole double range: exponent from frexp, mantissa through the
 // single-precision hardware log (v_log_f32).  log2_fast(0) = -inf.
 __device__ __forceinline__ double log2_fast(double x) {
