@@ -542,6 +542,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     const bool exSl = isP && !gcol && ui == uj && ui == 4, exEl = isP && !gcol && ui == uj && ui == 5;
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
+        // (Forming H = M'PM in ONE phase straight from P -- NX^2 FMAs per entry, no T -- was tried twice, before and after
+        // the sweep became straight-line code: 16 % / 6 % SLOWER on cfg2 / cfg3; 49 broadcast loads and FMAs per lane cost
+        // more than the LDS round trip they save, and the registers cost a resident wave.)
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
         // dot products of length 6); the sigma_k columns of T are zero and the sigma_{k+1} columns
         // are copies of P's sigma columns (M = [A 0 B 0; 0 0 0 I]).
