@@ -52,7 +52,8 @@ struct LL {
     static constexpr int t = ig + MS, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
     static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
     static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
-    static constexpr int G = Fph + LMAXF;                      // (n_ss_max + 2) x ldg, sized at launch (last region)
+    static constexpr int dmy = Fph + LMAXF;                    // sink of address-predicated stores
+    static constexpr int G = dmy + 2;                          // (n_ss_max + 2) x ldg, sized at launch (last region)
     static constexpr int ldg(int n_ss_max) { return (n_ss_max + 1) | 1; }   // odd stride: conflict-free row-per-lane access
     static constexpr size_t bytes(int n_ss_max) { return (size_t)(G + (n_ss_max + 4) * ldg(n_ss_max)) * 8; }   // +2 rows: the blocked Cholesky reads (not uses) up to row n+2
 };
@@ -63,8 +64,11 @@ struct LCtx {
 };
 
 #define LDS(i) sm[(i)]
+#define LSINK(cond, off) seli((cond), (off), L::dmy)
 
 // rows c_j(v) for the current iterate; rp = c - t
+// (l_rows / l_lagr keep their per-kind branches: a straight-line rewrite measured +0.8 % only, and any change of the
+// rounding in this kernel re-rolls the racing-game closed loop, DESIGN.md section 5.3 "sensitivity")
 template <int NMAX>
 __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc_kparams& kp) {
     using L = LL<NMAX>;
@@ -381,23 +385,38 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             TICK();   // 4
             // ---- K_u (lower triangle) + extra rows Phi (6) and rhs_u ----
-            for (int en = lane; en < nv * (nv + 1) / 2; en += WAVE) {
-                int a = (int)((sqrt(8.0 * en + 1.0) - 1.0) * 0.5);
-                if (a * (a + 1) / 2 > en) a--;
-                if ((a + 1) * (a + 2) / 2 <= en) a++;
+            // straight-line passes: lanes past the last entry recompute entry 0 (same value); the stage loop runs over all
+            // stages for every entry -- S[k][.][a] is zero for k <= a/2, so the bound was only a (divergent) shortcut
+            for (int e0 = 0; e0 < nv * (nv + 1) / 2; e0 += WAVE) {
+                const int en = e0 + lane < nv * (nv + 1) / 2 ? e0 + lane : 0;
+                int a = (int)((__builtin_amdgcn_sqrtf(8.0f * (float)en + 1.0f) - 1.0f) * 0.5f);
+                a = a * (a + 1) / 2 > en ? a - 1 : a;
+                a = (a + 1) * (a + 2) / 2 <= en ? a + 1 : a;
                 const int b = en - a * (a + 1) / 2;
-                double s = LDS(L::Hu + a * L::NU2 + b);
-                if (a == b && a < nu2) s += LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1)) + LDS(L::dnu + 4 * (a >> 1) + 2 * (a & 1) + 1);
-#pragma unroll 4
-                for (int k = a < nu2 ? (a >> 1) + 1 : 1; k < N; k++) {
-                    s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a) * LDS(L::w0 + k), LDS(L::S + (k * 6 + 0) * L::NU2 + b), s);
-                    s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a) * LDS(L::w5 + k), LDS(L::S + (k * 6 + 5) * L::NU2 + b), s);
+                const int ad = a < nu2 ? a : 0;
+                const double h0 = LDS(L::Hu + a * L::NU2 + b), d0 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1)), d1 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1) + 1);
+                double s = h0 + sel(a == b && a < nu2, d0 + d1, 0.0);
+                for (int k = 1; k < N; k += 2) {
+                    const int k2 = k + 1 < N ? k + 1 : k;
+                    const double sa0 = LDS(L::S + (k * 6 + 0) * L::NU2 + a), sb0 = LDS(L::S + (k * 6 + 0) * L::NU2 + b);
+                    const double sa5 = LDS(L::S + (k * 6 + 5) * L::NU2 + a), sb5 = LDS(L::S + (k * 6 + 5) * L::NU2 + b);
+                    const double ta0 = LDS(L::S + (k2 * 6 + 0) * L::NU2 + a), tb0 = LDS(L::S + (k2 * 6 + 0) * L::NU2 + b);
+                    const double ta5 = LDS(L::S + (k2 * 6 + 5) * L::NU2 + a), tb5 = LDS(L::S + (k2 * 6 + 5) * L::NU2 + b);
+                    const double w0k = LDS(L::w0 + k), w5k = LDS(L::w5 + k);
+                    const double w0n = sel(k + 1 < N, LDS(L::w0 + k2), 0.0), w5n = sel(k + 1 < N, LDS(L::w5 + k2), 0.0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    s = fma(sa0 * w0k, sb0, s);
+                    s = fma(sa5 * w5k, sb5, s);
+                    s = fma(ta0 * w0n, tb0, s);
+                    s = fma(ta5 * w5n, tb5, s);
                 }
                 LDS(L::K + a * L::LDK + b) = s;
             }
-            for (int en = lane; en < 7 * nv; en += WAVE) {
+            for (int e0 = 0; e0 < 7 * nv; e0 += WAVE) {
+                const int en = e0 + lane < 7 * nv ? e0 + lane : 0;
                 const int r = en / nv, j = en - r * nv;
-                LDS(L::K + (nv + r) * L::LDK + j) = r < 6 ? LDS(L::S + (N * 6 + r) * L::NU2 + j) : -LDS(L::ru + j);
+                const double sv = LDS(L::S + (N * 6 + (r < 6 ? r : 0)) * L::NU2 + j), rv = LDS(L::ru + j);
+                LDS(L::K + (nv + r) * L::LDK + j) = sel(r < 6, sv, -rv);
             }
             SYNC();
             TICK();   // 5
@@ -465,24 +484,28 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             TICK();   // 7
             // ---- G = D_lambda + T T' (lower triangle, lane i = row i) with extra rows cl and 1 ----
-            if (lane < M) {
-                const int go = L::G + lane * ldg;
-                const double dl = LDS(L::dnu + x.r_lam + lane);
-                for (int j0 = 0; j0 <= lane; j0 += 4) {   // rows past `lane` are fetched (neighbouring LDS words) but never stored
-                    double sv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], LDS(L::T + 6 * (j0 + q) + c6), s);
-                        sv[q] = j0 + q == lane ? s + dl : s;
-                    }
+            {   // every lane runs the full row loop (rows past its own are computed and dropped): no lane-dependent trip count
+                const bool lv = lane < M;
+                const int lc = lv ? lane : 0;
+                const int go = L::G + lc * ldg;
+                const double dl = LDS(L::dnu + x.r_lam + lc), clv = LDS(L::cl + lc);
+                for (int j0 = 0; j0 < M; j0 += 4) {
+                    double tt[4][6];
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        if (j0 + q <= lane) LDS(go + j0 + q) = sv[q];
+#pragma unroll
+                        for (int c6 = 0; c6 < 6; c6++) tt[q][c6] = LDS(L::T + 6 * (j0 + q) + c6);   // rows past M: neighbouring LDS words, never stored
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        double sq = 0.0;
+#pragma unroll
+                        for (int c6 = 0; c6 < 6; c6++) sq = fma(Tj[c6], tt[q][c6], sq);
+                        LDS(LSINK(lv && j0 + q <= lane, go + j0 + q)) = sel(j0 + q == lane, sq + dl, sq);
+                    }
                 }
-                LDS(L::G + M * ldg + lane) = LDS(L::cl + lane);
-                LDS(L::G + (M + 1) * ldg + lane) = 1.0;
+                LDS(LSINK(lv, L::G + M * ldg + lane)) = clv;
+                LDS(LSINK(lv, L::G + (M + 1) * ldg + lane)) = 1.0;
             }
             SYNC();
             TICK();   // 8

@@ -119,36 +119,48 @@ __device__ __forceinline__ double frsqrt(double x) {
 __device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int n, int extra, int lane) {
     const int rows = n + extra;
     const int ri = base + lane * LD;
+    int ok = 1;
     for (int j0 = 0; j0 < n; j0 += 4) {
         const bool mine = lane >= j0 && lane < rows;
+        // lanes without a row in this panel run the same instructions on row j0 (valid data) and store nothing:
+        // no predicated region around the panel loop
+        const int rr = mine ? ri : base + j0 * LD;
         double s[4], l[4];
         const int r0 = base + j0 * LD;
 #pragma unroll
-        for (int c = 0; c < 4; c++) s[c] = (mine && j0 + c < n) ? sm[ri + j0 + c] : 0.0;
-        if (mine) {
-#pragma unroll 2
-            for (int k = 0; k < j0; k++) {
-                const double a = sm[ri + k];
+        for (int c = 0; c < 4; c++) s[c] = sm[rr + j0 + c];
+        // panel product against the finished columns, four at a time (j0 is a multiple of 4): 20 LDS operands are
+        // loaded back to back, then 16 FMAs on four independent accumulators
+        for (int k = 0; k < j0; k += 4) {
+            double a[4], b[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) s[c] = fma(-a, sm[r0 + c * LD + k], s[c]);   // rows j0+c <= n+2: inside the array
-            }
+            for (int kk = 0; kk < 4; kk++) a[kk] = sm[rr + k + kk];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) b[c][kk] = sm[r0 + c * LD + k + kk];   // rows j0+c <= n+2: inside the array
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) s[c] = fma(-a[kk], b[c][kk], s[c]);
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int j = j0 + c;
-            if (j < n) {
+            const bool col = j < n;               // wave-uniform
+            const int jc = col ? j : n - 1;
 #pragma unroll
-                for (int cc = 0; cc < c; cc++) s[c] = fma(-l[cc], lane_f64(l[cc], j), s[c]);
-                const double d = lane_f64(s[c], j);
-                if (!(d > 0.0)) return 0;
-                const double rinv = frsqrt(d);
-                l[c] = lane == j ? d * rinv : s[c] * rinv;
-                if (lane >= j && lane < rows) sm[ri + j] = l[c];
-                if (lane == 0) sm[inv + j] = rinv;
-            } else {
-                l[c] = 0.0;
-            }
+            for (int cc = 0; cc < c; cc++) s[c] = fma(-l[cc], lane_f64(l[cc], jc), s[c]);
+            const double d = lane_f64(s[c], jc);
+            if (col && !(d > 0.0)) ok = 0;
+            const double rinv = frsqrt(d);
+            l[c] = sel(col, sel(lane == j, d, s[c]) * rinv, 0.0);
+            const int sink = base + LD - 1;       // last column of row 0: upper triangle, never read
+            sm[seli(col && mine && lane >= j, ri + j, sink)] = l[c];
+            sm[seli(lane == 0 && col, inv + j, sink)] = rinv;
         }
+        if (!ok) return 0;
         SYNC();
     }
     return 1;
@@ -164,25 +176,23 @@ __device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, in
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             rinv[q] = sm[inv + j - q];
-            lj[q] = lane < j - q ? sm[base + (j - q) * LD + lane] : 0.0;
+            lj[q] = sel(lane < j - q, sm[base + (j - q) * LD + seli(lane < j - q, lane, 0)], 0.0);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const double xj = lane_f64(b[r], j - q) * rinv[q];
-                if (lane == j - q) b[r] = xj;
-                b[r] = fma(-lj[q], xj, b[r]);
+                b[r] = sel(lane == j - q, xj, fma(-lj[q], xj, b[r]));      // lj = 0 on the pivot lane
             }
     }
     for (; j >= 0; j--) {
         const double rinv = sm[inv + j];
-        const double lj = lane < j ? sm[base + j * LD + lane] : 0.0;
+        const double lj = sel(lane < j, sm[base + j * LD + seli(lane < j, lane, 0)], 0.0);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const double xj = lane_f64(b[r], j) * rinv;
-            if (lane == j) b[r] = xj;
-            b[r] = fma(-lj, xj, b[r]);
+            b[r] = sel(lane == j, xj, fma(-lj, xj, b[r]));
         }
     }
 }
