@@ -76,6 +76,13 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
     if (const bool ev = (lane_) + q_ * WAVE < (n_); true) if (const int e = ev ? (lane_) + q_ * WAVE : 0; true)
 
 #define SINK(cond, off) seli((cond), (off), L::dmy)
+// The CBF rows (k, ob) of a problem, one lane each (N * NOBS <= 72): j is the row index, ev false on lanes past the last
+// row, which recompute row (0, 0).  The row passes skip these rows (ROW_IS_CBF) -- evaluating them there meant every
+// lane of EVERY pass ran the degree-6 evaluation for the sake of a dozen rows.
+#define CBF_ROWS(j, k, ob, ev, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (NMAX * NOBS + WAVE - 1) / WAVE; q_++) \
+    if (const bool ev = (lane_) + q_ * WAVE < (n_) * NOBS; true) if (const int e_ = ev ? (lane_) + q_ * WAVE : 0; true) \
+    if (const int k = e_ / L::NO; true) if (const int ob = e_ - k * L::NO; true) if (const int j = k * NR + 8 + NOBS + ob; true)
+#define ROW_IS_CBF(j, n_) (NOBS > 0 && (j) < (n_) * NR && (j) % NR >= 8 + NOBS)
 // nothing moves across: placed after the loads of a phase so that they are issued back to back
 #define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
 
@@ -1066,36 +1073,39 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
         double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
         LogAcc lg0;
-        ROWS(j, jv, lane, m) {
-            const double sc = LD(L::rsc + j);
-            const bool on = sc != 0.0, cnt = jv && on;
-            // J dz straight from the step (differencing row values would lose eps*|x|, which the
-            // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
-            const int pk = si[L::riv + j];
-            double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
-            if (NOBS) {   // CBF rows: the full Jacobian row (every lane forms the dot product of a clamped row; selected below)
-                const int k0 = j / NR, r = j - k0 * NR;
-                const bool iscbf = j < N * NR && r >= 8 + NOBS;
-                const int k = seli(iscbf, k0, 0), ob = seli(iscbf, r - 8 - NOBS, 0);
-                const double* J = sm + L::Jc + (k * L::NO + ob) * NZ;
-                double jc = 0.0;
-#pragma unroll
-                for (int a = 0; a < NZ; a++) jc += J[a] * LD(L::dZ + k * NZ + a);
-                jd = sel(iscbf, jc, jd);
-            }
+        // (jd = J dz of the row; shared tail of the simple-row passes and of the CBF pass)
+        auto row_step = [&](int j, bool cnt, bool store, double sc, double jd) {
+            const bool on = sc != 0.0;
             const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j);
             const double rp = LD(L::rc + j) - t;
             const double dt = sel(on, jd + rp, 0.0);
             // dnu = (mu - t nu - nu dt)/t = mu/t - nu - Sigma dt = -w + Sigma (rp - dt)
             const double rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
             const double dnu = sel(on, -rwj + rsj * (rp - dt), 0.0);
-            LD(L::rdt + j) = dt;
+            LD(SINK(store, L::rdt + j)) = dt;
             const double dtr = dt * rti;                       // dt / t
-            rp_max = fmax(rp_max, -dtr);
-            rd_max = fmax(rd_max, sel(on, -dnu * frcp(nu), 0.0));
-            theta += sel(cnt, fabs(rp), 0.0);
-            Dphi -= sel(cnt, mu * dtr, 0.0);
-            lg0.mul(sel(jv, t, 1.0));
+            rp_max = fmax(rp_max, sel(cnt, -dtr, 0.0));
+            rd_max = fmax(rd_max, sel(cnt && on, -dnu * frcp(nu), 0.0));
+            theta += sel(cnt && on, fabs(rp), 0.0);
+            Dphi -= sel(cnt && on, mu * dtr, 0.0);
+            lg0.mul(sel(cnt, t, 1.0));
+        };
+        ROWS(j, jv, lane, m) {
+            // J dz straight from the step (differencing row values would lose eps*|x|, which the
+            // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
+            const bool simple = !ROW_IS_CBF(j, N);
+            const int pk = si[L::riv + j];
+            const double sc = LD(L::rsc + j), jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
+            row_step(j, jv && simple, simple, sc, jd);
+        }
+        if (NOBS) {
+            CBF_ROWS(j, k, ob, ev, lane, N) {   // the full Jacobian row
+                const double* J = sm + L::Jc + (k * L::NO + ob) * NZ;
+                double jc = 0.0;
+#pragma unroll
+                for (int a = 0; a < NZ; a++) jc += J[a] * LD(L::dZ + k * NZ + a);
+                row_step(j, ev, true, LD(L::rsc + j), jc);
+            }
         }
         rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
         const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
@@ -1122,24 +1132,26 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
-            ROWS(j, jv, lane, m) {
-                const double sc = LD(L::rsc + j);
-                const double t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
-                double cn = cj + al * (dt - (cj - t));         // linear rows: exact
-                if (NOBS) {   // CBF rows: evaluated (every lane evaluates a clamped row; selected below)
-                    const int k0 = j / NR, r = j - k0 * NR;
-                    const bool iscbf = j < N * NR && r >= 8 + NOBS && sc != 0.0;
-                    const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, seli(iscbf, k0, 0), seli(iscbf, r - 8 - NOBS, 0), al);
-                    cn = sel(iscbf, cv, cn);
-                }
+            auto row_trial = [&](int j, bool cnt, bool store, double sc, double cn, double t, double dt) {
                 double tn = t + al * dt;
                 tn = sel(cn > tn, cn, tn);                     // slack reset
                 const bool off = sc == 0.0;
                 tn = sel(off, 1.0, tn);
                 cn = sel(off, 1.0, cn);
-                LD(L::rtt + j) = tn;
-                lg.mul(sel(jv, tn, 1.0));
-                thn += sel(jv, fabs(cn - tn), 0.0);
+                LD(SINK(store, L::rtt + j)) = tn;
+                lg.mul(sel(cnt, tn, 1.0));
+                thn += sel(cnt, fabs(cn - tn), 0.0);
+            };
+            ROWS(j, jv, lane, m) {
+                const bool simple = !ROW_IS_CBF(j, N);
+                const double sc = LD(L::rsc + j), t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
+                row_trial(j, jv && simple, simple, sc, cj + al * (dt - (cj - t)), t, dt);   // linear rows: exact
+            }
+            if (NOBS) {
+                CBF_ROWS(j, k, ob, ev, lane, N) {   // evaluated at Z + al dZ
+                    const double sc = LD(L::rsc + j), t = LD(L::rt + j), dt = LD(L::rdt + j);
+                    row_trial(j, ev, true, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, al), t, dt);
+                }
             }
             const double phin = fn - mu * lg.wave_total();
             thn = wave_sum(thn);
@@ -1186,23 +1198,14 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
         double numax = 0.0, th = 0.0;
         nus = 0.0; cmax = 0.0; cmin = INFINITY;
-        ROWS(j, jv, lane, m) {
-            const double sc = LD(L::rsc + j);
-            const bool on = sc != 0.0, cnt = jv && on;
+        auto row_accept = [&](int j, bool own, double sc, double v) {   // own: this lane is the one that updates row j
+            const bool on = sc != 0.0, cnt = own && on;
             const double tn = LD(L::rtt + j);
             const double mut = mu * frcp(tn);
             const double rp = LD(L::rc + j) - LD(L::rt + j);   // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
             const double dnu = -LD(L::rw + j) + LD(L::rsig + j) * (rp - LD(L::rdt + j));
             double nn = LD(L::rnu + j) + a_d * dnu;
             nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
-            const int pk = si[L::riv + j];
-            double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
-            if (NOBS) {
-                const int k0 = j / NR, r = j - k0 * NR;
-                const bool iscbf = j < N * NR && r >= 8 + NOBS && on;
-                const double cv = sc * cbf_value<NOBS, NMAX>(sm, c, seli(iscbf, k0, 0), seli(iscbf, r - 8 - NOBS, 0), 0.0);
-                v = sel(iscbf, cv, v);
-            }
             LD(SINK(cnt, L::rt + j)) = tn;
             LD(SINK(cnt, L::rnu + j)) = nn;             // read-modify-write
             numax = fmax(numax, sel(cnt, nn, 0.0));     // cnt, not on: a lane past the last row re-reads row 0 AFTER its update
@@ -1210,7 +1213,18 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             nus += sel(cnt, nn, 0.0);
             cmax = fmax(cmax, sel(cnt, tn * nn, 0.0));
             cmin = fmin(cmin, sel(cnt, tn * nn, INFINITY));
-            LD(L::rc + j) = sel(on, v, 1.0);
+            LD(SINK(own, L::rc + j)) = sel(on, v, 1.0);
+        };
+        ROWS(j, jv, lane, m) {
+            const int pk = si[L::riv + j];
+            const double sc = LD(L::rsc + j), v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
+            row_accept(j, jv && !ROW_IS_CBF(j, N), sc, v);
+        }
+        if (NOBS) {
+            CBF_ROWS(j, k, ob, ev, lane, N) {
+                const double sc = LD(L::rsc + j);
+                row_accept(j, ev, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, 0.0));
+            }
         }
         SYNC();
         numax = wave_max(numax); th = wave_max(th);
