@@ -653,11 +653,14 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
             LOADS_DONE();
             const double exS = sel(k >= 1, kSv, 0.0), exE = sel(k >= 1, kEv + 2.0 * wcv, 0.0);
+            // with C = L D kept beside L (C[i][q] = L[i][q] D[q]) every update on the pivot chain is ONE fma:
+            // d_j = H_jj - sum_q L[j][q] C[j][q],  C[i][j] = H_ij - sum_q L[i][q] C[j][q],  L[i][j] = C[i][j] / d_j
+            double Cf[NU][NU];
 #pragma unroll
             for (int j = 0; j < NU; j++) {
                 double d = Lf[j][j];
 #pragma unroll
-                for (int q = 0; q < j; q++) d -= Lf[j][q] * Lf[j][q] * Dp[q];
+                for (int q = 0; q < j; q++) d = fma(-Lf[j][q], Cf[j][q], d);
                 if (!(d > 0.0)) ok = false;
                 Dp[j] = d;
                 rD[j] = frcp(d);
@@ -665,7 +668,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 for (int i = j + 1; i < NU; i++) {
                     double u = Lf[i][j];
 #pragma unroll
-                    for (int q = 0; q < j; q++) u -= Lf[i][q] * Lf[j][q] * Dp[q];
+                    for (int q = 0; q < j; q++) u = fma(-Lf[i][q], Cf[j][q], u);
+                    Cf[i][j] = u;
                     Lf[i][j] = u * rD[j];
                 }
             }
