@@ -466,6 +466,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
     const int N = c.N, lane = c.lane;
+    const long long qs = CLK();
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
     {
         const double kSn = NOBS ? LD(L::kS + N - 1) : 0.0, kEn = (NOBS ? LD(L::kE + N - 1) : 0.0) + 2.0 * LD(L::wc + N - 1);
@@ -547,6 +548,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     const int kstr = seli(isK, seli(gcol, 1, NX), 0), kstep = seli(isK, seli(gcol, NU, NU * NX), 0);
     int kst = SINK(isK, seli(gcol, L::kf, L::Kk + uj) + (N - 1) * kstep);
     const bool exSl = isP && !gcol && ui == uj && ui == 4, exEl = isP && !gcol && ui == uj && ui == 5;
+    if (tsub) tsub[2] += CLK() - qs;   // set-up of the sweep (terminal P, lane maps, stage-invariant operands)
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
         // (Forming H = M'PM in ONE phase straight from P -- NX^2 FMAs per entry, no T -- was tried twice, before and after

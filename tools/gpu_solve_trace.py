@@ -20,7 +20,7 @@ else:
     p = synth.cfg2_mpccbf(8, N=12); d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
     call = lambda: gpu.cbf_solve(d, *[p[k][:1] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")])
 for mode, names in ((64, ["accept/first-order", "adjoint", "mu", "assemble", "riccati back", "forward", "row steps", "line search"]),
-                    (-64, ["ric: T", "ric: H", "ric: LDL", "ric: update", "riccati back", "forward", "row steps", "line search"])):
+                    (-64, ["ric: T", "ric: H", "ric: set-up", "ric: update", "riccati back", "forward", "row steps", "line search"])):
     L.crx_trace_enable(0, mode)
     r = call()
     buf = np.zeros((64, 16)); L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), 64)
