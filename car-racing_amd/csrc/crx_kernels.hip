@@ -82,6 +82,10 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 #define CBF_ROWS(j, k, ob, ev, lane_, n_) _Pragma("unroll") for (int q_ = 0; q_ < (NMAX * NOBS + WAVE - 1) / WAVE; q_++) \
     if (const bool ev = (lane_) + q_ * WAVE < (n_) * NOBS; true) if (const int e_ = ev ? (lane_) + q_ * WAVE : 0; true) \
     if (const int k = e_ / L::NO; true) if (const int ob = e_ - k * L::NO; true) if (const int j = k * NR + 8 + NOBS + ob; true)
+// in the planner instantiation (193 VGPRs, far from the 256 that would cost a resident wave) the row passes load all
+// their operands before computing; with obstacles the 1-obstacle instantiation sits at 255 VGPRs and the scheduler is
+// left alone
+#define ROW_LOADS_DONE() do { if (NOBS == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define ROW_IS_CBF(j, n_) (NOBS > 0 && (j) < (n_) * NR && (j) % NR >= 8 + NOBS)
 // nothing moves across: placed after the loads of a phase so that they are issued back to back
 #define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
@@ -1082,11 +1086,12 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         // (jd = J dz of the row; shared tail of the simple-row passes and of the CBF pass)
         auto row_step = [&](int j, bool cnt, bool store, double sc, double jd) {
             const bool on = sc != 0.0;
-            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j);
-            const double rp = LD(L::rc + j) - t;
+            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j);
+            const double rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
+            ROW_LOADS_DONE();
+            const double rp = rcj - t;
             const double dt = sel(on, jd + rp, 0.0);
             // dnu = (mu - t nu - nu dt)/t = mu/t - nu - Sigma dt = -w + Sigma (rp - dt)
-            const double rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
             const double dnu = sel(on, -rwj + rsj * (rp - dt), 0.0);
             LD(SINK(store, L::rdt + j)) = dt;
             const double dtr = dt * rti;                       // dt / t
@@ -1151,6 +1156,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             ROWS(j, jv, lane, m) {
                 const bool simple = !ROW_IS_CBF(j, N);
                 const double sc = LD(L::rsc + j), t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
+                ROW_LOADS_DONE();
                 row_trial(j, jv && simple, simple, sc, cj + al * (dt - (cj - t)), t, dt);   // linear rows: exact
             }
             if (NOBS) {
@@ -1206,11 +1212,13 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         nus = 0.0; cmax = 0.0; cmin = INFINITY;
         auto row_accept = [&](int j, bool own, double sc, double v) {   // own: this lane is the one that updates row j
             const bool on = sc != 0.0, cnt = own && on;
-            const double tn = LD(L::rtt + j);
+            const double tn = LD(L::rtt + j), rcj = LD(L::rc + j), rtj = LD(L::rt + j), rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
+            const double rdj = LD(L::rdt + j), rnj = LD(L::rnu + j);
+            ROW_LOADS_DONE();
             const double mut = mu * frcp(tn);
-            const double rp = LD(L::rc + j) - LD(L::rt + j);   // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
-            const double dnu = -LD(L::rw + j) + LD(L::rsig + j) * (rp - LD(L::rdt + j));
-            double nn = LD(L::rnu + j) + a_d * dnu;
+            const double rp = rcj - rtj;                       // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
+            const double dnu = -rwj + rsj * (rp - rdj);
+            double nn = rnj + a_d * dnu;
             nn = fmin(fmax(nn, mut * (1.0 / kappa_sigma)), kappa_sigma * mut);
             LD(SINK(cnt, L::rt + j)) = tn;
             LD(SINK(cnt, L::rnu + j)) = nn;             // read-modify-write
