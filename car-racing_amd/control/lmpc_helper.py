@@ -17,6 +17,11 @@ import numpy as np
 from utils import racing_env
 from utils.constants import U_DIM, X_DIM
 
+# What LMPCRacingGame.estimate_ABC does when a stage's normal matrix is singular (no stored sample within the bandwidth
+# of the linearisation point -- the previous plan left the data): "raise" = the reference's behaviour (cvxopt raises on
+# the singular system, lmpc_helper.py:358-366); "keep" = keep the stage's previous model and go on.
+ON_SINGULAR = "raise"
+
 # reference :42-49,57: bandwidth, features and feature scaling of the local regression
 _BANDWIDTH = 5.0
 _FEATURES = (0, 1, 2)

@@ -278,14 +278,24 @@ class LMPCRacingGame(ControlBase):
         """One local model per horizon stage from the two previous laps (:585-622)."""
         used_iter = range(self.iter - 2, self.iter)
         Atv, Btv, Ctv, index_used = [], [], [], []
+        last = getattr(self, "_last_models", None)
         for i in range(self.lmpc_param.num_horizon):
-            Ai, Bi, Ci, idx = lmpc_helper.regression_and_linearization(
-                self.lin_points, self.lin_input, used_iter, self.ss_xcurv, self.u_ss, self.time_ss, 40, None, None,
-                self.point_and_tangent, self.timestep, i)
+            try:
+                Ai, Bi, Ci, idx = lmpc_helper.regression_and_linearization(
+                    self.lin_points, self.lin_input, used_iter, self.ss_xcurv, self.u_ss, self.time_ss, 40, None, None,
+                    self.point_and_tangent, self.timestep, i)
+            except np.linalg.LinAlgError:
+                # no stored sample within the bandwidth of this linearisation point: the reference hands cvxopt a singular
+                # normal matrix here and raises.  lmpc_helper.ON_SINGULAR = "keep" keeps the previous model of the stage.
+                if lmpc_helper.ON_SINGULAR != "keep" or last is None:
+                    raise
+                print("local regression singular at stage %d: previous stage model kept" % i)
+                Ai, Bi, Ci, idx = last[i]
             Atv.append(Ai)
             Btv.append(Bi)
             Ctv.append(Ci)
             index_used.append(idx)
+        self._last_models = list(zip(Atv, Btv, Ctv, index_used))
         return Atv, Btv, Ctv, index_used
 
     def add_point(self, x, u, i):

@@ -8,6 +8,8 @@ import crx
 import control.control as cc
 import test_gpu_closed_loop as t
 orig = crx.lmpc_solve
+from control import lmpc_helper
+if len(sys.argv) > 3: lmpc_helper.ON_SINGULAR = sys.argv[3]
 size = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-10
 class Cap:
     def __init__(self): self.buf = io.StringIO()
@@ -17,10 +19,14 @@ class Cap:
 for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     rng = np.random.default_rng(seed)
     calls = [0, 0]
+    last = []
     def hooked(d, *args, **kw):
         r = orig(d, *args, **kw)
         r["U"] = r["U"] + size * rng.standard_normal(r["U"].shape)
         calls[0] += 1; calls[1] += int(r["status"][0] != 0)
+        last.append("call %d st %d it %d kkt %.1e max|X| %s max|U| %s" % (calls[0], r["status"][0], r["iters"][0], r["kkt"][0],
+                    np.array2string(np.abs(r["X"][0]).max(axis=0), precision=2), np.array2string(np.abs(r["U"][0]).max(axis=0), precision=2)))
+        del last[:-6]
         return r
     crx.lmpc_solve = hooked
     if hasattr(cc, "crx"): cc.crx.lmpc_solve = hooked
@@ -32,3 +38,5 @@ for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     except BaseException as e:
         res = "%s %s" % (type(e).__name__, str(e)[:80].replace("\n", " "))
     print("seed", seed, "noise", size, "lmpc calls", calls[0], "not converged", calls[1], "->", res, flush=True)
+    if res != "passed":
+        for l in last: print("seed", seed, "   ", l, flush=True)
