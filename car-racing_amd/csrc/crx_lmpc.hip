@@ -65,31 +65,35 @@ struct LCtx {
 
 #define LDS(i) sm[(i)]
 #define LSINK(cond, off) seli((cond), (off), L::dmy)
+// all rows of the problem, uniform trip count: a lane past the last row recomputes row 0 (rv = false); pure stores rewrite
+// row 0 with the same value, read-modify-write stores go to the sink, sums and products are masked with rv
+#define LROWS(r, rv, lane_, m_) for (int r0_ = 0; r0_ < (m_); r0_ += WAVE) \
+    if (const bool rv = r0_ + (lane_) < (m_); true) if (const int r = rv ? r0_ + (lane_) : 0; true)
 
 // rows c_j(v) for the current iterate; rp = c - t
-// (l_rows / l_lagr keep their per-kind branches: a straight-line rewrite measured +0.8 % only, and any change of the
-// rounding in this kernel re-rolls the racing-game closed loop, DESIGN.md section 5.3 "sensitivity")
 template <int NMAX>
 __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc_kparams& kp) {
     using L = LL<NMAX>;
-    for (int r = x.lane; r < x.m; r += WAVE) {
-        double cv;
-        if (r < x.r_st) {
-            int i = r >> 2, q = r & 3;
-            double ub = (q & 2) ? kp.a_max : kp.delta_max, uv = LDS(L::u + 2 * i + (q >> 1));
-            cv = (q & 1) ? ub - uv : uv + ub;
-        } else if (r < x.r_lam) {
-            int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1);
-            int comp = q ? 5 : 0;
-            double s = LDS(L::xf + 6 * k + comp);
-            const int so = L::S + (k * 6 + comp) * L::NU2;
+    // straight-line: every lane evaluates all three row kinds on clamped indices and selects; lanes past the last row
+    // recompute row 0.  The state rows sum over ALL inputs -- S[k][.][a] is zero for a >= 2k, the bound was a shortcut.
+    for (int r0 = 0; r0 < x.m; r0 += WAVE) {
+        const int r = r0 + x.lane < x.m ? r0 + x.lane : 0;
+        const bool isbox = r < x.r_st, isst = !isbox && r < x.r_lam;
+        const int rb = isbox ? r : 0, q = rb & 3;
+        const double ub = (q & 2) ? kp.a_max : kp.delta_max, uv = LDS(L::u + 2 * (rb >> 2) + (q >> 1));
+        const double cbox = (q & 1) ? ub - uv : uv + ub;
+        const int rr = isst ? r - x.r_st : 0, k = rr / 3 + 1, q3 = rr - 3 * (k - 1);
+        const int so = L::S + (k * 6 + (q3 ? 5 : 0)) * L::NU2;
+        double s0 = LDS(L::xf + 6 * k + (q3 ? 5 : 0)), s1 = 0.0;
 #pragma unroll 4
-            for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
-            for (int a = x.nu2; a < x.nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
-            cv = q == 0 ? kp.v_max - s : (q == 1 ? kp.ey_max - s : s + kp.ey_max);
-        } else {
-            cv = LDS(L::lam + (r - x.r_lam));
+        for (int a = 0; a < x.nv; a += 2) {
+            s0 = fma(LDS(so + a), LDS(L::u + a), s0);
+            s1 = fma(LDS(so + a + 1), LDS(L::u + a + 1), s1);
         }
+        const double sx = s0 + s1;
+        const double cst = q3 == 0 ? kp.v_max - sx : (q3 == 1 ? kp.ey_max - sx : sx + kp.ey_max);
+        const double clam = LDS(L::lam + ((!isbox && !isst) ? r - x.r_lam : 0));
+        const double cv = sel(isbox, cbox, sel(isst, cst, clam));
         LDS(L::c + r) = cv;
         LDS(L::rp + r) = cv - LDS(L::t + r);
     }
@@ -99,30 +103,38 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
 template <int NMAX>
 __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int wo) {
     using L = LL<NMAX>;
-    if (x.lane >= 1 && x.lane < x.N) {
-        int k = x.lane, r = x.r_st + 3 * (k - 1);
-        LDS(L::w0 + k) = LDS(wo + r);
-        LDS(L::w5 + k) = LDS(wo + r + 1) - LDS(wo + r + 2);
+    {
+        const bool kv = x.lane >= 1 && x.lane < x.N;
+        const int k = kv ? x.lane : 1, r = x.r_st + 3 * (k - 1);
+        const double a0 = LDS(wo + r), a1 = LDS(wo + r + 1), a2 = LDS(wo + r + 2);
+        LDS(LSINK(kv, L::w0 + k)) = a0;
+        LDS(LSINK(kv, L::w5 + k)) = a1 - a2;
     }
     SYNC();
-    if (x.lane < x.nv) {
-        const int a = x.lane, i = a >> 1, cc = a & 1;
+    {
+        const bool av = x.lane < x.nv;
+        const int a = av ? x.lane : 0, ab = a < x.nu2 ? a : 0, i = ab >> 1, cc = ab & 1;
         double s = LDS(L::gu + a);
+#pragma unroll
         for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + (x.N * 6 + c6) * L::NU2 + a), LDS(L::y + c6), s);
-        if (a < x.nu2) s -= LDS(wo + 4 * i + 2 * cc) - LDS(wo + 4 * i + 2 * cc + 1);
-        // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo)
+        const double bl = LDS(wo + 4 * i + 2 * cc), bh = LDS(wo + 4 * i + 2 * cc + 1);
+        s -= sel(a < x.nu2, bl - bh, 0.0);
+        // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo); all stages (S is zero for k <= a/2)
+        double s2 = 0.0;
 #pragma unroll 4
-        for (int k = a < x.nu2 ? i + 1 : 1; k < x.N; k++) {
+        for (int k = 1; k < x.N; k++) {
             s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a), LDS(L::w0 + k), s);
-            s = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s);
+            s2 = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s2);
         }
-        LDS(L::ru + a) = s;
+        LDS(LSINK(av, L::ru + a)) = s + s2;
     }
-    if (x.lane < x.M) {
-        const int j = x.lane;
+    {
+        const bool jv = x.lane < x.M;
+        const int j = jv ? x.lane : 0;
         double s = LDS(L::qf + j) + LDS(L::y + 6) - LDS(wo + x.r_lam + j);
+#pragma unroll
         for (int c6 = 0; c6 < 6; c6++) s = fma(-LDS(L::SS + c6 * L::MS + j), LDS(L::y + c6), s);
-        LDS(L::rl + j) = s;
+        LDS(LSINK(jv, L::rl + j)) = s;
     }
     SYNC();
 }
@@ -299,49 +311,55 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             TICK();
             // ---- rows, gradient, equality residual ----
             l_rows<NMAX>(sm, x, kp);
-            if (lane < nv) {
-                double s = LDS(L::g0u + lane);
-#pragma unroll 8
-                for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::u + b), s);
-                LDS(L::gu + lane) = s;
-            }
-            if (lane < 7) {
-                double s;
-                if (lane < 6) {
-                    s = LDS(L::xf + 6 * N + lane);
-                    const int so = L::S + (N * 6 + lane) * L::NU2;
-#pragma unroll 8
-                    for (int a = 0; a < nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
-#pragma unroll 8
-                    for (int j = 0; j < M; j++) s = fma(-LDS(L::SS + lane * L::MS + j), LDS(L::lam + j), s);
-                } else {
-                    s = -1.0;
-#pragma unroll 8
-                    for (int j = 0; j < M; j++) s += LDS(L::lam + j);
+            {   // gu = g0u + Hu u (lane = row); lanes past nv run row 0 and store to the sink.  Two accumulators.
+                const bool av = lane < nv;
+                const int a = av ? lane : 0;
+                double s0 = LDS(L::g0u + a), s1 = 0.0;
+#pragma unroll 4
+                for (int b = 0; b < nv; b += 2) {
+                    s0 = fma(LDS(L::Hu + a * L::NU2 + b), LDS(L::u + b), s0);
+                    s1 = fma(LDS(L::Hu + a * L::NU2 + b + 1), LDS(L::u + b + 1), s1);
                 }
-                LDS(L::e + lane) = s;
+                LDS(LSINK(av, L::gu + a)) = s0 + s1;
+            }
+            {   // e_c = x_N,c - SS_c lambd (c < 6), e_6 = 1'lambd - 1: every lane sums a strided part, one wave sum per row
+                double ec[7];
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const int so = L::S + (N * 6 + c6) * L::NU2;
+                    const int a = lane < nv ? lane : 0, j = lane < M ? lane : 0;
+                    const double pu = LDS(so + a) * LDS(L::u + a), pl = LDS(L::SS + c6 * L::MS + j) * LDS(L::lam + j);
+                    ec[c6] = sel(lane < nv, pu, 0.0) - sel(lane < M, pl, 0.0);
+                }
+                ec[6] = sel(lane < M, LDS(L::lam + (lane < M ? lane : 0)), 0.0);
+#pragma unroll
+                for (int c6 = 0; c6 < 7; c6++) ec[c6] = wave_sum(ec[c6]);
+                double ev = ec[6] - 1.0;
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) ev = sel(lane == c6, ec[c6] + LDS(L::xf + 6 * N + c6), ev);
+                LDS(LSINK(lane < 7, L::e + lane)) = ev;
             }
             SYNC();
             TICK();   // 1
             // ---- error measure ----
             l_lagr<NMAX>(sm, x, kp, L::nu);
             double nus = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
-            for (int r = lane; r < m; r += WAVE) {
+            LROWS(r, rv, lane, m) {
                 const double tt = LDS(L::t + r), nn = LDS(L::nu + r), rr = fabs(LDS(L::rp + r));
-                nus += nn;
+                nus += sel(rv, nn, 0.0);
                 e_p = fmax(e_p, rr);
-                theta += rr;
+                theta += sel(rv, rr, 0.0);
                 e_c = fmax(e_c, tt * nn);
             }
             double ys = 0.0, e_d = 0.0;
-            if (lane < 7) {
-                const double ee = fabs(LDS(L::e + lane));
-                ys = fabs(LDS(L::y + lane));
-                e_p = fmax(e_p, ee);
-                theta += ee;
+            {
+                const double ee = fabs(LDS(L::e + (lane < 7 ? lane : 0))), yy = fabs(LDS(L::y + (lane < 7 ? lane : 0)));
+                ys = sel(lane < 7, yy, 0.0);
+                e_p = fmax(e_p, sel(lane < 7, ee, 0.0));
+                theta += sel(lane < 7, ee, 0.0);
+                const double ruv = fabs(LDS(L::ru + (lane < nv ? lane : 0))), rlv = fabs(LDS(L::rl + (lane < M ? lane : 0)));
+                e_d = fmax(sel(lane < nv, ruv, 0.0), sel(lane < M, rlv, 0.0));
             }
-            if (lane < nv) e_d = fabs(LDS(L::ru + lane));
-            if (lane < M) e_d = fmax(e_d, fabs(LDS(L::rl + lane)));
             nus = wave_sum(nus);
             ys = wave_sum(ys);
             theta = wave_sum(theta);
@@ -358,7 +376,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             // ---- barrier update ----
             for (;;) {
                 double e_cm = 0.0;
-                for (int r = lane; r < m; r += WAVE) e_cm = fmax(e_cm, fabs(LDS(L::t + r) * LDS(L::nu + r) - mu));
+                LROWS(r, rv, lane, m) { (void)rv; e_cm = fmax(e_cm, fabs(LDS(L::t + r) * LDS(L::nu + r) - mu)); }
                 e_cm = wave_max(e_cm) / sc;
                 if (fmax(e_d, fmax(e_p, e_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
                     mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
@@ -369,7 +387,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             TICK();   // 3
             const double tau = fmax(o.tau_min, 1.0 - mu);
             // ---- Sigma (in dnu), omega = mu/t - Sigma rp (in wv); rhs = -(g + E'y - J'omega) ----
-            for (int r = lane; r < m; r += WAVE) {
+            LROWS(r, rv, lane, m) {
+                (void)rv;
                 const double ti = frcp(LDS(L::t + r)), sg = LDS(L::nu + r) * ti;
                 LDS(L::dnu + r) = sg;
                 LDS(L::wv + r) = fma(-sg, LDS(L::rp + r), mu * ti);
@@ -377,10 +396,12 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             l_lagr<NMAX>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
             // stage weights of the state rows for K_u
-            if (lane >= 1 && lane < N) {
-                const int r = x.r_st + 3 * (lane - 1);
-                LDS(L::w0 + lane) = LDS(L::dnu + r);
-                LDS(L::w5 + lane) = LDS(L::dnu + r + 1) + LDS(L::dnu + r + 2);
+            {
+                const bool kv = lane >= 1 && lane < N;
+                const int k = kv ? lane : 1, r = x.r_st + 3 * (k - 1);
+                const double d0 = LDS(L::dnu + r), d1 = LDS(L::dnu + r + 1), d2 = LDS(L::dnu + r + 2);
+                LDS(LSINK(kv, L::w0 + k)) = d0;
+                LDS(LSINK(kv, L::w5 + k)) = d1 + d2;
             }
             SYNC();
             TICK();   // 4
@@ -552,54 +573,55 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             TICK();   // 10
             // ---- row steps ----
             double rp_max = 0.0, rd_max = 0.0, Dphi = 0.0;
-            for (int r = lane; r < m; r += WAVE) {
-                double jd;
-                if (r < x.r_st) {
-                    const double d = LDS(L::du + 2 * (r >> 2) + ((r & 3) >> 1));
-                    jd = (r & 1) ? -d : d;
-                } else if (r < x.r_lam) {
-                    const int rr = r - x.r_st, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
-                    double s = 0.0;
+            LROWS(r, rv, lane, m) {
+                const bool isbox = r < x.r_st, isst = !isbox && r < x.r_lam;
+                const int rb = isbox ? r : 0;
+                const double db = LDS(L::du + 2 * (rb >> 2) + ((rb & 3) >> 1));
+                const double jbox = (rb & 1) ? -db : db;
+                const int rr = isst ? r - x.r_st : 0, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
+                double s0 = 0.0, s1 = 0.0;     // all inputs: S is zero for a >= 2k
 #pragma unroll 4
-                    for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
-                    for (int a = nu2; a < nv; a++) s = fma(LDS(so + a), LDS(L::du + a), s);
-                    jd = q == 2 ? s : -s;
-                } else {
-                    jd = LDS(L::dlam + (r - x.r_lam));
+                for (int a = 0; a < nv; a += 2) {
+                    s0 = fma(LDS(so + a), LDS(L::du + a), s0);
+                    s1 = fma(LDS(so + a + 1), LDS(L::du + a + 1), s1);
                 }
+                const double sx = s0 + s1, jst = q == 2 ? sx : -sx;
+                const double jlam = LDS(L::dlam + ((!isbox && !isst) ? r - x.r_lam : 0));
+                const double jd = sel(isbox, jbox, sel(isst, jst, jlam));
                 const double tt = LDS(L::t + r), nn = LDS(L::nu + r), ti = frcp(tt);
                 const double dtt = LDS(L::rp + r) + jd;
                 const double dn = (mu - tt * nn - nn * dtt) * ti;
                 LDS(L::wv + r) = jd;
                 LDS(L::dt + r) = dtt;
-                const double sg = LDS(L::dnu + r);
-                (void)sg;
                 rp_max = fmax(rp_max, -dtt * ti);
                 rd_max = fmax(rd_max, -dn * frcp(nn));
-                Dphi = fma(-mu * dtt, ti, Dphi);
+                Dphi = fma(sel(rv, -mu * dtt, 0.0), ti, Dphi);
                 LDS(L::c + r) = dn;   // dnu parked in c (c is recomputed at the top of the next iteration)
             }
             double gdv = 0.0, qd = 0.0;
-            if (lane < nv) {
-                const double d = LDS(L::du + lane);
-                gdv = LDS(L::gu + lane) * d;
-                double s = 0.0;
-#pragma unroll 8
-                for (int b = 0; b < nv; b++) s = fma(LDS(L::Hu + lane * L::NU2 + b), LDS(L::du + b), s);
-                qd = s * d;
+            {
+                const bool av = lane < nv;
+                const int a = av ? lane : 0, j = lane < M ? lane : 0;
+                const double d = LDS(L::du + a), gua = LDS(L::gu + a);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
+                for (int b = 0; b < nv; b += 2) {
+                    s0 = fma(LDS(L::Hu + a * L::NU2 + b), LDS(L::du + b), s0);
+                    s1 = fma(LDS(L::Hu + a * L::NU2 + b + 1), LDS(L::du + b + 1), s1);
+                }
+                qd = sel(av, (s0 + s1) * d, 0.0);
+                gdv = sel(av, gua * d, 0.0) + sel(lane < M, LDS(L::qf + j) * LDS(L::dlam + j), 0.0);
             }
-            if (lane < M) gdv = fma(LDS(L::qf + lane), LDS(L::dlam + lane), gdv);
             rp_max = wave_max(rp_max);
             rd_max = wave_max(rd_max);
             gdv = wave_sum(gdv);
             qd = wave_sum(qd);
             Dphi = wave_sum(Dphi) + gdv;
             const double a_p = rp_max > tau ? tau / rp_max : 1.0, a_d = rd_max > tau ? tau / rd_max : 1.0;
-            double esum = 0.0;
-            if (lane < 7) esum = fabs(LDS(L::e + lane));
+            double esum = sel(lane < 7, fabs(LDS(L::e + (lane < 7 ? lane : 0))), 0.0);
             esum = wave_sum(esum);
             LogAcc la0;
-            for (int r = lane; r < m; r += WAVE) la0.mul(LDS(L::t + r));
+            LROWS(r, rv, lane, m) la0.mul(sel(rv, LDS(L::t + r), 1.0));
             const double phi0 = f - mu * la0.wave_total();
             if (it == 0) {
                 theta_min = 1e-4 * fmax(1.0, theta);
@@ -613,12 +635,12 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 fn = f + al * (gdv + 0.5 * al * qd);
                 double thn = 0.0;
                 LogAcc la;
-                for (int r = lane; r < m; r += WAVE) {
+                LROWS(r, rv, lane, m) {
                     const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
                     double tn = fma(al, LDS(L::dt + r), LDS(L::t + r));
                     tn = fmax(tn, cj);
-                    la.mul(tn);
-                    thn += fabs(cj - tn);
+                    la.mul(sel(rv, tn, 1.0));
+                    thn += sel(rv, fabs(cj - tn), 0.0);
                 }
                 thn = wave_sum(thn) + (1.0 - al) * esum;
                 const double phin = fn - mu * la.wave_total();
@@ -647,19 +669,24 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             TICK();   // 12
             // ---- accept ----
             double numax = 0.0;
-            for (int r = lane; r < m; r += WAVE) {
+            LROWS(r, rv, lane, m) {
                 const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
                 const double tn = fmax(fma(al, LDS(L::dt + r), LDS(L::t + r)), cj);
                 double nn = fma(a_d, LDS(L::c + r), LDS(L::nu + r));
                 const double mut = mu * frcp(tn);
                 nn = fmin(fmax(nn, mut * 1e-10), mut * 1e10);
-                LDS(L::t + r) = tn;
-                LDS(L::nu + r) = nn;
-                numax = fmax(numax, nn);
+                LDS(LSINK(rv, L::t + r)) = tn;          // read-modify-write
+                LDS(LSINK(rv, L::nu + r)) = nn;
+                numax = fmax(numax, sel(rv, nn, 0.0));
             }
-            if (lane < nv) LDS(L::u + lane) = fma(al, LDS(L::du + lane), LDS(L::u + lane));
-            if (lane < M) LDS(L::lam + lane) = fma(al, LDS(L::dlam + lane), LDS(L::lam + lane));
-            if (lane < 7) LDS(L::y + lane) = fma(al, LDS(L::dy + lane), LDS(L::y + lane));
+            {
+                const int a = lane < nv ? lane : 0, j = lane < M ? lane : 0, q = lane < 7 ? lane : 0;
+                const double un = fma(al, LDS(L::du + a), LDS(L::u + a)), ln = fma(al, LDS(L::dlam + j), LDS(L::lam + j));
+                const double yn = fma(al, LDS(L::dy + q), LDS(L::y + q));
+                LDS(LSINK(lane < nv, L::u + a)) = un;
+                LDS(LSINK(lane < M, L::lam + j)) = ln;
+                LDS(LSINK(lane < 7, L::y + q)) = yn;
+            }
             f = fn;
             numax = wave_max(numax);
             SYNC();
