@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             if (!ok) break;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                double s = LDS(L::bx + i), sj = lane < M ? LDS(L::SS + i * L::MS + lane) : 0.0;
+                double s = LDS(L::bx + i), sj = sel(lane < M, LDS(L::SS + i * L::MS + (lane < M ? lane : 0)), 0.0);
 #pragma unroll
                 for (int k = 0; k < i; k++) {
                     s = fma(-Lw[i][k], tbx[k], s);
@@ -493,14 +493,16 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 tbx[i] = s * iw[i];
                 Tj[i] = sj * iw[i];
             }
-            if (lane < M) {
-                double s = -LDS(L::rl + lane);
+            {
+                const bool lv = lane < M;
+                const int lc = lv ? lane : 0;
+                double s = -LDS(L::rl + lc);
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
-                    LDS(L::T + 6 * lane + c6) = Tj[c6];
+                    LDS(LSINK(lv, L::T + 6 * lc + c6)) = Tj[c6];
                     s = fma(Tj[c6], tbx[c6], s);
                 }
-                LDS(L::cl + lane) = s;
+                LDS(LSINK(lv, L::cl + lc)) = s;
             }
             SYNC();
             TICK();   // 7
@@ -535,13 +537,13 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             if (!ok) break;
             {
                 double b2[2];
-                b2[0] = lane < M ? LDS(L::G + M * ldg + lane) : 0.0;
-                b2[1] = lane < M ? LDS(L::G + (M + 1) * ldg + lane) : 0.0;
+                b2[0] = sel(lane < M, LDS(L::G + M * ldg + (lane < M ? lane : 0)), 0.0);
+                b2[1] = sel(lane < M, LDS(L::G + (M + 1) * ldg + (lane < M ? lane : 0)), 0.0);
                 l_backsub<2>(sm, L::G, ldg, L::ig, M, lane, b2);
-                const double s1 = wave_sum(lane < M ? b2[0] : 0.0), s2 = wave_sum(lane < M ? b2[1] : 0.0);
+                const double s1 = wave_sum(sel(lane < M, b2[0], 0.0)), s2 = wave_sum(sel(lane < M, b2[1], 0.0));
                 const double dy1 = (s1 + LDS(L::e + 6)) / s2;
-                const double dl = lane < M ? b2[0] - b2[1] * dy1 : 0.0;
-                if (lane < M) LDS(L::dlam + lane) = dl;
+                const double dl = sel(lane < M, b2[0] - b2[1] * dy1, 0.0);
+                LDS(LSINK(lane < M, L::dlam + lane)) = dl;
                 double tb[6], dyx[6];
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) tb[c6] = tbx[c6] - wave_sum(Tj[c6] * dl);
@@ -559,15 +561,15 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 }
                 // du = L_u^-T (z - Y' dy_x)
                 double b1[1];
-                b1[0] = 0.0;
-                if (lane < nv) {
-                    double s = LDS(L::K + (nv + 6) * L::LDK + lane);
+                {
+                    const int a = lane < nv ? lane : 0;
+                    double s = LDS(L::K + (nv + 6) * L::LDK + a);
 #pragma unroll
-                    for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nv + r) * L::LDK + lane), dyx[r], s);
-                    b1[0] = s;
+                    for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nv + r) * L::LDK + a), dyx[r], s);
+                    b1[0] = sel(lane < nv, s, 0.0);
                 }
                 l_backsub<1>(sm, L::K, L::LDK, L::ik, nv, lane, b1);
-                if (lane < nv) LDS(L::du + lane) = b1[0];
+                LDS(LSINK(lane < nv, L::du + lane)) = b1[0];
             }
             SYNC();
             TICK();   // 10
