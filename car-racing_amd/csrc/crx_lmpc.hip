@@ -406,32 +406,37 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             TICK();   // 4
             // ---- K_u (lower triangle) + extra rows Phi (6) and rhs_u ----
-            // straight-line passes: lanes past the last entry recompute entry 0 (same value); the stage loop runs over all
-            // stages for every entry -- S[k][.][a] is zero for k <= a/2, so the bound was only a (divergent) shortcut
-            for (int e0 = 0; e0 < nv * (nv + 1) / 2; e0 += WAVE) {
-                const int en = e0 + lane < nv * (nv + 1) / 2 ? e0 + lane : 0;
-                int a = (int)((__builtin_amdgcn_sqrtf(8.0f * (float)en + 1.0f) - 1.0f) * 0.5f);
-                a = a * (a + 1) / 2 > en ? a - 1 : a;
-                a = (a + 1) * (a + 2) / 2 <= en ? a + 1 : a;
-                const int b = en - a * (a + 1) / 2;
-                const int ad = a < nu2 ? a : 0;
-                const double h0 = LDS(L::Hu + a * L::NU2 + b), d0 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1)), d1 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1) + 1);
-                double s = h0 + sel(a == b && a < nu2, d0 + d1, 0.0);
-                for (int k = 1; k < N; k += 2) {
-                    const int k2 = k + 1 < N ? k + 1 : k;
-                    const double sa0 = LDS(L::S + (k * 6 + 0) * L::NU2 + a), sb0 = LDS(L::S + (k * 6 + 0) * L::NU2 + b);
-                    const double sa5 = LDS(L::S + (k * 6 + 5) * L::NU2 + a), sb5 = LDS(L::S + (k * 6 + 5) * L::NU2 + b);
-                    const double ta0 = LDS(L::S + (k2 * 6 + 0) * L::NU2 + a), tb0 = LDS(L::S + (k2 * 6 + 0) * L::NU2 + b);
-                    const double ta5 = LDS(L::S + (k2 * 6 + 5) * L::NU2 + a), tb5 = LDS(L::S + (k2 * 6 + 5) * L::NU2 + b);
-                    const double w0k = LDS(L::w0 + k), w5k = LDS(L::w5 + k);
-                    const double w0n = sel(k + 1 < N, LDS(L::w0 + k2), 0.0), w5n = sel(k + 1 < N, LDS(L::w5 + k2), 0.0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    s = fma(sa0 * w0k, sb0, s);
-                    s = fma(sa5 * w5k, sb5, s);
-                    s = fma(ta0 * w0n, tb0, s);
-                    s = fma(ta5 * w5n, tb5, s);
+            // One lane per (row a, chunk of 6 columns b0..b0+5): the row's S entries and weights are loaded once per stage
+            // and feed six accumulators (an entry-per-lane map re-loaded them for every entry: 3x the LDS reads).  Rows
+            // 6g..6g+5 have g+1 chunks each, 3g(g+1) chunks precede group g.  Lanes past the last chunk recompute chunk 0;
+            // columns past the diagonal are computed and dropped; the stage loop is uniform (S[k][.][a] = 0 for k <= a/2).
+            {
+                const int gq = nv / 6, nchunk = 3 * gq * (gq + 1) + (nv - 6 * gq) * (gq + 1);
+                for (int c0 = 0; c0 < nchunk; c0 += WAVE) {
+                    const int cc = c0 + lane < nchunk ? c0 + lane : 0;
+                    const int g = (cc >= 6) + (cc >= 18) + (cc >= 36) + (cc >= 60) + (cc >= 90) + (cc >= 126);
+                    const int idx = cc - 3 * g * (g + 1);
+                    const int rg = (int)(((float)idx + 0.25f) / (float)(g + 1));
+                    const int a = 6 * g + rg, b0 = 6 * (idx - rg * (g + 1));
+                    const int ad = a < nu2 ? a : 0;
+                    const double d0 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1)), d1 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1) + 1);
+                    double acc[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) acc[q] = LDS(L::Hu + a * L::NU2 + b0 + q) + sel(b0 + q == a && a < nu2, d0 + d1, 0.0);
+                    for (int k = 1; k < N; k++) {
+                        const int r0 = L::S + (k * 6 + 0) * L::NU2, r5 = L::S + (k * 6 + 5) * L::NU2;
+                        const double sa0 = LDS(r0 + a), sa5 = LDS(r5 + a), w0k = LDS(L::w0 + k), w5k = LDS(L::w5 + k);
+                        double sb0[6], sb5[6];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) { sb0[q] = LDS(r0 + b0 + q); sb5[q] = LDS(r5 + b0 + q); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double t0 = sa0 * w0k, t5 = sa5 * w5k;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) acc[q] = fma(t5, sb5[q], fma(t0, sb0[q], acc[q]));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; q++) LDS(LSINK(b0 + q <= a, L::K + a * L::LDK + b0 + q)) = acc[q];
                 }
-                LDS(L::K + a * L::LDK + b) = s;
             }
             for (int e0 = 0; e0 < 7 * nv; e0 += WAVE) {
                 const int en = e0 + lane < 7 * nv ? e0 + lane : 0;
