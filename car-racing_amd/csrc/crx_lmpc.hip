@@ -498,53 +498,61 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 tbx[i] = s * iw[i];
                 Tj[i] = sj * iw[i];
             }
+            // ---- G = D_lambda + T T' is diagonal plus rank six: factorised in product form, never assembled.
+            //   G = L_1 ... L_6 D' L_6' ... L_1',  L_c = I + strict_lower(p_c beta_c'),  one rank-one update of the diagonal
+            //   factor per column tau_c of T (Gill-Golub-Murray-Saunders C1, positive updates):
+            //     p = (L_1..L_{c-1})^-1 tau_c,  t_j = 1 + sum_{i<=j} p_i^2/d_i,  d'_j = d_j t_j/t_{j-1},  beta_j = p_j/(d_j t_j).
+            //   With pd = p/d and pt_j = p_j/t_{j-1} both triangular solves collapse to ONE scan each:
+            //     L_c^-1 b = b - pt .* exclusive_prefix(pd .* b),   L_c^-T b = b - pd .* exclusive_suffix(pt .* b)
+            //   (lane j = element j, M <= 60): 21 scans to factorise, 12 scan steps for the two right-hand sides, instead
+            //   of a 44 x 44 Cholesky (30 % of the iteration), its assembly and its back substitution.  All sums are of
+            //   one sign or short; measured componentwise backward error 4e-14 for d spanning 1e-16..1e16 (dense
+            //   Cholesky: 8e-15), tools/ubench note in DESIGN.md section 5.3.  The oracle keeps the dense Cholesky.
+            double b2[2];
             {
                 const bool lv = lane < M;
                 const int lc = lv ? lane : 0;
                 double s = -LDS(L::rl + lc);
 #pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], tbx[c6], s);
+                double dcur = sel(lv, LDS(L::dnu + x.r_lam + lc), 1.0);
+                if (__any(!(dcur > 0.0))) ok = 0;
+                double pd[6], pt[6];
+#pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
-                    LDS(LSINK(lv, L::T + 6 * lc + c6)) = Tj[c6];
-                    s = fma(Tj[c6], tbx[c6], s);
+                    double pc = sel(lv, Tj[c6], 0.0);
+#pragma unroll
+                    for (int cc = 0; cc < c6; cc++) pc = fma(-pt[cc], excl_prefix(pd[cc] * pc, lane), pc);
+                    const double pdv = pc * frcp(dcur), w = pc * pdv;
+                    const double tprev = 1.0 + excl_prefix(w, lane), rtp = frcp(tprev);
+                    pd[c6] = pdv;
+                    pt[c6] = pc * rtp;
+                    dcur = dcur * (tprev + w) * rtp;
                 }
-                LDS(LSINK(lv, L::cl + lc)) = s;
+                const double rdf = frcp(dcur);
+                double y0 = sel(lv, s, 0.0), y1 = sel(lv, 1.0, 0.0);
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double e0 = excl_prefix(pd[c6] * y0, lane), e1 = excl_prefix(pd[c6] * y1, lane);
+                    y0 = fma(-pt[c6], e0, y0);
+                    y1 = fma(-pt[c6], e1, y1);
+                }
+                y0 *= rdf;
+                y1 *= rdf;
+#pragma unroll
+                for (int c6 = 5; c6 >= 0; c6--) {
+                    const double e0 = excl_suffix(pt[c6] * y0, lane), e1 = excl_suffix(pt[c6] * y1, lane);
+                    y0 = fma(-pd[c6], e0, y0);
+                    y1 = fma(-pd[c6], e1, y1);
+                }
+                b2[0] = y0;
+                b2[1] = y1;
             }
-            SYNC();
             TICK();   // 7
-            // ---- G = D_lambda + T T' (lower triangle, lane i = row i) with extra rows cl and 1 ----
-            {   // every lane runs the full row loop (rows past its own are computed and dropped): no lane-dependent trip count
-                const bool lv = lane < M;
-                const int lc = lv ? lane : 0;
-                const int go = L::G + lc * ldg;
-                const double dl = LDS(L::dnu + x.r_lam + lc), clv = LDS(L::cl + lc);
-                for (int j0 = 0; j0 < M; j0 += 4) {
-                    double tt[4][6];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-#pragma unroll
-                        for (int c6 = 0; c6 < 6; c6++) tt[q][c6] = LDS(L::T + 6 * (j0 + q) + c6);   // rows past M: neighbouring LDS words, never stored
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        double sq = 0.0;
-#pragma unroll
-                        for (int c6 = 0; c6 < 6; c6++) sq = fma(Tj[c6], tt[q][c6], sq);
-                        LDS(LSINK(lv && j0 + q <= lane, go + j0 + q)) = sel(j0 + q == lane, sq + dl, sq);
-                    }
-                }
-                LDS(LSINK(lv, L::G + M * ldg + lane)) = clv;
-                LDS(LSINK(lv, L::G + (M + 1) * ldg + lane)) = 1.0;
-            }
-            SYNC();
             TICK();   // 8
-            ok = l_chol(sm, L::G, ldg, L::ig, M, 2, lane);
             TICK();   // 9
             if (!ok) break;
             {
-                double b2[2];
-                b2[0] = sel(lane < M, LDS(L::G + M * ldg + (lane < M ? lane : 0)), 0.0);
-                b2[1] = sel(lane < M, LDS(L::G + (M + 1) * ldg + (lane < M ? lane : 0)), 0.0);
-                l_backsub<2>(sm, L::G, ldg, L::ig, M, lane, b2);
                 const double s1 = wave_sum(sel(lane < M, b2[0], 0.0)), s2 = wave_sum(sel(lane < M, b2[1], 0.0));
                 const double dy1 = (s1 + LDS(L::e + 6)) / s2;
                 const double dl = sel(lane < M, b2[0] - b2[1] * dy1, 0.0);

@@ -108,6 +108,38 @@ __device__ __forceinline__ double frsqrt(double x) {
     return r;
 }
 
+// Wave-wide exclusive prefix / suffix sums, lane i = element i: Hillis-Steele inside each 16-lane row with DPP row
+// shifts (zero fill), the three row totals added as scalars; the exclusive forms shift the input by one lane first
+// (wave_shr:1 / wave_shl:1) instead of subtracting the own element from the inclusive sum (no cancellation).
+// ~190 cycles as a dependent link (tools/ubench/scan.hip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_zfill_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double excl_prefix(double v, int lane) {
+    v = dpp_zfill_f64<0x138>(v);       // wave_shr:1
+    v += dpp_zfill_f64<0x111>(v);      // row_shr:1
+    v += dpp_zfill_f64<0x112>(v);      // row_shr:2
+    v += dpp_zfill_f64<0x114>(v);      // row_shr:4
+    v += dpp_zfill_f64<0x118>(v);      // row_shr:8
+    const double r0 = lane_f64(v, 15), r1 = lane_f64(v, 31), r2 = lane_f64(v, 47);
+    const int row = lane >> 4;
+    return v + sel(row >= 1, r0, 0.0) + sel(row >= 2, r1, 0.0) + sel(row >= 3, r2, 0.0);
+}
+__device__ __forceinline__ double excl_suffix(double v, int lane) {
+    v = dpp_zfill_f64<0x130>(v);       // wave_shl:1
+    v += dpp_zfill_f64<0x101>(v);      // row_shl:1
+    v += dpp_zfill_f64<0x102>(v);
+    v += dpp_zfill_f64<0x104>(v);
+    v += dpp_zfill_f64<0x108>(v);
+    const double r1 = lane_f64(v, 16), r2 = lane_f64(v, 32), r3 = lane_f64(v, 48);
+    const int row = lane >> 4;
+    return v + sel(row <= 2, r3, 0.0) + sel(row <= 1, r2, 0.0) + sel(row <= 0, r1, 0.0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense factorisations in LDS, one matrix row per lane (crx_lmpc.hip, crx_path kernel in crx_prep.hip)
 // ------------------------------------------------------------------------------------------------
