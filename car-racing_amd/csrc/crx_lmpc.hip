@@ -38,24 +38,28 @@ struct LL {
     static constexpr int NU2 = 2 * NMAX + 6 /* inputs + initial-state relaxation */, LDK = NU2 + 1, KR = NU2 + 7;
     static constexpr int MS = CRX_MAX_SS;
     static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS;
-    // offsets in doubles
-    static constexpr int A = 0, B = A + 36 * NMAX, C = B + 12 * NMAX, xf = C + 6 * NMAX;
+    // offsets in doubles.  A, B, C are read only while the roll-out xf and the sensitivities S are built (before the first
+    // iteration) and share the storage of K, which the first K_u assembly overwrites.
+    static constexpr int K = 0;                                // KR x LDK
+    static constexpr int A = K, B = A + 36 * NMAX, C = B + 12 * NMAX;
+    static_assert(54 * NMAX <= KR * LDK, "A, B, C fit under K");
+    static constexpr int xf = K + KR * LDK;
     static constexpr int S = xf + 6 * (NMAX + 1);              // S[(k*6+c)*NU2 + a], k = 0..NMAX
     static constexpr int Hu = S + 6 * (NMAX + 1) * NU2;        // NU2 x NU2, row-major, stride NU2
-    static constexpr int K = Hu + NU2 * NU2;                   // KR x LDK
-    static constexpr int SS = K + KR * LDK;                    // [6][MS]
-    static constexpr int qf = SS + 6 * MS, T = qf + MS;        // T[j*6+c]
-    static constexpr int u = T + 6 * MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
-    static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS, cl = rl + MS;
-    static constexpr int y = cl + MS, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
-    static constexpr int ik = Wt + 36, ig = ik + NU2;          // inverse pivots of L_u, L_g
-    static constexpr int t = ig + MS, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
+    static constexpr int SS = Hu + NU2 * NU2;                  // [6][MS]
+    static constexpr int qf = SS + 6 * MS;
+    static constexpr int u = qf + MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
+    static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS;
+    static constexpr int y = rl + MS, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
+    static constexpr int ik = Wt + 36;                         // inverse pivots of L_u
+    static constexpr int t = ik + NU2, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
     static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
     static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
     static constexpr int dmy = Fph + LMAXF;                    // sink of address-predicated stores
-    static constexpr int G = dmy + 2;                          // (n_ss_max + 2) x ldg, sized at launch (last region)
-    static constexpr int ldg(int n_ss_max) { return (n_ss_max + 1) | 1; }   // odd stride: conflict-free row-per-lane access
-    static constexpr size_t bytes(int n_ss_max) { return (size_t)(G + (n_ss_max + 4) * ldg(n_ss_max)) * 8; }   // +2 rows: the blocked Cholesky reads (not uses) up to row n+2
+    static constexpr int END = dmy + 2;
+    // (G = D + T T' is never assembled -- product-form factorisation in registers -- so the footprint no longer depends on
+    // the safe-set size: 50.9 KB at NMAX = 12 = three problems per CU, 77 KB before)
+    static constexpr size_t bytes(int /*n_ss_max*/) { return (size_t)END * 8; }
 };
 
 struct LCtx {
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     x.N = kp.N;
     x.nu2 = 2 * kp.N;
     x.M = min(max(kp.n_ss[pb], 1), kp.n_ss_max);   // device-resident counts cannot be validated on the host: clamp (M indexes LDS)
-    const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max, ldg = L::ldg(Mx);
+    const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max;
     const crx_ipm_opts& o = kp.opts;
     if (kp.poison) {   // diagnostics (crx_debug_poison_lds)
         for (int e = lane; e < (int)(L::bytes(Mx) / 8); e += WAVE) sm[e] = __longlong_as_double(0x7ff8dead0000beefLL);
