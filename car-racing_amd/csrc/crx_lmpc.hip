@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LROWS(r, rv, lane, m) { (void)rv; e_cm = fmax(e_cm, fabs(LDS(L::t + r) * LDS(L::nu + r) - mu)); }
                 e_cm = wave_max(e_cm) / sc;
                 if (fmax(e_d, fmax(e_p, e_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-                    mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                    mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, o.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, o.theta_mu)));
                     nf = 0;
                 } else
                     break;
@@ -667,7 +667,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 for (int i = 0; i < nf && okf; i++)
                     if (!(thn < LDS(L::Fth + i) || phin < LDS(L::Fph + i))) okf = 0;
                 if (okf) {
-                    const int sw = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                    // switching test al (-Dphi)^2.3 > theta^1.1 in the log2 domain (crx_kernels.hip: two pow() are ~2.6 k cycles)
+                    const int sw = (Dphi < 0.0) && (log2_fast(al) + 2.3 * log2_fast(-Dphi) > 1.1 * log2_fast(theta));
                     if (theta <= theta_min && sw) {
                         if (phin <= phi0 + 1e-8 * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
                     } else if (thn <= (1.0 - 1e-5) * theta || phin <= phi0 - 1e-8 * theta) {

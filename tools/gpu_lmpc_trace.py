@@ -13,7 +13,7 @@ L.crx_trace_enable(0, 64)
 r = gpu.lmpc_solve(d, *one)
 buf = np.zeros((64, 16)); L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), 64)
 n = int(r["iters"][0]); tr = buf[:n]
-names = ["rows/grad/e", "lagr+err", "mu", "sigma+lagr", "K asm", "chol K", "W,Lw,T", "G asm", "chol G", "backsub", "row steps", "line search", "accept", "TOTAL"]
+names = ["rows/grad/e", "lagr+err", "mu", "sigma+lagr", "K asm", "chol K", "W,Lw,T + G scans", "-", "-", "backsub", "row steps", "line search", "accept", "TOTAL"]
 print("iters", n, "status", r["status"][0])
 for q, nm in enumerate(names):
     print("%-12s %9.0f" % (nm, tr[:, q].mean()))
