@@ -521,17 +521,21 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 for (int c6 = 0; c6 < 6; c6++) s = fma(Tj[c6], tbx[c6], s);
                 double dcur = sel(lv, LDS(L::dnu + x.r_lam + lc), 1.0);
                 if (__any(!(dcur > 0.0))) ok = 0;
-                double pd[6], pt[6];
+                double pd[6], pt[6], pcol[6];
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) pcol[c6] = sel(lv, Tj[c6], 0.0);
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
-                    double pc = sel(lv, Tj[c6], 0.0);
-#pragma unroll
-                    for (int cc = 0; cc < c6; cc++) pc = fma(-pt[cc], excl_prefix(pd[cc] * pc, lane), pc);
+                    const double pc = pcol[c6];
                     const double pdv = pc * frcp(dcur), w = pc * pdv;
                     const double tprev = 1.0 + excl_prefix(w, lane), rtp = frcp(tprev);
                     pd[c6] = pdv;
                     pt[c6] = pc * rtp;
                     dcur = dcur * (tprev + w) * rtp;
+                    // L_c^-1 on the columns still to come: independent scans, in flight together (depth 2 per column of T
+                    // instead of c + 1)
+#pragma unroll
+                    for (int cc = c6 + 1; cc < 6; cc++) pcol[cc] = fma(-pt[c6], excl_prefix(pdv * pcol[cc], lane), pcol[cc]);
                 }
                 const double rdf = frcp(dcur);
                 double y0 = sel(lv, s, 0.0), y1 = sel(lv, 1.0, 0.0);
