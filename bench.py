@@ -249,9 +249,10 @@ def main():
     nz = nx + nu
     flop_iter = N * (2 * nx * nx * nz + 2 * nx * nz * nz + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nu * nx * (nx + 1)) \
         + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
-    if wl == "lmpc":   # Cholesky of K_u (2N) and G (M), 7 + 2 carried right-hand sides, assembly of K_u and G
+    if wl == "lmpc":   # Cholesky of K_u (2N) with 7 carried right-hand sides and its assembly; G = D + T T' in product form:
+        # 21 + 24 wave scans (6 adds per element) and ~12 element-wise operations per rank-one factor and solve step
         nu2, M = 2 * N, n_obs
-        flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + M ** 3 / 3 + 2 * 2 * M * M + 6 * M * M + 4 * (N - 1) * nu2 * nu2 / 2 \
+        flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + (45 * 6 + 6 * 12 + 24 * 4) * M + 4 * (N - 1) * nu2 * nu2 / 2 \
             + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
 
