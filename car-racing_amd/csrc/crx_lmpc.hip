@@ -44,8 +44,13 @@ struct LL {
     static constexpr int A = K, B = A + 36 * NMAX, C = B + 12 * NMAX;
     static_assert(54 * NMAX <= KR * LDK, "A, B, C fit under K");
     static constexpr int xf = K + KR * LDK;
-    static constexpr int S = xf + 6 * (NMAX + 1);              // S[(k*6+c)*NU2 + a], k = 0..NMAX
-    static constexpr int Hu = S + 6 * (NMAX + 1) * NU2;        // NU2 x NU2, row-major, stride NU2
+    // sensitivities dx_k/d(u, w), only the rows that are read after set-up: vx and ey of stages 1..N-1 (state rows), all six
+    // components of stage N (terminal equality).  Row r of the table is S + r * NU2.
+    static constexpr int SROWS = 2 * (NMAX - 1) + 6;
+    static constexpr int S = xf + 6 * (NMAX + 1);
+    static constexpr int srow(int k, int ey) { return 2 * (k - 1) + ey; }          // 1 <= k <= N-1
+    static constexpr int srowN(int c6) { return 2 * (NMAX - 1) + c6; }              // stage N
+    static constexpr int Hu = S + SROWS * NU2;                 // NU2 x NU2, row-major, stride NU2
     static constexpr int SS = Hu + NU2 * NU2;                  // [6][MS]
     static constexpr int qf = SS + 6 * MS;
     static constexpr int u = qf + MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
@@ -57,8 +62,11 @@ struct LL {
     static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
     static constexpr int dmy = Fph + LMAXF;                    // sink of address-predicated stores
     static constexpr int END = dmy + 2;
+    static constexpr int TB = t;                               // set-up / write-back scratch over the row arrays: one stage of the
+                                                               // full sensitivity block [6][NU2]; the plan X [NMAX+1][6]
+    static_assert(6 * NU2 <= 7 * MR && 6 * (NMAX + 1) <= 7 * MR, "scratch fits");
     // (G = D + T T' is never assembled -- product-form factorisation in registers -- so the footprint no longer depends on
-    // the safe-set size: 50.9 KB at NMAX = 12 = three problems per CU, 77 KB before)
+    // the safe-set size; with the compact sensitivity table 38.9 KB at NMAX = 12 = four problems per CU, 77 KB / two before)
     static constexpr size_t bytes(int /*n_ss_max*/) { return (size_t)END * 8; }
 };
 
@@ -87,7 +95,7 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
         const double ub = (q & 2) ? kp.a_max : kp.delta_max, uv = LDS(L::u + 2 * (rb >> 2) + (q >> 1));
         const double cbox = (q & 1) ? ub - uv : uv + ub;
         const int rr = isst ? r - x.r_st : 0, k = rr / 3 + 1, q3 = rr - 3 * (k - 1);
-        const int so = L::S + (k * 6 + (q3 ? 5 : 0)) * L::NU2;
+        const int so = L::S + L::srow(k, q3 ? 1 : 0) * L::NU2;
         double s0 = LDS(L::xf + 6 * k + (q3 ? 5 : 0)), s1 = 0.0;
 #pragma unroll 4
         for (int a = 0; a < x.nv; a += 2) {
@@ -120,15 +128,15 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
         const int a = av ? x.lane : 0, ab = a < x.nu2 ? a : 0, i = ab >> 1, cc = ab & 1;
         double s = LDS(L::gu + a);
 #pragma unroll
-        for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + (x.N * 6 + c6) * L::NU2 + a), LDS(L::y + c6), s);
+        for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::S + L::srowN(c6) * L::NU2 + a), LDS(L::y + c6), s);
         const double bl = LDS(wo + 4 * i + 2 * cc), bh = LDS(wo + 4 * i + 2 * cc + 1);
         s -= sel(a < x.nu2, bl - bh, 0.0);
         // state rows: c = bound -/+ x_k  ->  J'w = -S0 w_vx - S5 (w_eyhi - w_eylo); all stages (S is zero for k <= a/2)
         double s2 = 0.0;
 #pragma unroll 4
         for (int k = 1; k < x.N; k++) {
-            s = fma(LDS(L::S + (k * 6 + 0) * L::NU2 + a), LDS(L::w0 + k), s);
-            s2 = fma(LDS(L::S + (k * 6 + 5) * L::NU2 + a), LDS(L::w5 + k), s2);
+            s = fma(LDS(L::S + L::srow(k, 0) * L::NU2 + a), LDS(L::w0 + k), s);
+            s2 = fma(LDS(L::S + L::srow(k, 1) * L::NU2 + a), LDS(L::w5 + k), s2);
         }
         LDS(LSINK(av, L::ru + a)) = s + s2;
     }
@@ -172,7 +180,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     if (lane < M) LDS(L::qf + lane) = kp.qfun[(size_t)Mx * pb + lane];
     if (lane < 6) LDS(L::xf + lane) = kp.x0[6 * pb + lane];
     const double uold0 = kp.u_old[2 * pb], uold1 = kp.u_old[2 * pb + 1];
-    for (int i = lane; i < 6 * (NMAX + 1) * L::NU2; i += WAVE) LDS(L::S + i) = 0.0;
+    for (int i = lane; i < L::SROWS * L::NU2; i += WAVE) LDS(L::S + i) = 0.0;
     for (int i = lane; i < L::NU2 * L::NU2; i += WAVE) LDS(L::Hu + i) = 0.0;
     SYNC();
     // free response
@@ -184,87 +192,77 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         }
         SYNC();
     }
-    // sensitivities: lane a propagates column a of S (columns 2N..2N+5: dx_k/dx_0, used by the second attempt)
-    if (lane >= nu2 && lane < nu2 + 6) {
-        const int a = lane, c0 = lane - nu2;
-        double col[6];
-        for (int r = 0; r < 6; r++) {
-            col[r] = r == c0 ? 1.0 : 0.0;
-            LDS(L::S + (0 * 6 + r) * L::NU2 + a) = col[r];
+    // cost: f = 1/2 u'Hu u + g0u'u + f0 + qf'lambd; the R / dR part first, the tracking part (Q) stage by stage below
+    double f0 = kp.dR[0] * uold0 * uold0 + kp.dR[1] * uold1 * uold1;
+    const bool anyQ = kp.Q[0] != 0.0 || kp.Q[1] != 0.0 || kp.Q[2] != 0.0 || kp.Q[3] != 0.0 || kp.Q[4] != 0.0 || kp.Q[5] != 0.0;
+    if (lane < nu2) {
+        const int a = lane, i = a >> 1, cc = a & 1;
+        const double R = cc ? kp.R[1] : kp.R[0], dR = cc ? kp.dR[1] : kp.dR[0];
+        double dd = 2.0 * R + 2.0 * dR + (i + 1 < N ? 2.0 * dR : 0.0);
+        LDS(L::Hu + a * L::NU2 + a) = dd;
+        if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
+        if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
+        LDS(L::g0u + a) = i == 0 ? -2.0 * dR * (cc ? uold1 : uold0) : 0.0;
+    } else if (lane < nu2 + 6) {
+        LDS(L::Hu + lane * L::NU2 + lane) = 2.0 * kp.w_x0;
+        LDS(L::g0u + lane) = 0.0;
+    }
+    if (anyQ) {
+        for (int c6 = 0; c6 < 6; c6++) {
+            const double r0 = LDS(L::xf + c6) - kp.x_track[c6];
+            f0 += kp.Q[c6] * r0 * r0;
         }
+        if (lane >= nu2 && lane < nu2 + 6) {   // stage 0 of the second attempt: x_0 = xcurv + w, dx_0/dw = I
+            const int c6 = lane - nu2;
+            LDS(L::Hu + lane * L::NU2 + lane) += 2.0 * kp.Q[c6];
+            LDS(L::g0u + lane) += 2.0 * kp.Q[c6] * (LDS(L::xf + c6) - kp.x_track[c6]);
+        }
+    }
+    SYNC();
+    // sensitivities: lane a propagates column a of dx_k/d(u, w) through the stages (columns 2N..2N+5: dx_k/dx_0, used by the
+    // second attempt).  Only the rows read later are kept (LL::srow / srowN); the full block of the current stage passes
+    // through the scratch TB for the tracking cost.
+    {
+        const bool col_on = lane < nu2 + 6;
+        const int a = col_on ? lane : 0, ka = a >> 1, ca = a & 1;
+        double col[6];
+        for (int r = 0; r < 6; r++) col[r] = (a >= nu2 && r == a - nu2) ? 1.0 : 0.0;
         for (int k = 0; k < N; k++) {
             double nc[6];
             for (int r = 0; r < 6; r++) {
-                double s = 0.0;
+                double s = (a < nu2 && k == ka) ? LDS(L::B + 12 * k + 2 * r + ca) : 0.0;
                 for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * r + c6), col[c6], s);
                 nc[r] = s;
             }
-            for (int r = 0; r < 6; r++) {
-                col[r] = nc[r];
-                LDS(L::S + ((k + 1) * 6 + r) * L::NU2 + a) = nc[r];
-            }
-        }
-    }
-    if (lane < nu2) {
-        const int a = lane, ka = a >> 1, ca = a & 1;
-        double col[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = ka; k < N; k++) {
-            double nc[6];
-            if (k == ka) {
-                for (int r = 0; r < 6; r++) nc[r] = LDS(L::B + 12 * k + 2 * r + ca);
-            } else {
-                for (int r = 0; r < 6; r++) {
-                    double s = 0.0;
-                    for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * r + c6), col[c6], s);
-                    nc[r] = s;
+            for (int r = 0; r < 6; r++) col[r] = nc[r];
+            if (col_on) {
+                if (k + 1 < N) {
+                    LDS(L::S + L::srow(k + 1, 0) * L::NU2 + a) = nc[0];
+                    LDS(L::S + L::srow(k + 1, 1) * L::NU2 + a) = nc[5];
+                } else {
+                    for (int r = 0; r < 6; r++) LDS(L::S + L::srowN(r) * L::NU2 + a) = nc[r];
                 }
             }
-            for (int r = 0; r < 6; r++) {
-                col[r] = nc[r];
-                LDS(L::S + ((k + 1) * 6 + r) * L::NU2 + a) = nc[r];
+            if (anyQ) {
+                if (col_on)
+                    for (int r = 0; r < 6; r++) LDS(L::TB + r * L::NU2 + a) = nc[r];
+                SYNC();
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double q = kp.Q[c6];
+                    if (q == 0.0) continue;
+                    const double r0 = LDS(L::xf + 6 * (k + 1) + c6) - kp.x_track[c6];
+                    if (col_on) {
+                        const double sa = nc[c6];
+                        LDS(L::g0u + a) += 2.0 * q * r0 * sa;
+                        for (int b = 0; b < nu2 + 6; b++) LDS(L::Hu + a * L::NU2 + b) += 2.0 * q * sa * LDS(L::TB + c6 * L::NU2 + b);
+                    }
+                    f0 += q * r0 * r0;
+                }
+                SYNC();
             }
         }
     }
     SYNC();
-    // cost: f = 1/2 u'Hu u + g0u'u + f0 + qf'lambd (+ rho 1'(p+q))
-    double f0 = 0.0;
-    {
-        const bool anyQ = kp.Q[0] != 0.0 || kp.Q[1] != 0.0 || kp.Q[2] != 0.0 || kp.Q[3] != 0.0 || kp.Q[4] != 0.0 || kp.Q[5] != 0.0;
-        if (lane < nu2) {
-            const int a = lane, i = a >> 1, cc = a & 1;
-            const double R = cc ? kp.R[1] : kp.R[0], dR = cc ? kp.dR[1] : kp.dR[0];
-            double dd = 2.0 * R + 2.0 * dR + (i + 1 < N ? 2.0 * dR : 0.0);
-            LDS(L::Hu + a * L::NU2 + a) = dd;
-            if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
-            if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
-            LDS(L::g0u + a) = i == 0 ? -2.0 * dR * (cc ? uold1 : uold0) : 0.0;
-        } else if (lane < nu2 + 6) {
-            LDS(L::Hu + lane * L::NU2 + lane) = 2.0 * kp.w_x0;
-            LDS(L::g0u + lane) = 0.0;
-        }
-        f0 = kp.dR[0] * uold0 * uold0 + kp.dR[1] * uold1 * uold1;
-        SYNC();
-        if (anyQ) {
-            for (int k = 1; k <= N; k++)
-                for (int c6 = 0; c6 < 6; c6++) {
-                    const double q = kp.Q[c6];
-                    if (q == 0.0) continue;
-                    const double r0 = LDS(L::xf + 6 * k + c6) - kp.x_track[c6];
-                    const int so = L::S + (k * 6 + c6) * L::NU2;
-                    if (lane < nu2 + 6) {
-                        const double sa = LDS(so + lane);
-                        LDS(L::g0u + lane) += 2.0 * q * r0 * sa;
-                        for (int b = 0; b < nu2 + 6; b++) LDS(L::Hu + lane * L::NU2 + b) += 2.0 * q * sa * LDS(so + b);
-                    }
-                    f0 += q * r0 * r0;
-                }
-            for (int c6 = 0; c6 < 6; c6++) {
-                const double r0 = LDS(L::xf + c6) - kp.x_track[c6];
-                f0 += kp.Q[c6] * r0 * r0;
-            }
-            SYNC();
-        }
-    }
     // rows on the fixed x0 (i = 0) are constants: violated -> the reference's QP is infeasible
     int bad0 = 0;
     {
@@ -330,7 +328,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 double ec[7];
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
-                    const int so = L::S + (N * 6 + c6) * L::NU2;
+                    const int so = L::S + L::srowN(c6) * L::NU2;
                     const int a = lane < nv ? lane : 0, j = lane < M ? lane : 0;
                     const double pu = LDS(so + a) * LDS(L::u + a), pl = LDS(L::SS + c6 * L::MS + j) * LDS(L::lam + j);
                     ec[c6] = sel(lane < nv, pu, 0.0) - sel(lane < M, pl, 0.0);
@@ -428,7 +426,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
 #pragma unroll
                     for (int q = 0; q < 6; q++) acc[q] = LDS(L::Hu + a * L::NU2 + b0 + q) + sel(b0 + q == a && a < nu2, d0 + d1, 0.0);
                     for (int k = 1; k < N; k++) {
-                        const int r0 = L::S + (k * 6 + 0) * L::NU2, r5 = L::S + (k * 6 + 5) * L::NU2;
+                        const int r0 = L::S + L::srow(k, 0) * L::NU2, r5 = L::S + L::srow(k, 1) * L::NU2;
                         const double sa0 = LDS(r0 + a), sa5 = LDS(r5 + a), w0k = LDS(L::w0 + k), w5k = LDS(L::w5 + k);
                         double sb0[6], sb5[6];
 #pragma unroll
@@ -445,7 +443,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             for (int e0 = 0; e0 < 7 * nv; e0 += WAVE) {
                 const int en = e0 + lane < 7 * nv ? e0 + lane : 0;
                 const int r = en / nv, j = en - r * nv;
-                const double sv = LDS(L::S + (N * 6 + (r < 6 ? r : 0)) * L::NU2 + j), rv = LDS(L::ru + j);
+                const double sv = LDS(L::S + L::srowN(r < 6 ? r : 0) * L::NU2 + j), rv = LDS(L::ru + j);
                 LDS(L::K + (nv + r) * L::LDK + j) = sel(r < 6, sv, -rv);
             }
             SYNC();
@@ -601,7 +599,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const int rb = isbox ? r : 0;
                 const double db = LDS(L::du + 2 * (rb >> 2) + ((rb & 3) >> 1));
                 const double jbox = (rb & 1) ? -db : db;
-                const int rr = isst ? r - x.r_st : 0, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + (k * 6 + (q ? 5 : 0)) * L::NU2;
+                const int rr = isst ? r - x.r_st : 0, k = rr / 3 + 1, q = rr - 3 * (k - 1), so = L::S + L::srow(k, q ? 1 : 0) * L::NU2;
                 double s0 = 0.0, s1 = 0.0;     // all inputs: S is zero for a >= 2k
 #pragma unroll 4
                 for (int a = 0; a < nv; a += 2) {
@@ -729,15 +727,24 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         if (attempt == 0 && status == CRX_CONVERGED && !bad0) break;
         if (attempt == 1 && status == CRX_CONVERGED) status = CRX_INFEASIBLE;   // the reference's (pinned) QP was not solved
     }
-    // ---- write back ----
-    for (int i = lane; i < 6 * (N + 1); i += WAVE) {
-        const int k = i / 6, c6 = i - 6 * k;
-        double s = LDS(L::xf + i);
-        const int so = L::S + (k * 6 + c6) * L::NU2;
-        for (int a = 0; a < 2 * k; a++) s = fma(LDS(so + a), LDS(L::u + a), s);
-        for (int a = nu2; a < x.nv; a++) s = fma(LDS(so + a), LDS(L::u + a), s);   // second attempt: the plan starts at xcurv + w
-        kp.X[(size_t)6 * (N + 1) * pb + i] = s;
+    // ---- write back: the plan by a roll-out of the model from x_0 (+ w in the second attempt) with the optimal inputs;
+    // A, B, C come back from HBM into the K region, the states go through the scratch TB ----
+    for (int i = lane; i < 36 * N; i += WAVE) LDS(L::A + i) = kp.A[(size_t)36 * N * pb + i];
+    for (int i = lane; i < 12 * N; i += WAVE) LDS(L::B + i) = kp.B[(size_t)12 * N * pb + i];
+    for (int i = lane; i < 6 * N; i += WAVE) LDS(L::C + i) = kp.C[(size_t)6 * N * pb + i];
+    if (lane < 6) LDS(L::TB + lane) = LDS(L::xf + lane) + (x.nv > nu2 ? LDS(L::u + nu2 + lane) : 0.0);
+    SYNC();
+    for (int k = 0; k < N; k++) {
+        if (lane < 6) {
+            double s = LDS(L::C + 6 * k + lane);
+            for (int c6 = 0; c6 < 6; c6++) s = fma(LDS(L::A + 36 * k + 6 * lane + c6), LDS(L::TB + 6 * k + c6), s);
+            s = fma(LDS(L::B + 12 * k + 2 * lane), LDS(L::u + 2 * k), s);
+            s = fma(LDS(L::B + 12 * k + 2 * lane + 1), LDS(L::u + 2 * k + 1), s);
+            LDS(L::TB + 6 * (k + 1) + lane) = s;
+        }
+        SYNC();
     }
+    for (int i = lane; i < 6 * (N + 1); i += WAVE) kp.X[(size_t)6 * (N + 1) * pb + i] = LDS(L::TB + i);
     if (lane < nu2) kp.U[(size_t)nu2 * pb + lane] = LDS(L::u + lane);
     if (lane < Mx) kp.lambda[(size_t)Mx * pb + lane] = lane < M ? LDS(L::lam + lane) : 0.0;
     if (lane == 0) {

@@ -119,6 +119,17 @@ static int lmpc_setup(lw_t* w, int elastic) {
                 w->g0[a] += 2.0 * q * r0 * w->S[k][c][a];
                 for (int b = 0; b < 2 * k; b++) w->H[a][b] += 2.0 * q * w->S[k][c][a] * w->S[k][c][b];
             }
+            if (elastic) {   /* the relaxed initial state x_0 + w moves every tracked state: dx_k/dw = P[k] */
+                const int w0 = nu2 + M;
+                for (int e = 0; e < 6; e++) {
+                    w->g0[w0 + e] += 2.0 * q * r0 * w->P[k][c][e];
+                    for (int b = 0; b < 2 * k; b++) {
+                        w->H[w0 + e][b] += 2.0 * q * w->P[k][c][e] * w->S[k][c][b];
+                        w->H[b][w0 + e] += 2.0 * q * w->P[k][c][e] * w->S[k][c][b];
+                    }
+                    for (int e2 = 0; e2 < 6; e2++) w->H[w0 + e][w0 + e2] += 2.0 * q * w->P[k][c][e] * w->P[k][c][e2];
+                }
+            }
         }
     for (int i = 0; i < N; i++)
         for (int c = 0; c < 2; c++) {
@@ -138,7 +149,7 @@ static int lmpc_setup(lw_t* w, int elastic) {
         }
     for (int j = 0; j < M; j++) w->g0[nu2 + j] = w->qf[j];
     if (elastic)
-        for (int c = 0; c < 6; c++) w->H[nu2 + M + c][nu2 + M + c] = 2.0 * d->w_x0;
+        for (int c = 0; c < 6; c++) w->H[nu2 + M + c][nu2 + M + c] += 2.0 * d->w_x0;
     /* rows */
     int m = 0, bad0 = 0;
 #define NEWROW() do { memset(w->J[m], 0, sizeof(double) * n); w->jb[m] = 0.0; } while (0)

@@ -353,9 +353,11 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
     # learning-MPC QPs: ragged safe-set sizes (first n points of each recorded hull) and shorter horizons
     g = golden_racing_game
     ok = np.nonzero(g["lmpc_success"])[0][:24]
-    for N in (12, 9, 5, 14, 16):      # 14 and 16 (the second horizon class of the kernel): last stage model repeated
+    # 14 and 16 (the second horizon class of the kernel): last stage model repeated; the last case adds a tracking cost
+    # (matrix_Q, zero in the reference's LMPCRacingParam), which the kernel accumulates stage by stage at set-up
+    for N, Q in ((12, None), (9, None), (5, None), (14, None), (16, None), (12, (1.0, 0.0, 0.0, 0.5, 0.0, 4.0))):
         M = g["lmpc/ss"].shape[2]
-        d = abi.lmpc_desc(N=N, n_ss_max=M)
+        d = abi.lmpc_desc(N=N, n_ss_max=M) if Q is None else abi.lmpc_desc(N=N, n_ss_max=M, Q=Q)
         n_ss = rng.integers(8, M + 1, len(ok)).astype(np.int32)
         idx = np.minimum(np.arange(N), g["lmpc/A"].shape[1] - 1)
         args = (g["lmpc/x"][ok], g["lmpc/u_old"][ok], g["lmpc/A"][ok][:, idx], g["lmpc/B"][ok][:, idx], g["lmpc/C"][ok][:, idx],
