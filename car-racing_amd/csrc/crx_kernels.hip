@@ -117,20 +117,28 @@ struct Lay {
     static constexpr int rw = rsig + MR;             // w = nu - mu/t + Sigma*(c - t)
     static constexpr int rsc = rw + MR;              // row scale (0 = row absent)
     static constexpr int rb = rsc + MR;              // simple rows: bound (their sign lives in the riv table)
-    static constexpr int G = rb + MR;                // [NMAX][NO][8] CBF derivatives at the iterate
-    static constexpr int Hd = G + NMAX * NOBS * 8;   // [NV] stage Hessian diagonal
+    static constexpr int G = rb + MR;                // [NMAX][NO][4] CBF curvatures at the iterate: d2/ds2, d2/dey2 of the "next" term, then
+                                                     // of the "current" term (the gradients go straight into Jc)
+    static constexpr int Hd = G + NMAX * NOBS * 4;   // [NV] stage Hessian diagonal
     static constexpr int hg = Hd + NV;               // [NV] Newton gradient
     static constexpr int ga = hg;                    // Lagrangian gradient / reduced form: SAME storage -- assemble_newton turns ga[e]
                                                      // into hg[e] in place, and nothing reads ga again before first_order rebuilds it
     static constexpr int Jc = hg + NV;               // [NMAX][NO][NZ] CBF Jacobians (scaled)
     static constexpr int kS = Jc + NMAX * NOBS * NZ; // [NMAX] "next" CBF curvature on s_{k+1}
     static constexpr int kE = kS + (NOBS ? NMAX : 0);   //        ... on ey_{k+1}
-    static constexpr int P = kE + (NOBS ? NMAX : 0); // Riccati work
+    // Riccati work.  The backward sweep runs while two arrays are dead: the row steps rdt (rewritten by the row-step pass
+    // that follows the forward sweep) and the Newton step dZ beyond its first stage (rewritten by the forward sweep; the
+    // first stage receives sigma_0 at the end of the backward sweep).  P, pv, T live in the former and H in the latter
+    // wherever they fit (they do for every instantiation but H of <2,12> and <3,12>).
+    static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
+    static constexpr bool PT_ALIAS = NX * NX + NX + NX * NZ <= MR, H_ALIAS = NZ * HS <= NMAX * NZ;
+    static constexpr int WORK = kE + (NOBS ? NMAX : 0);
+    static constexpr int P = PT_ALIAS ? rdt : WORK;
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
-    static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
-    static constexpr int H = T + NX * NZ;            // [NZ][HS]
-    static constexpr int Kk = H + NZ * HS;           // [NMAX][NU][NX]
+    static constexpr int WORK2 = PT_ALIAS ? WORK : T + NX * NZ;
+    static constexpr int H = H_ALIAS ? dZ + NZ : WORK2;      // [NZ][HS]
+    static constexpr int Kk = H_ALIAS ? WORK2 : H + NZ * HS; // [NMAX][NU][NX]
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
     static constexpr int Fph = Fth + MAXF;
@@ -288,7 +296,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
             const int e0 = c.lane + q_ * WAVE;
             const int e = e0 < N * NOBS ? e0 : 0;          // lanes past the table recompute entry 0 (same values)
             const int k = e / L::NO, o = e - k * L::NO;
-            double* G = sm + L::G + (k * L::NO + o) * 8;
+            double* G = sm + L::G + (k * L::NO + o) * 4;
             double* J = sm + L::Jc + (k * L::NO + o) * L::NZ;
             // absent obstacle (o >= nobs): its data may be anything; every product below is discarded by a select, so
             // that 0 * (stale LDS) never becomes NaN in G / J
@@ -305,9 +313,8 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
             double m4[L::NZ], m5[L::NZ];
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) { m4[a] = LD(L::M + 4 * L::NZ + a); m5[a] = LD(L::M + 5 * L::NZ + a); }
-            G[0] = sel(here, gsn, 0.0); G[1] = sel(here, gen, 0.0); G[2] = sel(here, gsc, 0.0); G[3] = sel(here, gec, 0.0);
-            G[4] = sel(here, qq * p2sn * c.rLs * c.rLs, 0.0); G[5] = sel(here, qq * p2en * c.rWs * c.rWs, 0.0);
-            G[6] = sel(here, qq * p2sc * c.rLs * c.rLs, 0.0); G[7] = sel(here, qq * p2ec * c.rWs * c.rWs, 0.0);
+            G[0] = sel(here, qq * p2sn * c.rLs * c.rLs, 0.0); G[1] = sel(here, qq * p2en * c.rWs * c.rWs, 0.0);
+            G[2] = sel(here, qq * p2sc * c.rLs * c.rLs, 0.0); G[3] = sel(here, qq * p2ec * c.rWs * c.rWs, 0.0);
             // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) {
@@ -438,7 +445,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
                 const int j = kk * L::NR + 8 + NOBS + ob;
                 const double jca = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a), rwj = LD(L::rw + j);
                 g += sel(k < N, jca * rwj, 0.0);
-                const double cur = LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (kk * L::NO + ob) * 8 + (a == 4 ? 6 : 7));
+                const double cur = LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (kk * L::NO + ob) * 4 + (a == 4 ? 2 : 3));
                 h += sel(k < N && (a == 4 || a == 5), cur, 0.0);
             }
         }
@@ -453,8 +460,8 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         for (int o = 0; o < NOBS; o++) {
             const int j = k * L::NR + 8 + NOBS + o;
             const double nd = LD(L::rnu + j) * LD(L::rsc + j);
-            ks -= nd * LD(L::G + (k * L::NO + o) * 8 + 4);
-            ke -= nd * LD(L::G + (k * L::NO + o) * 8 + 5);
+            ks -= nd * LD(L::G + (k * L::NO + o) * 4 + 0);
+            ke -= nd * LD(L::G + (k * L::NO + o) * 4 + 1);
         }
         LD(L::kS + k) = ks;
         LD(L::kE + k) = ke;
