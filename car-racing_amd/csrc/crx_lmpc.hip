@@ -1,8 +1,8 @@
 // crx_lmpc.hip -- gfx950 kernel for the learning-MPC QP of car-racing (SURVEY.md section 8f row 1;
 // reference: /root/reference/car_racing/control/control.py:610-730 `lmpc`).
 //
-// One QP per 64-lane wavefront, everything in that wave's LDS slice, FP64, no MFMA (largest dense
-// block 60x60, factorised once per iteration along a serial dependency chain).
+// One QP per 64-lane wavefront, everything in that wave's LDS slice (38.9 KB at N <= 12: four problems per CU), FP64,
+// no MFMA (largest dense block 30x30, factorised once per iteration along a serial dependency chain).
 //
 //   variables   u_0..u_{N-1} (2N), lambd (M <= 60); states eliminated by the affine LTV roll-out
 //               x_k = xf_k + S_k u   (S_k = dx_k/du, built once per problem)
@@ -18,12 +18,16 @@
 //   K_u = H_u + J_u' Sigma J_u  (2N x 2N)          -> L_u, with Phi and rhs_u carried as extra rows,
 //                                                      so  Y = L_u^-1 Phi',  z = L_u^-1 rhs_u  come for free
 //   W   = Y Y'                     (6 x 6)          -> L_w   (per lane, registers)
-//   G   = D_lambda + T T',  T = SS' L_w^-T (M x 6) -> L_g, with the two right-hand sides as extra rows
+//   G   = D_lambda + T T',  T = SS' L_w^-T (M x 6) -> never assembled: product form L_1..L_6 D' L_6'..L_1' by six positive
+//                                                      rank-one updates of the diagonal factor, every triangular solve
+//                                                      ONE wave prefix / suffix scan (lane j = element j; see the block
+//                                                      comment in the kernel)
 //   dy_1 from 1'dlambd = -e_1, then dlambd, dy_x, du by back substitution.
 // A Schur complement on the 7 equalities (E K^-1 E') is NOT used: the active lambd's carry no
 // curvature but the barrier's, so K^-1 spans 1e-16..1e16 near the solution; G stays well scaled.
-// Lane i owns row i of each factor (left-looking Cholesky: row j is read as an LDS broadcast), the
-// pivots are broadcast with v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps.
+// Lane i owns row i of L_u (left-looking Cholesky blocked by four columns: rows are read as LDS broadcasts, the pivots of
+// a diagonal block are broadcast with v_readlane), 1/sqrt by v_rsq_f64 + 2 Newton steps.  The oracle factorises G with a
+// dense Cholesky: the parity tests compare the two routes.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
