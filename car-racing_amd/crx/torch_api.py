@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from . import binding, lib
+from . import _state, binding, lib
 
 
 def _ptr(t):
@@ -18,6 +18,11 @@ def _chk(t, dtype, shape, name):
     if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
         raise ValueError("%s: expected contiguous cuda %s tensor of shape %s, got %s %s %s" % (
             name, dtype, tuple(shape), t.device, t.dtype, tuple(t.shape)))
+    # the *_dev entry points launch on the device libcrx was initialised on: a tensor living elsewhere would be
+    # dereferenced on the wrong GPU
+    dev = _state["device"]
+    if dev is not None and t.device.index != dev:
+        raise ValueError("%s lives on %s but libcrx was initialised on cuda:%d (crx.init(device))" % (name, t.device, dev))
     return t
 
 
@@ -32,7 +37,8 @@ def _call(name, *args):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    binding()
+    return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", _state["device"])).cuda_stream)
 
 
 class CbfWorkspace:

@@ -159,12 +159,11 @@ void timing_begin(hipStream_t st) {
         (void)hipEventCreate(&g_ev0);
         (void)hipEventCreate(&g_ev1);
     }
-    (void)hipEventRecord(g_ev0, st);
+    g_ev_valid = g_ev0 && g_ev1 && hipEventRecord(g_ev0, st) == hipSuccess;
 }
 void timing_end(hipStream_t st) {
     if (!g_timing) return;
-    (void)hipEventRecord(g_ev1, st);
-    g_ev_valid = true;
+    g_ev_valid = g_ev_valid && hipEventRecord(g_ev1, st) == hipSuccess;
 }
 
 int check_opts(const crx_ipm_opts& o) {
@@ -247,8 +246,16 @@ int crx_init(int device) {
     if (device < 0 || device >= n) return fail(CRX_ERR_ARG, "device %d outside [0,%d)", device, n);
     HIP_TRY(hipSetDevice(device));
     if (g_init && g_device == device) return CRX_OK;
-    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-    g_in.release(); g_out.release(); g_hin.release(); g_hout.release();
+    if (g_init && g_device >= 0) {
+        // everything below belongs to the old device: release it there (events and the trace buffer included --
+        // recording a stale event fails silently and crx_last_kernel_ms would return garbage)
+        (void)hipSetDevice(g_device);
+        if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+        g_in.release(); g_out.release(); g_hin.release(); g_hout.release(); g_trace.release();
+        if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); g_ev0 = g_ev1 = nullptr; }
+        g_ev_valid = false; g_trace_rows = 0;
+        HIP_TRY(hipSetDevice(device));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     g_device = device;
     g_init = true;
@@ -259,7 +266,8 @@ void crx_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) return;
     (void)hipSetDevice(g_device);
-    g_in.release(); g_out.release(); g_hin.release(); g_hout.release();
+    g_in.release(); g_out.release(); g_hin.release(); g_hout.release(); g_trace.release();
+    g_trace_rows = 0;
     if (g_stream) (void)hipStreamDestroy(g_stream);
     if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); }
     g_stream = nullptr; g_ev0 = g_ev1 = nullptr; g_ev_valid = false;
@@ -429,13 +437,22 @@ int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const doub
 }
 
 // ---- selection -------------------------------------------------------------------------------------
+static int check_select(const crx_select_desc* d, int n_scen) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
+        return fail(CRX_ERR_ARG, "bad selection dimensions");
+    // the kernel wraps predicted s by lap_length (overtake_traj_planner.py:216-217): a zeroed descriptor must be a call
+    // failure, not a device loop
+    if (!(d->lap_length > 0.0) || !isfinite(d->lap_length)) return fail(CRX_ERR_ARG, "lap_length must be positive and finite");
+    if (!(d->veh_length >= 0.0) || !(d->veh_width >= 0.0)) return fail(CRX_ERR_ARG, "vehicle dimensions must be non-negative");
+    return 0;
+}
+
 int crx_select_dev(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X, const double* obs_s,
                    const double* obs_ey, const int32_t* old_flag, int32_t* flag, double* sel_cost, double* best_X,
                    void* stream) {
     if (int rc = ensure_init()) return rc;
-    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
-    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
-        return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (int rc = check_select(d, n_scen)) return rc;
     if (n_scen == 0) return CRX_OK;
     if (!n_veh || !X || !old_flag || !flag || !sel_cost || !best_X || (d->n_veh_max > 0 && (!obs_s || !obs_ey)))
         return fail(CRX_ERR_ARG, "NULL array argument");
@@ -453,9 +470,7 @@ int crx_select_dev(const crx_select_desc* d, int n_scen, const int32_t* n_veh, c
 int crx_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X, const double* obs_s,
                const double* obs_ey, const int32_t* old_flag, int32_t* flag, double* sel_cost, double* best_X) {
     if (int rc = ensure_init()) return rc;
-    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
-    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
-        return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (int rc = check_select(d, n_scen)) return rc;
     if (n_scen == 0) return CRX_OK;
     if (!n_veh || !X || !old_flag || !flag || !sel_cost || !best_X || (d->n_veh_max > 0 && (!obs_s || !obs_ey)))
         return fail(CRX_ERR_ARG, "NULL array argument");
@@ -768,8 +783,9 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
                          int32_t* flag, double* sel_cost, double* best_X, void* stream) {
     if (!d || !sd) return fail(CRX_ERR_ARG, "desc is NULL");
     if (sd->N != d->N) return fail(CRX_ERR_ARG, "planner and selection horizons differ");
-    if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
+    if (int rc = check_select(sd, n_scen)) return rc;   // before R = n_veh_max + 1 sizes the QP launch
     const int R = sd->n_veh_max + 1;
+    if ((long long)n_scen * R > 0x7fffffffLL) return fail(CRX_ERR_ARG, "n_scen * (n_veh_max + 1) overflows int");
     if (int rc = crx_planner_solve_dev(d, n_scen * R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters, stream)) return rc;
     return crx_select_dev(sd, n_scen, n_veh, X, obs_s, obs_ey, old_flag, flag, sel_cost, best_X, stream);
 }
@@ -785,7 +801,7 @@ int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n
     if (int rc = ensure_init()) return rc;
     crx_kparams chk;
     if (int rc = fill_planner(chk, d, 0)) return rc;
-    if (sd->n_veh_max < 0 || sd->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "bad selection dimensions");
+    if (int rc = check_select(sd, n_scen)) return rc;
     if (n_scen == 0) return CRX_OK;
     if (!x0 || !bez_s || !bez_ey || !ey_lb || !ey_ub || !n_veh || !old_flag || !X || !U || !cost || !status || !kkt || !iters ||
         !flag || !sel_cost || !best_X || (sd->n_veh_max > 0 && (!obs_s || !obs_ey)))

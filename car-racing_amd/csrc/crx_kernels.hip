@@ -1264,7 +1264,10 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     double* Ub = kp.U + (size_t)b * N * 2;
     if (kp.mode == 0 && status != 0) {
         // reference fall-back trajectory (overtake_traj_planner.py:365-374)
-        const double s0 = kp.x0[(size_t)b * 6 + 4], vx0 = kp.x0[(size_t)b * 6];
+        // The reference builds it from the start-line-WRAPPED ego state xcurv_ego (:366-369) although the QP's x_0 is the raw
+        // ego.xcurv (quirk Q5).  Only s differs between the two, and the wrapped s is the first Bezier control point
+        // (planner_helper.py:49; the Bernstein weights at t = 0 are exactly 1, 0, 0, 0), so it is read from there.
+        const double vx0 = kp.x0[(size_t)b * 6];
         double* bs = sm + L::hg;
         double* be = sm + L::Hd;
         for (int j = lane; j <= N; j += WAVE) {
@@ -1272,6 +1275,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             be[j] = kp.bez_ey[(size_t)b * (N + 1) + j];
         }
         SYNC();
+        const double s0 = bs[0];
         for (int e = lane; e < (N + 1) * 6; e += WAVE) {
             const int j = e / 6, i = e - j * 6;
             const double st = s0 + kp.fallback_gain * j * kp.dt_ref * vx0;
@@ -1319,7 +1323,7 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
                 const int v = side == 0 ? r - 1 : r;                                          // :213, :227
                 if (v < 0 || v >= nv) continue;
                 double os = sp.obs_s[((size_t)s * V + v) * (N + 1) + j];
-                while (os > sp.lap_length) os -= sp.lap_length;                               // :216-217
+                os = wrap_above(os, sp.lap_length);                                             // :216-217
                 const double ds = Xr[6 * j + 4] - os;
                 const double de = Xr[6 * j + 5] - sp.obs_ey[((size_t)s * V + v) * (N + 1) + j];
                 if (!(ds * ds + de * de - r2 >= 0.0)) hits += 1.0;                            // :220-223

@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(WAVE) crx_prep_kernel(const crx_prep_kparams p
         const int r = e / (N + 1), j = e - r * (N + 1);
         const int rr = r > nv ? nv : r;   // regions beyond this scenario's vehicles repeat the last one (never selected)
         double e12;
-        if (rr == 0) e12 = 0.8 * tw - (-vi[3 * rr + 1] - 0.5 * vw) * 0.2;                       // :98-104
+        // no vehicle at all (the reference never plans then: get_overtake_flag is false; its code would index an empty
+        // list): the single region gets the curve from the ego to the optimal line, and veh_info is not read
+        if (nv == 0) e12 = e3;
+        else if (rr == 0) e12 = 0.8 * tw - (-vi[3 * rr + 1] - 0.5 * vw) * 0.2;                       // :98-104
         else if (rr == nv) e12 = -0.8 * tw + (vi[3 * (rr - 1) + 1] - 0.5 * vw) * 0.2;           // :106-112
         else e12 = 0.7 * (vi[3 * rr + 1] + 0.5 * vw) + 0.3 * (vi[3 * (rr - 1) + 1] - 0.5 * vw);   // :113-119
         const double t = j * (1.0 / N), u = 1.0 - t;
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__(WAVE) crx_prep_kernel(const crx_prep_kparams p
             const int v = side == 0 ? r - 1 : r;                                                // sorted[r-1], sorted[r]
             if (v < 0 || v >= nv) continue;
             double os = pp.obs_s[((size_t)s * V + v) * (N + 1) + k];
-            while (os > L) os -= L;                                                             // :291-292
+            os = wrap_above(os, L);                                                             // :291-292
             if (s_nom >= os - win && s_nom <= os + win)
                 lb = fmax(lb, pp.obs_ey[((size_t)s * V + v) * (N + 1) + k] + vw + pp.safety_margin);
         }
@@ -122,8 +125,7 @@ __global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams 
     for (int it = 0; it < d.n_sub; it++) {
         // curvature at s (wrapped into one lap), first segment with lo <= s <= hi
         double sw = s;
-        while (sw > d.lap_length) sw -= d.lap_length;
-        while (sw < 0.0) sw += d.lap_length;
+        sw = wrap_below(wrap_above(sw, d.lap_length), d.lap_length);
         double curv = 0.0;
         for (int i = 0; i < d.n_seg; i++)
             if (sw >= seg_lo[i] && sw <= seg_hi[i]) { curv = seg_cv[i]; break; }

@@ -6,6 +6,23 @@
 #include <math.h>
 
 #define WAVE 64
+
+// `while (s > L) s -= L` of the reference (overtake_traj_planner.py:216-217, :291-292; racing_env.py curvature lookup)
+// with a bounded trip count: the first 4 laps are subtracted one by one (bit-identical to the reference's loop, which
+// never sees more than two), anything beyond is reduced in closed form, and a non-finite or non-positive-lap input
+// falls straight through -- garbage in a device-resident array must not be able to hang the GPU.
+__device__ __forceinline__ double wrap_above(double s, double L) {
+#pragma unroll 1
+    for (int i = 0; i < 4 && s > L; i++) s -= L;
+    if (s > L && L > 0.0 && s < 1e300) { s -= L * (ceil(s / L) - 1.0); if (s > L) s -= L; }
+    return s;
+}
+__device__ __forceinline__ double wrap_below(double s, double L) {   // `while (s < 0) s += L`
+#pragma unroll 1
+    for (int i = 0; i < 4 && s < 0.0; i++) s += L;
+    if (s < 0.0 && L > 0.0 && s > -1e300) { s += L * ceil(-s / L); }
+    return s;
+}
 // Every kernel that uses SYNC() runs ONE wavefront per workgroup.  Lanes of a wave execute in lockstep and the LDS
 // unit serves a wave's operations in issue order, so cross-lane exchange through LDS needs no s_barrier and no
 // s_waitcnt -- only that the compiler keeps the program order of the LDS accesses.  A wavefront-scope fence is

@@ -286,7 +286,8 @@ static void setup(work_t* w, const ocp_t* p, const crx_ipm_opts* o) {
     w->nred = N * w->nsv + p->nobs;
     int n = w->nred;
     /* sensitivities */
-    memset(w->Sx, 0, sizeof(w->Sx));
+    for (int k = 0; k <= N; k++)
+        for (int i = 0; i < 6; i++) memset(w->Sx[k][i], 0, sizeof(double) * n);
     for (int k = 0; k < N; k++)
         for (int i = 0; i < 6; i++) {
             for (int a = 0; a < n; a++) {
@@ -367,6 +368,19 @@ typedef struct {
     int status, iters;
     double kkt, cost;
 } result_t;
+
+/* One workspace per thread, allocated on first use and kept for the life of the thread (OpenMP keeps its
+ * pool between parallel regions).  work_t is ~1.3 MB: allocating it inside the parallel region on every
+ * call made the page faults of 128 fresh mappings the dominant cost of a 256-problem batch and the
+ * all-cores figure SLOWER than one thread. */
+static _Thread_local work_t* tl_work = NULL;
+static _Thread_local ocp_t* tl_ocp = NULL;
+static int thread_ws(work_t** w, ocp_t** p) {
+    if (!tl_work) tl_work = (work_t*)malloc(sizeof(work_t));
+    if (!tl_ocp) tl_ocp = (ocp_t*)calloc(1, sizeof(ocp_t));
+    *w = tl_work; *p = tl_ocp;
+    return tl_work && tl_ocp;
+}
 
 #include <stdio.h>
 static int g_verbose = 0;
@@ -615,10 +629,11 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
     const int N = d->N;
 #pragma omp parallel
     {
-    work_t* w = (work_t*)malloc(sizeof(work_t));
-    ocp_t* p = (ocp_t*)calloc(1, sizeof(ocp_t));
+    work_t* w; ocp_t* p;
+    const int have_ws = thread_ws(&w, &p);
 #pragma omp for schedule(dynamic, 4)
     for (int b = 0; b < batch; b++) {
+        if (!have_ws) { status[b] = CRX_MAX_ITER; continue; }
         const double* xb = x0 + 6 * b;
         const double* bs = bez_s + (size_t)(N + 1) * b;
         const double* be = bez_ey + (size_t)(N + 1) * b;
@@ -659,7 +674,9 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
             memset(Xb, 0, sizeof(double) * 6 * (N + 1));
             memset(Ub, 0, sizeof(double) * 2 * N);
             for (int j = 0; j <= N; j++) {
-                double st = xb[4] + d->fallback_gain * j * d->dt_ref * xb[0];
+                /* xcurv_ego (wrapped, :366) differs from ego.xcurv only in s; the wrapped s is the first Bezier
+                 * control point (planner_helper.py:49) */
+                double st = bs[0] + d->fallback_gain * j * d->dt_ref * xb[0];
                 Xb[6 * j + 0] = d->fallback_gain * xb[0];
                 Xb[6 * j + 4] = st;
                 Xb[6 * j + 5] = interp_lin(bs, be, N + 1, clip(st, bs[0], bs[N]));
@@ -668,7 +685,6 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
         }
         status[b] = r.status; kkt[b] = r.kkt; iters[b] = r.iters;
     }
-    free(w); free(p);
     }
     return CRX_OK;
 }
@@ -686,10 +702,11 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
             if (n_obs[b] < 0 || n_obs[b] > V) return CRX_ERR_ARG;
 #pragma omp parallel
     {
-    work_t* w = (work_t*)malloc(sizeof(work_t));
-    ocp_t* p = (ocp_t*)calloc(1, sizeof(ocp_t));
+    work_t* w; ocp_t* p;
+    const int have_ws = thread_ws(&w, &p);
 #pragma omp for schedule(dynamic, 4)
     for (int b = 0; b < batch; b++) {
+        if (!have_ws) { status[b] = CRX_MAX_ITER; continue; }
         const double* xb = x0 + 6 * b;
         memset(p, 0, sizeof(*p));
         p->N = N; p->nobs = n_obs ? n_obs[b] : V;
@@ -727,7 +744,6 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
                 sigma[((size_t)V * b + o) * (N + 1) + k] = o < p->nobs ? w->sig[o][k] : 0.0;
         cost[b] = r.cost; status[b] = r.status; kkt[b] = r.kkt; iters[b] = r.iters;
     }
-    free(w); free(p);
     }
     return CRX_OK;
 }

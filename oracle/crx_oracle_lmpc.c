@@ -556,9 +556,13 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
         if (n_ss[b] < 1 || n_ss[b] > Mx) return CRX_ERR_ARG;
 #pragma omp parallel
     {
-        lw_t* w = (lw_t*)malloc(sizeof(lw_t));
+        /* one workspace per thread for the life of the thread (see crx_oracle.c thread_ws) */
+        static _Thread_local lw_t* tl_w = NULL;
+        if (!tl_w) tl_w = (lw_t*)malloc(sizeof(lw_t));
+        lw_t* w = tl_w;
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < batch; b++) {
+            if (!w) { status[b] = CRX_MAX_ITER; continue; }
             w->d = d; w->N = N; w->M = n_ss[b];
             memcpy(w->x0, x0 + 6 * b, sizeof(w->x0));
             memcpy(w->uold, u_old + 2 * b, sizeof(w->uold));
@@ -589,7 +593,6 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
             cost[b] = r.cost;
             status[b] = r.status; kkt[b] = r.kkt; iters[b] = total;
         }
-        free(w);
     }
     return CRX_OK;
 }
