@@ -1,24 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X: NLP solves/s (N=12, 6-state bicycle).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|lmpc]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5|lmpc|races] [--scaling weak|strong]
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM.  Default workload = BASELINE.json configs[1]: MPC-CBF NLP (control/control.py:476-607 of
-the reference), 1 obstacle, batch 256, N = 12 -- per GPU (weak scaling: the batch shards by problem,
-no data-path collective).  `--workload cfg3` = 1024 planner scenarios x 4 region QPs + region
-selection per GPU, followed by ONE all-gather of the winning trajectories (the only exchange step
-the path has); cfg4 = 16384 tracking NLPs, N = 20, 3 obstacles; lmpc (not a
-BASELINE config) = 4096 learning-MPC QPs (control.py:610-730): the certified instances recorded from the
-reference's LMPC lap (tests/golden/racing_game.npz), tiled.
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.
 
-Rank 0 prints ONE JSON line.  `value` counts every problem handed to the solver per second of the
-timed region, whole job (all GPUs); converged fraction and KKT bound are reported beside it.
+Headline (`metric`/`value`, every N): BASELINE.json configs[1] -- MPC-CBF NLP (control/control.py:476-607 of the
+reference), 1 obstacle, batch 256 per GPU, N = 12, drawn exactly as SURVEY.md section 8d prescribes (no scenario filter
+since round 2: crash states are part of the batch and end in the restoration verdict).  The batch shards by problem, no
+data-path collective: weak scaling, `value` = problems of all ranks / max-over-ranks time.
+
+Without --workload the same run also measures the other single-GPU BASELINE configs and reports them in `configs`
+(each with its own roofline object): cfg3 (1024 planner scenarios x 4 region QPs + selection), cfg4 (16384 tracking NLPs,
+N = 20, 3 obstacles), lmpc (learning-MPC QPs) and cfg5 -- configs[4], the Monte-Carlo sweep
+of overtake-planner scenarios sharded by scenario over the ranks, raw scenario -> Bezier/bounds prep -> region QPs ->
+selection -> ONE all-gather of the winners (crx.pipeline.PlannerSweep), both weak (16384 scenarios per GPU) and strong
+(131072 scenarios in total); the collective is timed separately (`allgather_ms`).
+
+`--gpus N` with N > 1 and no torch.distributed environment re-launches itself under torch.distributed.run (one process per
+GPU, rendezvous on 127.0.0.1).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,18 +40,377 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_GFLOPS = 78600.0  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (vector FP64, spec)
+METRIC = "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency"
 
 
-def algorithmic_bytes(workload, N, n_obs):
+def algorithmic_bytes(kind, N, n_obs):
     """doubles in + doubles out per solve, times 8."""
-    if workload == "cfg3":
+    if kind == "planner":
         return (11 * N + 18) * 8                                   # a1: 1200 B at N = 12
-    if workload == "lmpc":                                          # n_obs carries M here
+    if kind == "lmpc":                                              # n_obs carries M here
         return (8 + 54 * N + 7 * n_obs + 1 + 6 * (N + 1) + 2 * N + n_obs + 3) * 8   # 8912 B at N = 12, M = 44
-    tgt = (N + 1) if workload == "cfg4" else 0                      # per-stage ey target
+    tgt = (N + 1) if kind == "cbf_tracking" else 0                  # per-stage ey target
     d_in = 6 + 6 + 2 * n_obs * (N + 1) + n_obs + tgt
     d_out = 6 * (N + 1) + 2 * N + n_obs * (N + 1) + 3
     return (d_in + d_out) * 8                                       # a5: 1256 B (N=12, 1 obs); a6: 3152 B
+
+
+class Ctx:
+    """Process-wide state of one bench invocation."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dev = torch.device("cuda", self.local)
+
+    def to_dev(self, a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        return t.to(dtype) if dtype is not None else t
+
+    def sync_all(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+class Workload:
+    """One measurable configuration: step() = one pass of the hot path, solve() = the dominant kernel alone (for the
+    HIP-event kernel time), ws = the solver's status/iters/kkt outputs, host_call() = one control step issued with host
+    arrays, cpu = (descriptor, host arrays) for the CPU baseline."""
+    name = key = kernel = ""
+    baseline_config = None
+    kind = "cbf"
+    N = n_obs = units = batch = 0
+    desc = ws = cpu = None
+    host_call = None
+    gather = None          # the collective alone (cfg5)
+    extra = None
+    scaling = "weak"
+
+    def step(self):
+        raise NotImplementedError
+
+    def solve(self):
+        raise NotImplementedError
+
+
+def make_cbf(cx, key, args, batch=None, filtered=False):
+    from crx import abi, synth, torch_api
+    A, B = synth.load_AB()
+    w = Workload()
+    seed_shift = 1000 * cx.rank
+    if key.startswith("cfg2"):
+        w.batch = batch or 256
+        p = synth.cfg2_mpccbf(w.batch, N=12, seed=2 + seed_shift, safe_start=filtered)
+        w.desc = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+        w.kind, w.baseline_config = "cbf", 1
+        w.name = "MPC-CBF NLP (control.py:476-607), l_shape model, 1 obstacle, N=12, batch %d/GPU, SURVEY 8d draw%s" % (
+            w.batch, " restricted to safe, non-doomed starts (round-1 scenario filter)" if filtered else "")
+    else:
+        w.batch = batch or 16384
+        p = synth.cfg4_tracking_cbf(w.batch, N=20, seed=4 + seed_shift, safe_start=filtered)
+        w.desc = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+        w.kind, w.baseline_config = "cbf_tracking", 3
+        w.name = "tracking NLP with CBF rows (control.py:251-473 form), 3 obstacles, N=20, batch %d/GPU" % w.batch
+    w.key, w.N, w.n_obs, w.units = key, w.desc.N, w.desc.n_obs_max, w.batch
+    w.kernel = "crx_solve_kernel<%d>" % w.n_obs
+    w.extra = {"scenario_filter": bool(filtered)}
+    t_in = [cx.to_dev(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [cx.to_dev(p["n_obs"], torch.int32)]
+    w.ws = torch_api.CbfWorkspace(w.desc, w.batch, cx.dev)
+    w.step = w.solve = lambda: torch_api.cbf_solve_dev(w.desc, *t_in, ws=w.ws)
+    keys = ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")
+    w.cpu = ("cbf", w.desc, {k: p[k] for k in keys})
+    import crx
+    hb = crx.binding()
+    a1 = tuple(p[k][:1] for k in keys)
+    w.host_call = lambda: hb.cbf_solve(w.desc, *a1)
+    return w
+
+
+def make_planner(cx, args, n_scen=None):
+    import crx
+    from crx import abi, synth, torch_api
+    A, B = synth.load_AB()
+    w = Workload()
+    n_scen = n_scen or 1024
+    p = synth.cfg3_planner(n_scen, N=12, seed=3 + 1000 * cx.rank)
+    N, V = 12, p["V"]
+    w.key, w.kind, w.baseline_config, w.N, w.n_obs = "cfg3", "planner", 2, N, 0
+    w.desc = abi.planner_desc(N, A, B)
+    sdesc = abi.select_desc(N, V, p["lap_length"])
+    t_in = [cx.to_dev(p[k]) for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
+    t_sel = [cx.to_dev(p["n_veh"], torch.int32), cx.to_dev(p["obs_s"]), cx.to_dev(p["obs_ey"]), cx.to_dev(p["old_flag"], torch.int32)]
+    w.batch = w.units = n_scen * (V + 1)
+    w.ws = torch_api.PlannerWorkspace(w.desc, w.batch, cx.dev)
+    sws = torch_api.SelectWorkspace(sdesc, n_scen, cx.dev)
+    w.kernel = "crx_solve_kernel<0>"
+    w.solve = lambda: torch_api.planner_solve_dev(w.desc, *t_in, ws=w.ws)
+
+    def step():
+        torch_api.planner_solve_dev(w.desc, *t_in, ws=w.ws)
+        torch_api.select_dev(sdesc, t_sel[0], w.ws.X.view(n_scen, V + 1, N + 1, 6), t_sel[1], t_sel[2], t_sel[3], ws=sws)
+
+    w.step = step
+    w.name = "overtake planner: %d scenarios x %d region QPs (overtake_traj_planner.py:248-379) + selection (:205-246), N=12, per GPU" % (n_scen, V + 1)
+    keys = ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")
+    w.cpu = ("planner", w.desc, {k: p[k] for k in keys})
+    hb = crx.binding()
+    R1 = V + 1
+    a1 = tuple(p[k][:R1] for k in keys) + tuple(p[k][:1] for k in ("n_veh", "obs_s", "obs_ey", "old_flag"))
+    w.host_call = lambda: hb.planner_plan(w.desc, sdesc, *a1)
+    return w
+
+
+def make_sweep(cx, args, scaling):
+    """BASELINE configs[4]: Monte-Carlo sweep of overtake-planner scenarios sharded by scenario over the ranks."""
+    from crx import dist as cdist
+    from crx import pipeline, synth
+    A, B = synth.load_AB()
+    w = Workload()
+    if scaling == "strong":
+        n_total = args.sweep_total
+        lo, hi = cdist.shard_bounds(n_total, cx.rank, cx.world)
+        raw_all = synth.cfg3_raw(n_total, N=12, seed=5)                       # same global draw on every rank, sliced
+        raw = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim and v.shape[0] == n_total else v) for k, v in raw_all.items()}
+    else:
+        n_local = args.sweep_per_gpu
+        n_total = n_local * cx.world
+        raw = synth.cfg3_raw(n_local, N=12, seed=5 + 1000 * cx.rank)
+    sw = pipeline.PlannerSweep(raw, A, B, n_total, cx.dev)
+    w.key, w.kind, w.baseline_config, w.N, w.n_obs, w.scaling = "cfg5_" + scaling, "planner", 4, 12, 0, scaling
+    w.desc, w.ws = sw.desc, sw.ws
+    w.batch = w.units = sw.n_local * (sw.V + 1)
+    w.kernel = "crx_solve_kernel<0>"
+    w.step, w.gather = sw.step, sw.gather
+    w.solve = lambda: sw.be.planner_solve_dev(sw.desc, sw.pws.x0, sw.pws.bez_s, sw.pws.bez_ey, sw.pws.ey_lb, sw.pws.ey_ub, ws=sw.ws)
+    w.name = ("Monte-Carlo overtake-planner sweep, %s scaling: %d scenarios in total, %d on this rank x %d region QPs; raw scenario -> "
+              "Bezier/bounds prep -> QPs -> selection on the device, then ONE all-gather of the winners over %d rank(s)" % (
+                  scaling, n_total, sw.n_local, sw.V + 1, cx.world))
+    w.extra = {"scenarios_total": int(n_total), "scenarios_this_rank": int(sw.n_local), "winner_record_bytes": int(sw.exchange.rec * 8),
+               "allgather_bytes_per_rank_out": int(sw.exchange.recv.numel() * 8)}
+    return w
+
+
+def make_lmpc(cx, args, batch=None):
+    import crx
+    from crx import abi, torch_api
+    w = Workload()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
+    ok = np.nonzero(g["lmpc_success"])[0]
+    w.batch = w.units = batch or 4096
+    idx = ok[(np.arange(w.batch) + 7 * cx.rank) % len(ok)]
+    N, M = g["lmpc/A"].shape[1], g["lmpc/ss"].shape[2]
+    w.key, w.kind, w.N, w.n_obs = "lmpc", "lmpc", N, M
+    w.desc = abi.lmpc_desc(N=N, n_ss_max=M)
+    p = dict(x0=g["lmpc/x"][idx], u_old=g["lmpc/u_old"][idx], A=g["lmpc/A"][idx].reshape(w.batch, N, 36),
+             B=g["lmpc/B"][idx].reshape(w.batch, N, 12), C=g["lmpc/C"][idx], ss=g["lmpc/ss"][idx], qfun=g["lmpc/qfun"][idx],
+             n_ss=np.full(w.batch, M, dtype=np.int32))
+    keys = ("x0", "u_old", "A", "B", "C", "ss", "qfun")
+    t_in = [cx.to_dev(p[k]) for k in keys] + [cx.to_dev(p["n_ss"], torch.int32)]
+    w.ws = torch_api.LmpcWorkspace(w.desc, w.batch, cx.dev)
+    w.kernel = "crx_lmpc_kernel"
+    w.step = w.solve = lambda: torch_api.lmpc_solve_dev(w.desc, *t_in, ws=w.ws)
+    w.name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, w.batch)
+    w.cpu = ("lmpc", w.desc, {k: p[k] for k in keys + ("n_ss",)})
+    hb = crx.binding()
+    a1 = tuple(p[k][:1] for k in keys + ("n_ss",))
+    w.host_call = lambda: hb.lmpc_solve(w.desc, *a1)
+    return w
+
+
+def make_races(cx, args, batch=None):
+    from crx import montecarlo, synth
+    from utils import racing_env
+    A, B = synth.load_AB()
+    w = Workload()
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+    w.batch = w.units = batch or 4096
+    rng = np.random.default_rng(50 + cx.rank)
+    s0 = np.sort(rng.uniform(3.0, 17.0, (w.batch, 2)), axis=1)
+    s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
+    races = montecarlo.MpccbfRaces(track.point_and_tangent, track.lap_length, track.width, A, B, np.zeros((w.batch, 6)),
+                                   np.zeros((w.batch, 6)), s0, rng.uniform(0.1, 0.4, (w.batch, 2)),
+                                   rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (w.batch, 2)), vt=0.8, N=10, device=cx.dev)
+    from crx import torch_api
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "races", "cbf", 10, 2, races.desc, races.ws
+    w.kernel = "crx_solve_kernel<2>"
+    w.step = races.step
+    w.solve = lambda: torch_api.cbf_solve_dev(races.desc, races.xc, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=races.ws)
+    w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
+              "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant)" % w.batch)
+    return w
+
+
+def measure(cx, w, steps, warmup, with_latency=True):
+    """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
+    import crx
+    L = crx.lib()
+    for _ in range(warmup):
+        w.step()
+    cx.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step()
+    cx.sync_all()
+    elapsed = time.perf_counter() - t0
+    if cx.world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cx.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    units_all = w.units
+    if cx.world > 1:                                   # shards may be ragged (strong scaling): sum the units of all ranks
+        t = torch.tensor([w.units], dtype=torch.int64, device=cx.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        units_all = int(t.item())
+    value = units_all * steps / elapsed
+    # ---- per-launch time of the dominant kernel: HIP events recorded by libcrx on the launch stream ----
+    L.crx_set_timing(1)
+    kms = []
+    for _ in range(min(50, max(5, steps))):
+        w.solve()
+        kms.append(L.crx_last_kernel_ms())
+    L.crx_set_timing(0)
+    k_ms = float(np.mean(kms))
+    allgather_ms = None
+    if w.gather is not None:                           # the collective alone, same barrier / synchronize bracket
+        reps = min(50, max(5, steps))
+        w.gather()
+        cx.sync_all()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            w.gather()
+        cx.sync_all()
+        allgather_ms = (time.perf_counter() - t1) / reps * 1e3
+    lat, hlat = [], []
+    if with_latency:
+        # latency of one synchronous step (what a 10 Hz controller sees): p50 over blocking calls
+        for _ in range(min(100, max(10, steps))):
+            t1 = time.perf_counter()
+            w.step()
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        # ONE control step as the reference's class surface issues it: host arrays in, host arrays out -- PCIe-inclusive
+        if w.host_call is not None:
+            w.host_call()
+            for _ in range(50):
+                t1 = time.perf_counter()
+                w.host_call()
+                hlat.append((time.perf_counter() - t1) * 1e3)
+        w.step()
+        torch.cuda.synchronize()
+    st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
+    conv = st == 0
+    N, n_obs = w.N, w.n_obs
+    abytes = algorithmic_bytes(w.kind, N, n_obs)
+    achieved = abytes * w.batch / (k_ms * 1e-3) / 1e9
+    # analytic FP64 work: Riccati factor + solves per interior-point iteration (DESIGN.md section 5)
+    nx, nu = 6 + n_obs, 2 + n_obs
+    nz = nx + nu
+    flop_iter = N * (2 * nx * nx * nz + 2 * nx * nz * nz + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nu * nx * (nx + 1)) \
+        + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
+    if w.kind == "lmpc":   # Cholesky of K_u (2N) with 7 carried right-hand sides and its assembly; G = D + T T' in product form
+        nu2, M = 2 * N, n_obs
+        flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + (45 * 6 + 6 * 12 + 24 * 4) * M + 4 * (N - 1) * nu2 * nu2 / 2 \
+            + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
+    gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
+    L.crx_debug_lds_bytes.restype = C.c_long
+    lk = 1 if w.kind == "lmpc" else 0
+    lds = int(L.crx_debug_lds_bytes(lk, int(N), int(n_obs)))
+    resident = int(L.crx_debug_resident_per_cu(lk, int(N), int(n_obs)))   # runtime: min(LDS, registers)
+    traffic = tnote = None
+    try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, rocprofv3 --pmc, calibrated)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        e = pm.get(w.key.replace("cfg2_filtered", "cfg2"))
+        if e and e["batch"] == w.batch:
+            traffic, tnote = e["traffic_bytes"], pm.get("note")
+    except Exception:
+        traffic = None
+    cfg = {"workload": w.name, "baseline_config": w.baseline_config, "batch_per_gpu": int(w.batch),
+           "horizon": int(N), "n_obs": 0 if w.kind == "lmpc" else int(n_obs), "n_ss": int(n_obs) if w.kind == "lmpc" else 0,
+           "tol": w.desc.opts.tol,
+           "status_frac": {"converged": float(conv.mean()), "max_iter": float((st == 1).mean()),
+                           "infeasible_or_restored": float((st == 2).mean())},
+           "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
+           "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)), "iters_max": int(it.max())}
+    if with_latency:
+        cfg.update({"p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99)),
+                    "p50_host_call_one_control_step_ms": float(np.median(hlat)) if hlat else None})
+    if w.extra:
+        cfg.update(w.extra)
+    rec = {"key": w.key, "value": value, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "scaling": w.scaling, "config": cfg,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,
+                        "kernel": w.kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
+                        "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
+                        "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
+                        "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // lds)}}
+    if allgather_ms is not None:
+        rec["allgather_ms"] = allgather_ms
+        rec["world_size"] = dist.get_world_size() if dist.is_initialized() else 1
+    return rec
+
+
+def cpu_baseline(w):
+    """B1/B2 of SURVEY.md section 8d on this box's host cores, bounded to ~25 s: the oracle (a C port of the same
+    iteration with a condensed dense Cholesky) on ONE thread and on all cores (OpenMP over problems), and scipy SLSQP on a
+    64-problem subsample.  B3, the reference's own CasADi/IPOPT path, is timed only if `import casadi` works here (it does
+    not in this image; nothing is substituted)."""
+    import oracle
+
+    orc = oracle.load()
+    kind, desc, p = w.cpu
+    cores = oracle.threads()
+
+    def run(n):
+        a = tuple(v[:n] for v in p.values())
+        return {"cbf": orc.cbf_solve, "planner": orc.planner_solve, "lmpc": orc.lmpc_solve}[kind](desc, *a)
+
+    def timed(n, budget):
+        run(min(n, 8))
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            run(n)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget or reps >= 2000:
+                return n * reps / el, reps, el
+
+    n = min(w.batch, 4096)
+    oracle.set_threads(1)
+    v1, r1, e1 = timed(min(n, 256), 8.0)
+    oracle.set_threads(cores)
+    vall, rall, eall = timed(n, 10.0)
+    out = {"value": vall, "unit": "solves/s", "cores": cores, "kind": "port",
+           "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (rall, n, eall),
+           "one_thread": {"value": v1, "cores": 1, "sample": "%d repetitions of the first %d problems, %.1f s wall" % (r1, min(n, 256), e1)}}
+    if kind == "cbf" and not desc.per_stage_target:
+        from oracle import slsqp_baseline
+        rate, costs, viol = slsqp_baseline.time_batch(desc, p, 64)
+        ro = run(64)
+        rel = np.abs(costs - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+        out["scipy_slsqp"] = {"value": rate, "cores": 1, "sample": "first 64 problems, zero start, analytic gradients, maxiter 300",
+                              "reached_port_cost_frac": float((rel <= 1e-6).mean()), "never_below_port_cost": bool((costs >= ro["cost"] - 1e-6 * np.maximum(1, np.abs(ro["cost"]))).all()),
+                              "max_constraint_violation": float(-viol.min())}
+    try:
+        import casadi  # noqa: F401
+        out["reference"] = "casadi importable: reference path NOT timed in this round"
+    except Exception:
+        out["reference"] = "casadi: unavailable (not installed; no network) -> reference CasADi/IPOPT path not timed"
+    return out
+
+
+def self_spawn(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -52,282 +418,64 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "lmpc", "races"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4) or scenarios (cfg3); 0 = BASELINE size")
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races"],
+                    help="measure only this workload (default: headline cfg2 + every other single-GPU config in `configs`)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="cfg5 only")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4/lmpc/races) or scenarios (cfg3); 0 = BASELINE size")
+    ap.add_argument("--sweep-per-gpu", type=int, default=16384, help="cfg5 weak: scenarios per GPU")
+    ap.add_argument("--sweep-total", type=int, default=131072, help="cfg5 strong: scenarios in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--device-prep", action="store_true",
-                    help="cfg3: start each step from the raw scenarios (crx_planner_prep on the device) instead of prepared QP arrays")
-    ap.add_argument("--no-scenario-filter", action="store_true",
-                    help="keep doomed / unsafe-start scenarios in the synthetic batch (DESIGN.md section 6)")
+    ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus, file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+    cx = Ctx()
+    if args.gpus != cx.world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, cx.world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
+    torch.cuda.set_device(cx.local)
+    if cx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=cx.dev)
 
     import crx
-    from crx import abi, synth, torch_api
-
-    crx.init(local)
-    A, B = synth.load_AB()
-    wl = args.workload
-    seed_shift = 1000 * rank
-
-    def to_dev(a, dtype=None):
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        return t.to(dtype) if dtype is not None else t
-
-    races = None
-    if wl == "races":
-        # B closed-loop MPC-CBF races, one control step of all of them per bench step
-        from crx import montecarlo
-        from utils import racing_env
-        track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
-        batch = args.batch or 4096
-        rng = np.random.default_rng(50 + rank)
-        s0 = np.sort(rng.uniform(3.0, 17.0, (batch, 2)), axis=1)
-        s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
-        races = montecarlo.MpccbfRaces(track.point_and_tangent, track.lap_length, track.width, A, B, np.zeros((batch, 6)),
-                                       np.zeros((batch, 6)), s0, rng.uniform(0.1, 0.4, (batch, 2)),
-                                       rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (batch, 2)), vt=0.8, N=10, device=dev)
-        desc, ws, N, n_obs, units = races.desc, races.ws, 10, 2, batch
-        p = None
-        step = races.step
-        name = "closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per step (predictions, window filter, NLP N=10 with 2 scripted cars, plant)" % batch
-    elif wl == "lmpc":
-        g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
-        ok = np.nonzero(g["lmpc_success"])[0]
-        batch = args.batch or 4096
-        idx = ok[(np.arange(batch) + 7 * rank) % len(ok)]
-        N, M = g["lmpc/A"].shape[1], g["lmpc/ss"].shape[2]
-        desc = abi.lmpc_desc(N=N, n_ss_max=M)
-        p = dict(x0=g["lmpc/x"][idx], u_old=g["lmpc/u_old"][idx], A=g["lmpc/A"][idx].reshape(batch, N, 36),
-                 B=g["lmpc/B"][idx].reshape(batch, N, 12), C=g["lmpc/C"][idx], ss=g["lmpc/ss"][idx], qfun=g["lmpc/qfun"][idx],
-                 n_ss=np.full(batch, M, dtype=np.int32))
-        n_obs = M
-        t_in = [to_dev(p[k]) for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun")] + [to_dev(p["n_ss"], torch.int32)]
-        ws = torch_api.LmpcWorkspace(desc, batch, dev)
-        units = batch
-
-        def step():
-            torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
-
-        name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, batch)
-    elif wl in ("cfg2", "cfg4"):
-        if wl == "cfg2":
-            batch = args.batch or 256
-            p = synth.cfg2_mpccbf(batch, N=12, seed=2 + seed_shift, safe_start=not args.no_scenario_filter)
-            desc = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
-        else:
-            batch = args.batch or 16384
-            p = synth.cfg4_tracking_cbf(batch, N=20, seed=4 + seed_shift, safe_start=not args.no_scenario_filter)
-            desc = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
-        N, n_obs = desc.N, desc.n_obs_max
-        t_in = [to_dev(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [to_dev(p["n_obs"], torch.int32)]
-        ws = torch_api.CbfWorkspace(desc, batch, dev)
-        units = batch
-
-        def step():
-            torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
-
-        name = ("MPC-CBF NLP (control.py:476-607), l_shape model, 1 obstacle, N=12, batch 256/GPU" if wl == "cfg2"
-                else "tracking NLP with CBF rows (control.py:251-473 form), 3 obstacles, N=20, batch %d/GPU" % batch)
-    else:
-        n_scen = args.batch or 1024
-        p = synth.cfg3_planner(n_scen, N=12, seed=3 + seed_shift)
-        N, n_obs, V = 12, 0, p["V"]
-        desc = abi.planner_desc(N, A, B)
-        sdesc = abi.select_desc(N, V, p["lap_length"])
-        t_in = [to_dev(p[k]) for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
-        t_sel = [to_dev(p["n_veh"], torch.int32), to_dev(p["obs_s"]), to_dev(p["obs_ey"]), to_dev(p["old_flag"], torch.int32)]
-        batch = n_scen * (V + 1)
-        ws = torch_api.PlannerWorkspace(desc, batch, dev)
-        sws = torch_api.SelectWorkspace(sdesc, n_scen, dev)
-        gathered = torch.empty((world * n_scen, N + 1, 6), dtype=torch.float64, device=dev) if world > 1 else None
-        units = batch
-        if args.device_prep:
-            w = p["raw"]
-            pdesc = abi.prep_desc(N, V, len(w["opt_s"]), w["track_width"], w["lap_length"])
-            t_raw = [to_dev(w["x"]), to_dev(w["x"]), to_dev(w["n_veh"], torch.int32), to_dev(w["veh_info"]), to_dev(w["max_dv"]),
-                     to_dev(w["obs_s"]), to_dev(w["obs_ey"]), to_dev(w["opt_s"]), to_dev(w["opt_ey"])]
-            pws = torch_api.PrepWorkspace(pdesc, n_scen, dev)
-            t_in = [pws.x0, pws.bez_s, pws.bez_ey, pws.ey_lb, pws.ey_ub]
-
-        def step():
-            if args.device_prep:
-                torch_api.planner_prep_dev(pdesc, *t_raw, ws=pws)
-            torch_api.planner_solve_dev(desc, *t_in, ws=ws)
-            torch_api.select_dev(sdesc, t_sel[0], ws.X.view(n_scen, V + 1, N + 1, 6), t_sel[1], t_sel[2], t_sel[3], ws=sws)
-            if world > 1:  # the path's only exchange: winners to every rank (RCCL all-gather over xGMI)
-                dist.all_gather_into_tensor(gathered, sws.best_X)
-
-        name = "overtake planner: %d scenarios x %d region QPs (overtake_traj_planner.py:248-379) + selection (:205-246), N=12, per GPU%s" % (
-            n_scen, V + 1, "; Bezier references and ey bounds built on the device from the raw scenarios" if args.device_prep else "")
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = units * world * args.steps / elapsed
-
-    # ---- per-launch kernel time, measured with HIP events on the launch stream -----------------------
-    L = crx.lib()
-    L.crx_set_timing(1)
-    kms = []
-    for _ in range(min(50, max(5, args.steps))):
-        if wl == "cfg3":
-            torch_api.planner_solve_dev(desc, *t_in, ws=ws)
-        elif wl == "lmpc":
-            torch_api.lmpc_solve_dev(desc, *t_in, ws=ws)
-        elif wl == "races":
-            torch_api.cbf_solve_dev(desc, races.xc, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=ws)
-        else:
-            torch_api.cbf_solve_dev(desc, *t_in, ws=ws)
-        kms.append(L.crx_last_kernel_ms())
-    L.crx_set_timing(0)
-    k_ms = float(np.mean(kms))
-    # latency of one synchronous control step (what a 10 Hz controller sees): p50 over blocking calls
-    lat = []
-    for _ in range(min(100, max(10, args.steps))):
-        t1 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    # ONE control step as the reference's class surface issues it: host arrays in, host arrays out, the batch
-    # one step sees (1 NLP / 1 QP, or the V+1 region QPs + selection of one planner call) -- PCIe-inclusive
-    hb = crx.binding()
-    if wl == "races":
-        one = lambda: None  # noqa: E731  (the class-surface step of this scenario is the cfg2-type call)
-    elif wl == "cfg3":
-        R1 = V + 1
-        a1 = tuple(p[k][:R1] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")) + tuple(p[k][:1] for k in ("n_veh", "obs_s", "obs_ey", "old_flag"))
-        one = lambda: hb.planner_plan(desc, sdesc, *a1)  # noqa: E731
-    elif wl == "lmpc":
-        a1 = tuple(p[k][:1] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss"))
-        one = lambda: hb.lmpc_solve(desc, *a1)  # noqa: E731
-    else:
-        a1 = tuple(p[k][:1] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs"))
-        one = lambda: hb.cbf_solve(desc, *a1)  # noqa: E731
-    one()
-    hlat = []
-    for _ in range(50):
-        t1 = time.perf_counter()
-        one()
-        hlat.append((time.perf_counter() - t1) * 1e3)
-    st = ws.status.cpu().numpy()
-    it = ws.iters.cpu().numpy()
-    kkt = ws.kkt.cpu().numpy()
-    conv = st == 0
-    abytes = algorithmic_bytes(wl, N, n_obs)
-    achieved = abytes * batch / (k_ms * 1e-3) / 1e9
-    # analytic FP64 work: Riccati factor + solves per interior-point iteration
-    nx, nu = 6 + n_obs, 2 + n_obs
-    nz = nx + nu
-    flop_iter = N * (2 * nx * nx * nz + 2 * nx * nz * nz + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nu * nx * (nx + 1)) \
-        + N * (4 * nx * nz + 2 * nu * nx) + 40 * N * (8 + 2 * n_obs)
-    if wl == "lmpc":   # Cholesky of K_u (2N) with 7 carried right-hand sides and its assembly; G = D + T T' in product form:
-        # 21 + 24 wave scans (6 adds per element) and ~12 element-wise operations per rank-one factor and solve step
-        nu2, M = 2 * N, n_obs
-        flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + (45 * 6 + 6 * 12 + 24 * 4) * M + 4 * (N - 1) * nu2 * nu2 / 2 \
-            + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
-    gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
-
-    L.crx_debug_lds_bytes.restype = C.c_long
-    lds = int(L.crx_debug_lds_bytes(1 if wl == "lmpc" else 0, int(N), int(n_obs)))
-    resident = int(L.crx_debug_resident_per_cu(1 if wl == "lmpc" else 0, int(N), int(n_obs)))   # runtime: min(LDS, registers)
-    traffic = None
-    try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, collected with rocprofv3 --pmc)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-        if wl in pm and pm[wl]["batch"] == batch:
-            traffic = pm[wl]["traffic_bytes"]
-    except Exception:
-        traffic = None
-    out = {
-        "metric": "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency",
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": name, "baseline_config": {"cfg2": 1, "cfg3": 2, "cfg4": 3, "lmpc": None, "races": None}[wl], "batch_per_gpu": int(batch),
-                   "horizon": int(N), "n_obs": 0 if wl == "lmpc" else int(n_obs), "n_ss": int(n_obs) if wl == "lmpc" else 0,
-                   "tol": desc.opts.tol,
-                   "scenario_filter": not args.no_scenario_filter,
-                   "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
-                   "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
-                   "p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99)),
-                   "p50_host_call_one_control_step_ms": None if wl == "races" else float(np.median(hlat))},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "crx_lmpc_kernel" if wl == "lmpc" else "crx_solve_kernel<%d>" % n_obs, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
-                     "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
-                     "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
-                     "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // lds)},
-    }
-    if rank == 0 and not args.no_cpu_baseline and wl != "races":
-        out["cpu_baseline"] = cpu_baseline(wl, desc, p, batch)
-    if rank == 0:
+    crx.init(cx.local)
+    b = args.batch or None
+    make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
+            "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
+            "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b)}
+    head = make[args.workload or "cfg2"]()
+    rec = measure(cx, head, args.steps, args.warmup)
+    out = {"metric": METRIC, "value": rec["value"], "unit": "solves/s", "n_gpus": cx.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"]}
+    for k in ("allgather_ms", "world_size"):
+        if k in rec:
+            out[k] = rec[k]
+    if cx.rank == 0 and not args.no_cpu_baseline and head.cpu is not None:
+        out["cpu_baseline"] = cpu_baseline(head)
+    if args.workload is None and not args.no_sub_configs:
+        # every other single-GPU BASELINE config in the same driver-timed run; slow configs get fewer steps (stated)
+        subs = [("cfg2_filtered", lambda: make_cbf(cx, "cfg2_filtered", args, None, filtered=True), args.steps, args.warmup),
+                ("cfg3", lambda: make_planner(cx, args), args.steps, args.warmup),
+                ("cfg4", lambda: make_cbf(cx, "cfg4", args), min(args.steps, 30), min(args.warmup, 3)),
+                ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5)),
+                ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3)),
+                ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2))]
+        out["configs"] = []
+        for key, mk, st, wu in subs:
+            w = mk()
+            out["configs"].append(measure(cx, w, st, wu, with_latency=key in ("cfg3", "cfg4", "lmpc")))
+            del w
+            torch.cuda.empty_cache()
+    if cx.rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if cx.world > 1:
         dist.destroy_process_group()
-
-
-def cpu_baseline(wl, desc, p, batch):
-    """The oracle (a C port of the same iteration, condensed dense Cholesky) on the host cores of this
-    box, on a bounded sample of the same workload.  The reference's own CasADi/IPOPT path is timed
-    only if `import casadi` works here (it does not in this image; nothing is substituted)."""
-    import oracle
-
-    orc = oracle.load()
-    cores = oracle.threads()
-    n = min(batch, 1024)
-    if wl == "cfg3":
-        a = (p["x0"][:n], p["bez_s"][:n], p["bez_ey"][:n], p["ey_lb"][:n], p["ey_ub"][:n])
-        fn = lambda: orc.planner_solve(desc, *a)  # noqa: E731
-    elif wl == "lmpc":
-        a = tuple(p[k][:n] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss"))
-        fn = lambda: orc.lmpc_solve(desc, *a)  # noqa: E731
-    else:
-        a = (p["x0"][:n], p["xt"][:n], p["obs_s"][:n], p["obs_ey"][:n], p["lap_off"][:n], p["n_obs"][:n])
-        fn = lambda: orc.cbf_solve(desc, *a)  # noqa: E731
-    fn()
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        fn()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 8.0 or reps >= 400:
-            break
-    try:
-        import casadi  # noqa: F401
-        ref = "casadi importable: reference path NOT timed in this round"
-    except Exception:
-        ref = "casadi: unavailable (not installed; no network) -> reference CasADi/IPOPT path not timed"
-    return {"value": n * reps / el, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (reps, n, el),
-            "reference": ref}
 
 
 if __name__ == "__main__":

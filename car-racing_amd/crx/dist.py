@@ -1,8 +1,7 @@
 """Multi-GPU sharding of a scenario batch: one process per GPU, contiguous scenario blocks, and the
-path's single exchange step -- an all-gather of the fixed-size winner records.
+path's single exchange step -- ONE all-gather of the fixed-size winner records.
 
 Backend-agnostic (`nccl` = RCCL over xGMI on the GPU box, `gloo` in the CPU tests)."""
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -15,29 +14,52 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_winners(flag, best_X, n_total=None):
-    """Gather per-scenario winners from every rank in rank order.
+def shard_sizes(n_total, world):
+    return [hi - lo for lo, hi in (shard_bounds(n_total, r, world) for r in range(world))]
 
-    flag [n_local] int32, best_X [n_local, N+1, 6] float64 (same device).  Ragged shards are padded
-    to the largest shard for the collective and trimmed afterwards.  Returns (flag_all, best_X_all)."""
+
+class WinnerExchange:
+    """The all-gather of the winners, with its buffers allocated once.
+
+    A winner record is [flag, X (N+1)*6] as float64 (flags are small integers: exact).  Every rank knows the shard
+    sizes from (n_total, world) alone -- shard_bounds is a pure function -- so no size exchange is needed: ragged
+    shards are padded to the largest one and trimmed after the ONE collective."""
+
+    def __init__(self, n_total, N, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sizes = shard_sizes(n_total, self.world)
+        self.n_total, self.n_max, self.rec = int(n_total), max(self.sizes), 1 + (N + 1) * 6
+        self.shape_X = (N + 1, 6)
+        self.even = min(self.sizes) == self.n_max
+        self.send = torch.zeros((self.n_max, self.rec), dtype=torch.float64, device=device)
+        self.recv = torch.empty((self.world * self.n_max, self.rec), dtype=torch.float64, device=device)
+
+    def __call__(self, flag, best_X):
+        n = self.sizes[self.rank]
+        if flag.shape[0] != n or best_X.shape[0] != n:
+            raise ValueError("rank %d holds %d winners, its shard of %d over %d ranks is %d" % (self.rank, flag.shape[0], self.n_total, self.world, n))
+        self.send[:n, 0] = flag
+        self.send[:n, 1:] = best_X.reshape(n, self.rec - 1)
+        if self.world == 1:
+            allrec = self.send[:n]
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)   # the ONE collective of the path
+            if self.even:
+                allrec = self.recv
+            else:
+                out = self.recv.view(self.world, self.n_max, self.rec)
+                allrec = torch.cat([out[r, : self.sizes[r]] for r in range(self.world)], dim=0)
+        return allrec[:, 0].to(torch.int32), allrec[:, 1:].reshape(-1, *self.shape_X)
+
+
+def allgather_winners(flag, best_X, n_total=None):
+    """Gather per-scenario winners from every rank in rank order: flag [n_local] int32, best_X [n_local, N+1, 6] float64
+    -> (flag_all [n_total], best_X_all [n_total, N+1, 6]).  One collective.  `n_total` = scenarios over all ranks
+    (sharded by shard_bounds); None means every rank holds the same number."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return flag, best_X
-    world = dist.get_world_size()
-    n_local = torch.tensor([flag.shape[0]], dtype=torch.int64, device=flag.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
-    n_max = max(sizes)
-    rec = best_X.shape[1] * best_X.shape[2]
-    # one fixed-size record per scenario: [flag, X...] as float64
-    buf = torch.zeros((n_max, 1 + rec), dtype=torch.float64, device=flag.device)
-    buf[: flag.shape[0], 0] = flag.to(torch.float64)
-    buf[: flag.shape[0], 1:] = best_X.reshape(flag.shape[0], rec)
-    out = torch.empty((world * n_max, 1 + rec), dtype=torch.float64, device=flag.device)
-    dist.all_gather_into_tensor(out, buf)  # ONE collective: concatenation along dim 0, rank order
-    out = out.view(world, n_max, 1 + rec)
-    parts = [out[r, : sizes[r]] for r in range(world)]
-    allrec = torch.cat(parts, dim=0)
-    if n_total is not None:
-        assert allrec.shape[0] == n_total
-    return allrec[:, 0].to(torch.int32), allrec[:, 1:].reshape(-1, best_X.shape[1], best_X.shape[2])
+    if n_total is None:
+        n_total = flag.shape[0] * dist.get_world_size()
+    return WinnerExchange(n_total, best_X.shape[1] - 1, flag.device)(flag, best_X)

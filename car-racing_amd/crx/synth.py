@@ -117,13 +117,26 @@ def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True):
     return p
 
 
+def partial_sort_order(ey):
+    """planner_helper.sort_by_ey (the reference's partial sort, overtake_traj_planner.py:70-76, quirk Q3) for a whole
+    batch: ey [n, V] in iteration order -> order [n, V] (indices into the iteration order)."""
+    n, V = ey.shape
+    order = np.zeros((n, V), dtype=np.int64)
+    rows = np.arange(n)
+    for j in range(1, V):
+        front = ey[rows, j] >= ey[rows, order[:, 0]]
+        shifted = np.concatenate([np.full((n, 1), j), order[:, :-1]], axis=1)
+        appended = order.copy()
+        appended[:, j] = j
+        order = np.where(front[:, None], shifted, appended)
+    return order
+
+
 def cfg3_raw(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_SHAPE):
     """Raw overtake-planner scenarios, i.e. what OvertakeTrajPlanner.get_local_traj has in hand before
     its host prep (overtake_traj_planner.py:66-92): ego + V surrounding vehicles in the front interest
     window (planner_helper.py:231-236), constant-speed predictions.  veh_info rows (s, max ey, min ey)
     are in ITERATION order (quirk Q4), predictions in the reference's partial ey order (quirk Q3)."""
-    from planning import planner_helper as ph
-
     rng = np.random.default_rng(np.random.PCG64(seed))
     opt = np.genfromtxt(os.path.join(_ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
     j = np.arange(N + 1)
@@ -134,13 +147,10 @@ def cfg3_raw(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_S
     dv = np.abs(x[:, 0, None] - v_o)
     s_o = x[:, 4, None] + rng.uniform(0.0, 1.0, (n_scen, V)) * (4.5 * 0.4 + 0.5 * dv)
     ey_o = _lanes(rng, (n_scen, V))
-    obs_s = np.zeros((n_scen, V, N + 1))
-    obs_ey = np.zeros((n_scen, V, N + 1))
-    for i in range(n_scen):
-        order = ph.sort_by_ey(list(range(V)), lambda n: ey_o[i, n])
-        for k, n in enumerate(order):
-            obs_s[i, k] = s_o[i, n] + 0.1 * j * v_o[i, n]
-            obs_ey[i, k] = ey_o[i, n]
+    order = partial_sort_order(ey_o)
+    rows = np.arange(n_scen)[:, None]
+    obs_s = s_o[rows, order][:, :, None] + 0.1 * j[None, None, :] * v_o[rows, order][:, :, None]
+    obs_ey = np.repeat(ey_o[rows, order][:, :, None], N + 1, axis=2)
     return dict(
         x=x, veh_info=np.stack([s_o, ey_o, ey_o], axis=2), max_dv=dv.max(axis=1), obs_s=obs_s, obs_ey=obs_ey,
         n_veh=np.full(n_scen, V, dtype=np.int32), opt_s=np.ascontiguousarray(opt[:, 4]),

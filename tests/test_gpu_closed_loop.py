@@ -23,52 +23,21 @@ pytestmark = pytest.mark.gpu
 
 
 def _track(width=1.0):
-    from utils import racing_env
+    import scenarios
 
-    spec = np.genfromtxt(conftest.ROOT + "/data/track_layout/l_shape.csv", delimiter=",")
-    return racing_env.ClosedTrack(spec, track_width=width)
+    return scenarios.make_track("l_shape", width)
 
 
 def test_mpccbf_racing(tmp_path):
-    import sympy as sp
+    import scenarios
 
-    from racing import offboard
-    from utils import base
-    from utils.constants import X_DIM
-
-    track = _track(1.0)
-    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
-    ego.set_zero_noise()
-    mpc_cbf_param = base.MPCCBFRacingParam(vt=0.8)
-    ego.set_state_curvilinear(np.zeros((X_DIM,)))
-    ego.set_state_global(np.zeros((X_DIM,)))
-    ego.start_logging()
-    ego.set_ctrl_policy(offboard.MPCCBFRacing(mpc_cbf_param, ego.system_param))
-    ego.ctrl_policy.set_timestep(0.1)
-    ego.set_track(track)
-    ego.ctrl_policy.set_track(track)
-    t_symbol = sp.symbols("t")
-    car1 = offboard.NoDynamicsModel(name="car1", param=base.CarParam(edgecolor="orange"))
-    car1.set_track(track)
-    car1.set_state_curvilinear_func(t_symbol, 0.2 * t_symbol + 4.0, 0.1 + 0.0 * t_symbol)
-    car1.start_logging()
-    car2 = offboard.NoDynamicsModel(name="car2", param=base.CarParam(edgecolor="orange"))
-    car2.set_track(track)
-    car2.set_state_curvilinear_func(t_symbol, 0.2 * t_symbol + 10.0, -0.1 + 0.0 * t_symbol)
-    car2.start_logging()
-    simulator = offboard.CarRacingSim()
-    simulator.set_timestep(0.1)
-    simulator.set_track(track)
-    simulator.add_vehicle(ego)
-    ego.ctrl_policy.set_racing_sim(simulator)
-    simulator.add_vehicle(car1)
-    simulator.add_vehicle(car2)
-    simulator.sim(sim_time=40.0)
-    with open(str(tmp_path / "racing.obj"), "wb") as handle:  # the reference pickles the simulator (:42-43)
-        pickle.dump(simulator, handle, protocol=pickle.HIGHEST_PROTOCOL)
-    simulator.plot_simulation()
-    simulator.plot_state("ego")
-    simulator.animate(filename="racing", ani_time=40, imagemagick=True)
+    race = scenarios.mpccbf_race()
+    ego, track, (car1, car2) = race.ego, race.track, race.cars
+    with open(str(tmp_path / "racing.obj"), "wb") as handle:  # the simulator must stay picklable (the reference pickles it)
+        pickle.dump(race.sim, handle, protocol=pickle.HIGHEST_PROTOCOL)
+    race.sim.plot_simulation()
+    race.sim.plot_state("ego")
+    race.sim.animate(filename="racing", ani_time=40, imagemagick=True)
 
     e = np.array(ego.xcurv_log)
     assert e.shape == (400, 6) and np.isfinite(e).all()
@@ -152,95 +121,25 @@ def test_overtake_step(golden_planner):
 
 
 def test_racing_game(capsys):
-    import sympy as sp
-
+    import scenarios
     from control import lmpc_helper
-    from control.lmpc_helper import LMPCPrediction
-    from racing import offboard
-    from utils import base, racing_env
-    from utils.constants import X_DIM
 
-    # ---- reference tests/auto_racing_game_test.py:11-45 ----
-    track_spec = np.genfromtxt(conftest.ROOT + "/data/track_layout/l_shape.csv", delimiter=",")
-    track = racing_env.ClosedTrack(track_spec, track_width=1.0)
-    lap_number = 4
-    opti_traj_xcurv = np.genfromtxt(conftest.ROOT + "/data/optimal_traj/xcurv_l_shape.csv", delimiter=",")
-    opti_traj_xglob = np.genfromtxt(conftest.ROOT + "/data/optimal_traj/xglob_l_shape.csv", delimiter=",")
-    num_veh, alpha, timestep = 2, 0.8, 1.0 / 10.0
-    # set_up_ego (:116-135)
-    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
-    ego.set_timestep(timestep)
-    pid_controller = offboard.PIDTracking(vt=0.7, eyt=0.0)
-    pid_controller.set_timestep(timestep)
-    ego.set_ctrl_policy(pid_controller)
-    pid_controller.set_track(track)
-    ego.set_state_curvilinear(np.zeros((X_DIM,)))
-    ego.set_state_global(np.zeros((X_DIM,)))
-    ego.start_logging()
-    ego.set_track(track)
-    mpc_lti_controller = offboard.MPCTracking(base.MPCTrackingParam(vt=0.7, eyt=0.0), ego.system_param)
-    mpc_lti_controller.set_timestep(timestep)
-    mpc_lti_controller.set_track(track)
-    ego.set_zero_noise()
-    # set_up_lmpc (:138-147)
-    time_lmpc = 10000 * timestep
-    lmpc_param = base.LMPCRacingParam(timestep=timestep, lap_number=lap_number, time_lmpc=time_lmpc)
-    racing_game_param = base.RacingGameParam(timestep=timestep, alpha=alpha, num_horizon_planner=10)
-    lmpc_controller = offboard.LMPCRacingGame(lmpc_param, racing_game_param=racing_game_param, system_param=ego.system_param)
-    lmpc_controller.set_track(track)
-    lmpc_controller.set_timestep(timestep)
-    lmpc_controller.set_opti_traj(opti_traj_xcurv, opti_traj_xglob)
-    lmpc_controller.openloop_prediction = LMPCPrediction(lap_number=lap_number)
-    simulator = offboard.CarRacingSim()
-    simulator.set_timestep(timestep)
-    simulator.set_track(track)
-    simulator.add_vehicle(ego)
-    simulator.set_opti_traj(opti_traj_xglob)
-    t_symbol = sp.symbols("t")
-    vehicles = []
-    for index in range(num_veh):   # set_up_other_vehicles (:150-159)
-        vehicles.append(offboard.NoDynamicsModel(name="car" + str(index + 1), param=base.CarParam(edgecolor="orange")))
-        vehicles[index].set_track(track)
-    pid_controller.set_racing_sim(simulator)
-    mpc_lti_controller.set_racing_sim(simulator)
-    lmpc_controller.set_racing_sim(simulator)
-    lmpc_controller.set_vehicles_track()
     # The learning-MPC lap is sensitive at solver-tolerance level: in ~1 of 6 perturbed runs one plan
     # leaves the stored data and the next local regression is singular, where the reference (cvxopt) raises.  The test
     # runs the mirror's "keep the previous stage model" mode, in which 24 of 24 perturbed runs finish
     # (tools/racing_game_noise.py); the default stays the reference's behaviour.
     monkey_on_singular = lmpc_helper.ON_SINGULAR
     lmpc_helper.ON_SINGULAR = "keep"
-    # ---- :46-100 ----
-    for iter in range(lap_number):
-        if iter == 0:
-            simulator.sim(sim_time=90, one_lap=True, one_lap_name="ego")
-        elif iter == 1:
-            ego.set_ctrl_policy(mpc_lti_controller)
-            simulator.sim(sim_time=90, one_lap=True, one_lap_name="ego")
-        elif iter == 2:
-            lmpc_controller.add_trajectory(ego, 0)
-            lmpc_controller.add_trajectory(ego, 1)
-            ego.set_ctrl_policy(lmpc_controller)
-            simulator.sim(sim_time=time_lmpc, one_lap=True, one_lap_name="ego")
-            ego.ctrl_policy.add_trajectory(ego, 2)
-        else:
-            if iter == 3:
-                for index in range(0, num_veh):
-                    vehicles[index].set_state_curvilinear_func(
-                        t_symbol, (0.7 + index * 0.02) * t_symbol + 5.5 + index * 2, -0.5 + index * 0.3 + 0.0 * t_symbol)
-                    vehicles[index].start_logging()
-                    simulator.add_vehicle(vehicles[index])
-                ego.solver_time, ego.all_local_trajs, ego.all_splines = [], [], []
-                ego.xcurv_log, ego.lmpc_prediction, ego.mpc_cbf_prediction = [], [], []
-            simulator.sim(sim_time=time_lmpc, one_lap=True, one_lap_name="ego")
-            ego.ctrl_policy.add_trajectory(ego, iter)
-    simulator.plot_simulation()
-    simulator.plot_state("ego")
-    simulator.plot_input("ego")
-    simulator.animate(filename="racing_game_m_shape", ani_time=50, racing_game=True, imagemagick=True)
+    try:
+        race, lmpc_controller = scenarios.racing_game()
+    finally:
+        lmpc_helper.ON_SINGULAR = monkey_on_singular
+    ego, track, vehicles, timestep = race.ego, race.track, race.cars, race.dt
+    race.sim.plot_simulation()
+    race.sim.plot_state("ego")
+    race.sim.plot_input("ego")
+    race.sim.animate(filename="racing_game", ani_time=50, racing_game=True, imagemagick=True)
 
-    lmpc_helper.ON_SINGULAR = monkey_on_singular
     out = capsys.readouterr().out
     g = np.load(conftest.GOLDEN + "/racing_game.npz")
     # laps 0 (PID) and 1 (mpc-lti, 260 GPU solves in closed loop) against the reference's own run
@@ -318,34 +217,11 @@ def test_batched_closed_loop_races(AB):
     # (No safety property is asserted on random placements: the reference's CBF rows are soft, and its one-sided
     # lap correction -- quirk Q1, control.py:539-542 -- lets the ego drive through a car at the start line; both
     # paths reproduce that.)
-    import sympy as sp
+    import scenarios
 
-    from racing import offboard
-    from utils import base
-
-    t_symbol = sp.symbols("t")
     for b in (3, 127, 458):
-        ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
-        ego.set_zero_noise()
-        ego.set_state_curvilinear(np.zeros((6,)))
-        ego.set_state_global(np.zeros((6,)))
-        ego.start_logging()
-        ego.set_ctrl_policy(offboard.MPCCBFRacing(base.MPCCBFRacingParam(vt=0.8), ego.system_param))
-        ego.ctrl_policy.set_timestep(0.1)
-        ego.set_track(track)
-        ego.ctrl_policy.set_track(track)
-        simulator = offboard.CarRacingSim()
-        simulator.set_timestep(0.1)
-        simulator.set_track(track)
-        simulator.add_vehicle(ego)
-        ego.ctrl_policy.set_racing_sim(simulator)
-        for c in range(2):
-            car = offboard.NoDynamicsModel(name="car%d" % (c + 1), param=base.CarParam())
-            car.set_track(track)
-            car.set_state_curvilinear_func(t_symbol, float(v[b, c]) * t_symbol + float(s0[b, c]), float(ey[b, c]) + 0.0 * t_symbol)
-            car.start_logging()
-            simulator.add_vehicle(car)
-        simulator.sim(sim_time=12.0)
+        cars = [("car%d" % (c + 1), s0[b, c], v[b, c], ey[b, c]) for c in range(2)]
+        ego = scenarios.mpccbf_race(cars=cars, sim_time=12.0).ego
         one = np.array(ego.xcurv_log)
         np.testing.assert_allclose(x[1:one.shape[0] + 1, b], one, atol=1e-3, err_msg="race %d" % b)
 
@@ -397,37 +273,12 @@ def test_overtake_path_step(golden_path):
 def test_mpccbf_racing_m_shape():
     """The same MPC-CBF racing scenario on the m_shape layout (car_racing/tests/mpccbf_test.py --track-layout m_shape):
     another curvature table, a 49.8 m lap -- step by step against the reference's own closed loop on that track."""
-    import sympy as sp
-
-    from racing import offboard
-    from utils import base, racing_env
-    from utils.constants import X_DIM
+    import scenarios
 
     ref = np.load(conftest.GOLDEN + "/closed_loop_mpccbf_m_shape.npz")
     steps = int(ref["steps"])
-    track = racing_env.ClosedTrack(np.genfromtxt(conftest.ROOT + "/data/track_layout/m_shape.csv", delimiter=","), track_width=1.0)
-    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
-    ego.set_zero_noise()
-    ego.set_state_curvilinear(np.zeros((X_DIM,)))
-    ego.set_state_global(np.zeros((X_DIM,)))
-    ego.start_logging()
-    ego.set_ctrl_policy(offboard.MPCCBFRacing(base.MPCCBFRacingParam(vt=0.8), ego.system_param))
-    ego.ctrl_policy.set_timestep(0.1)
-    ego.set_track(track)
-    ego.ctrl_policy.set_track(track)
-    t_symbol = sp.symbols("t")
-    simulator = offboard.CarRacingSim()
-    simulator.set_timestep(0.1)
-    simulator.set_track(track)
-    simulator.add_vehicle(ego)
-    ego.ctrl_policy.set_racing_sim(simulator)
-    for name, s0, ey in (("car1", 4.0, 0.1), ("car2", 10.0, -0.1)):
-        car = offboard.NoDynamicsModel(name=name, param=base.CarParam(edgecolor="orange"))
-        car.set_track(track)
-        car.set_state_curvilinear_func(t_symbol, 0.2 * t_symbol + s0, ey + 0.0 * t_symbol)
-        car.start_logging()
-        simulator.add_vehicle(car)
-    simulator.sim(sim_time=steps * 0.1)
+    race = scenarios.mpccbf_race(dict(scenarios.MPCCBF, track="m_shape"), sim_time=steps * 0.1)
+    ego, track = race.ego, race.track
     e = np.array(ego.xcurv_log)
     assert e.shape == (steps, 6) and np.isfinite(e).all()
     bad = np.nonzero(~ref["solve_success"][1:])[0]

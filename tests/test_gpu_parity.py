@@ -1,12 +1,15 @@
 """libcrx (HIP, through the C ABI) against the CPU oracle and the golden fixtures.  GPU box only.
 
-Tolerances (float64 end to end; both sides run the same interior-point iteration with different
-linear algebra -- Riccati recursion on the GPU, dense condensed Cholesky in the oracle):
-  converged trajectories   |dX| <= 1e-5 on the cost-weighted states vx, s, ey; <= 5e-4 elsewhere
-                           (at tol = 1e-8 the barrier perturbation mu ~ 1e-9 is amplified by the 1e6..1e8
-                           conditioning of the unweighted states; one iteration more or less moves them)
-  cost                     relative 1e-7
-  status / iteration count identical except where noted
+Both sides run the same interior-point iteration with different linear algebra (Riccati recursion on the GPU, dense
+condensed Cholesky in the oracle), float64 end to end.  Two tolerance sets, the same ones the ORACLE is held to against
+the goldens (tests/test_oracle_golden.py):
+  DEFAULT  opts.tol = 1e-8 (IPOPT's default, the product default): the barrier perturbation mu ~ 1e-9 is amplified by the
+           1e6..1e8 conditioning of the unweighted directions -> cost-weighted states vx, s, ey 1e-5, other states 5e-4,
+           inputs 2e-3, cost 1e-7 relative
+  TIGHT    opts.tol = 1e-11: states 2e-7 (weighted 1e-7), INPUTS 2e-6, cost 1e-9 relative -- this is the level at which the
+           value the reference's controllers return, u_pred[0,:] (control/control.py:607, :473), is pinned
+Status and iteration count: identical, problem by problem; `_disagreements` lists every exception and the tests
+assert on the list (see KNOWN_ITER_FLIPS below for what is tolerated and why).
 """
 import numpy as np
 import pytest
@@ -15,7 +18,43 @@ import helpers
 
 pytestmark = pytest.mark.gpu
 
-XW, XALL, UALL, FREL = 1e-5, 5e-4, 2e-3, 1e-7
+DEFAULT = dict(tol=1e-8, x=5e-4, u=2e-3, f=1e-7, xw=1e-5)
+TIGHT = dict(tol=1e-11, x=2e-7, u=2e-6, f=1e-9, xw=1e-7)
+TOLS = pytest.mark.parametrize("T", [DEFAULT, TIGHT], ids=["tol1e-8", "tol1e-11"])
+# (batch, tol) -> problems allowed to differ by an iteration between the kernel and the oracle (see _assert_same_verdicts)
+KNOWN_ITER_FLIPS = {}
+XW, XALL, UALL, FREL = DEFAULT["xw"], DEFAULT["x"], DEFAULT["u"], DEFAULT["f"]
+
+
+def _with_tol(d, tol):
+    d.opts.tol = tol
+    return d
+
+
+def _disagreements(rg, ro):
+    """Every problem whose verdict or iteration count differs between the kernel and the oracle, as printable rows."""
+    sg, so, ig, io = rg["status"], ro["status"], rg["iters"], ro["iters"]
+    rows = []
+    for i in np.nonzero((sg != so) | (ig != io))[0]:
+        both = sg[i] == 0 and so[i] == 0
+        rows.append(dict(i=int(i), status=(int(sg[i]), int(so[i])), iters=(int(ig[i]), int(io[i])),
+                         kkt=(float(rg["kkt"][i]), float(ro["kkt"][i])),
+                         dX=float(np.abs(rg["X"][i] - ro["X"][i]).max()) if both else None))
+    return rows
+
+
+def _assert_same_verdicts(tag, rg, ro, max_iter_flips=0):
+    """Statuses identical problem by problem.  Iteration counts identical except for at most `max_iter_flips` problems
+    where both sides converge to the same point an iteration apart (a line-search / barrier-update test decided on a
+    quantity that differs in the last bits between the two factorisations); each such case is listed in the message."""
+    rows = _disagreements(rg, ro)
+    bad_status = [r for r in rows if r["status"][0] != r["status"][1]]
+    assert not bad_status, (tag, "status disagreements", bad_status[:20])
+    flips = [r for r in rows if r["status"][0] == r["status"][1]]
+    assert len(flips) <= max_iter_flips, (tag, "iteration-count disagreements", flips[:20])
+    for r in flips:
+        if r["status"][0] == 0:
+            assert r["dX"] is not None and r["dX"] <= XALL, (tag, r)
 
 
 @pytest.fixture(scope="module")
@@ -25,39 +64,53 @@ def gpu():
     return crx.init()
 
 
-def _cmp(tag, rg, ro, need_same_status=True):
+def _cmp(tag, rg, ro, need_same_status=True, T=DEFAULT):
     sg, so = rg["status"], ro["status"]
     if need_same_status:
         assert (sg == so).all(), (tag, np.nonzero(sg != so)[0][:10], sg[sg != so][:10], so[sg != so][:10])
     both = (sg == 0) & (so == 0)
     assert both.sum() > 0
-    assert rg["kkt"][both].max() <= 1e-8
+    assert rg["kkt"][both].max() <= T["tol"]
     dX = np.abs(rg["X"][both] - ro["X"][both])
-    assert dX[..., [0, 4, 5]].max() <= XW, (tag, dX[..., [0, 4, 5]].max())
-    assert dX.max() <= XALL, (tag, dX.max())
-    assert np.abs(rg["U"][both] - ro["U"][both]).max() <= UALL
+    assert dX[..., [0, 4, 5]].max() <= T["xw"], (tag, dX[..., [0, 4, 5]].max())
+    assert dX.max() <= T["x"], (tag, dX.max())
+    dU = np.abs(rg["U"][both] - ro["U"][both]).max()
+    assert dU <= T["u"], (tag, dU)
     rel = np.abs(rg["cost"][both] - ro["cost"][both]) / np.maximum(1.0, np.abs(ro["cost"][both]))
-    assert rel.max() <= FREL, (tag, rel.max())
+    assert rel.max() <= T["f"], (tag, rel.max())
     return both
 
 
-def test_golden_mpccbf(gpu, orc, AB, golden_mpccbf):
+@TOLS
+def test_golden_mpccbf(gpu, orc, AB, golden_mpccbf, T):
+    """control.mpccbf NLPs recorded from the reference: the kernel against the certified goldens at the oracle's own
+    tolerances -- in particular u_pred[0,:], the only thing mpccbf returns (control.py:607)."""
     A, B = AB
     for name in golden_mpccbf.names:
         g = golden_mpccbf.case(name)
         d, args = helpers.mpccbf_inputs(g, A, B)
+        _with_tol(d, T["tol"])
         rg = gpu.cbf_solve(d, *args)
         if not bool(g["success"]):
             assert rg["status"][0] != 0, name
             continue
         assert rg["status"][0] == 0, (name, rg["status"], rg["kkt"], rg["iters"])
-        assert abs(rg["cost"][0] - g["cert"][0]) <= 1e-7 * max(1.0, abs(g["cert"][0])), name
-        np.testing.assert_allclose(rg["X"][0][:, [0, 4, 5]], g["X"][:, [0, 4, 5]], atol=1e-5, err_msg=name)
-        np.testing.assert_allclose(rg["U"][0, 0], g["u_returned"], atol=2e-3, err_msg=name)
-        _cmp(name, rg, orc.cbf_solve(d, *args))
+        assert rg["kkt"][0] <= T["tol"]
+        assert abs(rg["cost"][0] - g["cert"][0]) <= T["f"] * max(1.0, abs(g["cert"][0])), name
+        np.testing.assert_allclose(rg["X"][0], g["X"], atol=T["x"], err_msg=name)
+        np.testing.assert_allclose(rg["X"][0][:, [0, 4, 5]], g["X"][:, [0, 4, 5]], atol=T["xw"], err_msg=name)
+        np.testing.assert_allclose(rg["U"][0], g["U"], atol=T["u"], err_msg=name)
+        np.testing.assert_allclose(rg["U"][0, 0], g["u_returned"], atol=T["u"], err_msg=name)
+        n = int(g["n_obs_in_problem"])
+        if n:
+            np.testing.assert_allclose(rg["sigma"][0, :n], g["sigma"], atol=1e-6, err_msg=name)
+        ro = orc.cbf_solve(d, *args)
+        _cmp(name, rg, ro, T=T)
+        assert rg["iters"][0] == ro["iters"][0], (name, rg["iters"], ro["iters"])
 
 
-def test_golden_planner_and_selection(gpu, orc, AB, golden_planner):
+@TOLS
+def test_golden_planner_and_selection(gpu, orc, AB, golden_planner, T):
     from crx import abi
 
     A, B = AB
@@ -66,61 +119,74 @@ def test_golden_planner_and_selection(gpu, orc, AB, golden_planner):
         if not bool(g["overtake_flag"]):
             continue
         d, args = helpers.planner_inputs(g, A, B)
+        _with_tol(d, T["tol"])
         rg = gpu.planner_solve(d, *args)
         ro = orc.planner_solve(d, *args)
         assert ((rg["status"] == 0) == g["region_success"]).all(), (name, rg["status"], g["region_success"])
         for reg, ok in enumerate(g["region_success"]):
-            tol = 1e-5 if ok else 1e-12
-            np.testing.assert_allclose(rg["X"][reg][:, [0, 4, 5]], g["region_X"][reg][:, [0, 4, 5]], atol=tol,
-                                       err_msg="%s/%d" % (name, reg))
-            if not ok:
+            tag = "%s/%d" % (name, reg)
+            if ok:
+                assert abs(rg["cost"][reg] - g["region_cert"][reg, 0]) <= T["f"] * max(1.0, abs(g["region_cert"][reg, 0])), tag
+                np.testing.assert_allclose(rg["X"][reg], g["region_X"][reg], atol=T["x"], err_msg=tag)
+                np.testing.assert_allclose(rg["X"][reg][:, [0, 4, 5]], g["region_X"][reg][:, [0, 4, 5]], atol=T["xw"], err_msg=tag)
+            else:
+                np.testing.assert_allclose(rg["X"][reg], g["region_X"][reg], atol=1e-12, err_msg=tag)
                 assert np.isinf(rg["cost"][reg])
+        _assert_same_verdicts(name, rg, ro)
         if g["region_success"].any():
-            _cmp(name, rg, ro, need_same_status=False)
+            _cmp(name, rg, ro, need_same_status=False, T=T)
         N, V = int(g["N"]), g["obs_pred"].shape[0]
         ds = abi.select_desc(N, V, float(g["lap_length"]))
         sel = gpu.select(ds, np.array([V]), rg["X"][None], g["obs_pred"][None, :, 4, :], g["obs_pred"][None, :, 5, :],
                          np.array([int(g["old_flag"])]))
         assert int(sel["flag"][0]) == int(g["direction_flag"]), name
-        np.testing.assert_allclose(sel["best_X"][0][:, [4, 5]], g["traj_xcurv"][:, [4, 5]], atol=1e-5)
+        np.testing.assert_allclose(sel["best_X"][0][:, [4, 5]], g["traj_xcurv"][:, [4, 5]], atol=T["xw"])
 
 
-def test_golden_mpc_multi_agents(gpu, orc, AB, golden_planner):
+@TOLS
+def test_golden_mpc_multi_agents(gpu, orc, AB, golden_planner, T):
+    """control.mpc_multi_agents NLPs: (u_pred[0,:], x_pred) as returned at control.py:473."""
     A, B = AB
     for name in golden_planner.names:
         g = golden_planner.case(name)
         if not bool(g["overtake_flag"]) or not bool(g["mma_present"]):
             continue
         d, args = helpers.mma_inputs(g, A, B)
+        _with_tol(d, T["tol"])
         rg = gpu.cbf_solve(d, *args)
         assert rg["status"][0] == 0, (name, rg["status"], rg["kkt"], rg["iters"])
-        np.testing.assert_allclose(rg["X"][0][:, [0, 4, 5]], g["mma_X"][:, [0, 4, 5]], atol=1e-5, err_msg=name)
-        np.testing.assert_allclose(rg["U"][0, 0], g["mma_u"], atol=2e-3, err_msg=name)
-        _cmp(name, rg, orc.cbf_solve(d, *args))
+        assert abs(rg["cost"][0] - g["mma_cert"][0]) <= T["f"] * max(1.0, abs(g["mma_cert"][0])), name
+        np.testing.assert_allclose(rg["X"][0], g["mma_X"], atol=T["x"], err_msg=name)
+        np.testing.assert_allclose(rg["X"][0][:, [0, 4, 5]], g["mma_X"][:, [0, 4, 5]], atol=T["xw"], err_msg=name)
+        np.testing.assert_allclose(rg["U"][0, 0], g["mma_u"], atol=T["u"], err_msg=name)
+        np.testing.assert_allclose(rg["X"][0], g["mma_x_pred"], atol=T["x"], err_msg=name)
+        ro = orc.cbf_solve(d, *args)
+        _cmp(name, rg, ro, T=T)
+        assert rg["iters"][0] == ro["iters"][0], (name, rg["iters"], ro["iters"])
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
-def test_synthetic_cbf_batches(gpu, orc, AB, cfg):
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg2_unfiltered", "cfg4"])
+@TOLS
+def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
+    """BASELINE configs[1] at its full batch (256, with and without the round-1 scenario filter) and configs[3] at 192
+    problems: same verdict and same iteration count as the oracle, problem by problem."""
     from crx import abi, synth
 
     A, B = AB
-    if cfg == "cfg2":
-        p = synth.cfg2_mpccbf(256)
+    if cfg.startswith("cfg2"):
+        p = synth.cfg2_mpccbf(256, safe_start=cfg == "cfg2")
         kw = {}
     else:
         p = synth.cfg4_tracking_cbf(192)
         kw = dict(Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
     d = abi.cbf_desc(p["N"], p["obs_s"].shape[1], A, B, alpha=p["alpha"], margin=p["margin"], **kw)
+    _with_tol(d, T["tol"])
     args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
     rg = gpu.cbf_solve(d, *args)
     ro = orc.cbf_solve(d, *args)
-    # both sides run the same iteration: same verdict, and the same iteration count for all but the
-    # few problems where round-off flips a line-search or inertia decision
-    agree = (rg["status"] == ro["status"]).mean()
-    assert agree >= 0.97, agree
-    both = _cmp(cfg, rg, ro, need_same_status=False)
-    assert both.mean() >= 0.95
-    assert (rg["iters"][both] == ro["iters"][both]).mean() >= 0.9
+    _assert_same_verdicts(cfg, rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get((cfg, T["tol"]), 0))
+    both = _cmp(cfg, rg, ro, need_same_status=False, T=T)
+    assert both.mean() >= (0.95 if cfg != "cfg2_unfiltered" else 0.9)
 
 
 @pytest.mark.parametrize("N", [12, 20])
@@ -449,3 +515,115 @@ def test_properties_at_full_size(gpu, AB):
     assert np.abs(res).max() <= 1e-10
     # bounds hold
     assert np.abs(U[..., 0]).max() <= 0.5 + 1e-7 and np.abs(U[..., 1]).max() <= 1.5 + 1e-7
+
+
+def test_cfg5_shard_full_size(gpu, orc, AB):
+    """BASELINE configs[4], one GPU's shard at full size: 16384 raw overtake scenarios (65536 region QPs) through the
+    device-resident chain bench.py times -- crx_planner_prep_dev -> crx_planner_solve_dev -> crx_select_dev
+    (crx.pipeline.PlannerSweep; the all-gather is the identity on one rank).  Oracle-free properties on all of it,
+    oracle parity on a 512-scenario subsample.  Replaces solve_optimization_problem for the sweep of
+    car_racing/tests/overtake_planner_test.py:307-309."""
+    import torch
+    from crx import abi, pipeline, synth
+
+    A, B = AB
+    S, N, V = 16384, 12, 3
+    R = V + 1
+    raw = synth.cfg3_raw(S, N=N, seed=5)
+    dev = torch.device("cuda", 0)
+    sw = pipeline.PlannerSweep(raw, A, B, S, dev)
+    flag, best = sw.step()
+    torch.cuda.synchronize()
+    out = {k: getattr(sw.ws, k).cpu().numpy() for k in ("X", "U", "status", "iters", "kkt", "cost")}
+    flag, best = flag.cpu().numpy().copy(), best.cpu().numpy().copy()
+    assert out["X"].shape == (S * R, N + 1, 6) and flag.shape == (S,)
+    ok = out["status"] == 0
+    assert 0.3 <= ok.mean() <= 0.9                      # a large share of the region QPs is infeasible by construction (SURVEY 8c)
+    assert set(np.unique(out["status"])) <= {0, 1, 2}
+    assert (out["status"] == 1).mean() <= 1e-3           # iteration cap / line-search failure: practically never
+    assert out["kkt"][ok].max() <= 1e-8
+    X, U = out["X"][ok], out["U"][ok]
+    assert np.abs(X[:, 1:] - (X[:, :-1] @ A.T + U @ B.T)).max() <= 1e-10      # dynamics
+    assert np.abs(U[..., 0]).max() <= 0.5 + 1e-7 and np.abs(U[..., 1]).max() <= 1.5 + 1e-7
+    assert X[:, 1:, 0].max() <= 5.0 + 1e-7
+    assert np.isinf(out["cost"][~ok]).all() and (out["U"][~ok] == 0).all()      # fall-back branch (:365-374)
+    # winners are rows of X
+    Xs = out["X"].reshape(S, R, N + 1, 6)
+    np.testing.assert_array_equal(best, Xs[np.arange(S), flag])
+    # bit-identical rerun
+    f2, b2 = sw.step()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(f2.cpu().numpy(), flag)
+    np.testing.assert_array_equal(b2.cpu().numpy(), best)
+    np.testing.assert_array_equal(sw.ws.iters.cpu().numpy(), out["iters"])
+    # permutation invariance: scenarios are independent
+    perm = np.random.default_rng(1).permutation(S)
+    rawp = {k: (v[perm] if isinstance(v, np.ndarray) and v.ndim and v.shape[0] == S else v) for k, v in raw.items()}
+    fp, bp = pipeline.PlannerSweep(rawp, A, B, S, dev).step()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fp.cpu().numpy(), flag[perm])
+    np.testing.assert_array_equal(bp.cpu().numpy(), best[perm])
+    # oracle on a subsample (the mirror's host prep is a Python loop per scenario): host prep + oracle QPs + oracle selection
+    sub = np.sort(np.random.default_rng(2).choice(S, 512, replace=False))
+    from crx import hostprep
+    from planning import planner_helper as ph
+    bez = np.zeros((len(sub), R, N + 1, 2))
+    for i, s in enumerate(sub):
+        cp = ph.bezier_control_points(V, raw["veh_info"][s], raw["max_dv"][s], 0.5, raw["track_width"], raw["lap_length"], 0.2, raw["opt"], raw["x"][s])
+        bez[i] = ph.bezier_polylines(cp, N)
+    lb, ub = hostprep.planner_ey_bounds(raw["x"][sub], raw["obs_s"][sub], raw["obs_ey"][sub], raw["n_veh"][sub], raw["track_width"], raw["lap_length"], N)
+    d = abi.planner_desc(N, A, B)
+    ro = orc.planner_solve(d, np.repeat(raw["x"][sub], R, axis=0), bez[..., 0].reshape(-1, N + 1), bez[..., 1].reshape(-1, N + 1),
+                           lb.reshape(-1, N), ub.reshape(-1))
+    idx = (sub[:, None] * R + np.arange(R)[None]).reshape(-1)
+    rg = {k: out[k][idx] for k in out}
+    _assert_same_verdicts("cfg5 subsample", rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("cfg5", 1e-8), 0))
+    _cmp("cfg5 subsample", rg, ro, need_same_status=False)
+    fb = ro["status"] != 0
+    np.testing.assert_allclose(rg["X"][fb], ro["X"][fb], atol=1e-12)
+    so = orc.select(abi.select_desc(N, V, raw["lap_length"]), raw["n_veh"][sub], ro["X"].reshape(len(sub), R, N + 1, 6),
+                    raw["obs_s"][sub], raw["obs_ey"][sub], raw["old_flag"][sub])
+    np.testing.assert_array_equal(so["flag"], flag[sub])
+    np.testing.assert_allclose(so["best_X"][..., [0, 4, 5]], best[sub][..., [0, 4, 5]], atol=XW)
+
+
+def test_cfg4_full_size(gpu, orc, AB):
+    """BASELINE configs[3] at its full batch: 16384 tracking NLPs (N = 20, 3 obstacles, CBF rows) in one launch.
+    Oracle-free properties on all of them, oracle parity (exact verdicts) on a 256-problem subsample."""
+    from crx import abi, synth
+
+    A, B = AB
+    Bn = 16384
+    p = synth.cfg4_tracking_cbf(Bn, N=20, seed=4, safe_start=False)
+    d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
+    r1 = gpu.cbf_solve(d, *args)
+    ok = r1["status"] == 0
+    assert ok.mean() >= 0.95, ok.mean()
+    assert (r1["status"] == 1).mean() <= 2e-3, (r1["status"] == 1).mean()       # every other problem ends with a defined verdict
+    assert r1["kkt"][ok].max() <= 1e-8
+    X, U, sg = r1["X"][ok], r1["U"][ok], r1["sigma"][ok]
+    assert np.abs(X[:, 1:] - (X[:, :-1] @ A.T + U @ B.T)).max() <= 1e-10
+    assert np.abs(U[..., 0]).max() <= 0.5 + 1e-7 and np.abs(U[..., 1]).max() <= 1.0 + 1e-7
+    assert sg.min() >= -1e-7
+    assert np.abs(X[..., 5]).max() <= 1.0 + 1e-7 and X[..., 0].min() >= -1e-7
+    # CBF rows hold on every converged trajectory: h_{i+1} - (1 - alpha) h_i >= 0 with the slack (control.py:527-558)
+    al, cm = 0.6, 1.15
+    ds = (X[:, None, :, 4] - p["obs_s"][ok] - 0.0) / 0.4
+    de = (X[:, None, :, 5] - p["obs_ey"][ok]) / 0.2
+    h = ds ** 6 + de ** 6 - cm - sg
+    row = h[:, :, 1:] - (1 - al) * h[:, :, :-1]
+    assert row.min() >= -1e-6 * max(1.0, np.abs(h).max() * 1e-9), row.min()
+    # bit-identical rerun, permutation invariance
+    r2 = gpu.cbf_solve(d, *args)
+    for k in ("X", "U", "status", "iters", "kkt"):
+        np.testing.assert_array_equal(r1[k], r2[k])
+    perm = np.random.default_rng(3).permutation(Bn)[:4096]
+    r3 = gpu.cbf_solve(d, *[a[perm] for a in args])
+    np.testing.assert_array_equal(r3["X"], r1["X"][perm])
+    np.testing.assert_array_equal(r3["status"], r1["status"][perm])
+    sub = np.sort(np.random.default_rng(4).choice(Bn, 256, replace=False))
+    ro = orc.cbf_solve(d, *[a[sub] for a in args])
+    rg = {k: r1[k][sub] for k in ("X", "U", "status", "iters", "kkt", "cost")}
+    _assert_same_verdicts("cfg4 subsample", rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("cfg4_full", 1e-8), 0))
+    _cmp("cfg4 subsample", rg, ro, need_same_status=False)
