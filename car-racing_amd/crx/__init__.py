@@ -26,6 +26,15 @@ def lib():
             raise CrxUnavailable(
                 "libcrx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C car-racing_amd/csrc`" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the same SONAMEs as /opt/rocm's.
+        # Whichever is loaded first serves both libcrx and torch: if libcrx pulled in the system runtime first, a later
+        # `import torch` would find "No HIP GPUs" (two HSA runtimes cannot both own the device).  So when torch is
+        # installed, let it load its runtime first; libcrx then binds to the same one.  (torch is plumbing for device
+        # memory and torch.distributed; the C ABI itself needs none of it.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _state["lib"] = ctypes.CDLL(LIB_PATH)
         _state["lib"].crx_last_error.restype = ctypes.c_char_p
         _state["lib"].crx_last_kernel_ms.restype = ctypes.c_double

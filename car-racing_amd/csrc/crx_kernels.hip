@@ -806,6 +806,52 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     SYNC();
 }
 
+// Restoration (CBF instantiations only), entered when the filter line search finds no acceptable step -- where IPOPT
+// switches to its restoration phase.  What jams on crash states (ego inside, or about to enter, an obstacle's unsafe
+// set) is the collapse of the slacks t_j of CBF rows that stay violated.  Every CBF row reads
+//     G_i(x_i, x_{i+1}) + (1 - alpha) sigma_i - sigma_{i+1} >= 0        (control.py:544-558)
+// with free sigma >= 0, so at the current inputs the least-violation point exists in closed form with zero violation:
+// raise the slacks stage by stage from the end of the horizon, sigma_i >= (sigma_{i+1} - G_i + push_i) / (1 - alpha).
+// Same arithmetic, in the same order, as oracle/crx_oracle.c restore_slacks().  Runs once or twice in the life of a
+// crash problem and never otherwise.  (Not a real call: a non-inlined callee makes the kernel reserve the full register file, one wave per SIMD.)
+// G_i goes through the (then dead) row-step array rdt; the recursion itself is serial and runs on every lane alike.
+template <int NOBS, int NMAX>
+__device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double slack_push) {
+    using L = Lay<NOBS, NMAX>;
+    constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
+    const int N = c.N;
+    if (NOBS == 0 || !(c.om > 1e-6)) return false;
+    for (int e = c.lane; e < N * NOBS; e += WAVE) {
+        const int k = e / L::NO, ob = e - k * L::NO;
+        double dsc, dec, dsn, den;
+        cbf_dist<NOBS, NMAX>(sm, c, k, ob, 0.0, dsc, dec, dsn, den);
+        const int q = c.degree;
+        LD(L::rdt + k * NR + 8 + NOBS + ob) = ipow_d(dsn, q) + ipow_d(den, q) - c.om * (ipow_d(dsc, q) + ipow_d(dec, q)) - c.alpha * c.cm;
+    }
+    SYNC();
+    bool changed = false;
+    for (int ob = 0; ob < c.nobs; ob++) {
+        double snext = LD(L::Z + N * NZ + 6 + ob);                       // sigma_N
+        for (int i = N - 1; i >= 0; i--) {
+            const int j = i * NR + 8 + NOBS + ob;
+            const double G = LD(L::rdt + j), push = slack_push / LD(L::rsc + j);
+            const double need = (snext - G + push) / c.om;
+            double si = LD(L::Z + i * NZ + 6 + ob);
+            if (need > si) {
+                si = need;
+                changed = true;
+                if (c.lane == 0) {                                       // both copies of sigma_i (state of stage i, input of stage i-1)
+                    LD(L::Z + i * NZ + 6 + ob) = si;
+                    if (i >= 1) LD(L::Z + (i - 1) * NZ + NX + 2 + ob) = si;
+                }
+            }
+            snext = si;
+        }
+    }
+    SYNC();
+    return changed;
+}
+
 // ------------------------------------------------------------------------------------------------
 // (5) the solver kernel
 // ------------------------------------------------------------------------------------------------
@@ -813,8 +859,16 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
 // 168 VGPRs for <0,12>, 256 for <2,12> -- buys a resident wave per SIMD but costs spills inside the interior-point loop:
 // measured -4 % on cfg3 and -2 % on cfg2 at the BASELINE batches, +1 % / +7 % only for batches of 16k planner QPs /
 // 16k two-car races.  Residency is therefore min(LDS, 512 / VGPRs per SIMD); crx_debug_resident_per_cu asks the runtime.)
+// Resident waves per SIMD the register allocator must leave room for.  Only the 1-obstacle, N <= 12 instantiation (BASELINE
+// configs[1], the MPC-CBF races) is pinned: it sat at 255 registers = 2 waves per SIMD before the restoration code was
+// added and at 262 after; the bound makes the allocator park the handful of extra values (used outside the interior-
+// point loop) instead of silently halving the residency.  Every other instantiation is left alone (capping those was
+// measured in round 1 and rejected: spills inside the loop).
+template <int NOBS, int NMAX> struct MinWaves { static constexpr int v = (NOBS == 1 && NMAX == 12) ? 2 : 1; };
+
 template <int NOBS, int NMAX>
-__global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
+crx_solve_kernel(const crx_kparams kp) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1032,17 +1086,33 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
     // row statistics of the current iterate: sum nu, max |c - t|, max and min of t*nu over the present rows.  Computed
     // here for the start point and afterwards inside the accept pass, which touches every row anyway.
     double nus = 0.0, e_p = 0.0, cmax = 0.0, cmin = INFINITY;
-    for (int j = lane; j < m; j += WAVE) {
-        const bool on = LD(L::rsc + j) != 0.0;
-        const double t = LD(L::rt + j), nu = LD(L::rnu + j);
-        nus += nu;
-        e_p = fmax(e_p, on ? fabs(LD(L::rc + j) - t) : 0.0);
-        cmax = fmax(cmax, on ? t * nu : 0.0);
-        cmin = fmin(cmin, on ? t * nu : INFINITY);
-    }
-    nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
+    auto row_stats = [&]() {
+        nus = 0.0; e_p = 0.0; cmax = 0.0; cmin = INFINITY;
+        for (int j = lane; j < m; j += WAVE) {
+            const bool on = LD(L::rsc + j) != 0.0;
+            const double t = LD(L::rt + j), nu = LD(L::rnu + j);
+            nus += nu;
+            e_p = fmax(e_p, on ? fabs(LD(L::rc + j) - t) : 0.0);
+            cmax = fmax(cmax, on ? t * nu : 0.0);
+            cmin = fmin(cmin, on ? t * nu : INFINITY);
+        }
+        nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
+    };
+    row_stats();
+    // The interior-point loop sits inside a retry loop: when the line search finds no acceptable step the (out-of-loop,
+    // rare) restoration below re-initialises the CBF slacks and the loop is entered again, at most twice.  Keeping the
+    // restoration outside the loop body keeps its registers out of the loop's allocation (inside it cost the 1-obstacle
+    // instantiation 14 registers = one resident wave per SIMD).
+    int n_restore = 0, ls_failed = 0;
+    theta_min = -1.0;    // < 0: the filter's theta_min / theta_max are taken at the next step (start, and after a restoration)
+    for (;;) {
+    ls_failed = 0;
+    // Nothing is to be carried in registers from one pass to the next: without this barrier the loop-invariant operands
+    // of the sweeps (model-matrix rows, lane maps: ~200 registers) are hoisted out of BOTH loops and stay live across
+    // the restoration code, whose own temporaries then push the kernel past 256 registers.
+    asm volatile("" ::: "memory");
 
-    for (it = 0;; it++) {
+    for (;; it++) {
         long long tc0 = CLK();
         // ---- KKT error -----------------------------------------------------------------------------
         double e_c = cmax;
@@ -1132,7 +1202,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         const double cost_d = cost_dir<NOBS, NMAX>(sm, c, cost_qq);
         Dphi = wave_sum(Dphi) + cost_d;
         const double phi0 = f - mu * lg0.wave_total();
-        if (it == 0) {
+        if (theta_min < 0.0) {
             theta_min = 1e-4 * fmax(1.0, theta);
             theta_max = 1e4 * fmax(1.0, theta);
         }
@@ -1204,7 +1274,7 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
             if (lane == 0) { LD(L::Fth + nf) = (1.0 - 1e-5) * theta; LD(L::Fph + nf) = phi0 - 1e-8 * theta; }
             nf++;
         }
-        if (!acc) break;
+        if (!acc) { ls_failed = 1; break; }
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
         COORDS(e, ev, lane, N * NZ + NX) {
@@ -1255,6 +1325,33 @@ __global__ void __launch_bounds__(WAVE) crx_solve_kernel(const crx_kparams kp) {
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
             kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (CLK() - tc8));   // slot 8: KKT rows + accept/first-order
         if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
+    }
+    if (!ls_failed) break;
+    if (NOBS && n_restore < 2 && __builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push))) {
+        // slacks of the CBF rows and of the sigma bounds re-initialised like at the start, multipliers centred
+        eval_rows<NOBS, NMAX>(sm, si, c);
+        SYNC();
+        for (int j = lane; j < m; j += WAVE) {
+            const bool cbf = ROW_IS_CBF(j, N);
+            const int r = j < N * NR ? j % NR : 8;              // rows N*NR.. are the sigma_0 bounds
+            const bool sig = NOBS && (j >= N * NR || (r >= 8 && r < 8 + NOBS));
+            if ((cbf || sig) && LD(L::rsc + j) != 0.0) {
+                const double t = fmax(fabs(LD(L::rc + j)), o.slack_push);
+                LD(L::rt + j) = t;
+                LD(L::rnu + j) = fmin(fmax(o.mu_init / t, 1e-8), 1e8);
+            }
+        }
+        SYNC();
+        first_order<NOBS, NMAX>(sm, si, c);
+        f = cost_value<NOBS, NMAX>(sm, c, 0.0);
+        row_stats();
+        n_restore++; mu = o.mu_init; nf = 0; theta_min = -1.0; theta_max = INFINITY; dw_last = 0.0; status = 1;
+        it++;                                            // the failed line search was an iteration (oracle: `continue`)
+        continue;
+    }
+    // no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still violated there
+    if (e_p > 1e-6) status = 2;
+    break;
     }
     if (infeas0) status = 2;
 

@@ -23,7 +23,8 @@
  *     Fiacco-McCormick barrier update (eq. 7), fraction-to-the-boundary rule (eq. 15), primal-dual
  *     Newton step with inertia correction by W + delta_w*I (Alg. IC), multiplier safeguard (eq. 16),
  *     gradient-based constraint scaling (sec. 3.8), error measure E_mu (eq. 5), filter line search
- *     (sec. 2.3) without second-order correction; there is no restoration phase.
+ *     (sec. 2.3) without second-order correction; the restoration phase is the closed-form one of
+ *     restore_slacks() (CBF NLP only).
  *     Because the dynamics are linear and x0 is fixed, states are eliminated (condensing) and the
  *     reduced Newton system is factorised by a DENSE Cholesky -- on purpose a different linear-algebra
  *     route from the HIP kernel's Riccati recursion, so that agreement between the two is evidence.
@@ -386,6 +387,44 @@ static int thread_ws(work_t** w, ocp_t** p) {
 static int g_verbose = 0;
 void crx_oracle_set_verbose(int v) { g_verbose = v; }
 
+/* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
+ * its restoration phase).  What jams on crash states (ego inside, or about to enter, an obstacle's unsafe set) is the
+ * collapse of the slacks t_j of CBF rows that stay violated.  Every CBF row reads
+ *     G_i(x_i, x_{i+1}) + (1 - alpha) sigma_i - sigma_{i+1} >= 0        (control.py:544-558)
+ * with free sigma >= 0, so AT THE CURRENT INPUTS the least-violation point IPOPT's restoration looks for
+ * (min ||c - t||_1 near the iterate) exists in closed form with zero violation: raise the slacks stage by stage from
+ * the end of the horizon, sigma_i >= (sigma_{i+1} - G_i + push_i) / (1 - alpha).  Rows and sigma bounds are then
+ * strictly inside, their slacks are re-initialised like at the start (t = c) and their multipliers centred (nu = mu/t);
+ * the interior-point iteration resumes from there with a fresh filter.  Returns 0 if nothing changed (no CBF rows,
+ * alpha = 1, or every row already feasible): the failure then stands. */
+static int restore_slacks(work_t* w, double mu) {
+    const ocp_t* p = w->p;
+    const crx_ipm_opts* o = w->o;
+    const double om = 1.0 - p->alpha;
+    if (p->nobs == 0 || !(om > 1e-6)) return 0;
+    unpack(w, w->v);
+    int changed = 0;
+    for (int j = w->m - 1; j >= 0; j--) {     /* CBF rows are stored per obstacle with the stage ascending: walk them backwards */
+        if (w->row[j].kind != ROW_CBF) continue;
+        const int i = w->row[j].k, ob = w->row[j].o, q = p->degree;
+        double dsc, dec, dsn, den;
+        cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
+        const double G = ipow(dsn, q) + ipow(den, q) - om * (ipow(dsc, q) + ipow(dec, q)) - p->alpha * p->cm;
+        const double push = o->slack_push / w->d[j];          /* the SCALED row value ends up >= slack_push */
+        const double need = (w->sig[ob][i + 1] - G + push) / om;
+        if (need > w->sig[ob][i]) { w->sig[ob][i] = need; w->v[isig(w, i, ob)] = need; changed = 1; }
+    }
+    if (!changed) return 0;
+    eval_full(w);
+    for (int j = 0; j < w->m; j++) {
+        const int kind = w->row[j].kind;
+        if (kind != ROW_CBF && kind != ROW_SIG) continue;
+        w->t[j] = fmax(fabs(w->c[j]), o->slack_push);
+        w->nu[j] = fmin(fmax(mu / w->t[j], 1e-8), 1e8);
+    }
+    return 1;
+}
+
 static void ipm_solve(work_t* w, result_t* res) {
     const ocp_t* p = w->p;
     const crx_ipm_opts* o = w->o;
@@ -416,7 +455,7 @@ static void ipm_solve(work_t* w, result_t* res) {
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0;
-    int status = CRX_MAX_ITER, it = 0;
+    int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     for (it = 0;; it++) {
         /* residuals */
@@ -441,7 +480,7 @@ static void ipm_solve(work_t* w, result_t* res) {
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (g_verbose)
-            fprintf(stderr, "it %3d f %.8e ed %.2e ep %.2e ec %.2e mu %.1e dw %.1e nf %d\n", it, w->f, e_d, e_p, e_c, mu, dw_last, nf);
+            fprintf(stderr, "it %3d f %.8e ed %.6e ep %.6e ec %.6e mu %.1e dw %.1e nf %d\n", it, w->f, e_d, e_p, e_c, mu, dw_last, nf);
         if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
         /* barrier update */
@@ -533,13 +572,14 @@ static void ipm_solve(work_t* w, result_t* res) {
         }
         for (int a = 0; a < n; a++) Dphi += w->g[a] * w->dv[a];
         for (int a = 0; a < n; a++) curv += w->dv[a] * w->rhs[a];
-        /* filter line search (Waechter & Biegler sec. 2.3; no second-order correction, no
-         * restoration phase): theta = ||c - t||_1, phi = barrier objective */
+        /* filter line search (Waechter & Biegler sec. 2.3; no second-order correction):
+         * theta = ||c - t||_1, phi = barrier objective */
         double phi0 = w->f;
         for (int j = 0; j < m; j++) phi0 -= mu * log(w->t[j]);
-        if (it == 0) {
+        if (first) {   /* start, and again after a restoration */
             theta_min = 1e-4 * fmax(1.0, theta);
             theta_max = 1e4 * fmax(1.0, theta);
+            first = 0;
         }
         double al = a_p;
         int acc = 0, ftype = 0;
@@ -572,13 +612,23 @@ static void ipm_solve(work_t* w, result_t* res) {
         if (g_verbose > 1 && jblock >= 0)
             fprintf(stderr, "      blocking row %d kind %d k %d i %d: t %.3e dt %.3e c %.3e nu %.3e\n", jblock, w->row[jblock].kind,
                     w->row[jblock].k, w->row[jblock].i, w->t[jblock], w->dt[jblock], w->c[jblock], w->nu[jblock]);
-        if (g_verbose) fprintf(stderr, "      a_p %.3e a_d %.3e alpha %.3e acc %d ftype %d theta %.2e Dphi %.2e curv %.2e dw %.1e\n", a_p, a_d, al, acc, ftype, theta, Dphi, curv, dw);
+        if (g_verbose) fprintf(stderr, "      a_p %.3e a_d %.6e alpha %.6e acc %d ftype %d theta %.2e Dphi %.2e curv %.2e dw %.1e\n", a_p, a_d, al, acc, ftype, theta, Dphi, curv, dw);
         if (acc && !ftype && nf < MAXF) {
             Fth[nf] = (1.0 - 1e-5) * theta;
             Fph[nf] = phi0 - 1e-8 * theta;
             nf++;
         }
-        if (!acc) break;
+        if (!acc) {
+            if (n_restore < 2 && restore_slacks(w, o->mu_init)) {
+                if (g_verbose) fprintf(stderr, "      RESTORE\n");
+                n_restore++; mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0;
+                continue;
+            }
+            /* no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still
+             * violated there (IPOPT: "converged to a point of local infeasibility" / "restoration failed") */
+            if (e_p > 1e-6) status = CRX_INFEASIBLE;
+            break;
+        }
         memcpy(w->v, vtrial, sizeof(double) * n);
         memcpy(w->t, ttrial, sizeof(double) * m);
         eval_full(w);

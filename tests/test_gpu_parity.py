@@ -26,6 +26,18 @@ KNOWN_ITER_FLIPS = {}
 XW, XALL, UALL, FREL = DEFAULT["xw"], DEFAULT["x"], DEFAULT["u"], DEFAULT["f"]
 
 
+def _report(tag, rows):
+    """Append disagreement rows to gpurun_out/parity_report.jsonl when CRX_PARITY_REPORT is set (diagnostics)."""
+    import json
+    import os
+
+    if os.environ.get("CRX_PARITY_REPORT") and rows:
+        import conftest
+        os.makedirs(os.path.join(conftest.ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(conftest.ROOT, "gpurun_out", "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"tag": tag, "rows": rows}) + "\n")
+
+
 def _with_tol(d, tol):
     d.opts.tol = tol
     return d
@@ -48,6 +60,7 @@ def _assert_same_verdicts(tag, rg, ro, max_iter_flips=0):
     where both sides converge to the same point an iteration apart (a line-search / barrier-update test decided on a
     quantity that differs in the last bits between the two factorisations); each such case is listed in the message."""
     rows = _disagreements(rg, ro)
+    _report(tag, rows)
     bad_status = [r for r in rows if r["status"][0] != r["status"][1]]
     assert not bad_status, (tag, "status disagreements", bad_status[:20])
     flips = [r for r in rows if r["status"][0] == r["status"][1]]
@@ -86,6 +99,7 @@ def test_golden_mpccbf(gpu, orc, AB, golden_mpccbf, T):
     """control.mpccbf NLPs recorded from the reference: the kernel against the certified goldens at the oracle's own
     tolerances -- in particular u_pred[0,:], the only thing mpccbf returns (control.py:607)."""
     A, B = AB
+    flips = []
     for name in golden_mpccbf.names:
         g = golden_mpccbf.case(name)
         d, args = helpers.mpccbf_inputs(g, A, B)
@@ -106,7 +120,10 @@ def test_golden_mpccbf(gpu, orc, AB, golden_mpccbf, T):
             np.testing.assert_allclose(rg["sigma"][0, :n], g["sigma"], atol=1e-6, err_msg=name)
         ro = orc.cbf_solve(d, *args)
         _cmp(name, rg, ro, T=T)
-        assert rg["iters"][0] == ro["iters"][0], (name, rg["iters"], ro["iters"])
+        if rg["iters"][0] != ro["iters"][0]:
+            flips.append((name, int(rg["iters"][0]), int(ro["iters"][0])))
+    _report("golden_mpccbf tol=%g" % T["tol"], flips)
+    assert len(flips) <= KNOWN_ITER_FLIPS.get(("golden_mpccbf", T["tol"]), 0), flips
 
 
 @TOLS
@@ -132,7 +149,7 @@ def test_golden_planner_and_selection(gpu, orc, AB, golden_planner, T):
             else:
                 np.testing.assert_allclose(rg["X"][reg], g["region_X"][reg], atol=1e-12, err_msg=tag)
                 assert np.isinf(rg["cost"][reg])
-        _assert_same_verdicts(name, rg, ro)
+        _assert_same_verdicts("golden_planner/" + name, rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("golden_planner", T["tol"]), 0))
         if g["region_success"].any():
             _cmp(name, rg, ro, need_same_status=False, T=T)
         N, V = int(g["N"]), g["obs_pred"].shape[0]
@@ -147,6 +164,7 @@ def test_golden_planner_and_selection(gpu, orc, AB, golden_planner, T):
 def test_golden_mpc_multi_agents(gpu, orc, AB, golden_planner, T):
     """control.mpc_multi_agents NLPs: (u_pred[0,:], x_pred) as returned at control.py:473."""
     A, B = AB
+    flips = []
     for name in golden_planner.names:
         g = golden_planner.case(name)
         if not bool(g["overtake_flag"]) or not bool(g["mma_present"]):
@@ -162,7 +180,10 @@ def test_golden_mpc_multi_agents(gpu, orc, AB, golden_planner, T):
         np.testing.assert_allclose(rg["X"][0], g["mma_x_pred"], atol=T["x"], err_msg=name)
         ro = orc.cbf_solve(d, *args)
         _cmp(name, rg, ro, T=T)
-        assert rg["iters"][0] == ro["iters"][0], (name, rg["iters"], ro["iters"])
+        if rg["iters"][0] != ro["iters"][0]:
+            flips.append((name, int(rg["iters"][0]), int(ro["iters"][0])))
+    _report("golden_mma tol=%g" % T["tol"], flips)
+    assert len(flips) <= KNOWN_ITER_FLIPS.get(("golden_mma", T["tol"]), 0), flips
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg2_unfiltered", "cfg4"])
@@ -199,9 +220,9 @@ def test_synthetic_planner_batch_and_selection(gpu, orc, AB, N):
     args = (p["x0"], p["bez_s"], p["bez_ey"], p["ey_lb"], p["ey_ub"])
     rg = gpu.planner_solve(d, *args)
     ro = orc.planner_solve(d, *args)
-    # feasibility verdict (converged vs fall-back) must be identical: it selects the code path the
-    # reference takes (overtake_traj_planner.py:361-374)
-    assert ((rg["status"] == 0) == (ro["status"] == 0)).all()
+    # the verdict (converged vs infeasible -> fall-back) must be identical problem by problem: it selects the code path
+    # the reference takes (overtake_traj_planner.py:361-374)
+    _assert_same_verdicts("cfg3 N=%d" % N, rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("cfg3", N), 0))
     _cmp("planner", rg, ro, need_same_status=False)
     fb = rg["status"] != 0
     np.testing.assert_allclose(rg["X"][fb], ro["X"][fb], atol=1e-12)
@@ -238,9 +259,8 @@ def test_golden_lmpc(gpu, orc, golden_racing_game):
     assert np.abs(rg["X"][ok] - ro["X"][ok]).max() <= 5e-6
     rel = np.abs(rg["cost"][ok] - ro["cost"][ok]) / np.abs(ro["cost"][ok])
     assert rel.max() <= 1e-8
-    # same verdict on every instance the oracle converges or declares infeasible on
-    same = (ro["status"] == 0) | (ro["status"] == 2)
-    assert (rg["status"][same] == ro["status"][same]).mean() >= 0.95
+    # same verdict and iteration count on every recorded instance (incl. the relaxed second attempt on the infeasible ones)
+    _assert_same_verdicts("lmpc recorded", rg, ro)
     # batch entries are independent
     r1 = gpu.lmpc_solve(d, *[a[3:9] for a in args])
     np.testing.assert_array_equal(r1["X"], rg["X"][3:9])
@@ -383,6 +403,7 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
     A, B = AB
     rng = np.random.default_rng(2024)
     checked = 0
+    verdict_flips, iter_flips = [], []
     for trial in range(14):
         N = int(rng.integers(3, 25))
         V = int(rng.integers(0, 4))
@@ -400,21 +421,27 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
             n = rng.integers(0, V + 1, nb).astype(np.int32)
             args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], n)
         rg, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
-        agree = ((rg["status"] == 0) == (ro["status"] == 0)).mean()
-        assert agree >= 0.9, (trial, N, V, agree)
+        rows = _disagreements(rg, ro)
+        _report("fuzz cbf trial %d N=%d V=%d" % (trial, N, V), rows)
+        verdict_flips += [(trial, r) for r in rows if (r["status"][0] == 0) != (r["status"][1] == 0)]
+        iter_flips += [(trial, r) for r in rows if r["status"][0] == r["status"][1]]
         both = (rg["status"] == 0) & (ro["status"] == 0)
         if both.any():
             dX = np.abs(rg["X"][both] - ro["X"][both])
             assert dX[..., [0, 4, 5]].max() <= XW and dX.max() <= XALL, (trial, N, V, dX.max())
             checked += int(both.sum())
     assert checked >= 300
+    # 14 x 48 problems over the whole descriptor space (degrees 2..6, horizons 3..24): converged-vs-not identical but for
+    # the listed cases, iteration counts likewise
+    assert len(verdict_flips) <= KNOWN_ITER_FLIPS.get(("fuzz", "verdict"), 0), verdict_flips[:20]
+    assert len(iter_flips) <= KNOWN_ITER_FLIPS.get(("fuzz", "iters"), 0), iter_flips[:20]
     # planner QPs at every horizon class
     for N in (3, 7, 12, 13, 19, 24):
         p = synth.cfg3_planner(16, N=N, seed=N)
         d = abi.planner_desc(N, A, B)
         args = (p["x0"], p["bez_s"], p["bez_ey"], p["ey_lb"], p["ey_ub"])
         rg, ro = gpu.planner_solve(d, *args), orc.planner_solve(d, *args)
-        assert ((rg["status"] == 0) == (ro["status"] == 0)).all(), N
+        _assert_same_verdicts("fuzz planner N=%d" % N, rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("fuzz planner", N), 0))
         _cmp("planner N=%d" % N, rg, ro, need_same_status=False)
     # learning-MPC QPs: ragged safe-set sizes (first n points of each recorded hull) and shorter horizons
     g = golden_racing_game
@@ -429,7 +456,7 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         args = (g["lmpc/x"][ok], g["lmpc/u_old"][ok], g["lmpc/A"][ok][:, idx], g["lmpc/B"][ok][:, idx], g["lmpc/C"][ok][:, idx],
                 g["lmpc/ss"][ok], g["lmpc/qfun"][ok], n_ss)
         rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
-        assert (rg["status"] == ro["status"]).mean() >= 0.9, (N, rg["status"], ro["status"])
+        _assert_same_verdicts("fuzz lmpc N=%d" % N, rg, ro, max_iter_flips=KNOWN_ITER_FLIPS.get(("fuzz lmpc", N), 0))
         both = (rg["status"] == ro["status"]) & (ro["status"] != 1)
         assert both.sum() >= (12 if N <= 12 else 4), (N, ro["status"])
         assert np.abs(rg["X"][both] - ro["X"][both]).max() <= 1e-5, N
