@@ -11,14 +11,14 @@ import numpy as np
 CRX_MAX_N = 24
 CRX_MAX_OBS = 3
 
-CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE = 0, 1, 2
+CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED = 0, 1, 2, 3
 
 
 class IpmOpts(C.Structure):
     _fields_ = [
         ("tol", C.c_double),
         ("max_iter", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("restore_iters", C.c_int32),
         ("mu_init", C.c_double),
         ("kappa_eps", C.c_double),
         ("kappa_mu", C.c_double),
@@ -31,7 +31,7 @@ class IpmOpts(C.Structure):
 
 def default_opts():
     """IPOPT defaults the reference inherits (control.py:593 passes print options only)."""
-    return IpmOpts(1e-8, 200, 0, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0)
+    return IpmOpts(1e-8, 200, 25, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0)
 
 
 class PlannerDesc(C.Structure):

@@ -1103,7 +1103,12 @@ crx_solve_kernel(const crx_kparams kp) {
     // rare) restoration below re-initialises the CBF slacks and the loop is entered again, at most twice.  Keeping the
     // restoration outside the loop body keeps its registers out of the loop's allocation (inside it cost the 1-obstacle
     // instantiation 14 registers = one resident wave per SIMD).
-    int n_restore = 0, ls_failed = 0;
+    // ls_failed: 1 = no acceptable step, 2 = jam (JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the
+    // constraints are still violated: the slacks of violated CBF rows are collapsing and every step is cut to nothing --
+    // IPOPT's alpha < alpha_min test sends it to restoration from the same situation)
+    constexpr int JAM_COUNT = 5;
+    const double JAM_ALPHA = 1e-3;
+    int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0;
     theta_min = -1.0;    // < 0: the filter's theta_min / theta_max are taken at the next step (start, and after a restoration)
     for (;;) {
     ls_failed = 0;
@@ -1124,6 +1129,7 @@ crx_solve_kernel(const crx_kparams kp) {
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (E0 <= o.tol) { status = 0; break; }
         if (it >= o.max_iter) break;
+        if (NOBS && n_restore > 0 && it >= it_limit) { status = 3; break; }   // restoration budget used up (CRX_RESTORED)
         // ---- barrier update ------------------------------------------------------------------------
         for (;;) {
             // max_j |t_j nu_j - mu| from the extremes of t*nu: no pass over the rows
@@ -1216,7 +1222,12 @@ crx_solve_kernel(const crx_kparams kp) {
         // v_log_f32 of the mantissa, ~1e-7 absolute).  Two pow() calls were ~2.6 k cycles of this iteration and kept ~50
         // VGPRs of polynomial constants alive; the test is a heuristic threshold, a tie within 1e-7 may fall either way.
         const double sw_gap = sw_try ? 2.3 * log2_fast(-Dphi) - 1.1 * log2_fast(theta) : 0.0;
-        for (int ls = 0; ls < 40; ls++) {
+        // A step length below 1e-12 is the quotient of two numbers that have both lost every digit (slacks of violated rows
+        // collapsed to ~1e-20 on an infeasible problem): it carries no information, and whether the filter happens to
+        // accept it is decided by rounding.  Such a step counts as "no acceptable step" (IPOPT's tiny-step test plays
+        // the same role), which makes the iteration at which an infeasible problem is given up reproducible.
+        const int ls_max = (a_p < 1e-12) ? 0 : 40;
+        for (int ls = 0; ls < ls_max; ls++) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
@@ -1275,6 +1286,10 @@ crx_solve_kernel(const crx_kparams kp) {
             nf++;
         }
         if (!acc) { ls_failed = 1; break; }
+        if (NOBS) {
+            jam = (jam_on && al < JAM_ALPHA && e_p > o.tol) ? jam + 1 : 0;
+            if (jam >= JAM_COUNT && n_restore < 2) { ls_failed = 2; break; }
+        }
         // ---- accept ------------------------------------------------------------------------------------
         SYNC();
         COORDS(e, ev, lane, N * NZ + NX) {
@@ -1327,7 +1342,7 @@ crx_solve_kernel(const crx_kparams kp) {
         if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
     }
     if (!ls_failed) break;
-    if (NOBS && n_restore < 2 && __builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push))) {
+    if (NOBS && o.restore_iters >= 0 && n_restore < 2 && __builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push))) {
         // slacks of the CBF rows and of the sigma bounds re-initialised like at the start, multipliers centred
         eval_rows<NOBS, NMAX>(sm, si, c);
         SYNC();
@@ -1345,8 +1360,15 @@ crx_solve_kernel(const crx_kparams kp) {
         first_order<NOBS, NMAX>(sm, si, c);
         f = cost_value<NOBS, NMAX>(sm, c, 0.0);
         row_stats();
-        n_restore++; mu = o.mu_init; nf = 0; theta_min = -1.0; theta_max = INFINITY; dw_last = 0.0; status = 1;
-        it++;                                            // the failed line search was an iteration (oracle: `continue`)
+        if (n_restore++ == 0) it_limit = it + 1 + o.restore_iters;
+        mu = o.mu_init; nf = 0; theta_min = -1.0; theta_max = INFINITY; dw_last = 0.0; status = 1; jam = 0;
+        it++;                                            // the abandoned step was an iteration (oracle: `continue`)
+        continue;
+    }
+    if (ls_failed == 2) {
+        // jammed, but nothing to restore (the violated rows are not CBF rows): stop looking for jams and redo this
+        // iteration -- same state, same step, accepted this time (the oracle simply goes on to accept it)
+        jam_on = 0; jam = 0;
         continue;
     }
     // no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still violated there

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 100 /* 0.1.0 */
+#define CRX_VERSION 110 /* 0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0) */
 #define CRX_NX 6
 #define CRX_NU 2
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
@@ -64,7 +64,13 @@ typedef enum crx_err {
 typedef enum crx_status {
     CRX_CONVERGED = 0,     /* KKT error <= tol */
     CRX_MAX_ITER = 1,      /* iteration cap or line-search failure; last iterate returned */
-    CRX_INFEASIBLE = 2     /* constraints cannot be met (incl. a bound already violated by the fixed x0) */
+    CRX_INFEASIBLE = 2,    /* constraints cannot be met (incl. a bound already violated by the fixed x0), or no acceptable
+                              step exists at a point that still violates them (IPOPT: local infeasibility) */
+    CRX_RESTORED = 3       /* MPC-CBF NLPs only: the solve went through its restoration phase (the step jammed on violated
+                              CBF rows, or the line search failed: a crash state) and used up opts.restore_iters further
+                              iterations without converging.  The returned iterate satisfies every CBF row through its
+                              slacks sigma (least-violation point, zero violation) but is not optimal.  Like every status
+                              != 0 it selects the reference's "use the last iterate" branch (control.py:600-603). */
 } crx_status;
 
 /* Interior-point options.  Defaults (crx_ipm_opts_default) restate IPOPT 3.x defaults that the
@@ -72,7 +78,8 @@ typedef enum crx_status {
 typedef struct crx_ipm_opts {
     double tol;            /* 1e-8  convergence tolerance on the scaled KKT error */
     int32_t max_iter;      /* 200   (IPOPT: 3000; capped, status CRX_MAX_ITER beyond) */
-    int32_t reserved0;
+    int32_t restore_iters; /* 25    iterations allowed after the first restoration (CRX_RESTORED beyond); < 0: no restoration
+                              phase at all (a failed line search then ends the solve, as in libcrx 0.1.0) */
     double mu_init;        /* 0.1   */
     double kappa_eps;      /* 10    barrier sub-problem tolerance factor */
     double kappa_mu;       /* 0.2   linear decrease factor */

@@ -455,7 +455,9 @@ static void ipm_solve(work_t* w, result_t* res) {
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0;
-    int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1;
+    enum { JAM_COUNT = 5 };
+    const double JAM_ALPHA = 1e-3;
+    int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     for (it = 0;; it++) {
         /* residuals */
@@ -483,6 +485,7 @@ static void ipm_solve(work_t* w, result_t* res) {
             fprintf(stderr, "it %3d f %.8e ed %.6e ep %.6e ec %.6e mu %.1e dw %.1e nf %d\n", it, w->f, e_d, e_p, e_c, mu, dw_last, nf);
         if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
+        if (n_restore > 0 && it >= it_limit) { status = CRX_RESTORED; break; }   /* restoration budget used up */
         /* barrier update */
         for (;;) {
             double e_cm = 0.0;
@@ -583,7 +586,9 @@ static void ipm_solve(work_t* w, result_t* res) {
         }
         double al = a_p;
         int acc = 0, ftype = 0;
-        for (int ls = 0; ls < 40; ls++) {
+        /* a step length below 1e-12 carries no information (see the kernel): no acceptable step */
+        const int ls_max = (a_p < 1e-12) ? 0 : 40;
+        for (int ls = 0; ls < ls_max; ls++) {
             for (int a = 0; a < n; a++) vtrial[a] = w->v[a] + al * w->dv[a];
             double fn;
             eval_fc(w, vtrial, &fn, ctrial);
@@ -618,12 +623,20 @@ static void ipm_solve(work_t* w, result_t* res) {
             Fph[nf] = phi0 - 1e-8 * theta;
             nf++;
         }
-        if (!acc) {
-            if (n_restore < 2 && restore_slacks(w, o->mu_init)) {
-                if (g_verbose) fprintf(stderr, "      RESTORE\n");
-                n_restore++; mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0;
+        /* jam: JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the constraints are still violated -- the
+         * slacks of violated CBF rows are collapsing and every step is cut to nothing (IPOPT's alpha < alpha_min test
+         * sends it to restoration from the same situation) */
+        if (acc && jam_on && al < JAM_ALPHA && e_p > o->tol) jam++; else jam = 0;
+        if (!acc || jam >= JAM_COUNT) {
+            if (o->restore_iters >= 0 && n_restore < 2 && restore_slacks(w, o->mu_init)) {
+                if (g_verbose) fprintf(stderr, "      RESTORE (acc %d jam %d)\n", acc, jam);
+                if (n_restore++ == 0) it_limit = it + 1 + o->restore_iters;
+                mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0; jam = 0;
                 continue;
             }
+            if (acc) { jam_on = 0; jam = 0; }   /* nothing to restore: the jam is not about CBF rows; carry on, stop looking */
+        }
+        if (!acc) {
             /* no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still
              * violated there (IPOPT: "converged to a point of local infeasibility" / "restoration failed") */
             if (e_p > 1e-6) status = CRX_INFEASIBLE;
@@ -666,7 +679,7 @@ static double interp_lin(const double* xs, const double* ys, int n, double x) {
 static double clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
-    o->tol = 1e-8; o->max_iter = 200; o->reserved0 = 0; o->mu_init = 0.1; o->kappa_eps = 10.0;
+    o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2;
     o->grad_scale_max = 100.0;
 }

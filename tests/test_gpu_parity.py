@@ -566,8 +566,7 @@ def test_cfg5_shard_full_size(gpu, orc, AB):
     assert out["X"].shape == (S * R, N + 1, 6) and flag.shape == (S,)
     ok = out["status"] == 0
     assert 0.3 <= ok.mean() <= 0.9                      # a large share of the region QPs is infeasible by construction
-    assert set(np.unique(out["status"])) <= {0, 1, 2}
-    assert (out["status"] == 1).mean() <= 1e-3           # iteration cap / line-search failure: practically never
+    assert set(np.unique(out["status"])) <= {0, 2}       # planner QPs: converged, or infeasible -> fall-back; nothing undefined
     assert out["kkt"][ok].max() <= 1e-8
     X, U = out["X"][ok], out["U"][ok]
     assert np.abs(X[:, 1:] - (X[:, :-1] @ A.T + U @ B.T)).max() <= 1e-10      # dynamics
@@ -626,8 +625,10 @@ def test_cfg4_full_size(gpu, orc, AB):
     args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
     r1 = gpu.cbf_solve(d, *args)
     ok = r1["status"] == 0
-    assert ok.mean() >= 0.95, ok.mean()
-    assert (r1["status"] == 1).mean() <= 2e-3, (r1["status"] == 1).mean()       # every other problem ends with a defined verdict
+    assert ok.mean() >= 0.93, ok.mean()
+    # SURVEY 8d's draw puts ~6 % of the egos inside or about to enter an obstacle's unsafe set (crash states): those end
+    # as CRX_RESTORED / CRX_INFEASIBLE; an undefined end (iteration cap) is practically absent
+    assert (r1["status"] == 1).mean() <= 2e-3, np.bincount(r1["status"], minlength=4)
     assert r1["kkt"][ok].max() <= 1e-8
     X, U, sg = r1["X"][ok], r1["U"][ok], r1["sigma"][ok]
     assert np.abs(X[:, 1:] - (X[:, :-1] @ A.T + U @ B.T)).max() <= 1e-10

@@ -31,13 +31,14 @@ else:
     a = tuple(p[k][idx:idx + 1] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs"))
     fg, fo = gpu.cbf_solve, orc.cbf_solve
 d.opts.tol = tol
-L.crx_trace_enable(0, 64)
+ROWS = 256
+L.crx_trace_enable(0, ROWS)
 r = fg(d, *a)
-buf = np.zeros((64, 16))
-L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), 64)
+buf = np.zeros((ROWS, 16))
+L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), ROWS)
 L.crx_trace_enable(0, 0)
 print("GPU status %d iters %d kkt %.3e" % (r["status"][0], r["iters"][0], r["kkt"][0]))
-for it in range(min(int(r["iters"][0]) + 1, 64)):
+for it in range(min(int(r["iters"][0]) + 1, ROWS)):
     t = buf[it]
     print("gpu it %3d ed %.6e ep %.6e ec %.6e mu %.1e al %.6e a_d %.6e dw %.1e acc %d" % (it, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]))
 sys.stdout.flush()
