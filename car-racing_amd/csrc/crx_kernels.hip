@@ -1106,7 +1106,7 @@ crx_solve_kernel(const crx_kparams kp) {
     // ls_failed: 1 = no acceptable step, 2 = jam (JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the
     // constraints are still violated: the slacks of violated CBF rows are collapsing and every step is cut to nothing --
     // IPOPT's alpha < alpha_min test sends it to restoration from the same situation)
-    constexpr int JAM_COUNT = 5;
+    constexpr int JAM_COUNT = 5, STALL_ITERS = 50;
     const double JAM_ALPHA = 1e-3;
     int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0;
     theta_min = -1.0;    // < 0: the filter's theta_min / theta_max are taken at the next step (start, and after a restoration)
@@ -1222,12 +1222,11 @@ crx_solve_kernel(const crx_kparams kp) {
         // v_log_f32 of the mantissa, ~1e-7 absolute).  Two pow() calls were ~2.6 k cycles of this iteration and kept ~50
         // VGPRs of polynomial constants alive; the test is a heuristic threshold, a tie within 1e-7 may fall either way.
         const double sw_gap = sw_try ? 2.3 * log2_fast(-Dphi) - 1.1 * log2_fast(theta) : 0.0;
-        // A step length below 1e-12 is the quotient of two numbers that have both lost every digit (slacks of violated rows
-        // collapsed to ~1e-20 on an infeasible problem): it carries no information, and whether the filter happens to
-        // accept it is decided by rounding.  Such a step counts as "no acceptable step" (IPOPT's tiny-step test plays
-        // the same role), which makes the iteration at which an infeasible problem is given up reproducible.
-        const int ls_max = (a_p < 1e-12) ? 0 : 40;
-        for (int ls = 0; ls < ls_max; ls++) {
+        // The backtracking stops at alpha_min = 1e-10 ("no acceptable step"; IPOPT's alpha_min plays the same role): below it
+        // a step changes nothing in double precision relative to the iterate, the trial values differ from the current
+        // ones by rounding only, and whether the filter happens to accept one of them is noise -- on infeasible problems
+        // (slacks collapsed to ~1e-20) that noise used to decide at which iteration the solve gave up.
+        for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {
             fn = f + al * (cost_d + al * cost_qq);   // exact: the cost is quadratic along the step
             double thn = 0.0;
             LogAcc lg;
@@ -1288,6 +1287,9 @@ crx_solve_kernel(const crx_kparams kp) {
         if (!acc) { ls_failed = 1; break; }
         if (NOBS) {
             jam = (jam_on && al < JAM_ALPHA && e_p > o.tol) ? jam + 1 : 0;
+            // stall: STALL_ITERS iterations without a restoration and still infeasible (the same crawl with steps just above
+            // JAM_ALPHA; healthy problems are done -- p99 16 iterations, max 30 on the BASELINE draws -- or feasible by then)
+            if (jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
             if (jam >= JAM_COUNT && n_restore < 2) { ls_failed = 2; break; }
         }
         // ---- accept ------------------------------------------------------------------------------------

@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             // ---- filter line search (all rows linear: c(v + al dv) = c + al J dv) ----
             double al = a_p, fn = f;
             int acc = 0, ftype = 0;
-            for (int ls = 0; ls < 40; ls++) {
+            for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {   // alpha_min: see crx_kernels.hip
                 fn = f + al * (gdv + 0.5 * al * qd);
                 double thn = 0.0;
                 LogAcc la;

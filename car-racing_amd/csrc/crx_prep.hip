@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(WAVE) crx_path_kernel(const crx_path_kparams p
         if (it == 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
         double al = a_p, fn = f, tLn = tL, tUn = tU;
         int acc = 0, ftype = 0;
-        for (int ls = 0; ls < 40; ls++) {
+        for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {   // alpha_min: see crx_kernels.hip
             fn = f + al * (gdv + 0.5 * al * qd);
             const double vt = vi + al * d;
             tLn = hasL ? fmax(tL + al * dtL, vt - lj) : 1.0;

@@ -455,7 +455,7 @@ static void ipm_solve(work_t* w, result_t* res) {
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0;
-    enum { JAM_COUNT = 5 };
+    enum { JAM_COUNT = 5, STALL_ITERS = 50 };
     const double JAM_ALPHA = 1e-3;
     int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
@@ -586,9 +586,8 @@ static void ipm_solve(work_t* w, result_t* res) {
         }
         double al = a_p;
         int acc = 0, ftype = 0;
-        /* a step length below 1e-12 carries no information (see the kernel): no acceptable step */
-        const int ls_max = (a_p < 1e-12) ? 0 : 40;
-        for (int ls = 0; ls < ls_max; ls++) {
+        /* backtracking stops at alpha_min = 1e-10: below it a trial point differs from the iterate by rounding only */
+        for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {
             for (int a = 0; a < n; a++) vtrial[a] = w->v[a] + al * w->dv[a];
             double fn;
             eval_fc(w, vtrial, &fn, ctrial);
@@ -627,6 +626,9 @@ static void ipm_solve(work_t* w, result_t* res) {
          * slacks of violated CBF rows are collapsing and every step is cut to nothing (IPOPT's alpha < alpha_min test
          * sends it to restoration from the same situation) */
         if (acc && jam_on && al < JAM_ALPHA && e_p > o->tol) jam++; else jam = 0;
+        /* stall: STALL_ITERS iterations without a restoration and still infeasible -- the same crawl with steps just above
+         * JAM_ALPHA; healthy problems are done (p99 16 iterations, max 30 on the BASELINE draws) or at least feasible by then */
+        if (acc && jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
         if (!acc || jam >= JAM_COUNT) {
             if (o->restore_iters >= 0 && n_restore < 2 && restore_slacks(w, o->mu_init)) {
                 if (g_verbose) fprintf(stderr, "      RESTORE (acc %d jam %d)\n", acc, jam);

@@ -492,7 +492,7 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
         }
         double al = a_p, fn = f;
         int acc = 0, ftype = 0;
-        for (int ls = 0; ls < 40; ls++) {
+        for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {   /* alpha_min: see crx_oracle.c */
             for (int a = 0; a < n; a++) vtr[a] = w->v[a] + al * dv[a];
             fn = lmpc_f(w, vtr);
             double phin = fn, thn = 0.0;
@@ -735,7 +735,7 @@ int crx_oracle_path_solve(const crx_path_desc* d, int batch, const double* opt, 
             if (it == 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
             double al = a_p, fn = f, vt[CRX_MAX_N], tt[2 * CRX_MAX_N];
             int acc = 0, ftype = 0;
-            for (int ls = 0; ls < 40; ls++) {
+            for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {   /* alpha_min: see crx_oracle.c */
                 for (int i = 0; i < n; i++) vt[i] = v[i] + al * dv[i];
                 PF(vt, fn);
                 double phin = fn, thn = 0.0;
