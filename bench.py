@@ -325,7 +325,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
     traffic = tnote = None
     try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, rocprofv3 --pmc, calibrated)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-        e = pm.get(w.key.replace("cfg2_filtered", "cfg2"))
+        e = pm.get(w.key.replace("cfg2_filtered", "cfg2").replace("cfg5_weak", "cfg5"))
         if e and e["batch"] == w.batch:
             traffic, tnote = e["traffic_bytes"], pm.get("note")
     except Exception:

@@ -1467,8 +1467,15 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
 template <int NOBS, int NMAX>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
+    // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
+    static int attr_set_on = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (attr_set_on != dev) {
+        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        attr_set_on = dev;
+    }
     hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
 }

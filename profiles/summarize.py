@@ -1,35 +1,50 @@
-"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel-trace database into the text summary that
-is committed under profiles/.  Usage: python profiles/summarize.py <results.db> [<bench.json>]"""
+"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel-trace database into the text summary that is committed under
+profiles/.  Usage: python profiles/summarize.py <results.db> [<bench.json>]
+
+Launches of one kernel are bucketed by grid size: a bench run issues the full-batch launches it times AND a few batch-1
+launches (the "one control step with host arrays" latency probe); averaging the two would describe neither."""
+import collections
 import json
 import sqlite3
 import sys
+
+
+def pct(d, q):
+    return d[min(len(d) - 1, int(q * len(d)))]
 
 
 def main():
     db = sqlite3.connect(sys.argv[1])
     print("# rocprofv3 --kernel-trace --stats summary of %s" % sys.argv[1])
     print("%-48s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
-    for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        print("%-48s %8d %14.1f %12.2f %8.3f" % (name[:48], calls, total, avg, pct))
+    for name, calls, total, avg, pct_ in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print("%-48s %8d %14.1f %12.2f %8.3f" % (name[:48], calls, total, avg, pct_))
     print()
-    print("# per-kernel launch geometry / resources (first dispatch of each kernel)")
-    print("%-48s %10s %6s %9s %8s %6s %6s" % ("kernel", "grid_x", "wg_x", "lds_B", "scratch", "vgpr", "sgpr"))
-    seen = set()
-    for r in db.execute("select name,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels order by id"):
-        if r[0] in seen:
-            continue
-        seen.add(r[0])
-        print("%-48s %10d %6d %9d %8d %6d %6d" % (r[0][:48], r[1], r[2], r[3], r[4], r[5] + r[6], r[7]))
-    print()
-    print("# duration distribution of the solver kernel (us)")
-    for (name,) in db.execute("select distinct name from kernels where name like '%crx_solve%'"):
-        d = sorted(x[0] / 1e3 for x in db.execute("select duration from kernels where name=?", (name,)))
-        n = len(d)
-        print("%-48s n=%d min=%.1f p50=%.1f p90=%.1f max=%.1f" % (name[:48], n, d[0], d[n // 2], d[int(n * 0.9)], d[-1]))
+    print("# per kernel and launch geometry: resources and duration distribution (us); grid_x = 64 x problems (one wave each)")
+    print("%-44s %10s %6s %8s %6s %6s %6s | %9s %9s %9s %9s %9s" % ("kernel", "grid_x", "n", "lds_B", "scr", "vgpr", "sgpr", "min", "p50", "avg", "p90", "max"))
+    rows = collections.defaultdict(list)
+    meta = {}
+    for name, gx, wg, lds, scr, vg, ag, sg, dur in db.execute(
+            "select name,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count,duration from kernels order by id"):
+        rows[(name, gx)].append(dur / 1e3)
+        meta[(name, gx)] = (lds, scr, vg + ag, sg)
+    for (name, gx), d in sorted(rows.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+        d.sort()
+        lds, scr, vg, sg = meta[(name, gx)]
+        print("%-44s %10d %6d %8d %6d %6d %6d | %9.1f %9.1f %9.1f %9.1f %9.1f" % (
+            name[:44], gx, len(d), lds, scr, vg, sg, d[0], pct(d, 0.5), sum(d) / len(d), pct(d, 0.9), d[-1]))
     if len(sys.argv) > 2:
         print()
-        print("# bench.py line of the same run")
-        print(open(sys.argv[2]).read().strip())
+        print("# bench.py line of the same run (roofline.kernel_ms = HIP-event average over the full-batch launches)")
+        line = open(sys.argv[2]).read().strip().splitlines()[-1]
+        try:
+            j = json.loads(line)
+            keep = {k: j[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step") if k in j}
+            keep["config"] = j.get("config")
+            keep["roofline"] = j.get("roofline")
+            print(json.dumps(keep))
+        except Exception:
+            print(line[:4000])
 
 
 if __name__ == "__main__":
