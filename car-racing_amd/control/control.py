@@ -55,7 +55,7 @@ def _solve_cbf(desc, x, xt, preds, lap_length):
     else:
         keep, lap_off = np.zeros((1, 0), dtype=bool), np.zeros((1, 0))
     nmax = desc.n_obs_max
-    ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s[:, :V], obs_ey[:, :V], lap_off, nmax) if nmax else (
+    ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s[:, :V], obs_ey[:, :V], lap_off, nmax, ego_s=x[:, 4]) if nmax else (
         np.zeros((1, 0, N + 1)), np.zeros((1, 0, N + 1)), np.zeros((1, 0)), np.zeros(1, dtype=np.int32))
     return crx.cbf_solve(desc, x, xt, ps, pe, po, n)
 
@@ -86,6 +86,9 @@ def mpccbf(xcurv, xtarget, mpc_cbf_param, vehicles, agent_name, lap_length, time
         keep, _ = hostprep.cbf_window(x1, np.array([[p[4, 0] for p in preds]]), lap_length)
         preds = [p for p, k in zip(preds, keep[0]) if k]
     ego, first = vehicles[agent_name], (vehicles[others[0]] if others else vehicles[agent_name])
+    # the reference takes (l, w) per obstacle (control.py:529-535); the C ABI carries one (l_sum, w_sum) per call
+    if any((vehicles[n].param.length, vehicles[n].param.width) != (first.param.length, first.param.width) for n in others):
+        raise ValueError("mpccbf: libcrx needs all obstacle vehicles to share one length and width (crx_cbf_desc.l_sum / w_sum)")
     desc = abi.cbf_desc(
         N, min(len(preds), _N_OBS_MAX), mpc_cbf_param.matrix_A, mpc_cbf_param.matrix_B,
         Q=np.diag(mpc_cbf_param.matrix_Q), R=np.diag(mpc_cbf_param.matrix_R), alpha=mpc_cbf_param.alpha,

@@ -68,7 +68,7 @@ def cbf_window(x_raw, obs_pred_s0, lap_length, safety_time=2.0):
     return keep, lap_off
 
 
-def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max):
+def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max, ego_s=None):
     """Compact the kept obstacles to the front (dict order of the reference's obs_infos) and pad."""
     B, V, L = obs_s.shape
     out_s = np.zeros((B, n_obs_max, L))
@@ -78,7 +78,15 @@ def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max):
     for b in range(B):
         idx = np.nonzero(keep[b])[0]
         if len(idx) > n_obs_max:
-            raise ValueError("more obstacles in the window (%d) than n_obs_max (%d)" % (len(idx), n_obs_max))
+            # libcrx carries at most CRX_MAX_OBS obstacles per NLP (the reference has no limit, control.py:524-562): keep
+            # the ones nearest to the ego at the first prediction step, in the reference's order, and say so
+            import warnings
+
+            if ego_s is None:
+                raise ValueError("more obstacles in the window (%d) than n_obs_max (%d)" % (len(idx), n_obs_max))
+            near = np.argsort(np.abs(obs_s[b, idx, 0] + lap_off[b, idx] - ego_s[b]), kind="stable")
+            warnings.warn("%d obstacles pass the window test, libcrx keeps the %d nearest (CRX_MAX_OBS)" % (len(idx), n_obs_max))
+            idx = np.sort(idx[near[:n_obs_max]])
         n[b] = len(idx)
         out_s[b, : len(idx)] = obs_s[b, idx]
         out_e[b, : len(idx)] = obs_ey[b, idx]

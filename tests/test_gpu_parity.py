@@ -267,7 +267,9 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
     # restoration turns failed line searches into defined ends: no problem is left at the iteration cap
     assert (g1["status"] == 1).sum() == 0, np.bincount(g1["status"], minlength=4)
     assert g1["iters"].max() <= 50 + 1 + 25 + 25, g1["iters"].max()      # stall trigger + restoration budget (+ a second restoration)
-    assert (g1["status"] == 0).sum() >= (g0["status"] == 0).sum() - 1
+    # bounded effort has a price: a crash state that would have crawled to a KKT point in 50..200 iterations now ends as
+    # CRX_RESTORED after at most 76 (raise opts.restore_iters / max_iter to trade latency back for convergence)
+    assert (g1["status"] == 0).sum() >= 0.95 * (g0["status"] == 0).sum()
     # crash states that do converge carry slacks of 1e2..1e6 (cost 1e6..1e10): their trajectories agree to the default set only
     both = _cmp(cfg, g0, o0, need_same_status=False, T=DEFAULT if "unfiltered" in cfg else T)
     assert both.mean() >= (0.85 if "unfiltered" in cfg else 0.95)

@@ -199,3 +199,39 @@ def test_path_planner_regions(orc, golden_path):
         assert costs.index(min(costs)) == int(c["direction_flag"]), name
         seen_ok += int(ok.sum()); seen_bad += int((~ok).sum())
     assert seen_ok >= 8 and seen_bad >= 4
+
+
+def test_nonconvex_crosscheck(orc, AB, golden_mpccbf, golden_planner):
+    """The non-convex goldens (control.mpccbf / control.mpc_multi_agents NLPs) against the independent cross-check recorded
+    by tests/golden/tools/crosscheck.py in the build container (nonconvex_crosscheck.npz, numbers only): for each of the
+    17 recorded NLPs the golden solver from 8 random dynamically-consistent starts and scipy SLSQP on the condensed
+    problem from the reference's own zero start.  Pins: (i) every certified end point of every start IS the golden point
+    -- one KKT point per NLP, so "which local solution would IPOPT return from the zero start" has one candidate; (ii) no
+    feasible point below the golden cost was ever found; (iii) the oracle's cost is that golden cost."""
+    import os
+
+    import conftest
+
+    z = np.load(os.path.join(conftest.GOLDEN, "nonconvex_crosscheck.npz"), allow_pickle=False)
+    names = [str(n) for n in z["names"]]
+    assert len(names) == 17
+    same_slsqp = 0
+    A, B = AB
+    for n in names:
+        assert bool(z[n + "/golden_certified"]), n
+        assert int(z[n + "/n_random_certified"]) >= 7, n
+        assert z[n + "/distinct_costs"].shape == (1,), (n, z[n + "/distinct_costs"])          # a single KKT point was found
+        assert bool(z[n + "/golden_is_global_among_found"]) and bool(z[n + "/golden_is_lowest_from_zero_start"]), n
+        assert bool(z[n + "/slsqp_condensed_not_below_golden"]), n
+        same_slsqp += int(bool(z[n + "/slsqp_condensed_same_point"]))
+        kind, case = n.split("/")
+        if kind == "mpccbf":
+            g = golden_mpccbf.case(case)
+            d, args = helpers.mpccbf_inputs(g, A, B)
+        else:
+            g = golden_planner.case(case)
+            d, args = helpers.mma_inputs(g, A, B)
+        r = orc.cbf_solve(_with_tol(d, 1e-11), *args)
+        assert r["status"][0] == 0
+        assert _close_cost(r["cost"][0], float(z[n + "/golden_cost"]), 1e-9), (n, r["cost"][0], float(z[n + "/golden_cost"]))
+    assert same_slsqp >= 12, same_slsqp      # SLSQP stalls early on the rest (higher cost, never lower)
