@@ -110,6 +110,20 @@ class PrepDesc(C.Structure):
     ]
 
 
+class LmpcPrepDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("n_points", C.c_int32), ("n_laps", C.c_int32), ("n_ss_per_lap", C.c_int32),
+        ("n_ss_laps", C.c_int32), ("max_neighbours", C.c_int32), ("n_seg", C.c_int32), ("shift", C.c_int32),
+        ("bandwidth", C.c_double), ("scale", C.c_double * 5), ("dt", C.c_double), ("lap_length", C.c_double),
+    ]
+
+
+def lmpcprep_desc(N, n_points, n_laps, n_seg, dt, lap_length, n_ss_per_lap=22, n_ss_laps=2, max_neighbours=40, shift=0):
+    """Literals of control/lmpc_helper.py:42-57, utils/base.py:605 and LMPCRacingParam (utils/base.py:351-376)."""
+    return LmpcPrepDesc(int(N), int(n_points), int(n_laps), int(n_ss_per_lap), int(n_ss_laps), int(max_neighbours), int(n_seg),
+                        int(shift), 5.0, _arr(C.c_double, 5, (0.1, 1.0, 1.0, 1.0, 1.0)), float(dt), float(lap_length))
+
+
 class PathDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("reserved0", C.c_int32), ("alpha", C.c_double), ("w_rate", C.c_double), ("opts", IpmOpts)]
 
@@ -342,6 +356,23 @@ class Binding:
             _p(n_ss), _p(out["X"]), _p(out["U"]), _p(out["lam"]), _p(out["cost"]), _p(out["status"]),
             _p(out["kkt"]), _p(out["iters"]),
         )
+        return out
+
+    def lmpc_prep(self, desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan=False):
+        """crx_lmpc_prep: stage models + safe-set selection.  ss_xcurv (Bn,L,P,6), u_ss (Bn,L,P,2), qfun (Bn,L,P)."""
+        N, P, L, M = desc.N, desc.n_points, desc.n_laps, desc.n_ss_per_lap * desc.n_ss_laps
+        x = np.ascontiguousarray(x, dtype=_D)
+        Bn = x.shape[0]
+        ss_xcurv, u_ss, qfun = _in(ss_xcurv, _D, (Bn, L, P, 6)), _in(u_ss, _D, (Bn, L, P, 2)), _in(qfun, _D, (Bn, L, P))
+        time_ss, it, x = _in(time_ss, _I, (Bn, L)), _in(it, _I, (Bn,)), _in(x, _D, (Bn, 6))
+        lin_points, lin_input = _in(lin_points, _D, (Bn, N + 1, 6)), _in(lin_input, _D, (Bn, N, 2))
+        track = _in(track, _D, (desc.n_seg, 6))
+        out = dict(A=np.zeros((Bn, N, 6, 6)), B=np.zeros((Bn, N, 6, 2)), C=np.zeros((Bn, N, 6)), ss=np.zeros((Bn, 6, M)),
+                   qfun=np.zeros((Bn, M)), status=np.zeros(Bn, dtype=_I))
+        getattr(self.lib, self.prefix + "lmpc_prep").restype = C.c_int
+        self._call("lmpc_prep", C.byref(desc), C.c_int(Bn), _p(ss_xcurv), _p(u_ss), _p(qfun), _p(time_ss), _p(it), _p(x),
+                   _p(lin_points), _p(lin_input), C.c_int(int(bool(from_plan))), _p(track), _p(out["A"]), _p(out["B"]),
+                   _p(out["C"]), _p(out["ss"]), _p(out["qfun"]), _p(out["status"]))
         return out
 
     def planner_prep(self, desc, x_wrapped, x_raw, n_veh, veh_info, max_dv, obs_s, obs_ey, opt_s, opt_ey):

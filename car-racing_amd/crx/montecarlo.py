@@ -108,3 +108,80 @@ def mpccbf_races(track_table, lap_length, track_width, A, B, xcurv0, xglob0, car
             log_st.append(r.ws.status.clone())
     return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(),
                 status=torch.stack(log_st).cpu().numpy(), laps=r.laps.cpu().numpy())
+
+
+class LmpcLaps:
+    """B learning-MPC laps at once, device-resident (SURVEY.md section 8f rows 1 + 4): the lap of the reference's racing
+    game in which LMPCRacingGame drives alone (tests/auto_racing_game_test.py:60-66 -> utils/base.py:468-517), with the
+    race index as the batch dimension.  Per control step and without touching the host:
+
+        crx_lmpc_prep_dev      N stage models from the two previous laps + safe-set selection   (estimate_ABC, control.lmpc :625-639)
+        crx_lmpc_solve_dev     the learning-MPC QP                                               (control.lmpc :640-730)
+        crx_lmpc_addpoint_dev  the applied (x, u) extends the previous lap's safe set            (add_point)
+        crx_plant_step_wrap_dev  plant + lap bookkeeping                                         (forward_dynamics, update_memory)
+
+    Four libcrx launches per step; torch owns the memory and copies u_old.  Every race carries its own safe set
+    (ss_xcurv [B, L, P, 6], u_ss [B, L, P, 2], qfun [B, L, P], time_ss [B, L]: the reference's arrays stored lap-major)."""
+
+    def __init__(self, track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
+                 N=12, timestep=0.1, device=None):
+        dev = torch.device(device if device is not None else "cuda")
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+
+        def t(a, kw):
+            return torch.as_tensor(np.ascontiguousarray(a), **kw).clone()
+
+        self.ss, self.us, self.qf = t(ss_xcurv, f64), t(u_ss, f64), t(qfun, f64)
+        self.time_ss, self.it = t(time_ss, i32), t(it, i32)
+        Bn, L, P, _ = self.ss.shape
+        self.batch, self.N, self.lap_length, self.timestep = Bn, N, lap_length, timestep
+        self.xc, self.xg = t(xcurv0, f64), t(xglob0, f64)
+        self.lin_points, self.lin_input = t(lin_points, f64), t(lin_input, f64)
+        self.tab = t(track_table, f64)
+        self.pdesc = abi.lmpcprep_desc(N, P, L, self.tab.shape[0], timestep, lap_length)
+        self.desc = abi.lmpc_desc(N=N, n_ss_max=self.pdesc.n_ss_per_lap * self.pdesc.n_ss_laps, ey_max=track_width)
+        self.plant = abi.plant_desc(self.tab.shape[0], lap_length, timestep=timestep)
+        self.pws = torch_api.LmpcPrepWorkspace(self.pdesc, Bn, dev)
+        self.ws = torch_api.LmpcWorkspace(self.desc, Bn, dev)
+        self.n_ss = torch.full((Bn,), self.desc.n_ss_max, **i32)
+        self.u_old = torch.zeros((Bn, 2), **f64)
+        self.step_no = torch.zeros((Bn,), **i32)
+        self.laps = torch.zeros((Bn,), **i32)
+        self.xg_next, self.xc_next = torch.empty_like(self.xg), torch.empty_like(self.xc)
+        self.k = 0
+
+    def step(self):
+        N = self.N
+        if self.k == 0:     # first call of the lap: linearisation points handed over by the previous controller (utils/base.py:651-653)
+            torch_api.lmpc_prep_dev(self.pdesc, self.ss, self.us, self.qf, self.time_ss, self.it, self.xc, self.lin_points, self.lin_input,
+                                    self.tab, False, ws=self.pws)
+        else:               # afterwards: the previous plan, shifted by one stage inside the kernel (control.py:726-728)
+            torch_api.lmpc_prep_dev(self.pdesc, self.ss, self.us, self.qf, self.time_ss, self.it, self.xc, self.ws.X, self.ws.U,
+                                    self.tab, True, ws=self.pws)
+        torch_api.lmpc_solve_dev(self.desc, self.xc, self.u_old, self.pws.A, self.pws.B, self.pws.C, self.pws.ss, self.pws.qfun, self.n_ss,
+                                 ws=self.ws)
+        torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.step_no, self.xc, self.ws.U, 2 * N)
+        torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps)
+        self.xg, self.xg_next = self.xg_next, self.xg
+        self.xc, self.xc_next = self.xc_next, self.xc
+        self.u_old.copy_(self.ws.U[:, 0, :])
+        self.step_no += 1
+        self.k += 1
+
+
+def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, steps,
+              N=12, timestep=0.1, device=None):
+    """Run `steps` control steps of B learning-MPC laps; returns host logs xcurv [steps+1, B, 6], u [steps, B, 2], status [steps, B]
+    (QP status), prep_status [steps, B] (singular regression), laps [B]."""
+    r = LmpcLaps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, N=N,
+                 timestep=timestep, device=device)
+    log_x, log_u, log_st, log_ps = [r.xc.clone()], [], [], []
+    for _ in range(steps):
+        r.step()
+        log_x.append(r.xc.clone())
+        log_u.append(r.u_old.clone())
+        log_st.append(r.ws.status.clone())
+        log_ps.append(r.pws.status.clone())
+    return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(), status=torch.stack(log_st).cpu().numpy(),
+                prep_status=torch.stack(log_ps).cpu().numpy(), laps=r.laps.cpu().numpy())

@@ -226,3 +226,51 @@ def plant_step_wrap_dev(desc, track, xglob, xcurv, u, u_stride, xglob_next, xcur
         raise ValueError("u: expected a contiguous cuda float64 tensor holding %d inputs at stride %d" % (Bn, u_stride))
     _call("crx_plant_step_wrap_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
           C.c_int(u_stride), _ptr(xglob_next), _ptr(xcurv_next), _ptr(laps), _stream())
+
+
+class LmpcPrepWorkspace:
+    """Outputs of lmpc_prep_dev = the model and safe-set inputs of lmpc_solve_dev (same layout)."""
+
+    def __init__(self, desc, batch, device):
+        N, M = desc.N, desc.n_ss_per_lap * desc.n_ss_laps
+        f64 = dict(dtype=torch.float64, device=device)
+        self.A = torch.empty((batch, N, 36), **f64)
+        self.B = torch.empty((batch, N, 12), **f64)
+        self.C = torch.empty((batch, N, 6), **f64)
+        self.ss = torch.empty((batch, 6, M), **f64)
+        self.qfun = torch.empty((batch, M), **f64)
+        self.status = torch.empty(batch, dtype=torch.int32, device=device)
+
+
+def lmpc_prep_dev(desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan, ws=None):
+    """crx_lmpc_prep_dev: the N stage models and the safe-set selection of every race."""
+    N, P, L, Bn = desc.N, desc.n_points, desc.n_laps, x.shape[0]
+    _chk(ss_xcurv, torch.float64, (Bn, L, P, 6), "ss_xcurv")
+    _chk(u_ss, torch.float64, (Bn, L, P, 2), "u_ss")
+    _chk(qfun, torch.float64, (Bn, L, P), "qfun")
+    _chk(time_ss, torch.int32, (Bn, L), "time_ss")
+    _chk(it, torch.int32, (Bn,), "iter")
+    _chk(x, torch.float64, (Bn, 6), "x")
+    _chk(lin_points, torch.float64, (Bn, N + 1, 6), "lin_points")
+    _chk(lin_input, torch.float64, (Bn, N, 2), "lin_input")
+    _chk(track, torch.float64, (desc.n_seg, 6), "track")
+    ws = ws or LmpcPrepWorkspace(desc, Bn, x.device)
+    _call("crx_lmpc_prep_dev", C.byref(desc), C.c_int(Bn), _ptr(ss_xcurv), _ptr(u_ss), _ptr(qfun), _ptr(time_ss), _ptr(it), _ptr(x),
+          _ptr(lin_points), _ptr(lin_input), C.c_int(int(bool(from_plan))), _ptr(track), _ptr(ws.A), _ptr(ws.B), _ptr(ws.C),
+          _ptr(ws.ss), _ptr(ws.qfun), _ptr(ws.status), _stream())
+    return ws
+
+
+def lmpc_addpoint_dev(desc, ss_xcurv, u_ss, time_ss, it, step, x, u, u_stride):
+    """crx_lmpc_addpoint_dev: LMPCRacingGame.add_point for every race (in place)."""
+    Bn, P, L = x.shape[0], desc.n_points, desc.n_laps
+    _chk(ss_xcurv, torch.float64, (Bn, L, P, 6), "ss_xcurv")
+    _chk(u_ss, torch.float64, (Bn, L, P, 2), "u_ss")
+    _chk(time_ss, torch.int32, (Bn, L), "time_ss")
+    _chk(it, torch.int32, (Bn,), "iter")
+    _chk(step, torch.int32, (Bn,), "step")
+    _chk(x, torch.float64, (Bn, 6), "x")
+    if not u.is_cuda or u.dtype != torch.float64 or not u.is_contiguous() or u.numel() < (Bn - 1) * u_stride + 2:
+        raise ValueError("u: expected a contiguous cuda float64 tensor holding %d inputs at stride %d" % (Bn, u_stride))
+    _call("crx_lmpc_addpoint_dev", C.byref(desc), C.c_int(Bn), _ptr(ss_xcurv), _ptr(u_ss), _ptr(time_ss), _ptr(it), _ptr(step),
+          _ptr(x), _ptr(u), C.c_int(u_stride), _stream())

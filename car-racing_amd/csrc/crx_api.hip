@@ -775,6 +775,96 @@ int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const do
     return sg.down(g_stream);
 }
 
+// ---- learning-MPC host prep on the device ------------------------------------------------------------
+void crx_lmpcprep_desc_default(crx_lmpcprep_desc* d, int N, int n_points, int n_laps, int n_seg, double dt, double lap_length) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->n_points = n_points; d->n_laps = n_laps; d->n_ss_per_lap = 22; d->n_ss_laps = 2; d->max_neighbours = 40;
+    d->n_seg = n_seg; d->shift = 0; d->bandwidth = 5.0;
+    d->scale[0] = 0.1; d->scale[1] = d->scale[2] = d->scale[3] = d->scale[4] = 1.0;
+    d->dt = dt; d->lap_length = lap_length;
+}
+
+static int check_lmpcprep(const crx_lmpcprep_desc* d, int batch) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 2 || d->N > CRX_LMPC_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [2,%d]", d->N, CRX_LMPC_MAX_N);
+    if (d->n_points < 2 || d->n_points > 65535 || d->n_laps < 2) return fail(CRX_ERR_ARG, "n_points outside [2,65535] or n_laps < 2");
+    if (d->n_ss_laps < 1 || d->n_ss_laps > 2 || d->n_ss_per_lap < 1 || d->n_ss_laps * d->n_ss_per_lap > CRX_MAX_SS)
+        return fail(CRX_ERR_ARG, "n_ss_laps outside [1,2] or more than %d safe-set points", CRX_MAX_SS);
+    if (d->max_neighbours < 1 || d->max_neighbours > 64) return fail(CRX_ERR_ARG, "max_neighbours outside [1,64]");
+    if (d->n_seg < 1 || !(d->bandwidth > 0.0) || !(d->dt > 0.0) || !(d->lap_length > 0.0) || !isfinite(d->lap_length))
+        return fail(CRX_ERR_ARG, "n_seg, bandwidth, dt and lap_length must be positive");
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (crx_lmpcprep_lds_bytes(d->n_points) > 160 * 1024) return fail(CRX_ERR_ARG, "n_points=%d needs more than 160 KiB of LDS", d->n_points);
+    return 0;
+}
+
+int crx_lmpc_prep_dev(const crx_lmpcprep_desc* d, int batch, const double* ss_xcurv, const double* u_ss, const double* qfun,
+                      const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                      const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                      double* ss_sel, double* q_sel, int32_t* status, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_lmpcprep(d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!ss_xcurv || !u_ss || !qfun || !time_ss || !iter || !x || !lin_points || !lin_input || !track || !A || !B || !C || !ss_sel ||
+        !q_sel || !status)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_lmpcprep_kparams kp;
+    kp.d = *d; kp.batch = batch; kp.from_plan = from_plan ? 1 : 0;
+    kp.ss_xcurv = ss_xcurv; kp.u_ss = u_ss; kp.qfun = qfun; kp.time_ss = time_ss; kp.iter = iter; kp.x = x;
+    kp.lin_points = lin_points; kp.lin_input = lin_input; kp.track = track;
+    kp.A = A; kp.B = B; kp.C = C; kp.ss_sel = ss_sel; kp.q_sel = q_sel; kp.status = status;
+    hipError_t e = crx_launch_lmpcprep(kp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc prep launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_lmpc_prep(const crx_lmpcprep_desc* d, int batch, const double* ss_xcurv, const double* u_ss, const double* qfun,
+                  const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                  const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                  double* ss_sel, double* q_sel, int32_t* status) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_lmpcprep(d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!ss_xcurv || !u_ss || !qfun || !time_ss || !iter || !x || !lin_points || !lin_input || !track || !A || !B || !C || !ss_sel ||
+        !q_sel || !status)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    const size_t Bn = (size_t)batch, N = (size_t)d->N, P = (size_t)d->n_points, L = (size_t)d->n_laps;
+    const size_t M = (size_t)d->n_ss_per_lap * d->n_ss_laps;
+    for (size_t b = 0; b < Bn; b++) {
+        if (iter[b] < 2 || iter[b] > (int)L) return fail(CRX_ERR_ARG, "iter[%zu]=%d outside [2,%zu]", b, iter[b], L);
+        for (int k = 0; k < 2; k++) {
+            const int t = time_ss[b * L + iter[b] - 2 + k];
+            if (t < 2 || t > (int)P) return fail(CRX_ERR_ARG, "time_ss of a lap used by race %zu is %d, outside [2,%zu]", b, t, P);
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    Stage sg;
+    if (int rc = sg.reserve((Bn * L * P * 9 + Bn * (6 + (N + 1) * 6 + N * 2) + (size_t)d->n_seg * 6) * 8 + Bn * (L + 1) * 4,
+                            (Bn * N * 54 + Bn * 7 * M) * 8 + Bn * 4)) return rc;
+    double* dss = sg.in(ss_xcurv, Bn * L * P * 6); double* dus = sg.in(u_ss, Bn * L * P * 2); double* dqf = sg.in(qfun, Bn * L * P);
+    double* dx = sg.in(x, Bn * 6); double* dlp = sg.in(lin_points, Bn * (N + 1) * 6); double* dli = sg.in(lin_input, Bn * N * 2);
+    double* dtr = sg.in(track, (size_t)d->n_seg * 6);
+    int32_t* dts = sg.in(time_ss, Bn * L); int32_t* dit = sg.in(iter, Bn);
+    double* dA = sg.out(A, Bn * N * 36); double* dB = sg.out(B, Bn * N * 12); double* dC = sg.out(C, Bn * N * 6);
+    double* dsel = sg.out(ss_sel, Bn * 6 * M); double* dq = sg.out(q_sel, Bn * M); int32_t* dst = sg.out(status, Bn);
+    if (int rc = sg.up(g_stream)) return rc;
+    if (int rc = crx_lmpc_prep_dev(d, batch, dss, dus, dqf, dts, dit, dx, dlp, dli, from_plan, dtr, dA, dB, dC, dsel, dq, dst, g_stream)) return rc;
+    return sg.down(g_stream);
+}
+
+int crx_lmpc_addpoint_dev(const crx_lmpcprep_desc* d, int batch, double* ss_xcurv, double* u_ss, const int32_t* time_ss,
+                          const int32_t* iter, const int32_t* step, const double* x, const double* u, int u_stride, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_lmpcprep(d, batch)) return rc;
+    if (u_stride < 2) return fail(CRX_ERR_ARG, "u_stride < 2");
+    if (batch == 0) return CRX_OK;
+    if (!ss_xcurv || !u_ss || !time_ss || !iter || !step || !x || !u) return fail(CRX_ERR_ARG, "NULL array argument");
+    hipError_t e = crx_launch_lmpc_addpoint(*d, batch, ss_xcurv, u_ss, time_ss, iter, step, x, u, u_stride, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc addpoint launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
 // ---- fused planner step ------------------------------------------------------------------------------
 int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
                          const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,

@@ -86,6 +86,16 @@ struct crx_cbfprep_kparams {
     int32_t* n_obs;
 };
 
+struct crx_lmpcprep_kparams {
+    crx_lmpcprep_desc d;
+    int batch, from_plan;
+    const double *ss_xcurv, *u_ss, *qfun;
+    const int32_t *time_ss, *iter;
+    const double *x, *lin_points, *lin_input, *track;
+    double *A, *B, *C, *ss_sel, *q_sel;
+    int32_t* status;
+};
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
@@ -97,6 +107,11 @@ hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
+hipError_t crx_launch_lmpcprep(const crx_lmpcprep_kparams& kp, hipStream_t st);
+size_t crx_lmpcprep_lds_bytes(int n_points);
+hipError_t crx_launch_lmpc_addpoint(const crx_lmpcprep_desc& d, int batch, double* ss_xcurv, double* u_ss, const int32_t* time_ss,
+                                    const int32_t* iter, const int32_t* step, const double* x, const double* u, int u_stride,
+                                    hipStream_t st);
 size_t crx_lmpc_lds_bytes(int N, int n_ss_max);
 int crx_lmpc_resident_per_cu(int N, int n_ss_max);
 #endif

@@ -371,6 +371,53 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
                        int32_t* status, double* kkt, int32_t* iters, void* stream);
 
 /*
+ * Host work in front of the learning-MPC QP, on the device (second half): per race, the
+ * N local LTV stage models of LMPCRacingGame.estimate_ABC (utils/base.py:585-622 -> control/lmpc_helper.py:26-189:
+ * kernel-weighted least squares for the vx / vy / wz rows from the two previous laps, analytic Jacobian of the Euler
+ * step for the epsi / s / ey rows) and the safe-set points and cost-to-go control.lmpc selects (control.py:625-639 ->
+ * lmpc_helper.py:278-293).  Outputs are exactly the A, B, C, ss, qfun inputs of crx_lmpc_solve.
+ *   ss_xcurv [batch][n_laps][n_points][6], u_ss [batch][n_laps][n_points][2], qfun [batch][n_laps][n_points]
+ *            the sampled safe set (LMPCRacingGame.ss_xcurv / u_ss / Qfun, stored lap-major here)
+ *   time_ss  [batch][n_laps]   samples per stored lap;  iter [batch]   index of the running lap (>= 2)
+ *   x        [batch][6]        current state (start-line wrapped, as LMPCRacingGame.calc_input passes it)
+ *   lin_points [batch][N+1][6], lin_input [batch][N][2]   linearisation points; with from_plan != 0 they are the X and U
+ *            of the previous crx_lmpc_solve and are shifted by one stage here (control.py:726-728)
+ *   track    [n_seg][6]        rows (x, y, psi, s_start, length, curvature)
+ *   A [batch][N][36], B [batch][N][12], C [batch][N][6];  ss_sel [batch][6][M], q_sel [batch][M], M = n_ss_laps * n_ss_per_lap
+ *   status   [batch]           0, or 1 if a stage's normal matrix was singular (the reference's cvxopt raises there)
+ * The reference's normal equations reach condition numbers of 3e11: coefficients agree with the reference's to ~1e-5
+ * relative only (any two LAPACK routes differ that much); what the models predict at their own query points agrees tightly.
+ */
+typedef struct crx_lmpcprep_desc {
+    int32_t N;              /* 12   LMPCRacingParam.num_horizon */
+    int32_t n_points;       /* rows per lap in the safe-set arrays */
+    int32_t n_laps;         /* laps per race in the safe-set arrays */
+    int32_t n_ss_per_lap;   /* 22   num_ss_points / num_ss_iter (control.py:627-632) */
+    int32_t n_ss_laps;      /* 2    num_ss_iter */
+    int32_t max_neighbours; /* 40   utils/base.py:605 */
+    int32_t n_seg;          /* rows of the track table */
+    int32_t shift;          /* 0    LMPCRacingParam.shift */
+    double bandwidth;       /* 5.0  lmpc_helper.py:42 */
+    double scale[5];        /* 0.1, 1, 1, 1, 1   feature scaling of the distance (:49-57) */
+    double dt;              /* control period */
+    double lap_length;
+} crx_lmpcprep_desc;
+void crx_lmpcprep_desc_default(crx_lmpcprep_desc* d, int N, int n_points, int n_laps, int n_seg, double dt, double lap_length);
+int crx_lmpc_prep(const crx_lmpcprep_desc* d, int batch, const double* ss_xcurv, const double* u_ss, const double* qfun,
+                  const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                  const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                  double* ss_sel, double* q_sel, int32_t* status);
+int crx_lmpc_prep_dev(const crx_lmpcprep_desc* d, int batch, const double* ss_xcurv, const double* u_ss, const double* qfun,
+                      const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                      const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                      double* ss_sel, double* q_sel, int32_t* status, void* stream);
+/* LMPCRacingGame.add_point (utils/base.py:624-629): the running lap extends the previous lap's safe set past the finish
+ * line -- row time_ss[iter-1] + step + 1 of lap iter-1 becomes x + (0,0,0,0,lap_length,0) / u.  Device-resident race loops. */
+int crx_lmpc_addpoint_dev(const crx_lmpcprep_desc* d, int batch, double* ss_xcurv, double* u_ss, const int32_t* time_ss,
+                          const int32_t* iter, const int32_t* step, const double* x, const double* u, int u_stride,
+                          void* stream);
+
+/*
  * MPC-CBF NLPs.
  *   x0      [batch][6]
  *   xt      [batch][6] or [batch][N+1][6]   tracking target(s) (d->per_stage_target)

@@ -13,9 +13,9 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "crx_oracle.c")
-    hdr = os.path.join(_HERE, "..", "include", "crx.h")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    srcs = [os.path.join(_HERE, f) for f in ("crx_oracle.c", "crx_oracle_lmpc.c", "crx_oracle_lmpc_prep.c")]
+    srcs.append(os.path.join(_HERE, "..", "include", "crx.h"))
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return _LIB
 

@@ -83,3 +83,18 @@ def path_inputs(c):
     bez = ph.bezier_polylines(cps, N)
     qp = opp.path_qp_inputs(x[4], x[5], obs_infos, info, cps, bez, opt[:, 4], opt[:, 5], N, float(c["width"]), L, 4.5, 0.5, 0.4, 0.2)
     return abi.path_desc(N, float(c["alpha"])), qp
+
+
+def lmpc_lap_setup(g, track):
+    """The state of the reference's racing game at the start of its first learning-MPC lap, from tests/golden/racing_game.npz,
+    in libcrx's lap-major safe-set layout: (prep desc, ss [L,P,6], us [L,P,2], qf [L,P], time_ss [L], lin_points [N+1,6],
+    lin_input [N,2])."""
+    N = 12
+    ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1))
+    us = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
+    qf = np.ascontiguousarray(g["ss/Qfun0"].T)
+    time_ss = g["ss/time_ss"].astype(np.int32)
+    tab = track.point_and_tangent
+    d = abi.lmpcprep_desc(N, ss.shape[1], ss.shape[0], tab.shape[0], float(g["timestep"]), float(g["lap_length"]))
+    # LMPCRacingGame.add_trajectory hands over the linearisation points of lap 0 (utils/base.py:651-653)
+    return d, ss, us, qf, time_ss, ss[0, 1:N + 2].copy(), us[0, 1:N + 1].copy()

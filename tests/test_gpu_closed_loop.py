@@ -289,3 +289,43 @@ def test_mpccbf_racing_m_shape():
     # past the first uncertified golden solve the two runs apply different non-converged iterates (the reference keeps
     # IPOPT's, control.py:600-603); they must still tell the same story
     assert abs(e[-1, 4] - ref["ego_xcurv"][-1, 4]) <= 0.5 and np.abs(e[:, 5]).max() <= track.width
+
+
+def test_batched_lmpc_laps(golden_racing_game):
+    """crx.montecarlo.lmpc_laps: the learning-MPC lap of the racing game with the race index as the batch dimension,
+    device-resident (crx_lmpc_prep_dev -> crx_lmpc_solve_dev -> crx_lmpc_addpoint_dev -> crx_plant_step_wrap_dev).
+    Copies of the reference's own scenario (safe set of its PID and mpc-lti laps, tests/golden/racing_game.npz) must retrace
+    the reference's recorded closed loop up to its first infeasible QP, agree with each other bit for bit, and finish the
+    lap faster than the laps they learned from; perturbed starts must stay on the track and finish too."""
+    import helpers
+    from crx import montecarlo
+
+    g = golden_racing_game
+    track = _track(1.0)
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    Bn, steps = 16, 230
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1))
+    xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    rng = np.random.default_rng(9)
+    x0[8:, 0] += rng.uniform(-0.03, 0.03, Bn - 8)       # perturbed speed / lateral offset on half of the races
+    x0[8:, 5] += rng.uniform(-0.05, 0.05, Bn - 8)
+    xg0[8:, 0] = x0[8:, 0]
+    r = montecarlo.lmpc_laps(track.point_and_tangent, track.lap_length, track.width, np.tile(ss[None], (Bn, 1, 1, 1)),
+                             np.tile(us[None], (Bn, 1, 1, 1)), np.tile(qf[None], (Bn, 1, 1)), np.tile(time_ss[None], (Bn, 1)),
+                             np.full(Bn, 2, dtype=np.int32), x0, xg0, np.tile(lin_points[None], (Bn, 1, 1)), np.tile(lin_input[None], (Bn, 1, 1)),
+                             steps)
+    x = r["xcurv"]
+    assert np.isfinite(x).all() and (r["prep_status"] == 0).all()
+    np.testing.assert_array_equal(x[:, 1:8], x[:, :1].repeat(7, axis=1))           # identical races, identical bits
+    n = int(g["lmpc_first_uncertified"])
+    np.testing.assert_allclose(x[:n + 1, 0], g["lmpc/x"][:n + 1], atol=1e-5)      # the reference's own closed loop
+    np.testing.assert_allclose(r["u"][:n, 0], g["lmpc/U"][:n, 0], atol=1e-5)
+    assert (r["status"][:n, 0] == 0).all()
+    # every race completes the lap, faster than the mpc-lti lap it learned from (260 steps), and stays on the track
+    assert (r["laps"] >= 1).all(), r["laps"]
+    s = x[:, :, 4]
+    done = np.array([int(np.nonzero(np.diff(s[:, b]) < -5.0)[0][0]) + 1 for b in range(Bn)])
+    assert (done < 200).all() and (done > 100).all(), done
+    for b in range(Bn):
+        assert np.abs(x[:done[b], b, 5]).max() <= track.width
+        assert x[:done[b], b, 0].max() > 1.0                                       # it did accelerate beyond the 0.74 m/s of the stored laps

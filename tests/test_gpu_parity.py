@@ -727,3 +727,64 @@ def test_cfg4_full_size(gpu, orc, AB):
     touched = frozenset(np.nonzero((rg0["status"] != rg["status"]) | (rg0["iters"] != rg["iters"]) | (ro0["status"] != ro["status"]) | (ro0["iters"] != ro["iters"]))[0].tolist())
     _assert_same_verdicts("cfg4 subsample", rg, ro, restored=touched, max_restored_verdict=max(2, len(touched) // 5))
     _cmp("cfg4 subsample", rg0, ro0, need_same_status=False)
+
+
+def test_lmpc_prep_device(gpu, orc, golden_racing_game):
+    """crx_lmpc_prep (regression + linearisation + safe-set selection on the device, one wave per race) against the oracle,
+    which tests/test_oracle_golden.py pins to the reference's own recorded stage models.  Kernel and oracle run the same
+    operations in the same order without fused multiply-adds: the regression rows must agree to rounding of the final
+    divisions although the normal matrices have condition 3e11; the kinematic rows differ by the device's sin / cos."""
+    import os
+
+    import conftest
+    from utils import racing_env
+
+    g = golden_racing_game
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(conftest.ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    tab, N, L = track.point_and_tangent, d.N, float(g["lap_length"])
+    n = int(g["lmpc_first_uncertified"]) + 1
+    # the recorded calls as ONE batch: every call has its own copy of the safe set (extended by the calls before it)
+    SS, US, LP, LI, XS = [], [], [], [], []
+    for c in range(n):
+        SS.append(ss.copy()); US.append(us.copy()); LP.append(lin_points.copy()); LI.append(lin_input.copy()); XS.append(g["lmpc/x"][c])
+        X, U = g["lmpc/X"][c], g["lmpc/U"][c]
+        lin_points, lin_input = np.concatenate((X[1:], X[-1:]), axis=0), np.vstack((U[1:], U[-1]))
+        ss[1, time_ss[1] + c + 1] = g["lmpc/x"][c] + np.array([0, 0, 0, 0, L, 0])
+        us[1, time_ss[1] + c + 1] = U[0]
+    # plus perturbed copies (other linearisation points, other states -> other neighbour sets and nearest points)
+    rng = np.random.default_rng(5)
+    for c in range(n, 64):
+        k = c % n
+        SS.append(SS[k]); US.append(US[k])
+        LP.append(LP[k] + rng.normal(0, [0.05, 0.01, 0.05, 0.01, 0.1, 0.02], (N + 1, 6)))
+        LI.append(LI[k] + rng.normal(0, 0.02, (N, 2)))
+        XS.append(XS[k] + rng.normal(0, [0.05, 0.01, 0.05, 0.01, 0.3, 0.02]))
+    Bn = len(SS)
+    args = (np.stack(SS), np.stack(US), np.tile(qf[None], (Bn, 1, 1)), np.tile(time_ss[None], (Bn, 1)), np.full(Bn, 2, dtype=np.int32),
+            np.stack(XS), np.stack(LP), np.stack(LI), tab)
+    rg, ro = gpu.lmpc_prep(d, *args), orc.lmpc_prep(d, *args)
+    np.testing.assert_array_equal(rg["status"], ro["status"])
+    assert (ro["status"] == 0).all()
+    np.testing.assert_array_equal(rg["ss"], ro["ss"])                  # selection: index work, bit-exact
+    np.testing.assert_array_equal(rg["qfun"], ro["qfun"])
+    scale = np.maximum(1.0, np.abs(ro["A"]).max(axis=(2, 3), keepdims=True))
+    assert (np.abs(rg["A"][:, :, :3] - ro["A"][:, :, :3]) / scale).max() <= 1e-12, (np.abs(rg["A"][:, :, :3] - ro["A"][:, :, :3]) / scale).max()
+    np.testing.assert_allclose(rg["B"], ro["B"], rtol=0, atol=1e-12 * float(scale.max()))
+    np.testing.assert_allclose(rg["C"][:, :, :3], ro["C"][:, :, :3], rtol=0, atol=1e-12 * float(scale.max()))
+    np.testing.assert_allclose(rg["A"][:, :, 3:], ro["A"][:, :, 3:], rtol=0, atol=1e-13)      # kinematic rows
+    np.testing.assert_allclose(rg["C"][:, :, 3:], ro["C"][:, :, 3:], rtol=0, atol=1e-12)
+    # and, through the oracle's pin, the reference's own models: predictions at the query points
+    for c in range(n):
+        Ag, Bg, Cg = g["lmpc/A"][c], g["lmpc/B"][c], g["lmpc/C"][c]
+        pred = np.einsum("nij,nj->ni", rg["A"][c], LP[c][:N]) + np.einsum("nij,nj->ni", rg["B"][c], LI[c]) + rg["C"][c]
+        pred_g = np.einsum("nij,nj->ni", Ag, LP[c][:N]) + np.einsum("nij,nj->ni", Bg, LI[c]) + Cg
+        np.testing.assert_allclose(pred, pred_g, atol=1e-5)
+        np.testing.assert_array_equal(rg["ss"][c], g["lmpc/ss"][c])
+    # from_plan: the shift of the previous plan done inside the kernel
+    Xp, Up = np.stack([g["lmpc/X"][c % n] for c in range(Bn)]), np.stack([g["lmpc/U"][c % n] for c in range(Bn)])
+    a2 = args[:6] + (Xp, Up, tab)
+    rp = gpu.lmpc_prep(d, *a2, from_plan=True)
+    rq = gpu.lmpc_prep(d, *(args[:6] + (np.concatenate((Xp[:, 1:], Xp[:, -1:]), axis=1), np.concatenate((Up[:, 1:], Up[:, -1:]), axis=1), tab)))
+    for k in ("A", "B", "C"):
+        np.testing.assert_array_equal(rp[k], rq[k])

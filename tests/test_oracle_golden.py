@@ -235,3 +235,53 @@ def test_nonconvex_crosscheck(orc, AB, golden_mpccbf, golden_planner):
         assert r["status"][0] == 0
         assert _close_cost(r["cost"][0], float(z[n + "/golden_cost"]), 1e-9), (n, r["cost"][0], float(z[n + "/golden_cost"]))
     assert same_slsqp >= 12, same_slsqp      # SLSQP stalls early on the rest (higher cost, never lower)
+
+
+def test_lmpc_prep_regression_and_safe_set(orc, golden_racing_game):
+    """crx_oracle_lmpc_prep (local LTV regression + kinematic linearisation + safe-set selection) against the stage models
+    and safe-set points the reference itself computed in its learning-MPC lap (tests/golden/racing_game.npz), replayed call
+    by call exactly as LMPCRacingGame does: linearisation points from the previous (golden) solution, safe set extended by
+    add_point.  The reference's normal matrices reach cond 3e11, so coefficients are pinned loosely (any two LAPACK routes
+    differ by ~1e-5 relative) and what the models PREDICT at their own query points tightly; the closed-form kinematic rows
+    and the selection (indices, cost-to-go) exactly."""
+    import os
+
+    import conftest
+    from utils import racing_env
+
+    g = golden_racing_game
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(conftest.ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    N, L = d.N, float(g["lap_length"])
+    it = np.array([2], dtype=np.int32)
+    worst_c = worst_p = 0.0
+    for c in range(int(g["lmpc_first_uncertified"]) + 1):
+        r = orc.lmpc_prep(d, ss[None], us[None], qf[None], time_ss[None], it, g["lmpc/x"][c][None], lin_points[None], lin_input[None],
+                          track.point_and_tangent)
+        assert r["status"][0] == 0
+        Ag, Bg, Cg = g["lmpc/A"][c], g["lmpc/B"][c], g["lmpc/C"][c]
+        np.testing.assert_allclose(r["A"][0][:, 3:], Ag[:, 3:], atol=1e-12)          # kinematic rows: closed form
+        np.testing.assert_allclose(r["C"][0][:, 3:], Cg[:, 3:], atol=1e-12)
+        assert (r["B"][0][:, 3:] == 0).all()
+        scale = max(1.0, np.abs(Ag).max())
+        worst_c = max(worst_c, np.abs(r["A"][0] - Ag).max() / scale, np.abs(r["B"][0] - Bg).max() / scale)
+        assert np.abs(r["A"][0] - Ag).max() <= (1e-8 if c < 2 else 2e-5) * scale, c
+        pred = np.einsum("nij,nj->ni", r["A"][0], lin_points[:N]) + np.einsum("nij,nj->ni", r["B"][0], lin_input) + r["C"][0]
+        pred_g = np.einsum("nij,nj->ni", Ag, lin_points[:N]) + np.einsum("nij,nj->ni", Bg, lin_input) + Cg
+        worst_p = max(worst_p, np.abs(pred - pred_g).max())
+        np.testing.assert_allclose(pred, pred_g, atol=1e-5)
+        np.testing.assert_array_equal(r["ss"][0], g["lmpc/ss"][c])                   # the points the reference put into its QP
+        np.testing.assert_array_equal(r["qfun"][0], g["lmpc/qfun"][c])
+        # next call: plan shifted by one stage (control.py:726-728), safe set extended (utils/base.py:624-629)
+        X, U = g["lmpc/X"][c], g["lmpc/U"][c]
+        r2 = orc.lmpc_prep(d, ss[None], us[None], qf[None], time_ss[None], it, g["lmpc/x"][c][None], X[None], U[None],
+                           track.point_and_tangent, from_plan=True)
+        lin_points, lin_input = np.concatenate((X[1:], X[-1:]), axis=0), np.vstack((U[1:], U[-1]))
+        r3 = orc.lmpc_prep(d, ss[None], us[None], qf[None], time_ss[None], it, g["lmpc/x"][c][None], lin_points[None], lin_input[None],
+                           track.point_and_tangent)
+        for k in ("A", "B", "C"):
+            np.testing.assert_array_equal(r2[k], r3[k])                                # from_plan = the shift done inside
+        row = time_ss[1] + c + 1
+        ss[1, row] = g["lmpc/x"][c] + np.array([0, 0, 0, 0, L, 0])
+        us[1, row] = U[0]
+    assert worst_c <= 2e-5 and worst_p <= 1e-5, (worst_c, worst_p)
