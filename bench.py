@@ -246,6 +246,37 @@ def make_races(cx, args, batch=None):
     return w
 
 
+def make_game(cx, args, batch=None):
+    """SURVEY.md section 8f rows 1 + 4: B learning-MPC laps of the racing game, device-resident (regression + safe-set
+    selection, QP, add_point, plant per control step); every race starts from the reference's recorded safe set."""
+    from crx import abi, montecarlo
+    from utils import racing_env
+    w = Workload()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+    w.batch = w.units = batch or 1024
+    Bn, N = w.batch, 12
+    ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1)); us = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
+    qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
+    rng = np.random.default_rng(60 + cx.rank)
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    x0[:, 0] += rng.uniform(-0.03, 0.03, Bn); x0[:, 5] += rng.uniform(-0.05, 0.05, Bn); xg0[:, 0] = x0[:, 0]
+    laps = montecarlo.LmpcLaps(track.point_and_tangent, track.lap_length, track.width, np.tile(ss[None], (Bn, 1, 1, 1)),
+                               np.tile(us[None], (Bn, 1, 1, 1)), np.tile(qf[None], (Bn, 1, 1)), np.tile(time_ss[None], (Bn, 1)),
+                               np.full(Bn, 2, dtype=np.int32), x0, xg0, np.tile(ss[0, 1:N + 2][None], (Bn, 1, 1)),
+                               np.tile(us[0, 1:N + 1][None], (Bn, 1, 1)), N=N, device=cx.dev)
+    from crx import torch_api
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "game", "lmpc", N, laps.desc.n_ss_max, laps.desc, laps.ws
+    w.kernel = "crx_lmpc_kernel"
+    w.step = laps.step
+    w.solve = lambda: torch_api.lmpc_solve_dev(laps.desc, laps.xc, laps.u_old, laps.pws.A, laps.pws.B, laps.pws.C, laps.pws.ss, laps.pws.qfun,
+                                               laps.n_ss, ws=laps.ws)
+    w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
+              "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
+    w.extra = {"note": "keep steps + warmup below ~120: past the finish line the loop has no new safe set (add_trajectory is not part of it)"}
+    return w
+
+
 def measure(cx, w, steps, warmup, with_latency=True):
     """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
     import crx
@@ -423,7 +454,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races"],
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game"],
                     help="measure only this workload (default: headline cfg2 + every other single-GPU config in `configs`)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="cfg5 only")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4/lmpc/races) or scenarios (cfg3); 0 = BASELINE size")
@@ -452,7 +483,8 @@ def main():
     b = args.batch or None
     make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
-            "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b)}
+            "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
+            "game": lambda: make_game(cx, args, b)}
     head = make[args.workload or "cfg2"]()
     rec = measure(cx, head, args.steps, args.warmup)
     out = {"metric": METRIC, "value": rec["value"], "unit": "solves/s", "n_gpus": cx.world, "steps": args.steps, "warmup": args.warmup,
@@ -470,7 +502,8 @@ def main():
                 ("cfg4", lambda: make_cbf(cx, "cfg4", args), min(args.steps, 30), min(args.warmup, 3)),
                 ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5)),
                 ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3)),
-                ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2))]
+                ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2)),
+                ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5))]
         out["configs"] = []
         for key, mk, st, wu in subs:
             w = mk()

@@ -191,11 +191,17 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
             double* Ai = kp.A + ((size_t)b * N + i) * 36;
             double* Bi = kp.B + ((size_t)b * N + i) * 12;
             double* Ci = kp.C + ((size_t)b * N + i) * 6;
-            for (int k = 0; k < 36; k++) Ai[k] = 0.0;
-            for (int k = 0; k < 12; k++) Bi[k] = 0.0;
-            for (int k = 0; k < 3; k++) { Ai[0 * 6 + k] = ba[0][k]; Ai[1 * 6 + k] = bd[0][k]; Ai[2 * 6 + k] = bd[1][k]; }
-            Bi[0 * 2 + 1] = ba[0][3]; Bi[1 * 2 + 0] = bd[0][3]; Bi[2 * 2 + 0] = bd[1][3];
-            Ci[0] = ba[0][4]; Ci[1] = bd[0][4]; Ci[2] = bd[1][4];
+            // a singular normal matrix (no stored sample near this linearisation point; the reference's cvxopt raises) leaves
+            // the three regression rows of the stage UNTOUCHED: a device-resident loop thereby keeps the previous step's
+            // model of the stage, and status reports it
+            if (ok_a && ok_d) {
+                for (int k = 0; k < 18; k++) Ai[k] = 0.0;
+                for (int k = 0; k < 6; k++) Bi[k] = 0.0;
+                for (int k = 0; k < 3; k++) { Ai[0 * 6 + k] = ba[0][k]; Ai[1 * 6 + k] = bd[0][k]; Ai[2 * 6 + k] = bd[1][k]; }
+                Bi[0 * 2 + 1] = ba[0][3]; Bi[1 * 2 + 0] = bd[0][3]; Bi[2 * 2 + 0] = bd[1][3];
+                Ci[0] = ba[0][4]; Ci[1] = bd[0][4]; Ci[2] = bd[1][4];
+            }
+            for (int k = 6; k < 12; k++) Bi[k] = 0.0;
             // kinematic rows: analytic Jacobian of the Euler step (lmpc_helper.py:130-189, incl. `den * 2` at :163)
             const double vx = x0[0], vy = x0[1], wz = x0[2], epsi = x0[3], s = x0[4], ey = x0[5], dt = d.dt;
             const double cur = lp_curvature(kp.track, d.n_seg, d.lap_length, s);

@@ -384,7 +384,10 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
  *            of the previous crx_lmpc_solve and are shifted by one stage here (control.py:726-728)
  *   track    [n_seg][6]        rows (x, y, psi, s_start, length, curvature)
  *   A [batch][N][36], B [batch][N][12], C [batch][N][6];  ss_sel [batch][6][M], q_sel [batch][M], M = n_ss_laps * n_ss_per_lap
- *   status   [batch]           0, or 1 if a stage's normal matrix was singular (the reference's cvxopt raises there)
+ *   status   [batch]           0, or 1 if a stage's normal matrix was singular (no stored sample near its linearisation
+ *                              point; the reference's cvxopt raises there).  The three regression rows of such a stage are
+ *                              left UNTOUCHED in A, B, C: a device-resident loop that reuses its buffers keeps the previous
+ *                              step's model of the stage.
  * The reference's normal equations reach condition numbers of 3e11: coefficients agree with the reference's to ~1e-5
  * relative only (any two LAPACK routes differ that much); what the models predict at their own query points agrees tightly.
  */

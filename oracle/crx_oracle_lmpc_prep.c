@@ -155,12 +155,16 @@ int crx_oracle_lmpc_prep(const crx_lmpcprep_desc* d, int batch, const double* ss
             double* Ai = A + ((size_t)b * N + i) * 36;
             double* Bi = B + ((size_t)b * N + i) * 12;
             double* Ci = C + ((size_t)b * N + i) * 6;
-            memset(Ai, 0, sizeof(double) * 36); memset(Bi, 0, sizeof(double) * 12); memset(Ci, 0, sizeof(double) * 6);
             const int ok = solve5(Qa, ba, 1) & solve5(Qd, bd, 2);
-            if (!ok) status[b] = 1;   /* singular normal matrix: the reference's cvxopt raises (lmpc_helper.py:358-366) */
-            for (int k = 0; k < 3; k++) { Ai[0 * 6 + k] = ba[0][k]; Ai[1 * 6 + k] = bd[0][k]; Ai[2 * 6 + k] = bd[1][k]; }
-            Bi[0 * 2 + 1] = ba[0][3]; Bi[1 * 2 + 0] = bd[0][3]; Bi[2 * 2 + 0] = bd[1][3];
-            Ci[0] = ba[0][4]; Ci[1] = bd[0][4]; Ci[2] = bd[1][4];
+            if (!ok) status[b] = 1;   /* singular normal matrix: the reference's cvxopt raises (lmpc_helper.py:358-366); the
+                                         regression rows of the stage are left untouched (see the kernel) */
+            else {
+                memset(Ai, 0, sizeof(double) * 18); memset(Bi, 0, sizeof(double) * 6);
+                for (int k = 0; k < 3; k++) { Ai[0 * 6 + k] = ba[0][k]; Ai[1 * 6 + k] = bd[0][k]; Ai[2 * 6 + k] = bd[1][k]; }
+                Bi[0 * 2 + 1] = ba[0][3]; Bi[1 * 2 + 0] = bd[0][3]; Bi[2 * 2 + 0] = bd[1][3];
+                Ci[0] = ba[0][4]; Ci[1] = bd[0][4]; Ci[2] = bd[1][4];
+            }
+            memset(Bi + 6, 0, sizeof(double) * 6);
             /* kinematic rows: analytic Jacobian of the Euler step (lmpc_helper.py:130-189, incl. `den * 2` at :163) */
             const double vx = x0[0], vy = x0[1], wz = x0[2], epsi = x0[3], s = x0[4], ey = x0[5], dt = d->dt;
             const double cur = curvature(track, d->n_seg, d->lap_length, s);
