@@ -124,6 +124,16 @@ def lmpcprep_desc(N, n_points, n_laps, n_seg, dt, lap_length, n_ss_per_lap=22, n
                         int(shift), 5.0, _arr(C.c_double, 5, (0.1, 1.0, 1.0, 1.0, 1.0)), float(dt), float(lap_length))
 
 
+class SceneDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("n_all_max", C.c_int32), ("n_veh_max", C.c_int32), ("reserved0", C.c_int32),
+                ("safety_factor", C.c_double), ("prediction_factor", C.c_double), ("veh_length", C.c_double), ("lap_length", C.c_double)]
+
+
+def scene_desc(N, n_all_max, n_veh_max, lap_length, safety_factor=4.5, prediction_factor=0.5, veh_length=0.4):
+    """RacingGameParam.safety_factor / planning_prediction_factor, CarParam.length (utils/base.py:379-408, :700)."""
+    return SceneDesc(int(N), int(n_all_max), int(n_veh_max), 0, safety_factor, prediction_factor, veh_length, float(lap_length))
+
+
 class PathDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("reserved0", C.c_int32), ("alpha", C.c_double), ("w_rate", C.c_double), ("opts", IpmOpts)]
 
@@ -373,6 +383,21 @@ class Binding:
         self._call("lmpc_prep", C.byref(desc), C.c_int(Bn), _p(ss_xcurv), _p(u_ss), _p(qfun), _p(time_ss), _p(it), _p(x),
                    _p(lin_points), _p(lin_input), C.c_int(int(bool(from_plan))), _p(track), _p(out["A"]), _p(out["B"]),
                    _p(out["C"]), _p(out["ss"]), _p(out["qfun"]), _p(out["status"]))
+        return out
+
+    def planner_scene(self, desc, ego_xcurv, n_all, veh_xcurv, pred_s, pred_ey):
+        """crx_planner_scene: interest test, partial sort, veh_infos, max_delta_v, predictions in sorted order."""
+        N1, VA, V = desc.N + 1, desc.n_all_max, desc.n_veh_max
+        n_all = np.ascontiguousarray(n_all, dtype=_I)
+        S = n_all.shape[0]
+        ego_xcurv, veh_xcurv = _in(ego_xcurv, _D, (S, 6)), _in(veh_xcurv, _D, (S, VA, 6))
+        pred_s, pred_ey = _in(pred_s, _D, (S, VA, N1)), _in(pred_ey, _D, (S, VA, N1))
+        out = dict(n_veh=np.zeros(S, dtype=_I), overflow=np.zeros(S, dtype=_I), order=np.zeros((S, V), dtype=_I), veh_info=np.zeros((S, V, 3)),
+                   max_dv=np.zeros(S), obs_s=np.zeros((S, V, N1)), obs_ey=np.zeros((S, V, N1)))
+        getattr(self.lib, self.prefix + "planner_scene").restype = C.c_int
+        self._call("planner_scene", C.byref(desc), C.c_int(S), _p(ego_xcurv), _p(n_all), _p(veh_xcurv), _p(pred_s), _p(pred_ey),
+                   _p(out["n_veh"]), _p(out["overflow"]), _p(out["order"]), _p(out["veh_info"]), _p(out["max_dv"]), _p(out["obs_s"]),
+                   _p(out["obs_ey"]))
         return out
 
     def planner_prep(self, desc, x_wrapped, x_raw, n_veh, veh_info, max_dv, obs_s, obs_ey, opt_s, opt_ey):

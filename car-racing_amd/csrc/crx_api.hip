@@ -775,6 +775,66 @@ int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const do
     return sg.down(g_stream);
 }
 
+// ---- planner front (interest test, partial sort, vehicle infos) on the device ------------------------
+void crx_scene_desc_default(crx_scene_desc* d, int N, int n_all_max, int n_veh_max, double lap_length) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->n_all_max = n_all_max; d->n_veh_max = n_veh_max;
+    d->safety_factor = 4.5; d->prediction_factor = 0.5; d->veh_length = 0.4; d->lap_length = lap_length;
+}
+
+static int check_scene(const crx_scene_desc* d, int n_scen) {
+    if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
+    if (d->N < 1 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [1,%d]", d->N, CRX_MAX_N);
+    if (d->n_all_max < 1 || d->n_all_max > 64) return fail(CRX_ERR_ARG, "n_all_max=%d outside [1,64]", d->n_all_max);
+    if (d->n_veh_max < 1 || d->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [1,%d]", d->n_veh_max, CRX_MAX_OBS);
+    if (!(d->lap_length > 0.0) || !isfinite(d->lap_length)) return fail(CRX_ERR_ARG, "lap_length must be positive and finite");
+    if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
+    return 0;
+}
+
+int crx_planner_scene_dev(const crx_scene_desc* d, int n_scen, const double* ego_xcurv, const int32_t* n_all,
+                          const double* veh_xcurv, const double* pred_s, const double* pred_ey, int32_t* n_veh,
+                          int32_t* overflow, int32_t* order, double* veh_info, double* max_dv, double* obs_s, double* obs_ey,
+                          void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_scene(d, n_scen)) return rc;
+    if (n_scen == 0) return CRX_OK;
+    if (!ego_xcurv || !n_all || !veh_xcurv || !pred_s || !pred_ey || !n_veh || !overflow || !order || !veh_info || !max_dv || !obs_s || !obs_ey)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_scene_kparams sp;
+    sp.d = *d; sp.n_scen = n_scen; sp.ego_xcurv = ego_xcurv; sp.n_all = n_all; sp.veh_xcurv = veh_xcurv; sp.pred_s = pred_s;
+    sp.pred_ey = pred_ey; sp.n_veh = n_veh; sp.overflow = overflow; sp.order = order; sp.veh_info = veh_info; sp.max_dv = max_dv;
+    sp.obs_s = obs_s; sp.obs_ey = obs_ey;
+    hipError_t e = crx_launch_scene(sp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "scene launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_planner_scene(const crx_scene_desc* d, int n_scen, const double* ego_xcurv, const int32_t* n_all, const double* veh_xcurv,
+                      const double* pred_s, const double* pred_ey, int32_t* n_veh, int32_t* overflow, int32_t* order,
+                      double* veh_info, double* max_dv, double* obs_s, double* obs_ey) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_scene(d, n_scen)) return rc;
+    if (n_scen == 0) return CRX_OK;
+    if (!ego_xcurv || !n_all || !veh_xcurv || !pred_s || !pred_ey || !n_veh || !overflow || !order || !veh_info || !max_dv || !obs_s || !obs_ey)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    for (int i = 0; i < n_scen; i++)
+        if (n_all[i] < 0 || n_all[i] > d->n_all_max) return fail(CRX_ERR_ARG, "n_all[%d]=%d outside [0,%d]", i, n_all[i], d->n_all_max);
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t S = (size_t)n_scen, VA = (size_t)d->n_all_max, V = (size_t)d->n_veh_max, N1 = (size_t)d->N + 1;
+    Stage sg;
+    if (int rc = sg.reserve((S * 6 + S * VA * 6 + 2 * S * VA * N1) * 8 + S * 4, (S * V * 3 + S + 2 * S * V * N1) * 8 + (2 * S + S * V) * 4)) return rc;
+    double* dego = sg.in(ego_xcurv, S * 6); double* dvx = sg.in(veh_xcurv, S * VA * 6);
+    double* dps = sg.in(pred_s, S * VA * N1); double* dpe = sg.in(pred_ey, S * VA * N1); int32_t* dna = sg.in(n_all, S);
+    int32_t* dnv = sg.out(n_veh, S); int32_t* dov = sg.out(overflow, S); int32_t* dor = sg.out(order, S * V);
+    double* dvi = sg.out(veh_info, S * V * 3); double* dmd = sg.out(max_dv, S);
+    double* dos = sg.out(obs_s, S * V * N1); double* doe = sg.out(obs_ey, S * V * N1);
+    if (int rc = sg.up(g_stream)) return rc;
+    if (int rc = crx_planner_scene_dev(d, n_scen, dego, dna, dvx, dps, dpe, dnv, dov, dor, dvi, dmd, dos, doe, g_stream)) return rc;
+    return sg.down(g_stream);
+}
+
 // ---- learning-MPC host prep on the device ------------------------------------------------------------
 void crx_lmpcprep_desc_default(crx_lmpcprep_desc* d, int N, int n_points, int n_laps, int n_seg, double dt, double lap_length) {
     memset(d, 0, sizeof(*d));

@@ -86,6 +86,15 @@ struct crx_cbfprep_kparams {
     int32_t* n_obs;
 };
 
+struct crx_scene_kparams {
+    crx_scene_desc d;
+    int n_scen;
+    const double *ego_xcurv, *veh_xcurv, *pred_s, *pred_ey;
+    const int32_t* n_all;
+    int32_t *n_veh, *overflow, *order;
+    double *veh_info, *max_dv, *obs_s, *obs_ey;
+};
+
 struct crx_lmpcprep_kparams {
     crx_lmpcprep_desc d;
     int batch, from_plan;
@@ -106,6 +115,7 @@ hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);
 hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
+hipError_t crx_launch_scene(const crx_scene_kparams& sp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
 hipError_t crx_launch_lmpcprep(const crx_lmpcprep_kparams& kp, hipStream_t st);
 size_t crx_lmpcprep_lds_bytes(int n_points);

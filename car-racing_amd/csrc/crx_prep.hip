@@ -90,6 +90,68 @@ __global__ void __launch_bounds__(WAVE) crx_prep_kernel(const crx_prep_kparams p
     if (lane < R) pp.ey_ub[(size_t)s * R + lane] = ub;
 }
 
+// crx_scene_kernel: the front of OvertakeTrajPlanner (get_overtake_flag, the partial ey sort, veh_infos, agent_info.max_delta_v,
+// predictions in sorted order), one wavefront per scenario: the decisions are a few dozen scalar operations every lane runs
+// alike, the lanes share the copying of the predictions.  Restates planner_helper.py:177-201, :218-266 and
+// overtake_traj_planner.py:29-42, :66-92 (quirks Q3, Q4).
+__global__ void __launch_bounds__(WAVE) crx_scene_kernel(const crx_scene_kparams sp) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= sp.n_scen) return;
+    const crx_scene_desc& d = sp.d;
+    const int N1 = d.N + 1, VA = d.n_all_max, V = d.n_veh_max;
+    const double* ego = sp.ego_xcurv + (size_t)6 * s;
+    const double* vx_ = sp.veh_xcurv + (size_t)6 * VA * s;
+    const int na = min(max(sp.n_all[s], 0), VA);
+    const double L = d.lap_length, s_e = wrap_above(ego[4], L);
+    // vehicles of interest, in dict order (get_overtake_flag :29-42 -> check_ego_agent_distance planner_helper.py:218-266)
+    int idx[CRX_MAX_OBS], nv = 0, over = 0;
+    for (int v = 0; v < na; v++) {
+        const double dv = fabs(ego[0] - vx_[6 * v]);
+        const double s_a = wrap_above(vx_[6 * v + 4], L);
+        const double ahead = d.safety_factor * d.veh_length + d.prediction_factor * dv, behind = 1.0 * d.veh_length;
+        const bool hit = (s_a - s_e <= ahead && s_a >= s_e) || (s_a + L - s_e <= ahead && s_a + L >= s_e) ||
+                         (s_e - s_a <= behind && s_a <= s_e) || (s_e + L - s_a <= behind && s_a <= s_e + L);
+        if (hit) { if (nv < V) idx[nv++] = v; else over++; }
+    }
+    // partial "sort" (:66-76, quirk Q3): a new vehicle goes to the FRONT if its ey >= the current first one's, else to the back
+    int ord[CRX_MAX_OBS];
+    for (int k = 0; k < nv; k++) {
+        const double e = vx_[6 * idx[k] + 5];
+        if (k == 0) ord[0] = idx[0];
+        else if (e >= vx_[6 * ord[0] + 5]) { for (int q = k; q > 0; q--) ord[q] = ord[q - 1]; ord[0] = idx[k]; }
+        else ord[k] = idx[k];          // (e <= first; a NaN would be dropped by the reference, not representable here)
+    }
+    // agent_info.max_delta_v over the sorted vehicles (planner_helper.py:177-201)
+    double mdv = 0.0;
+    for (int k = 0; k < nv; k++) mdv = fmax(mdv, fabs(ego[0] - vx_[6 * ord[k]]));
+    if (lane == 0) { sp.n_veh[s] = nv; sp.overflow[s] = over; sp.max_dv[s] = mdv; }
+    if (lane < V) sp.order[(size_t)V * s + lane] = lane < nv ? ord[lane] : -1;
+    // veh_info rows in ITERATION order (:87-92, quirk Q4): (s, max ey over the prediction, min ey)
+    if (lane < V) {
+        double vi0 = 0.0, mx = 0.0, mn = 0.0;
+        if (lane < nv) {
+            const double* pe = sp.pred_ey + ((size_t)s * VA + idx[lane]) * N1;
+            vi0 = vx_[6 * idx[lane] + 4]; mx = pe[0]; mn = pe[0];
+            for (int j = 1; j < N1; j++) { mx = fmax(mx, pe[j]); mn = fmin(mn, pe[j]); }
+        }
+        double* vi = sp.veh_info + ((size_t)s * V + lane) * 3;
+        vi[0] = vi0; vi[1] = mx; vi[2] = mn;
+    }
+    // predictions of the sorted vehicles
+    for (int e = lane; e < V * N1; e += WAVE) {
+        const int k = e / N1, j = e - k * N1;
+        const size_t src = ((size_t)s * VA + (k < nv ? ord[k] : 0)) * N1 + j;
+        sp.obs_s[((size_t)s * V + k) * N1 + j] = k < nv ? sp.pred_s[src] : 0.0;
+        sp.obs_ey[((size_t)s * V + k) * N1 + j] = k < nv ? sp.pred_ey[src] : 0.0;
+    }
+}
+
+hipError_t crx_launch_scene(const crx_scene_kparams& sp, hipStream_t st) {
+    if (sp.n_scen == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_scene_kernel, dim3(sp.n_scen), dim3(WAVE), 0, st, sp);
+    return hipGetLastError();
+}
+
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st) {
     if (pp.n_scen == 0) return hipSuccess;
     hipLaunchKernelGGL(crx_prep_kernel, dim3(pp.n_scen), dim3(WAVE), 0, st, pp);

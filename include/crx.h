@@ -296,6 +296,41 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
                          double* bez_s, double* bez_ey, double* ey_lb, double* ey_ub, void* stream);
 
 /*
+ * The front of OvertakeTrajPlanner on the device (remainder): per scenario
+ *   which vehicles are of interest   get_overtake_flag -> planner_helper.check_ego_agent_distance (:218-266)
+ *   the reference's partial ey "sort" overtake_traj_planner.py:66-76 (quirk Q3: every vehicle is compared with the CURRENT FIRST only)
+ *   veh_info rows (s, max ey, min ey)  :87-92, in ITERATION order although consumed as if sorted (quirk Q4)
+ *   agent_info.max_delta_v            planner_helper.get_agent_info (:177-201)
+ *   predictions of the sorted vehicles  obs_infos[name][4:6, :] (:77-85)
+ * Outputs are exactly the vehicle inputs of crx_planner_prep and crx_select.
+ *   ego_xcurv [S][6]         the ego vehicle's state (the vehicle object's xcurv: both tests read it)
+ *   n_all     [S]            vehicles in the scenario besides the ego, 0..n_all_max, in the reference's dict order
+ *   veh_xcurv [S][VA][6]     their current states;  pred_s, pred_ey [S][VA][N+1]  their predictions (get_trajectory_nsteps rows 4, 5)
+ *   n_veh [S]                out: vehicles of interest (the planner runs iff > 0);  overflow [S]: of-interest vehicles beyond
+ *                            n_veh_max that were dropped (the reference has no limit; libcrx plans around at most CRX_MAX_OBS)
+ *   order [S][V]             out: vehicle index (0..n_all-1) of sorted vehicle k, -1 beyond n_veh
+ *   veh_info [S][V][3], max_dv [S], obs_s, obs_ey [S][V][N+1]   out
+ */
+typedef struct crx_scene_desc {
+    int32_t N;
+    int32_t n_all_max;       /* VA: leading dimension of the vehicle arrays */
+    int32_t n_veh_max;       /* V <= CRX_MAX_OBS */
+    int32_t reserved0;
+    double safety_factor;    /* 4.5  RacingGameParam.safety_factor */
+    double prediction_factor;/* 0.5  planning_prediction_factor */
+    double veh_length;       /* 0.4  ego.param.length */
+    double lap_length;
+} crx_scene_desc;
+void crx_scene_desc_default(crx_scene_desc* d, int N, int n_all_max, int n_veh_max, double lap_length);
+int crx_planner_scene(const crx_scene_desc* d, int n_scen, const double* ego_xcurv, const int32_t* n_all, const double* veh_xcurv,
+                      const double* pred_s, const double* pred_ey, int32_t* n_veh, int32_t* overflow, int32_t* order,
+                      double* veh_info, double* max_dv, double* obs_s, double* obs_ey);
+int crx_planner_scene_dev(const crx_scene_desc* d, int n_scen, const double* ego_xcurv, const int32_t* n_all,
+                          const double* veh_xcurv, const double* pred_s, const double* pred_ey, int32_t* n_veh,
+                          int32_t* overflow, int32_t* order, double* veh_info, double* max_dv, double* obs_s, double* obs_ey,
+                          void* stream);
+
+/*
  * One control step of the plant for a batch of vehicles: n_sub explicit Euler
  * sub-steps of the dynamic bicycle with Pacejka tyres (system/vehicle_dynamics.py:4-49) in global and
  * curvilinear coordinates, the curvature looked up from the track table at every sub-step

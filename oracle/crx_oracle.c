@@ -822,6 +822,60 @@ int crx_oracle_threads(void) { return 1; }
 void crx_oracle_set_threads(int n) { (void)n; }
 #endif
 
+/* The front of OvertakeTrajPlanner: planning/overtake_traj_planner.py:29-42 (get_overtake_flag), :66-76 (partial ey sort,
+ * quirk Q3), :77-92 (predictions, veh_infos in iteration order, quirk Q4); planning/planner_helper.py:218-266
+ * (check_ego_agent_distance), :177-201 (get_agent_info: max_delta_v). */
+int crx_oracle_planner_scene(const crx_scene_desc* d, int n_scen, const double* ego_xcurv, const int32_t* n_all,
+                             const double* veh_xcurv, const double* pred_s, const double* pred_ey, int32_t* n_veh,
+                             int32_t* overflow, int32_t* order, double* veh_info, double* max_dv, double* obs_s, double* obs_ey) {
+    if (!d || d->N < 1 || d->N > MAXN || d->n_veh_max < 1 || d->n_veh_max > MAXO || d->n_all_max < 1 || n_scen < 0) return CRX_ERR_ARG;
+    const int N1 = d->N + 1, VA = d->n_all_max, V = d->n_veh_max;
+    const double L = d->lap_length;
+    for (int s = 0; s < n_scen; s++) {
+        const double* ego = ego_xcurv + (size_t)6 * s;
+        const double* vx = veh_xcurv + (size_t)6 * VA * s;
+        const int na = n_all[s];
+        if (na < 0 || na > VA) return CRX_ERR_ARG;
+        double s_e = ego[4];
+        while (s_e > L) s_e -= L;                                                    /* planner_helper.py:222-223 */
+        int idx[MAXO], nv = 0, over = 0;
+        for (int v = 0; v < na; v++) {
+            const double dv = fabs(ego[0] - vx[6 * v]);
+            double s_a = vx[6 * v + 4];
+            while (s_a > L) s_a -= L;
+            const double ahead = d->safety_factor * d->veh_length + d->prediction_factor * dv, behind = 1.0 * d->veh_length;
+            const int hit = (s_a - s_e <= ahead && s_a >= s_e) || (s_a + L - s_e <= ahead && s_a + L >= s_e) ||
+                            (s_e - s_a <= behind && s_a <= s_e) || (s_e + L - s_a <= behind && s_a <= s_e + L);
+            if (hit) { if (nv < V) idx[nv++] = v; else over++; }
+        }
+        int ord[MAXO];
+        for (int k = 0; k < nv; k++) {                                                /* overtake_traj_planner.py:70-76 */
+            const double e = vx[6 * idx[k] + 5];
+            if (k == 0) ord[0] = idx[0];
+            else if (e >= vx[6 * ord[0] + 5]) { for (int q = k; q > 0; q--) ord[q] = ord[q - 1]; ord[0] = idx[k]; }
+            else ord[k] = idx[k];
+        }
+        double mdv = 0.0;
+        for (int k = 0; k < nv; k++) mdv = fmax(mdv, fabs(ego[0] - vx[6 * ord[k]]));
+        n_veh[s] = nv; overflow[s] = over; max_dv[s] = mdv;
+        for (int k = 0; k < V; k++) {
+            order[(size_t)V * s + k] = k < nv ? ord[k] : -1;
+            double* vi = veh_info + ((size_t)s * V + k) * 3;
+            vi[0] = vi[1] = vi[2] = 0.0;
+            if (k < nv) {                                                             /* :87-92, iteration order */
+                const double* pe = pred_ey + ((size_t)s * VA + idx[k]) * N1;
+                vi[0] = vx[6 * idx[k] + 4]; vi[1] = pe[0]; vi[2] = pe[0];
+                for (int j = 1; j < N1; j++) { vi[1] = fmax(vi[1], pe[j]); vi[2] = fmin(vi[2], pe[j]); }
+            }
+            for (int j = 0; j < N1; j++) {
+                obs_s[((size_t)s * V + k) * N1 + j] = k < nv ? pred_s[((size_t)s * VA + ord[k]) * N1 + j] : 0.0;
+                obs_ey[((size_t)s * V + k) * N1 + j] = k < nv ? pred_ey[((size_t)s * VA + ord[k]) * N1 + j] : 0.0;
+            }
+        }
+    }
+    return CRX_OK;
+}
+
 /* planning/overtake_traj_planner.py:205-246 */
 int crx_oracle_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh, const double* X,
                       const double* obs_s, const double* obs_ey, const int32_t* old_flag,

@@ -98,3 +98,22 @@ def lmpc_lap_setup(g, track):
     d = abi.lmpcprep_desc(N, ss.shape[1], ss.shape[0], tab.shape[0], float(g["timestep"]), float(g["lap_length"]))
     # LMPCRacingGame.add_trajectory hands over the linearisation points of lap 0 (utils/base.py:651-653)
     return d, ss, us, qf, time_ss, ss[0, 1:N + 2].copy(), us[0, 1:N + 1].copy()
+
+
+def random_scenes(S, VA, N, lap_length, seed=0):
+    """Random planner scenes for the scene stage: ego + up to VA other vehicles around it (ahead, behind, across the start
+    line), constant-speed predictions.  Returns (ego_xcurv, n_all, veh_xcurv, pred_s, pred_ey)."""
+    rng = np.random.default_rng(seed)
+    ego = np.zeros((S, 6))
+    ego[:, 0] = rng.uniform(0.5, 1.6, S)
+    ego[:, 4] = rng.uniform(0.0, lap_length * 1.02, S)        # some egos just past the lap length (raw state before the wrap)
+    ego[:, 5] = rng.uniform(-0.6, 0.6, S)
+    n_all = rng.integers(0, VA + 1, S).astype(np.int32)
+    veh = np.zeros((S, VA, 6))
+    veh[:, :, 0] = rng.uniform(0.3, 1.4, (S, VA))
+    veh[:, :, 4] = (ego[:, 4, None] + rng.uniform(-1.0, 4.0, (S, VA))) % lap_length
+    veh[:, :, 5] = 0.7 - 0.1 * rng.integers(0, 15, (S, VA))   # lanes repeat: ties in the partial sort
+    j = np.arange(N + 1)
+    pred_s = veh[:, :, 4, None] + 0.1 * j[None, None, :] * veh[:, :, 0, None]
+    pred_ey = veh[:, :, 5, None] + 0.01 * np.sin(j[None, None, :] + veh[:, :, 4, None])
+    return ego, n_all, veh, pred_s, pred_ey

@@ -171,3 +171,72 @@ def test_lmpc_regression_and_safe_set(golden_racing_game):
         lin_points, lin_input = np.concatenate((X[1:], X[-1:]), axis=0), np.vstack((U[1:], U[-1]))
         ss[time_ss[1] + c + 1, :, 1] = g["lmpc/x"][c] + np.array([0, 0, 0, 0, L, 0])
         us[time_ss[1] + c + 1, :, 1] = U[0]
+
+
+def test_scene_oracle_vs_mirror_and_reference(orc, golden_planner):
+    """crx_oracle_planner_scene (interest test, partial ey sort, veh_infos, max_delta_v, sorted predictions) against
+    (i) what the reference itself decided in the recorded planner scenarios (tests/golden/planner.npz: which vehicles were
+    of interest, their sorted order, the predictions it planned against) and (ii) the host mirror (planning/planner_helper,
+    itself pinned to the reference elsewhere in this file) on random scenes incl. ties, empty scenes and overflow."""
+    import types
+
+    import helpers
+    from crx import abi
+    from planning import planner_helper as ph
+
+    checked = 0
+    for name in golden_planner.names:
+        c = golden_planner.case(name)
+        names = [str(x) for x in c["veh_names"]]
+        VA, N = len(names), int(c["N"])
+        if not bool(c["overtake_flag"]):
+            d = abi.scene_desc(N, VA, 3, float(c["lap_length"]))
+            r = orc.planner_scene(d, c["x_raw"][None], np.array([VA]), c["veh_xcurv"][None], np.zeros((1, VA, N + 1)), np.zeros((1, VA, N + 1)))
+            assert r["n_veh"][0] == 0, name
+            continue
+        sorted_names = [str(x) for x in c["sorted_vehicles"]]
+        V = len(sorted_names)
+        pred_s, pred_ey = np.zeros((1, VA, N + 1)), np.zeros((1, VA, N + 1))
+        for k, n in enumerate(sorted_names):
+            pred_s[0, names.index(n)], pred_ey[0, names.index(n)] = c["obs_pred"][k, 4], c["obs_pred"][k, 5]
+        d = abi.scene_desc(N, VA, 3, float(c["lap_length"]))
+        r = orc.planner_scene(d, c["x_raw"][None], np.array([VA]), c["veh_xcurv"][None], pred_s, pred_ey)
+        assert r["n_veh"][0] == V and r["overflow"][0] == 0, name
+        assert [names[i] for i in r["order"][0, :V]] == sorted_names, name                 # the reference's own sorted_vehicles
+        got_interest = sorted(names[i] for i in r["order"][0, :V])
+        assert got_interest == sorted(n for n, f in zip(names, c["veh_is_interest"]) if f), name
+        np.testing.assert_array_equal(r["obs_s"][0, :V], c["obs_pred"][:, 4, :])
+        np.testing.assert_array_equal(r["obs_ey"][0, :V], c["obs_pred"][:, 5, :])
+        interest = [n for n, f in zip(names, c["veh_is_interest"]) if f]                    # iteration order
+        vi = np.array([[c["veh_xcurv"][names.index(n)][4], pred_ey[0, names.index(n)].max(), pred_ey[0, names.index(n)].min()] for n in interest])
+        np.testing.assert_array_equal(r["veh_info"][0, :V], vi)
+        assert r["max_dv"][0] == max(abs(c["x_raw"][0] - c["veh_xcurv"][names.index(n)][0]) for n in interest)
+        checked += 1
+    assert checked >= 8
+    # random scenes against the mirror
+    L, N, VA, V, S = 19.22957795362994, 12, 6, 3, 400
+    ego, n_all, veh, ps, pe = helpers.random_scenes(S, VA, N, L, seed=3)
+    d = abi.scene_desc(N, VA, V, L)
+    r = orc.planner_scene(d, ego, n_all, veh, ps, pe)
+    par = types.SimpleNamespace(safety_factor=4.5, planning_prediction_factor=0.5)
+    mk = lambda x: types.SimpleNamespace(xcurv=x, param=types.SimpleNamespace(length=0.4, width=0.2))  # noqa: E731
+    seen_over = seen_empty = 0
+    for s in range(S):
+        e = mk(ego[s])
+        hit = [v for v in range(n_all[s]) if ph.check_ego_agent_distance(e, mk(veh[s, v]), par, L)]
+        keep = hit[:V]
+        assert r["n_veh"][s] == len(keep) and r["overflow"][s] == len(hit) - len(keep), s
+        seen_over += len(hit) > V
+        seen_empty += len(hit) == 0
+        order = ph.sort_by_ey(keep, lambda v: veh[s, v, 5])
+        assert list(r["order"][s, :len(keep)]) == order and (r["order"][s, len(keep):] == -1).all(), s
+        if keep:
+            vehicles = {"ego": e, **{v: mk(veh[s, v]) for v in keep}}
+            info = ph.get_agent_info(vehicles, order, types.SimpleNamespace(lap_length=L))
+            assert r["max_dv"][s] == info.max_delta_v, s
+            for k, v in enumerate(keep):
+                assert tuple(r["veh_info"][s, k]) == (veh[s, v, 4], pe[s, v].max(), pe[s, v].min()), (s, k)
+            for k, v in enumerate(order):
+                np.testing.assert_array_equal(r["obs_s"][s, k], ps[s, v])
+                np.testing.assert_array_equal(r["obs_ey"][s, k], pe[s, v])
+    assert seen_over >= 3 and seen_empty >= 3
