@@ -417,7 +417,14 @@ def cpu_baseline(w):
     v1, r1, e1 = timed(min(n, 256), 8.0)
     oracle.set_threads(cores)
     vall, rall, eall = timed(n, 10.0)
-    out = {"value": vall, "unit": "solves/s", "cores": cores, "kind": "port",
+    quota = None
+    try:   # cgroup v2 CPU quota of the box, if any: omp_get_max_threads() counts the host's cores, not what the container may use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        quota = None
+    out = {"value": vall, "unit": "solves/s", "cores": cores, "cpu_quota_cores": quota, "affinity_cores": len(os.sched_getaffinity(0)),
+           "speedup_vs_one_thread": vall / v1, "kind": "port",
            "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (rall, n, eall),
            "one_thread": {"value": v1, "cores": 1, "sample": "%d repetitions of the first %d problems, %.1f s wall" % (r1, min(n, 256), e1)}}
     if kind == "cbf" and not desc.per_stage_target:

@@ -859,12 +859,21 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
 // 168 VGPRs for <0,12>, 256 for <2,12> -- buys a resident wave per SIMD but costs spills inside the interior-point loop:
 // measured -4 % on cfg3 and -2 % on cfg2 at the BASELINE batches, +1 % / +7 % only for batches of 16k planner QPs /
 // 16k two-car races.  Residency is therefore min(LDS, 512 / VGPRs per SIMD); crx_debug_resident_per_cu asks the runtime.)
-// Resident waves per SIMD the register allocator must leave room for.  Only the 1-obstacle, N <= 12 instantiation (BASELINE
-// configs[1], the MPC-CBF races) is pinned: it sat at 255 registers = 2 waves per SIMD before the restoration code was
+// Resident waves per SIMD the register allocator must leave room for.  The planner instantiation is pinned at CRX_PLANNER_WAVES
+// (below); of the obstacle instantiations only the 1-obstacle, N <= 12 one (BASELINE configs[1], the MPC-CBF races) is pinned: it sat at 255 registers = 2 waves per SIMD before the restoration code was
 // added and at 262 after; the bound makes the allocator park the handful of extra values (used outside the interior-
 // point loop) instead of silently halving the residency.  Every other instantiation is left alone (capping those was
 // measured in round 1 and rejected: spills inside the loop).
-template <int NOBS, int NMAX> struct MinWaves { static constexpr int v = (NOBS == 1 && NMAX == 12) ? 2 : 1; };
+#ifndef CRX_PLANNER_WAVES
+// Planner instantiation <0,12>: 3 = a third resident wave per SIMD (193 -> 168 registers, 21 dwords parked in scratch), which
+// lifts the residency from 8 (register-bound) to 11 problems per CU (LDS-bound).  Measured round 2 (tools/ab_planner_waves.sh):
+// 4096 QPs +0.4 %, 65536 QPs (the cfg5 shard) +10.6 %.  (Round 1 had measured -4 % at 4096 with the allocator's choice of
+// spills then; make EXTRA=-DCRX_PLANNER_WAVES=1 restores the uncapped build.)
+#define CRX_PLANNER_WAVES 3
+#endif
+template <int NOBS, int NMAX> struct MinWaves {
+    static constexpr int v = (NOBS == 1 && NMAX == 12) ? 2 : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
+};
 
 template <int NOBS, int NMAX>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
