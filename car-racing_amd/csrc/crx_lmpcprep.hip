@@ -38,31 +38,50 @@ __device__ static double lp_curvature(const double* track, int n_seg, double lap
 // Gaussian elimination with partial pivoting, 5x5, nrhs right-hand sides; every lane runs it on the same numbers.
 // Operation for operation oracle/crx_oracle_lmpc_prep.c solve5().
 template <int NRHS>
-__device__ static bool lp_solve5(double (&Q)[5][5], double (&rhs)[NRHS][5]) {
-#pragma unroll 1
+__device__ __forceinline__ bool lp_solve5(double (&Q)[5][5], double (&rhs)[NRHS][5]) {
+    // every index below is a compile-time constant after unrolling (the pivot row is applied through selects over the
+    // candidate rows): the matrices stay in registers.  With a run-time row index they lived in scratch memory and the
+    // 24 solves of a race cost ~1 ms of dependent scratch round trips -- 45 % of a whole control step of the batched lap.
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 5; c++) {
         int p = c;
         double best = fabs(Q[c][c]);
-        for (int r = c + 1; r < 5; r++)
-            if (fabs(Q[r][c]) > best) { best = fabs(Q[r][c]); p = r; }
-        if (!(best > 0.0) || !isfinite(best)) return false;
-        if (p != c) {
-            for (int k = 0; k < 5; k++) { const double t = Q[c][k]; Q[c][k] = Q[p][k]; Q[p][k] = t; }
-            for (int q = 0; q < NRHS; q++) { const double t = rhs[q][c]; rhs[q][c] = rhs[q][p]; rhs[q][p] = t; }
+#pragma unroll
+        for (int r = c + 1; r < 5; r++) {
+            const double a = fabs(Q[r][c]);
+            const bool gt = a > best;
+            best = gt ? a : best;
+            p = gt ? r : p;
         }
+        if (!(best > 0.0) || !isfinite(best)) ok = false;
+#pragma unroll
+        for (int r = c + 1; r < 5; r++) {
+            const bool sw = p == r;
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const double t = Q[c][k], u = Q[r][k]; Q[c][k] = sw ? u : t; Q[r][k] = sw ? t : u; }
+#pragma unroll
+            for (int q = 0; q < NRHS; q++) { const double t = rhs[q][c], u = rhs[q][r]; rhs[q][c] = sw ? u : t; rhs[q][r] = sw ? t : u; }
+        }
+#pragma unroll
         for (int r = c + 1; r < 5; r++) {
             const double f = Q[r][c] / Q[c][c];
+#pragma unroll
             for (int k = c; k < 5; k++) { const double t = f * Q[c][k]; Q[r][k] = Q[r][k] - t; }
+#pragma unroll
             for (int q = 0; q < NRHS; q++) { const double t = f * rhs[q][c]; rhs[q][r] = rhs[q][r] - t; }
         }
     }
+#pragma unroll
     for (int q = 0; q < NRHS; q++)
+#pragma unroll
         for (int r = 4; r >= 0; r--) {
             double s = rhs[q][r];
+#pragma unroll
             for (int k = r + 1; k < 5; k++) { const double t = Q[r][k] * rhs[q][k]; s = s - t; }
             rhs[q][r] = s / Q[r][r];
         }
-    return true;
+    return ok;
 }
 
 // LDS: feat [2][P][5] | dist [P] | wsel [2*MAXNB] | sums [48] | isel int[2*MAXNB]
@@ -120,21 +139,70 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
                 inside += __popcll(__ballot(s < d.bandwidth));
             }
             SYNC();
-            // selected set: everything inside the bandwidth, or the max_neighbours nearest (rank by (distance, index));
-            // compaction keeps ascending index order
+            // selected set: everything inside the bandwidth, or the max_neighbours nearest by (distance, index) -- the oracle's
+            // `rank < max_neighbours`.  Ranking every sample against every other is 2 M double compares per race and step
+            // (4 ms per step of 1024 races); instead the max_neighbours-th smallest distance is found by bisection on the
+            // bit pattern of the (non-negative) distances -- 63 counting passes -- and ties at that value are taken in
+            // ascending index order.  Compaction keeps ascending index order.
             int nsel = 0;
             const bool top = inside >= d.max_neighbours;
+            unsigned long long vstar = 0x7ff0000000000000ull;            // +inf: nothing is cut
+            int n_less = 0;
+            if (top) {
+                unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;
+                constexpr int KP = 8;                                     // laps of up to 512 samples keep their keys in registers
+                if (n <= KP * WAVE) {
+                    unsigned long long keys[KP];
+#pragma unroll
+                    for (int q = 0; q < KP; q++) {
+                        const int j = q * WAVE + lane;
+                        keys[q] = j < n ? (unsigned long long)__double_as_longlong(dist[j]) : ~0ull;
+                    }
+                    while (lo < hi) {
+                        const unsigned long long mid = lo + ((hi - lo) >> 1);
+                        int cnt = 0;
+#pragma unroll
+                        for (int q = 0; q < KP; q++)
+                            if (q * WAVE < n) cnt += __popcll(__ballot(keys[q] <= mid));
+                        if (cnt >= d.max_neighbours) hi = mid; else lo = mid + 1;
+                    }
+                } else {
+                    while (lo < hi) {
+                        const unsigned long long mid = lo + ((hi - lo) >> 1);
+                        int cnt = 0;
+                        for (int j0 = 0; j0 < n; j0 += WAVE) {
+                            const int j = j0 + lane;
+                            const unsigned long long key = j < n ? (unsigned long long)__double_as_longlong(dist[j]) : ~0ull;
+                            cnt += __popcll(__ballot(key <= mid));
+                        }
+                        if (cnt >= d.max_neighbours) hi = mid; else lo = mid + 1;
+                    }
+                }
+                vstar = lo;
+                for (int j0 = 0; j0 < n; j0 += WAVE) {
+                    const int j = j0 + lane;
+                    const unsigned long long key = j < n ? (unsigned long long)__double_as_longlong(dist[j]) : ~0ull;
+                    n_less += __popcll(__ballot(key < vstar));
+                }
+            }
+            int eq_taken = 0;
             for (int j0 = 0; j0 < n; j0 += WAVE) {
                 const int j = j0 + lane;
-                bool sel = false;
+                bool sel = false, eq = false;
                 if (j < n) {
                     const double dj = dist[j];
                     if (top) {
-                        int rank = 0;
-                        for (int k = 0; k < n; k++) { const double dk = dist[k]; rank += (dk < dj) || (dk == dj && k < j); }
-                        sel = rank < d.max_neighbours;
+                        const unsigned long long key = (unsigned long long)__double_as_longlong(dj);
+                        sel = key < vstar;
+                        eq = key == vstar;
                     } else
                         sel = dj < d.bandwidth;
+                }
+                if (top) {
+                    const unsigned long long me = __ballot(eq);
+                    const int r = eq_taken + __popcll(me & ((1ull << lane) - 1ull));
+                    sel = sel || (eq && n_less + r < d.max_neighbours);
+                    eq_taken += __popcll(me);
                 }
                 const unsigned long long m = __ballot(sel);
                 const int pos = nsel + __popcll(m & ((1ull << lane) - 1ull));
@@ -161,18 +229,30 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
                 c2 = r2 + t;
             } else { kind = 2 + (e - 30) / 5; r2 = (e - 30) % 5; c2 = 0; }
             const bool use_a = kind == 0 || kind == 2;          // the vx row is driven by a (feature 4), vy / wz by delta (feature 3)
+            // which two numbers of a sample's row this lane multiplies (offsets into [vx vy wz delta a | next vx vy wz]; -1 = the constant 1)
+            const int fr = r2 < 3 ? r2 : (r2 == 3 ? (use_a ? 4 : 3) : -1);
+            const int fc = kind < 2 ? (c2 < 3 ? c2 : (c2 == 3 ? (use_a ? 4 : 3) : -1)) : 5 + (kind - 2);
             double acc = 0.0;
-            for (int q = 0; q < nsel_tot; q++) {
-                const int pk = isel[q], lapk = pk >> 16, j = pk & 0xFFFF;
-                const double* F = feat + ((size_t)lapk * P + j) * 5;
-                const double K = wsel[q];
-                const double mr = r2 < 3 ? F[r2] : (r2 == 3 ? (use_a ? F[4] : F[3]) : 1.0);
-                double other;
-                if (kind < 2) other = c2 < 3 ? F[c2] : (c2 == 3 ? (use_a ? F[4] : F[3]) : 1.0);
-                else other = F[5 + (kind - 2)];                   // next sample's vx / vy / wz
-                const double km = K * mr;
-                const double t = km * other;
-                acc = acc + t;
+            // four samples per step: their loads are independent (one at a time each sample cost two dependent LDS round trips),
+            // the additions stay in sample order; a slot past the last sample adds +0.0, which changes nothing
+            for (int q0 = 0; q0 < nsel_tot; q0 += 4) {
+                double K[4], a[4], c[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u < nsel_tot ? q0 + u : nsel_tot - 1;
+                    const int pk = isel[q], lapk = pk >> 16, j = pk & 0xFFFF;
+                    const double* F = feat + ((size_t)lapk * P + j) * 5;
+                    K[u] = wsel[q];
+                    a[u] = F[fr >= 0 ? fr : 0];
+                    c[u] = F[fc >= 0 ? fc : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double mr = fr >= 0 ? a[u] : 1.0, other = fc >= 0 ? c[u] : 1.0;
+                    const double km = K[u] * mr;
+                    const double t = km * other;
+                    acc = acc + (q0 + u < nsel_tot ? t : 0.0);
+                }
             }
             if (lane < 45) sums[lane] = acc;
         }
