@@ -469,6 +469,8 @@ def main():
     ap.add_argument("--sweep-total", type=int, default=131072, help="cfg5 strong: scenarios in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -481,12 +483,16 @@ def main():
         print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(cx.local)
-    if cx.world > 1:
+    if cx.world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=cx.dev)
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
 
     import crx
     crx.init(cx.local)
+    if args.force_collective:
+        from crx import dist as cdist
+        cdist.FORCE_COLLECTIVE = True
     b = args.batch or None
     make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
@@ -519,7 +525,7 @@ def main():
             torch.cuda.empty_cache()
     if cx.rank == 0:
         print(json.dumps(out))
-    if cx.world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

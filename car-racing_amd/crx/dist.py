@@ -6,6 +6,10 @@ import torch
 import torch.distributed as dist
 
 
+# bench.py --force-collective: issue the all-gather through the backend even with one rank (RCCL plumbing check on a 1-GPU box)
+FORCE_COLLECTIVE = False
+
+
 def shard_bounds(n_items, rank, world):
     """Contiguous block [lo, hi) of rank `rank`; all V+1 regions of a scenario stay on one rank, so
     the region arg-min (overtake_traj_planner.py:244) needs no communication."""
@@ -42,7 +46,7 @@ class WinnerExchange:
             raise ValueError("rank %d holds %d winners, its shard of %d over %d ranks is %d" % (self.rank, flag.shape[0], self.n_total, self.world, n))
         self.send[:n, 0] = flag
         self.send[:n, 1:] = best_X.reshape(n, self.rec - 1)
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVE):
             allrec = self.send[:n]
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)   # the ONE collective of the path
