@@ -523,10 +523,18 @@ def main():
             out["configs"].append(measure(cx, w, st, wu, with_latency=key in ("cfg3", "cfg4", "lmpc")))
             del w
             torch.cuda.empty_cache()
-    if cx.rank == 0:
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if cx.rank == 0:
+        # the JSON line must be the LAST line on stdout: RCCL prints its version banner through C stdio, which (on a pipe)
+        # is flushed only at exit, i.e. after anything Python printed -- flush C stdio first, then print
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
