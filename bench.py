@@ -277,6 +277,40 @@ def make_game(cx, args, batch=None):
     return w
 
 
+def make_overtake(cx, args, batch=None):
+    """SURVEY.md section 8f row 4, the row's stated purpose: closed-loop Monte-Carlo of the racing game WITH traffic -- B laps,
+    every race against two scripted cars at random gaps / speeds / lanes, both branches of LMPCRacingGame.calc_input on the
+    device (crx.montecarlo.GameLaps)."""
+    from crx import montecarlo, synth
+    from utils import racing_env
+    A, B = synth.load_AB()
+    w = Workload()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
+    track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
+    opt = np.genfromtxt(os.path.join(ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
+    w.batch = w.units = batch or 1024
+    Bn, N = w.batch, 12
+    ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1)); us = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
+    qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
+    rng = np.random.default_rng(70 + cx.rank)
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    s0 = np.sort(rng.uniform(1.5, 8.0, (Bn, 2)), axis=1); s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 1.2)   # traffic close ahead: most steps overtake
+    v = rng.uniform(0.5, 0.9, (Bn, 2)); ey = rng.choice([-0.5, -0.2, 0.1, 0.4], (Bn, 2))
+    tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
+    laps = montecarlo.GameLaps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
+                               np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey, device=cx.dev)
+    from crx import torch_api
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 2, laps.track_desc, laps.tws
+    w.kernel = "crx_solve_kernel<2>"
+    w.step = laps.step
+    w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws)
+    w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against two "
+              "scripted cars each, one control step of every race per step: scene, Bezier/bounds, 3 region QPs + selection, tracking NLP (N=10, CBF rows), "
+              "12 regressions + LMPC QP, add_point, plant -- both branches computed, the race's own applied" % Bn)
+    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch; keep steps + warmup below ~120"}
+    return w
+
+
 def measure(cx, w, steps, warmup, with_latency=True):
     """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
     import crx
@@ -461,7 +495,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game"],
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game", "overtake"],
                     help="measure only this workload (default: headline cfg2 + every other single-GPU config in `configs`)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="cfg5 only")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4/lmpc/races) or scenarios (cfg3); 0 = BASELINE size")
@@ -497,7 +531,7 @@ def main():
     make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
-            "game": lambda: make_game(cx, args, b)}
+            "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}
     head = make[args.workload or "cfg2"]()
     rec = measure(cx, head, args.steps, args.warmup)
     out = {"metric": METRIC, "value": rec["value"], "unit": "solves/s", "n_gpus": cx.world, "steps": args.steps, "warmup": args.warmup,
@@ -516,7 +550,8 @@ def main():
                 ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5)),
                 ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3)),
                 ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2)),
-                ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5))]
+                ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5)),
+                ("overtake", lambda: make_overtake(cx, args), min(args.steps, 60), min(args.warmup, 5))]
         out["configs"] = []
         for key, mk, st, wu in subs:
             w = mk()

@@ -185,3 +185,114 @@ def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_s
         log_ps.append(r.pws.status.clone())
     return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(), status=torch.stack(log_st).cpu().numpy(),
                 prep_status=torch.stack(log_ps).cpu().numpy(), laps=r.laps.cpu().numpy())
+
+
+class GameLaps:
+    """B laps of the racing game WITH traffic at once, device-resident (the row's stated purpose:
+    the closed-loop Monte-Carlo of the overtaking game, car_racing/tests/overtake_planner_test.py:307-309): per control step,
+    LMPCRacingGame.calc_input (utils/base.py:456-583) for every race --
+
+        scripted cars' states and predictions (NoDynamicsModel, utils/base.py:847-890; element-wise torch ops)
+        crx_planner_scene_dev      vehicles of interest, partial sort, veh_infos                 (get_overtake_flag, get_local_traj :64-92)
+      overtake branch (:518-582)
+        crx_planner_prep_dev       Bezier references, ey bounds                                   (:94-117, 277-324)
+        crx_planner_plan_dev       the region QPs + selection                                     (solve_optimization_problem)
+        crx_track_prep_dev         per-stage targets, obstacle window / packing                   (control.mpc_multi_agents :293-382)
+        crx_cbf_solve_dev          the tracking NLP with CBF rows                                 (:270-473)
+      learning-MPC branch (:468-517)
+        crx_lmpc_prep_dev, crx_lmpc_solve_dev, crx_lmpc_addpoint_dev
+      crx_plant_step_wrap_dev
+
+    BOTH branches are computed for every race and the applied input, the plan hand-over (u_old, linearisation points),
+    add_point and the direction flag are taken from the branch the race is in (a wavefront per race either way; the
+    branch a race is not in costs its share of two more launches, no host round trip).  Nine libcrx launches per step."""
+
+    def __init__(self, track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0,
+                 lin_points, lin_input, car_s0, car_v, car_ey, N=12, N_plan=10, timestep=0.1, device=None):
+        self.lm = LmpcLaps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
+                           N=N, timestep=timestep, device=device)
+        lm = self.lm
+        dev = lm.xc.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        Bn = lm.batch
+        self.s0, self.v, self.ey = (torch.as_tensor(np.ascontiguousarray(a), **f64) for a in (car_s0, car_v, car_ey))
+        VA = self.s0.shape[1]
+        V = min(VA, abi.CRX_MAX_OBS)
+        self.Np, self.V, self.VA, self.L = N_plan, V, VA, lap_length
+        self.scene = abi.scene_desc(N_plan, VA, V, lap_length)
+        self.prep = abi.prep_desc(N_plan, V, opt_xcurv.shape[0], track_width, lap_length)
+        self.plan, self.sel = abi.planner_desc(N_plan, A, B), abi.select_desc(N_plan, V, lap_length)
+        self.track_desc = abi.cbf_desc(N_plan, V, A, B, Q=(10.0, 0, 0, 5.0, 0, 50.0), R=(0.1, 0.1), alpha=0.6, margin=0.15,
+                                       ey_max=track_width, per_stage_target=True, l_sum=0.4, w_sum=0.2)
+        self.opt_s = torch.as_tensor(np.ascontiguousarray(opt_xcurv[:, 4]), **f64)
+        self.opt_ey = torch.as_tensor(np.ascontiguousarray(opt_xcurv[:, 5]), **f64)
+        self.sws = torch_api.SceneWorkspace(self.scene, Bn, dev)
+        self.pws = torch_api.PrepWorkspace(self.prep, Bn, dev)
+        self.qws = torch_api.PlannerWorkspace(self.plan, Bn * (V + 1), dev)
+        self.selws = torch_api.SelectWorkspace(self.sel, Bn, dev)
+        self.tws = torch_api.CbfWorkspace(self.track_desc, Bn, dev)
+        self.xt = torch.empty((Bn, N_plan + 1, 6), **f64)
+        self.obs_s, self.obs_e = torch.empty((Bn, V, N_plan + 1), **f64), torch.empty((Bn, V, N_plan + 1), **f64)
+        self.lap_off, self.n_obs = torch.empty((Bn, V), **f64), torch.empty((Bn,), **i32)
+        self.n_all = torch.full((Bn,), VA, **i32)
+        self.old_flag = torch.full((Bn,), -1, **i32)
+        self.jdt = torch.arange(N_plan + 1, **f64) * timestep
+        self.veh = torch.zeros((Bn, VA, 6), **f64)
+        self.u = torch.zeros((Bn, 2), **f64)
+        self.lin_points, self.lin_input = lm.lin_points.clone(), lm.lin_input.clone()
+        self.neg = torch.full((Bn,), -(1 << 20), **i32)
+        self.overtake = torch.zeros((Bn,), dtype=torch.bool, device=dev)
+        self.t = 0.0
+
+    def step(self):
+        lm, L, N = self.lm, self.L, self.lm.N
+        # scripted cars at their own clock t: s = v t + s0 (wrapped once past the line, update_memory), predictions unwrapped (quirk Q6)
+        s_now = self.v * self.t + self.s0
+        self.veh[:, :, 0] = self.v
+        self.veh[:, :, 4] = torch.where(s_now > L, s_now - L, s_now)
+        self.veh[:, :, 5] = self.ey
+        pred_s = (self.v[:, :, None] * (self.t + self.jdt)[None, None, :] + self.s0[:, :, None]).contiguous()
+        pred_e = (self.ey[:, :, None] + 0.0 * self.jdt[None, None, :]).contiguous()
+        torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, pred_s, pred_e, ws=self.sws)
+        self.overtake = self.sws.n_veh > 0
+        # ---- overtake branch
+        torch_api.planner_prep_dev(self.prep, lm.xc, lm.xc, self.sws.n_veh, self.sws.veh_info, self.sws.max_dv, self.sws.obs_s, self.sws.obs_ey,
+                                   self.opt_s, self.opt_ey, ws=self.pws)
+        torch_api.planner_plan_dev(self.plan, self.sel, self.pws.x0, self.pws.bez_s, self.pws.bez_ey, self.pws.ey_lb, self.pws.ey_ub,
+                                   self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.old_flag, self.qws, self.selws)
+        torch_api.track_prep_dev(self.Np, self.V, L, lm.xc, self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.selws.best_X, self.xt,
+                                 self.obs_s, self.obs_e, self.lap_off, self.n_obs)
+        torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws)
+        # ---- learning-MPC branch
+        torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws)
+        torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws)
+        # ---- the branch each race is in
+        ot = self.overtake
+        self.u.copy_(torch.where(ot[:, None], self.tws.U[:, 0, :], lm.ws.U[:, 0, :]))
+        torch_api.lmpc_addpoint_dev(lm.pdesc, lm.ss, lm.us, lm.time_ss, lm.it, torch.where(ot, self.neg, lm.step_no), lm.xc, self.u, 2)
+        lm.u_old.copy_(torch.where(ot[:, None], lm.u_old, lm.ws.U[:, 0, :]))
+        X, U = lm.ws.X, lm.ws.U
+        self.lin_points.copy_(torch.where(ot[:, None, None], self.lin_points, torch.cat((X[:, 1:], X[:, -1:]), dim=1)))
+        self.lin_input.copy_(torch.where(ot[:, None, None], self.lin_input, torch.cat((U[:, 1:], U[:, -1:]), dim=1)))
+        lm.step_no += (~ot).to(torch.int32)
+        self.old_flag.copy_(torch.where(ot, self.selws.flag, torch.full_like(self.old_flag, -1)))
+        torch_api.plant_step_wrap_dev(lm.plant, lm.tab, lm.xg, lm.xc, self.u, 2, lm.xg_next, lm.xc_next, lm.laps)
+        lm.xg, lm.xg_next = lm.xg_next, lm.xg
+        lm.xc, lm.xc_next = lm.xc_next, lm.xc
+        self.t += lm.timestep
+
+
+def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
+              car_s0, car_v, car_ey, steps, device=None):
+    """Run `steps` control steps of B racing-game laps with scripted traffic.  Host logs: xcurv [steps+1, B, 6], u [steps, B, 2],
+    overtake [steps, B] (which branch), flag [steps, B] (direction flag, -1 in the LMPC branch), cars_s [steps, B, V], laps [B]."""
+    r = GameLaps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
+                 car_s0, car_v, car_ey, device=device)
+    lx, lu, lo, lf, lc = [r.lm.xc.clone()], [], [], [], []
+    for _ in range(steps):
+        lc.append((r.v * r.t + r.s0).clone())
+        r.step()
+        lx.append(r.lm.xc.clone()); lu.append(r.u.clone()); lo.append(r.overtake.clone()); lf.append(r.old_flag.clone())
+    return dict(xcurv=torch.stack(lx).cpu().numpy(), u=torch.stack(lu).cpu().numpy(), overtake=torch.stack(lo).cpu().numpy(),
+                flag=torch.stack(lf).cpu().numpy(), cars_s=torch.stack(lc).cpu().numpy(), laps=r.lm.laps.cpu().numpy())

@@ -274,3 +274,53 @@ def lmpc_addpoint_dev(desc, ss_xcurv, u_ss, time_ss, it, step, x, u, u_stride):
         raise ValueError("u: expected a contiguous cuda float64 tensor holding %d inputs at stride %d" % (Bn, u_stride))
     _call("crx_lmpc_addpoint_dev", C.byref(desc), C.c_int(Bn), _ptr(ss_xcurv), _ptr(u_ss), _ptr(time_ss), _ptr(it), _ptr(step),
           _ptr(x), _ptr(u), C.c_int(u_stride), _stream())
+
+
+class SceneWorkspace:
+    def __init__(self, desc, n_scen, device):
+        N1, V = desc.N + 1, desc.n_veh_max
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.n_veh, self.overflow = torch.empty(n_scen, **i32), torch.empty(n_scen, **i32)
+        self.order = torch.empty((n_scen, V), **i32)
+        self.veh_info = torch.empty((n_scen, V, 3), **f64)
+        self.max_dv = torch.empty(n_scen, **f64)
+        self.obs_s, self.obs_ey = torch.empty((n_scen, V, N1), **f64), torch.empty((n_scen, V, N1), **f64)
+
+
+def planner_scene_dev(desc, ego_xcurv, n_all, veh_xcurv, pred_s, pred_ey, ws=None):
+    """crx_planner_scene_dev: interest test, partial sort, veh_infos, max_delta_v, predictions in sorted order."""
+    N1, VA, S = desc.N + 1, desc.n_all_max, ego_xcurv.shape[0]
+    _chk(ego_xcurv, torch.float64, (S, 6), "ego_xcurv")
+    _chk(n_all, torch.int32, (S,), "n_all")
+    _chk(veh_xcurv, torch.float64, (S, VA, 6), "veh_xcurv")
+    _chk(pred_s, torch.float64, (S, VA, N1), "pred_s")
+    _chk(pred_ey, torch.float64, (S, VA, N1), "pred_ey")
+    ws = ws or SceneWorkspace(desc, S, ego_xcurv.device)
+    _call("crx_planner_scene_dev", C.byref(desc), C.c_int(S), _ptr(ego_xcurv), _ptr(n_all), _ptr(veh_xcurv), _ptr(pred_s), _ptr(pred_ey),
+          _ptr(ws.n_veh), _ptr(ws.overflow), _ptr(ws.order), _ptr(ws.veh_info), _ptr(ws.max_dv), _ptr(ws.obs_s), _ptr(ws.obs_ey), _stream())
+    return ws
+
+
+def planner_plan_dev(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag, ws, sws):
+    """crx_planner_plan_dev: all region QPs of every scenario + the selection, on one stream."""
+    S = n_veh.shape[0]
+    _call("crx_planner_plan_dev", C.byref(desc), C.byref(sdesc), C.c_int(S), _ptr(x0), _ptr(bez_s), _ptr(bez_ey), _ptr(ey_lb), _ptr(ey_ub),
+          _ptr(n_veh), _ptr(obs_s), _ptr(obs_ey), _ptr(old_flag), _ptr(ws.X), _ptr(ws.U), _ptr(ws.cost), _ptr(ws.status), _ptr(ws.kkt),
+          _ptr(ws.iters), _ptr(sws.flag), _ptr(sws.sel_cost), _ptr(sws.best_X), _stream())
+
+
+def track_prep_dev(N, V, lap_length, x, n_veh, obs_s_in, obs_ey_in, traj, xt, obs_s, obs_ey, lap_off, n_obs, safety_time=2.0, dt_ref=0.1):
+    """crx_track_prep_dev: per-stage targets and obstacle arrays of the tracking NLP from the planner's outputs."""
+    Bn = x.shape[0]
+    _chk(x, torch.float64, (Bn, 6), "x")
+    _chk(n_veh, torch.int32, (Bn,), "n_veh")
+    for name, a in (("obs_s_in", obs_s_in), ("obs_ey_in", obs_ey_in), ("obs_s", obs_s), ("obs_ey", obs_ey)):
+        _chk(a, torch.float64, (Bn, V, N + 1), name)
+    _chk(traj, torch.float64, (Bn, N + 1, 6), "traj")
+    _chk(xt, torch.float64, (Bn, N + 1, 6), "xt")
+    _chk(lap_off, torch.float64, (Bn, V), "lap_off")
+    _chk(n_obs, torch.int32, (Bn,), "n_obs")
+    _call("crx_track_prep_dev", C.c_int(N), C.c_int(V), C.c_double(lap_length), C.c_double(safety_time), C.c_double(dt_ref), C.c_int(Bn),
+          _ptr(x), _ptr(n_veh), _ptr(obs_s_in), _ptr(obs_ey_in), _ptr(traj), _ptr(xt), _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs),
+          _stream())

@@ -835,6 +835,24 @@ int crx_planner_scene(const crx_scene_desc* d, int n_scen, const double* ego_xcu
     return sg.down(g_stream);
 }
 
+// ---- inputs of the tracking NLP from the planner's outputs, on the device ----------------------------
+int crx_track_prep_dev(int N, int V, double lap_length, double safety_time, double dt_ref, int batch, const double* x,
+                       const int32_t* n_veh, const double* obs_s_in, const double* obs_ey_in, const double* traj, double* xt,
+                       double* obs_s, double* obs_ey, double* lap_off, int32_t* n_obs, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (N < 1 || N > CRX_MAX_N || V < 1 || V > CRX_MAX_OBS || batch < 0 || !(lap_length > 0.0) || !isfinite(lap_length))
+        return fail(CRX_ERR_ARG, "bad track prep dimensions");
+    if (batch == 0) return CRX_OK;
+    if (!x || !n_veh || !obs_s_in || !obs_ey_in || !traj || !xt || !obs_s || !obs_ey || !lap_off || !n_obs) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_trackprep_kparams tp;
+    tp.N = N; tp.V = V; tp.batch = batch; tp.lap_length = lap_length; tp.safety_time = safety_time; tp.dt_ref = dt_ref;
+    tp.x = x; tp.n_veh = n_veh; tp.obs_s_in = obs_s_in; tp.obs_ey_in = obs_ey_in; tp.traj = traj;
+    tp.xt = xt; tp.obs_s = obs_s; tp.obs_ey = obs_ey; tp.lap_off = lap_off; tp.n_obs = n_obs;
+    hipError_t e = crx_launch_trackprep(tp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "track prep launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
 // ---- learning-MPC host prep on the device ------------------------------------------------------------
 void crx_lmpcprep_desc_default(crx_lmpcprep_desc* d, int N, int n_points, int n_laps, int n_seg, double dt, double lap_length) {
     memset(d, 0, sizeof(*d));

@@ -86,6 +86,15 @@ struct crx_cbfprep_kparams {
     int32_t* n_obs;
 };
 
+struct crx_trackprep_kparams {
+    int N, V, batch;
+    double lap_length, safety_time, dt_ref;
+    const double *x, *obs_s_in, *obs_ey_in, *traj;
+    const int32_t* n_veh;
+    double *xt, *obs_s, *obs_ey, *lap_off;
+    int32_t* n_obs;
+};
+
 struct crx_scene_kparams {
     crx_scene_desc d;
     int n_scen;
@@ -116,6 +125,7 @@ hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_scene(const crx_scene_kparams& sp, hipStream_t st);
+hipError_t crx_launch_trackprep(const crx_trackprep_kparams& tp, hipStream_t st);
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st);
 hipError_t crx_launch_lmpcprep(const crx_lmpcprep_kparams& kp, hipStream_t st);
 size_t crx_lmpcprep_lds_bytes(int n_points);

@@ -146,6 +146,64 @@ __global__ void __launch_bounds__(WAVE) crx_scene_kernel(const crx_scene_kparams
     }
 }
 
+// crx_trackprep_kernel: the inputs of control.mpc_multi_agents' NLP from the planner's outputs, one thread per race:
+// per-stage targets (control/control.py:373-382: the selected trajectory's ey, linearly interpolated at the clipped nominal s)
+// and the window filter / lap offsets / packing of the sorted vehicles' predictions (:293-309).  Arithmetic of
+// crx/hostprep.py tracking_targets, cbf_window, pack_obstacles.
+__global__ void __launch_bounds__(256) crx_trackprep_kernel(const crx_trackprep_kparams tp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= tp.batch) return;
+    const int N = tp.N, V = tp.V, N1 = N + 1;
+    const double* x = tp.x + (size_t)6 * b;
+    const double* tr = tp.traj + (size_t)b * N1 * 6;
+    const double L = tp.lap_length, vx = x[0], se = x[4];
+    // targets: s clipped to the trajectory's range, scipy interp1d(kind="linear") (searchsorted-left, index in [1, n-1], slope form)
+    const double s_lo = tr[4], s_hi = tr[(size_t)N * 6 + 4];
+    for (int i = 0; i <= N; i++) {
+        double s = se + vx * tp.dt_ref * i;
+        s = s < s_lo ? s_lo : s;
+        s = s >= s_hi ? s_hi : s;
+        int hi = 0;
+        while (hi < N1 && tr[(size_t)hi * 6 + 4] < s) hi++;
+        hi = hi < 1 ? 1 : (hi > N1 - 1 ? N1 - 1 : hi);
+        const int lo = hi - 1;
+        const double slope = (tr[(size_t)hi * 6 + 5] - tr[(size_t)lo * 6 + 5]) / (tr[(size_t)hi * 6 + 4] - tr[(size_t)lo * 6 + 4]);
+        double* xt = tp.xt + ((size_t)b * N1 + i) * 6;
+        xt[0] = vx; xt[1] = 0.0; xt[2] = 0.0; xt[3] = 0.0; xt[4] = 0.0;
+        xt[5] = slope * (s - tr[(size_t)lo * 6 + 4]) + tr[(size_t)lo * 6 + 5];
+    }
+    // obstacles: +-safety_time*vx window on the lap-folded positions (int() truncation as in the reference), lap offsets, packing
+    const double margin = tp.safety_time * vx;
+    const double nce = trunc(se / L), dist_ego = se - nce * L;
+    const int nv = min(max(tp.n_veh[b], 0), V);
+    int n = 0;
+    for (int v = 0; v < nv; v++) {
+        const double* is = tp.obs_s_in + ((size_t)b * V + v) * N1;
+        const double* ie = tp.obs_ey_in + ((size_t)b * V + v) * N1;
+        const double nco = trunc(is[0] / L), dist_obs = is[0] - nco * L;
+        if (dist_ego > dist_obs - margin && dist_ego < dist_obs + margin) {
+            double* os = tp.obs_s + ((size_t)b * V + n) * N1;
+            double* oe = tp.obs_ey + ((size_t)b * V + n) * N1;
+            for (int j = 0; j < N1; j++) { os[j] = is[j]; oe[j] = ie[j]; }
+            tp.lap_off[(size_t)b * V + n] = (nce - nco) * L;
+            n++;
+        }
+    }
+    for (int v = n; v < V; v++) {
+        double* os = tp.obs_s + ((size_t)b * V + v) * N1;
+        double* oe = tp.obs_ey + ((size_t)b * V + v) * N1;
+        for (int j = 0; j < N1; j++) { os[j] = 0.0; oe[j] = 0.0; }
+        tp.lap_off[(size_t)b * V + v] = 0.0;
+    }
+    tp.n_obs[b] = n;
+}
+
+hipError_t crx_launch_trackprep(const crx_trackprep_kparams& tp, hipStream_t st) {
+    if (tp.batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_trackprep_kernel, dim3((tp.batch + 255) / 256), dim3(256), 0, st, tp);
+    return hipGetLastError();
+}
+
 hipError_t crx_launch_scene(const crx_scene_kparams& sp, hipStream_t st) {
     if (sp.n_scen == 0) return hipSuccess;
     hipLaunchKernelGGL(crx_scene_kernel, dim3(sp.n_scen), dim3(WAVE), 0, st, sp);

@@ -380,6 +380,20 @@ int crx_cbf_prep_dev(int N, int V, double lap_length, double t, double dt, doubl
                      double* obs_s, double* obs_ey, double* lap_off, int32_t* n_obs, void* stream);
 
 /*
+ * Inputs of control.mpc_multi_agents' NLP (crx_cbf_solve with per_stage_target = 1) from the planner's outputs, on the device
+ * (device-resident race loops): per-stage targets xt_i = [vx_0, 0, 0, 0, 0, f_traj(clip(s_0 + dt_ref i vx_0))] from the
+ * selected trajectory (control/control.py:373-382; f_traj = linear interpolation of its (s, ey) samples) and the obstacle
+ * arrays: the sorted vehicles' predictions filtered by the +-safety_time*vx window on the lap-folded positions, lap
+ * offsets, kept vehicles packed to the front (control.py:293-309, 311-319).  Horizon of the controller = horizon of the
+ * planner here (the reference's defaults: 10 and 10).
+ *   x [batch][6];  n_veh [batch];  obs_s_in, obs_ey_in [batch][V][N+1] (crx_planner_scene order);  traj [batch][N+1][6] (best_X)
+ *   xt [batch][N+1][6];  obs_s, obs_ey [batch][V][N+1];  lap_off [batch][V];  n_obs [batch]
+ */
+int crx_track_prep_dev(int N, int V, double lap_length, double safety_time, double dt_ref, int batch, const double* x,
+                       const int32_t* n_veh, const double* obs_s_in, const double* obs_ey_in, const double* traj, double* xt,
+                       double* obs_s, double* obs_ey, double* lap_off, int32_t* n_obs, void* stream);
+
+/*
  * Learning-MPC QPs: control.lmpc (control.py:610-730) after its safe-set
  * selection (:625-639), one problem per batch entry.  LTV affine model x_{i+1} = A_i x_i + B_i u_i + C_i
  * as estimated by the caller (utils/base.py:585-622).

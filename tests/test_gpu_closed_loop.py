@@ -337,3 +337,81 @@ def test_batched_lmpc_laps(golden_racing_game):
         assert (r["prep_status"][:done[b], b] != 0).mean() <= 0.05, b
         assert np.abs(x[:done[b], b, 5]).max() <= track.width
         assert x[:done[b], b, 0].max() > 1.0                                       # it did accelerate beyond the 0.74 m/s of the stored laps
+
+
+def test_batched_game_laps(AB, golden_racing_game):
+    """crx.montecarlo.game_laps: laps of the racing game WITH traffic, batched and device-resident -- scene -> prep -> region
+    QPs -> selection -> tracking NLP in the overtake branch, regression -> LMPC QP -> add_point in the learning-MPC branch,
+    both computed for every race, the branch a race is in applied.  (a) Copies of one scenario are bit-identical.  (b) The
+    reference's own traffic (tests/auto_racing_game_test.py cars) on the lap after the mpc-lti lap: the batched loop must
+    retrace the class-surface path (LMPCRacingGame.calc_input through the mirror, one race, host control flow) -- tightly
+    while the ego drives alone, loosely through the overtakes (the learning-MPC lap amplifies 1e-8 differences, DESIGN.md
+    section 5.3), with the same branch and direction-flag sequence up to isolated steps -- and pass both cars without contact.
+    (c) Random traffic: every race stays finite and on the track; most finish the lap."""
+    import helpers
+    import scenarios
+    from control import lmpc_helper
+    from crx import montecarlo
+
+    A, B = AB
+    g = golden_racing_game
+    track = _track(1.0)
+    opt = scenarios.table("optimal_traj", "xcurv_l_shape")
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    cars = scenarios.RACING_GAME["cars"]
+    Bn, steps = 64, 200
+    rng = np.random.default_rng(21)
+    s0 = np.tile([c[1] for c in cars], (Bn, 1)); v = np.tile([c[2] for c in cars], (Bn, 1)); ey = np.tile([c[3] for c in cars], (Bn, 1))
+    s0[8:] = np.sort(rng.uniform(3.0, 16.0, (Bn - 8, 2)), axis=1); s0[8:, 1] = np.maximum(s0[8:, 1], s0[8:, 0] + 1.2)
+    v[8:] = rng.uniform(0.5, 0.9, (Bn - 8, 2)); ey[8:] = rng.choice([-0.5, -0.2, 0.1, 0.4], (Bn - 8, 2))
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
+    r = montecarlo.game_laps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
+                             np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(lin_points), tile(lin_input), s0, v, ey, steps)
+    x = r["xcurv"]
+    assert np.isfinite(x).all()
+    np.testing.assert_array_equal(x[:, 1:8], x[:, :1].repeat(7, axis=1))                      # (a)
+    # (b) the same lap through the class surface
+    keep = lmpc_helper.ON_SINGULAR
+    lmpc_helper.ON_SINGULAR = "keep"
+    try:
+        race, ctrl = scenarios.racing_game(dict(scenarios.RACING_GAME, lap_plan=("pid", "mpc-lti", "lmpc+traffic")))
+    finally:
+        lmpc_helper.ON_SINGULAR = keep
+    one = np.array(race.ego.xcurvs[2])
+    n1 = min(len(one), steps + 1)
+    ot = r["overtake"][:, 0]
+    first_ot = int(np.nonzero(ot)[0][0])
+    assert 30 <= first_ot <= 120, first_ot
+    # same arithmetic through another control flow: 1e-8 apart at the start.  The learning-MPC lap then amplifies that by
+    # about a decade every five steps (28 % of its QPs are infeasible as the reference builds them; DESIGN.md section 5.3,
+    # tools/game_debug.py prints the step-by-step comparison), so the two runs are pinned tightly over the first 15 steps
+    # and must tell the same story afterwards: same side chosen, positions within a car length and a half, same lap time
+    np.testing.assert_allclose(x[:15, 0], one[:15], atol=1e-5)
+    dev = np.abs(x[:n1, 0, [0, 4, 5]] - one[:n1][:, [0, 4, 5]])
+    dev[:, 1] = np.minimum(dev[:, 1], np.abs(dev[:, 1] - track.lap_length))
+    assert dev[:, 1].max() <= 0.6 and dev[:, 2].max() <= 0.35, dev.max(axis=0)
+    done = int(np.nonzero(np.diff(x[:, 0, 4]) < -5.0)[0][0]) + 1
+    assert abs(done - (len(one) - 1)) <= 10, (done, len(one) - 1)                              # lap time within 1 s
+    flags = r["flag"][:, 0][ot]
+    ref_ot = np.array([p is None for p in race.ego.lmpc_prediction])                           # the class surface's branch per step
+    assert abs(int(ot[:done].sum()) - int(ref_ot.sum())) <= 15, (ot[:done].sum(), ref_ot.sum())
+    assert (np.diff(flags[: int(ot[:done].sum())]) != 0).sum() <= 8                           # the chosen region changes rarely (w_switch = 100)
+    assert ot.sum() >= 10
+    L = track.lap_length
+    passed_ref = []
+    e_ref = np.array(race.ego.xcurvs[2])
+    for c, car in enumerate(race.cars):
+        cl = np.array(car.xcurv_log)[: len(e_ref) - 1]
+        dsr = (e_ref[1:len(cl) + 1, 4] - cl[:, 4] + 0.5 * L) % L - 0.5 * L
+        passed_ref.append(bool(dsr[0] < 0 < dsr[-1]))
+    for c in range(2):                                                                           # the same cars passed, no contact
+        cs = r["cars_s"][:done, 0, c]
+        ds = (x[:done, 0, 4] - cs + 0.5 * L) % L - 0.5 * L
+        dey = x[:done, 0, 5] - ey[0, c]
+        assert bool(ds[0] < 0 < ds[-1]) == passed_ref[c], (c, ds[0], ds[-1], passed_ref)
+        assert ((ds / 0.4) ** 6 + (dey / 0.2) ** 6).min() >= 1.0, c
+    assert passed_ref[0]                                                                         # the first car is overtaken within the lap
+    # (c) random traffic
+    assert np.abs(x[:, :, 5]).max() <= 1.3 * track.width
+    assert (r["laps"] >= 1).mean() >= 0.8, r["laps"]

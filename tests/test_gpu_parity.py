@@ -829,3 +829,42 @@ def test_scene_device(gpu, orc, AB):
     assert len(diff) <= 3, len(diff)
     for i in diff:
         assert abs(pl["sel_cost"][i, pl["flag"][i]] - pl["sel_cost"][i, so["flag"][i]]) <= 1e-4, (i, pl["sel_cost"][i], so["sel_cost"][i])
+
+
+def test_track_prep_device(gpu):
+    """crx_track_prep_dev (per-stage targets + obstacle window / packing of the tracking NLP, on the device) against the host
+    prep of the mirror (crx.hostprep tracking_targets / cbf_window / pack_obstacles, the functions the golden mpc_multi_agents
+    tests feed the solver through, tests/helpers.py mma_inputs): same arithmetic: window / packing / offsets bit-exact, interpolated targets to 1 ulp (the kernel contracts a*b+c)."""
+    import torch
+    from crx import hostprep, torch_api
+
+    rng = np.random.default_rng(31)
+    Bn, N, V, L = 512, 10, 3, 19.22957795362994
+    x = np.zeros((Bn, 6)); x[:, 0] = rng.uniform(0.5, 1.6, Bn); x[:, 4] = rng.uniform(0, L, Bn); x[:, 5] = rng.uniform(-0.5, 0.5, Bn)
+    n_veh = rng.integers(0, V + 1, Bn).astype(np.int32)
+    vo = rng.uniform(0.3, 1.2, (Bn, V))
+    so = x[:, 4, None] + rng.uniform(-3.0, 4.0, (Bn, V))
+    so[::7] += L                                                       # predictions one lap ahead of the ego: lap offsets
+    j = np.arange(N + 1)
+    obs_s = so[:, :, None] + 0.1 * j * vo[:, :, None]
+    obs_ey = rng.uniform(-0.7, 0.7, (Bn, V, 1)) + np.zeros((1, 1, N + 1))
+    traj = np.zeros((Bn, N + 1, 6))
+    traj[:, :, 4] = x[:, 4, None] + np.cumsum(rng.uniform(0.05, 0.2, (Bn, N + 1)), axis=1)
+    traj[:, :, 5] = rng.uniform(-0.6, 0.6, (Bn, N + 1))
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)   # noqa: E731
+    xt = torch.empty((Bn, N + 1, 6), dtype=torch.float64, device=dev)
+    os_, oe_ = torch.empty((Bn, V, N + 1), dtype=torch.float64, device=dev), torch.empty((Bn, V, N + 1), dtype=torch.float64, device=dev)
+    lo, no = torch.empty((Bn, V), dtype=torch.float64, device=dev), torch.empty((Bn,), dtype=torch.int32, device=dev)
+    torch_api.track_prep_dev(N, V, L, t(x), t(n_veh, torch.int32), t(obs_s), t(obs_ey), t(traj), xt, os_, oe_, lo, no)
+    torch.cuda.synchronize()
+    for b in range(Bn):
+        np.testing.assert_allclose(xt[b].cpu().numpy(), hostprep.tracking_targets(x[b], traj[b], N), rtol=0, atol=1e-15)   # fma in the interpolation
+        nv = int(n_veh[b])
+        keep, off = hostprep.cbf_window(x[b:b + 1], obs_s[b:b + 1, :nv, 0], L)
+        ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s[b:b + 1, :nv], obs_ey[b:b + 1, :nv], off, V) if nv else (
+            np.zeros((1, V, N + 1)), np.zeros((1, V, N + 1)), np.zeros((1, V)), np.zeros(1, dtype=np.int32))
+        assert int(no[b]) == int(n[0]), b
+        np.testing.assert_array_equal(os_[b].cpu().numpy(), ps[0]); np.testing.assert_array_equal(oe_[b].cpu().numpy(), pe[0])
+        np.testing.assert_array_equal(lo[b].cpu().numpy(), po[0])
+    assert (no.cpu().numpy() > 0).sum() > 100 and (lo.cpu().numpy() != 0).sum() > 10
