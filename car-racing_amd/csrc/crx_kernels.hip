@@ -402,6 +402,58 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     return wave_max(emax);
 }
 
+// Infeasibility certificate for the instantiations whose rows are all linear (NOBS == 0: planner region QPs, 0-obstacle
+// NLPs) [r2]; same test as oracle/crx_oracle.c box_certificate().  With y >= 0 on the state rows c_j = +-(x_ki - bound),
+// S(v) = sum_j y_j c_j(v) is linear in the inputs and the inputs live in their box: max over the box of S negative means
+// no input sequence satisfies every state row -- a proof of infeasibility for ANY y >= 0 (Farkas), and the interior-point
+// multipliers of the violated rows are the y that make S negative.  On the BASELINE planner draw (41 % infeasible QPs)
+// the proof exists after 2.7 iterations on average; the divergence test (multipliers past 1e12) needed 9.3, up to 27.
+//   max_box S = S(v) + sum over inputs a of (w_a > 0 ? w_a (hi_a - v_a) : w_a (-hi_a - v_a)),   w = J_s' y
+// w comes from one adjoint sweep over the state-row multipliers alone (the structure of dual_infeasibility(): costate
+// in registers, lanes >= NX receive B' lam); the stage gradients go through dZ, dead between the accept pass and the next
+// forward sweep.  Entered only while the iterate still violates its rows after a step (a feasible problem: 0.14 times per
+// solve on average).  Returns max_box S (wave-uniform).
+template <int NOBS, int NMAX>
+__device__ __forceinline__ double box_certificate(double* sm, const int* si, const Ctx& c, double delta_max, double a_max) {
+    using L = Lay<NOBS, NMAX>;
+    const int N = c.N, lane = c.lane;
+    double S = 0.0;
+    COORDS(e, ev, lane, N * L::NZ + L::NX) {
+        const int k = e / L::NZ, a = e - k * L::NZ;
+        const short* sh = (const short*)(si + L::SH_OFF);
+        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
+        const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
+        const double nl = LD(L::rnu + il), nh = LD(L::rnu + ih), cl = LD(L::rc + il), ch = LD(L::rc + ih);
+        const bool st = ev && a < 6;                       // rows on states only: the input box is the domain
+        const bool hl = st && rl >= 0, hh = st && rh >= 0;
+        S += sel(hl, nl * cl, 0.0) + sel(hh, nh * ch, 0.0);
+        LD(SINK(ev, L::dZ + e)) = sel(hh, nh, 0.0) - sel(hl, nl, 0.0);     // -J_s' y per stage coordinate
+        (void)k;
+    }
+    SYNC();
+    double mcol[L::NX];
+#pragma unroll
+    for (int i = 0; i < L::NX; i++) mcol[i] = LD(L::M + i * L::NZ + (lane < L::NZ ? lane : 0));
+    const int la = lane < L::NZ ? lane : 0;
+    const bool isu = lane >= L::NX && lane < L::NX + 2;
+    const double hi = lane == L::NX ? delta_max : a_max;
+    double tot = LD(L::dZ + N * L::NZ + la);
+    double gk = LD(L::dZ + (N - 1) * L::NZ + la), uk = LD(L::Z + (N - 1) * L::NZ + la);
+    for (int k = N - 1; k >= 0; k--) {
+        const int kn = k >= 1 ? k - 1 : 0;
+        const double gn = LD(L::dZ + kn * L::NZ + la), un = LD(L::Z + kn * L::NZ + la);
+        double t = gk;
+#pragma unroll
+        for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+        tot = t;
+        const double w = -tot;                            // input lanes: (J_s' y) of input a at stage k
+        S += sel(isu, w * (sel(w > 0.0, hi, -hi) - uk), 0.0);
+        gk = gn; uk = un;
+    }
+    SYNC();
+    return wave_sum(S);
+}
+
 // Barrier-dependent assembly for the Newton system at barrier parameter mu:
 //   per row   Sigma = nu/t,  w = nu - mu/t + Sigma*(c - t)          (one division per row)
 //   per coord Hd = cost diag + Sigma of its bound rows + "current" CBF curvature,
@@ -1351,6 +1403,10 @@ crx_solve_kernel(const crx_kparams kp) {
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
             kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (CLK() - tc8));   // slot 8: KKT rows + accept/first-order
         if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
+        // still violated after the step: look for the proof that it must be (linear rows only)
+        if (NOBS == 0 && th > 1e-6) {
+            if (box_certificate<NOBS, NMAX>(sm, si, c, kp.delta_max, kp.a_max) < -1e-8 * numax) { status = 2; it++; break; }
+        }
     }
     if (!ls_failed) break;
     if (NOBS && o.restore_iters >= 0 && n_restore < 2 && __builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push))) {

@@ -378,6 +378,28 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             E0 = fmax(e_d, fmax(e_p, e_c));
             if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
             if (it >= o.max_iter) break;
+            // Still violated: look for the proof that it must be (first attempt only; oracle/crx_oracle_lmpc.c
+            // lmpc_certificate()) [r2].  Domain D: inputs in their box, lambd in the unit simplex.  With nu >= 0 on the state
+            // rows and ANY y on x_N - SS lambd = 0,  F(v) = sum nu_j c_j(u) - y'e(v)  is linear and >= 0 at every feasible v:
+            //     max_D F = F(v) + sum_a (|w_a| ub_a - w_a u_a) + (max_i w_i - sum_i w_i lambd_i) < 0   proves infeasibility.
+            // grad F comes out of what l_lagr just stored: w_u = -(ru - gu + nu_lo - nu_hi), w_lambd = qf + y_6 - nu_lambd - rl.
+            // A QP that cannot reach the safe set is proven so after 1..10 iterations; the divergence test needed 10..30.
+            if (attempt == 0 && it > 0 && theta > 1e-6) {
+                double F = 0.0;
+                LROWS(r, rv, lane, m) { F += sel(rv && r >= x.r_st && r < x.r_lam, LDS(L::nu + r) * LDS(L::c + r), 0.0); }
+                const int q6 = lane < 6 ? lane : 0;
+                F -= sel(lane < 6, LDS(L::y + q6) * LDS(L::e + q6), 0.0);
+                const bool av = lane < nu2;
+                const int a = av ? lane : 0, bi = 4 * (a >> 1) + 2 * (a & 1);
+                const double wu = -(LDS(L::ru + a) - LDS(L::gu + a) + LDS(L::nu + bi) - LDS(L::nu + bi + 1));
+                F += sel(av, fabs(wu) * ((a & 1) ? kp.a_max : kp.delta_max) - wu * LDS(L::u + a), 0.0);
+                const bool jv = lane < M;
+                const int j = jv ? lane : 0;
+                const double wlam = LDS(L::qf + j) + LDS(L::y + 6) - LDS(L::nu + x.r_lam + j) - LDS(L::rl + j);
+                F -= sel(jv, wlam * LDS(L::lam + j), 0.0);
+                F = wave_sum(F) + wave_max(sel(jv, wlam, -HUGE_VAL));
+                if (F < -1e-8 * (nus + ys)) { status = CRX_INFEASIBLE; break; }
+            }
             TICK();   // 2
             // ---- barrier update ----
             for (;;) {

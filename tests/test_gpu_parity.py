@@ -834,7 +834,7 @@ def test_scene_device(gpu, orc, AB):
 def test_track_prep_device(gpu):
     """crx_track_prep_dev (per-stage targets + obstacle window / packing of the tracking NLP, on the device) against the host
     prep of the mirror (crx.hostprep tracking_targets / cbf_window / pack_obstacles, the functions the golden mpc_multi_agents
-    tests feed the solver through, tests/helpers.py mma_inputs): same arithmetic: window / packing / offsets bit-exact, interpolated targets to 1 ulp (the kernel contracts a*b+c)."""
+    tests feed the solver through, tests/helpers.py mma_inputs): same arithmetic: window / packing / offsets bit-exact, interpolated targets to 1e-13 (the kernel contracts a*b+c)."""
     import torch
     from crx import hostprep, torch_api
 
@@ -859,7 +859,7 @@ def test_track_prep_device(gpu):
     torch_api.track_prep_dev(N, V, L, t(x), t(n_veh, torch.int32), t(obs_s), t(obs_ey), t(traj), xt, os_, oe_, lo, no)
     torch.cuda.synchronize()
     for b in range(Bn):
-        np.testing.assert_allclose(xt[b].cpu().numpy(), hostprep.tracking_targets(x[b], traj[b], N), rtol=0, atol=1e-15)   # fma in the interpolation
+        np.testing.assert_allclose(xt[b].cpu().numpy(), hostprep.tracking_targets(x[b], traj[b], N), rtol=0, atol=1e-13)   # fma in the interpolation (slope * dx cancels)
         nv = int(n_veh[b])
         keep, off = hostprep.cbf_window(x[b:b + 1], obs_s[b:b + 1, :nv, 0], L)
         ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s[b:b + 1, :nv], obs_ey[b:b + 1, :nv], off, V) if nv else (

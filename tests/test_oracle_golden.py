@@ -285,3 +285,53 @@ def test_lmpc_prep_regression_and_safe_set(orc, golden_racing_game):
         ss[1, row] = g["lmpc/x"][c] + np.array([0, 0, 0, 0, L, 0])
         us[1, row] = U[0]
     assert worst_c <= 2e-5 and worst_p <= 1e-5, (worst_c, worst_p)
+
+
+def test_planner_verdicts_against_an_lp_solver(orc, AB):
+    """Every verdict of the oracle on 1024 region QPs of the BASELINE cfg3 draw against HiGHS (scipy.optimize.linprog) on
+    the QP's feasible set: condensed inputs in their box, vx_k <= vx_max (k >= 1), ey_lb[k] <= ey_k <= ey_ub (1 <= k < N)
+    (overtake_traj_planner.py:276-324).  Infeasible verdicts come from box_certificate() (a Farkas proof over the input
+    box, found after ~3 iterations) or from the divergence test; "infeasible" must mean infeasible, because the verdict
+    selects the reference's fall-back trajectory (:365-374)."""
+    from scipy.optimize import linprog
+    from crx import abi, synth
+    A, B = AB
+    N = 12
+    p = synth.cfg3_planner(256, N=N, seed=11)
+    d = abi.planner_desc(N, A, B)
+    r = orc.planner_solve(d, *[p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")])
+    st, it = np.asarray(r["status"]), np.asarray(r["iters"])
+    # x_k = A^k x0 + sum_j A^(k-1-j) B u_j
+    Ap = [np.eye(6)]
+    for _ in range(N):
+        Ap.append(A @ Ap[-1])
+    G = np.zeros((N + 1, 6, 2 * N))
+    for k in range(1, N + 1):
+        for j in range(k):
+            G[k][:, 2 * j:2 * j + 2] = Ap[k - 1 - j] @ B
+    bounds = [(-d.delta_max, d.delta_max), (-d.a_max, d.a_max)] * N
+    wrong, n_inf, margin = [], 0, 1e-7
+    for b in range(len(st)):
+        x0, lb, ub = p["x0"][b], p["ey_lb"][b], p["ey_ub"][b]
+        free = [Ap[k] @ x0 for k in range(N + 1)]
+        rows, rhs = [], []
+        for k in range(1, N + 1):
+            rows.append(G[k][0]); rhs.append(d.vx_max - free[k][0])
+            if k < N:
+                if np.isfinite(ub):
+                    rows.append(G[k][5]); rhs.append(ub - free[k][5])
+                if np.isfinite(lb[k]):
+                    rows.append(-G[k][5]); rhs.append(free[k][5] - lb[k])
+        lp = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs), bounds=bounds, method="highs")
+        infeas0 = x0[5] < lb[0] - 1e-8 or x0[5] > ub + 1e-8      # a row on the fixed x0 (quirk: IPOPT cannot succeed)
+        lp_infeasible = lp.status == 2
+        n_inf += int(lp_infeasible or infeas0)
+        if (st[b] != 0) != (lp_infeasible or infeas0):
+            # a feasible set thinner than the solvers' tolerances may fall either way: re-test with the rows moved by `margin`
+            lo = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs) - margin, bounds=bounds, method="highs").status == 2
+            hi = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs) + margin, bounds=bounds, method="highs").status == 2
+            if lo == hi:
+                wrong.append((b, int(st[b]), int(it[b]), int(lp.status)))
+    assert not wrong, wrong
+    assert 300 < n_inf < 600                                   # ~41 % of the draw, as BASELINE's cfg3 recipe produces them
+    assert it[st != 0].mean() < 5.0 and it[st != 0].max() <= 20   # the proof is found early
