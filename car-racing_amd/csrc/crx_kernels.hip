@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "crx_kparams.h"
 #include "crx_wave.h"
@@ -90,10 +91,17 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 // nothing moves across: placed after the loads of a phase so that they are issued back to back
 #define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
 
-#define RIV_SIMPLE (1 << 29) /* table-driven row that is present: c = +-(z[iv] - bound) */
-#define RIV_NEG (1 << 30)
-#define RIV_IDX(pk) ((pk) & 0xFFFF)
+// row table entries (unsigned 16-bit): index into Z / dZ in bits 0..12 (<= 25 * 14 coordinates), flags above
+#define RIV_SIMPLE (1 << 13) /* table-driven row that is present: c = +-(z[iv] - bound) */
+#define RIV_NEG (1 << 14)
+#define RIV_IDX(pk) ((pk) & 0x1FFF)
 #define RIV_SGN(pk) (((pk) & RIV_SIMPLE) ? (((pk) & RIV_NEG) ? -1.0 : 1.0) : 0.0)
+// the index tables behind the doubles: ints at si, 16-bit entries at SH16(si), row-of-coordinate entries (8 bits while the
+// instantiation has <= 127 rows) at VROW(si)
+#define SH16(si_) ((unsigned short*)((si_) + L::SH_OFF))
+#define RIVT(si_, j) ((int)SH16(si_)[L::riv + (j)])
+#define UPDP(si_, l_) ((int)SH16(si_)[L::updP + (l_)])
+#define VROW(si_) ((typename L::vrow_t*)(SH16(si_) + L::END_S16))
 
 template <int NOBS, int NMAX>
 struct Lay {
@@ -146,16 +154,21 @@ struct Lay {
     static constexpr int dmy = cst + 16;             // sink of the address-predicated stores (lanes without an entry write here)
     static constexpr int END_D = dmy + 2;
     // int tables (stored after the doubles)
-    static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
-    static constexpr int triH = riv + MR;            // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
-    static constexpr int updP = triH + (NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2);  // [64] packed (i << 8 | j) lane map of the Riccati update
-    static constexpr int END_I = updP + 64;
-    // int16 tables (stored after the ints; viewed through SH())
-    static constexpr int vlo = 0;                    // [NV]  row index of the lower-bound row of a coordinate (-1 none)
-    static constexpr int vhi = vlo + NV;             // [NV]  ... upper-bound row
-    static constexpr int END_S = vhi + NV;
+    static constexpr int triH = 0;                   // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
+    static constexpr int END_I = triH + (NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2);
     static constexpr int SH_OFF = (END_I + 1) & ~1;  // in ints, from si
-    static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)SH_OFF * 4 + (size_t)((END_S + 3) & ~3) * 2;
+    // 16-bit tables (after the ints; SH16())
+    static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
+    static constexpr int updP = riv + MR;            // [64] packed (i << 8 | j) lane map of the Riccati update
+    static constexpr int END_S16 = (updP + 64 + 1) & ~1;
+    // row index of the lower- / upper-bound row of a coordinate (-1 none), after the 16-bit tables (VROW()): one byte
+    // each while the row count allows -- with the 16-bit row table this takes the planner instantiation from 14 080 to
+    // 13 552 B = 12 instead of 11 problems per CU (the runtime grants 12 up to 13 632 B: tools/ubench/lds_occupancy.hip)
+    using vrow_t = std::conditional_t<(MR <= 127), signed char, short>;
+    static constexpr int vlo = 0;                    // [NV]
+    static constexpr int vhi = vlo + NV;             // [NV]
+    static constexpr int END_V = vhi + NV;
+    static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)SH_OFF * 4 + (size_t)END_S16 * 2 + (((size_t)END_V * sizeof(vrow_t) + 7) & ~(size_t)7);
 };
 
 // problem context kept in registers (all wave-uniform)
@@ -274,7 +287,7 @@ __device__ __forceinline__ void eval_rows(double* sm, const int* si, const Ctx& 
     using L = Lay<NOBS, NMAX>;
     for (int j = c.lane; j < c.m; j += WAVE) {
         const double sc = LD(L::rsc + j);
-        const int pk = si[L::riv + j];
+        const int pk = RIVT(si, j);
         double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
         if (NOBS && j < c.N * L::NR) {
             const int k = j / L::NR, r = j - k * L::NR;
@@ -343,8 +356,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         double g = w2 * (LD(L::Z + e) - ref);
         g += (k == N && a == 4) ? c.lin_sN : 0.0;
         g += sig_on ? c.wsig : 0.0;
-        const short* sh = (const short*)(si + L::SH_OFF);
-        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
+        const int rl = VROW(si)[L::vlo + e], rh = VROW(si)[L::vhi + e];
         const double nl = LD(L::rnu + (rl >= 0 ? rl : 0)), nh = LD(L::rnu + (rh >= 0 ? rh : 0));
         g -= sel(rl >= 0, nl, 0.0);
         g += sel(rh >= 0, nh, 0.0);
@@ -420,8 +432,7 @@ __device__ __forceinline__ double box_certificate(double* sm, const int* si, con
     double S = 0.0;
     COORDS(e, ev, lane, N * L::NZ + L::NX) {
         const int k = e / L::NZ, a = e - k * L::NZ;
-        const short* sh = (const short*)(si + L::SH_OFF);
-        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
+        const int rl = VROW(si)[L::vlo + e], rh = VROW(si)[L::vhi + e];
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
         const double nl = LD(L::rnu + il), nh = LD(L::rnu + ih), cl = LD(L::rc + il), ch = LD(L::rc + ih);
         const bool st = ev && a < 6;                       // rows on states only: the input box is the domain
@@ -484,8 +495,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         double h = sel(isx || isu, 2.0 * cw, 0.0);
         // absent obstacle: pin its sigma_0 (state copy at k = 0) and sigma_{k+1} (input copy)
         h += ((iss0 && k == 0 && o >= c.nobs) || (iss1 && o >= c.nobs)) ? 1.0 : 0.0;
-        const short* sh = (const short*)(si + L::SH_OFF);
-        const int rl = sh[L::vlo + e], rh = sh[L::vhi + e];
+        const int rl = VROW(si)[L::vlo + e], rh = VROW(si)[L::vhi + e];
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
         const double sgl = LD(L::rsig + il), sgh = LD(L::rsig + ih), wl = LD(L::rw + il), wh = LD(L::rw + ih);
         h += sel(rl >= 0, sgl, 0.0) + sel(rh >= 0, sgh, 0.0);
@@ -600,7 +610,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
     // [NP, NP+NX+1) one feedback column each (<= 64 lanes for NX <= 9)
     constexpr int NP = NX * (NX + 1) / 2 + NX;
-    const int upk = si[L::updP + lane];
+    const int upk = UPDP(si, lane);
     const int ui = upk >> 8, uj = upk & 255;     // feedback lanes: column uj, ui = 0 (unused)
     const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
     const bool gcol = uj >= NX;                   // gradient column = column NZ of H
@@ -956,8 +966,7 @@ crx_solve_kernel(const crx_kparams kp) {
         } else if (a == NX + 2 + (i - 6)) v = 1.0;
         LD(L::M + e) = v;
     }
-    short* sh = (short*)(si + L::SH_OFF);
-    for (int e = lane; e < (N + 1) * NZ; e += WAVE) { LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0; sh[L::vlo + e] = -1; sh[L::vhi + e] = -1; }
+    for (int e = lane; e < (N + 1) * NZ; e += WAVE) { LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0; VROW(si)[L::vlo + e] = -1; VROW(si)[L::vhi + e] = -1; }
     if (lane < 16) {
         double v = 0.0;
         if (lane < 6) v = kp.wq[lane];
@@ -979,7 +988,7 @@ crx_solve_kernel(const crx_kparams kp) {
             j = i + rem;
         }
         if (j < 0 || j > NX) j = 0;
-        si[L::updP + lane] = (i << 8) | j;
+        SH16(si)[L::updP + lane] = (unsigned short)((i << 8) | j);
     }
     SYNC();
     if (lane < 6) LD(L::Z + lane) = kp.x0[(size_t)b * 6 + lane];
@@ -1066,10 +1075,10 @@ crx_solve_kernel(const crx_kparams kp) {
             }
         }
         if (simple && on != 0.0) {
-            if (sg > 0.0) sh[L::vlo + iv] = (short)j; else sh[L::vhi + iv] = (short)j;
+            if (sg > 0.0) VROW(si)[L::vlo + iv] = (typename L::vrow_t)j; else VROW(si)[L::vhi + iv] = (typename L::vrow_t)j;
         }
         if (on == 0.0 || !simple) { sg = 0.0; bd = 0.0; iv = 0; }
-        si[L::riv + j] = iv | (sg != 0.0 ? RIV_SIMPLE : 0) | (sg < 0.0 ? RIV_NEG : 0);
+        SH16(si)[L::riv + j] = (unsigned short)(iv | (sg != 0.0 ? RIV_SIMPLE : 0) | (sg < 0.0 ? RIV_NEG : 0));
         LD(L::rb + j) = bd;
         LD(L::rsc + j) = on;
         LD(L::rnu + j) = on;       // multiplier start 1 (0 for absent rows)
@@ -1119,7 +1128,7 @@ crx_solve_kernel(const crx_kparams kp) {
     (void)dual_infeasibility<NOBS, NMAX>(sm, c);  // ga <- reduced cost gradient (inputs, sigma_0)
     for (int j = lane; j < m; j += WAVE) {
         double nu = LD(L::rtt + j);
-        const int pk = si[L::riv + j];
+        const int pk = RIVT(si, j);
         if (nu != 0.0 && (pk & RIV_SIMPLE)) {
             const int iv = RIV_IDX(pk);
             const int kk = iv / NZ, a = iv - kk * NZ;
@@ -1249,7 +1258,7 @@ crx_solve_kernel(const crx_kparams kp) {
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
             // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
             const bool simple = !ROW_IS_CBF(j, N);
-            const int pk = si[L::riv + j];
+            const int pk = RIVT(si, j);
             const double sc = LD(L::rsc + j), jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
             row_step(j, jv && simple, simple, sc, jd);
         }
@@ -1385,7 +1394,7 @@ crx_solve_kernel(const crx_kparams kp) {
             LD(SINK(own, L::rc + j)) = sel(on, v, 1.0);
         };
         ROWS(j, jv, lane, m) {
-            const int pk = si[L::riv + j];
+            const int pk = RIVT(si, j);
             const double sc = LD(L::rsc + j), v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
             row_accept(j, jv && !ROW_IS_CBF(j, N), sc, v);
         }

@@ -306,6 +306,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         int nf = 0, it = 0;
         status = CRX_MAX_ITER;
         f = f0;
+        // stagnation (oracle/crx_oracle_lmpc.c): 25 iterations with the barrier parameter below 1e-6 without reaching tol --
+        // the iterate sits on the noise floor of a QP whose unstable local model makes 1e7-sized free responses
+        int late = 0;
         for (it = 0;; it++) {
             long long tk[14] = {};
             [[maybe_unused]] int tn = 0;
@@ -378,6 +381,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             E0 = fmax(e_d, fmax(e_p, e_c));
             if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
             if (it >= o.max_iter) break;
+            if (mu < 1e-6 && ++late >= 25) break;
             // Still violated: look for the proof that it must be (first attempt only; oracle/crx_oracle_lmpc.c
             // lmpc_certificate()) [r2].  Domain D: inputs in their box, lambd in the unit simplex.  With nu >= 0 on the state
             // rows and ANY y on x_N - SS lambd = 0,  F(v) = sum nu_j c_j(u) - y'e(v)  is linear and >= 0 at every feasible v:

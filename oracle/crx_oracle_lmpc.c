@@ -364,6 +364,15 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
     enum { MAXF = 16 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0, status = CRX_MAX_ITER, it = 0;
+    /* Stagnation [r2]: LATE_ITERS iterations with the barrier parameter below 1e-6 (its last two values, 2.5e-9 and tol / 10,
+     * at the defaults) without reaching tol; a healthy QP needs 2..6 iterations there.  The local models the regression
+     * returns are often unstable (|A| entries of 50 and more: the reference's own recorded models are), the free response
+     * over 12 stages then reaches 1e7 and the KKT error of the scaled problem cannot go below ~1e-6 > tol: the iterate sits
+     * on that noise floor (the barrier parameter often cannot even take its last step), and the remaining iterations up to
+     * max_iter return the same point with the same status CRX_MAX_ITER.  (One such QP among the 1024 of a batched step
+     * held the whole launch for 200 iterations.) */
+    enum { LATE_ITERS = 25 };
+    int late = 0;
     double f = lmpc_f(w, w->v);
     for (it = 0;; it++) {
         for (int j = 0; j < m; j++) {
@@ -405,6 +414,7 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
         if (lv) fprintf(stderr, "it %3d f %.10e ed %.2e ep %.2e ec %.2e mu %.1e theta %.2e nf %d sd %.1f\n", it, f, e_d, e_p, e_c, mu, theta, nf, sd);
         if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
+        if (mu < 1e-6 && ++late >= LATE_ITERS) break;
         /* still violated: look for the proof that it must be (first attempt only; scale = sum of all multipliers) */
         if (!w->elastic && it > 0 && theta > 1e-6 && lmpc_certificate(w, c, e) < -1e-8 * (nus + ys)) { status = CRX_INFEASIBLE; break; }
         for (;;) {

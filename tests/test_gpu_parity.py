@@ -333,6 +333,28 @@ def test_golden_lmpc(gpu, orc, golden_racing_game):
     np.testing.assert_array_equal(r1["X"], rg["X"][3:9])
 
 
+def test_lmpc_noise_floor_qps(gpu, orc):
+    """Eight learning-MPC QPs captured from the batched closed loop (tools/lmpc_stragglers.py) whose local model is unstable
+    (|A| entries of 50, as in the reference's own recorded models): the free response reaches 1e7 and the KKT error of the
+    relaxed second attempt cannot go below ~1e-6.  They used to run to max_iter (218 iterations in total, holding a
+    1024-race launch for 6 ms); the first attempt now ends with the infeasibility proof and the second with the
+    stagnation rule (25 iterations with mu < 1e-6), on the device and in the oracle alike."""
+    import os
+
+    import conftest
+    from crx import abi
+    z = np.load(os.path.join(conftest.ROOT, "tests", "golden", "lmpc_noise_floor.npz"))
+    d = abi.lmpc_desc(12, 44)
+    args = [z[k] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss")]
+    rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
+    assert (rg["status"] != 0).all() and (ro["status"] != 0).all()
+    assert rg["iters"].max() <= 80 and ro["iters"].max() <= 80, (rg["iters"], ro["iters"])
+    np.testing.assert_array_equal(rg["status"], ro["status"])
+    assert np.abs(rg["iters"] - ro["iters"]).max() <= 2, (rg["iters"], ro["iters"])   # the first attempt's proof may come one iteration apart
+    # the "last iterate" the reference would consume (control.py:708-722): same plan from both
+    assert np.abs(rg["U"][:, 0] - ro["U"][:, 0]).max() <= 1e-4
+
+
 def test_device_prep(gpu, golden_planner):
     """crx_planner_prep (Bezier references + ey bounds on the device) against the host prep of the mirror
     (planner_helper / hostprep, themselves pinned to the reference at 1e-13 by test_host_mirror) and

@@ -335,3 +335,15 @@ def test_planner_verdicts_against_an_lp_solver(orc, AB):
     assert not wrong, wrong
     assert 300 < n_inf < 600                                   # ~41 % of the draw, as BASELINE's cfg3 recipe produces them
     assert it[st != 0].mean() < 5.0 and it[st != 0].max() <= 20   # the proof is found early
+
+
+def test_lmpc_noise_floor_qps_end_early(orc):
+    """tests/golden/lmpc_noise_floor.npz (see tests/test_gpu_parity.py::test_lmpc_noise_floor_qps): the oracle leaves these
+    QPs after < 80 iterations with a status != 0, not after max_iter."""
+    import os
+
+    import conftest
+    from crx import abi
+    z = np.load(os.path.join(conftest.ROOT, "tests", "golden", "lmpc_noise_floor.npz"))
+    r = orc.lmpc_solve(abi.lmpc_desc(12, 44), *[z[k] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss")])
+    assert (r["status"] != 0).all() and r["iters"].max() <= 80 and np.isfinite(r["U"]).all()
