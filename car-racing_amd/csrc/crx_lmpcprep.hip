@@ -84,20 +84,30 @@ __device__ __forceinline__ bool lp_solve5(double (&Q)[5][5], double (&rhs)[NRHS]
     return ok;
 }
 
-// LDS: feat [2][P][5] | dist [P] | wsel [2*MAXNB] | sums [48] | isel int[2*MAXNB]
+// LDS: feat [2][P][5] | per wave: dist [P] | wsel [2*MAXNB] | sums [48] | isel int[2*MAXNB]
 #define LP_MAXNB 64
+// LP_WAVES wavefronts per race [r2]: the stages are independent (each has its own linearisation point), wave w takes
+// stages w, w + LP_WAVES, ...; the feature table is staged once by all of them and shared, every wave has its own
+// distance / selection / sums scratch, so that past the staging barrier the waves never meet again (SYNC() stays a
+// wavefront fence) until the status word is collected.  One wave per race left a CU with two or three waves in flight,
+// each running 12 stages of dependent LDS round trips one after the other: 1.15 ms per 1024 races; with four waves
+// per race (three stages each, eight waves per CU) the same arithmetic, bit for bit, takes a third of that.
+#define LP_WAVES 4
+#define LP_WAVE_DOUBLES(P_) ((size_t)(P_) + 2 * LP_MAXNB + 48 + LP_MAXNB /* isel: 2*MAXNB ints */)
 
-__global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_kparams kp) {
+__global__ void __launch_bounds__(WAVE * LP_WAVES) crx_lmpc_prep_kernel(const crx_lmpcprep_kparams kp) {
     extern __shared__ __attribute__((aligned(16))) double lsm[];
+    __shared__ int sbad;
     const crx_lmpcprep_desc& d = kp.d;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     if (b >= kp.batch) return;
     const int N = d.N, P = d.n_points, L = d.n_laps, M = d.n_ss_per_lap * d.n_ss_laps;
     double* feat = lsm;
-    double* dist = feat + (size_t)2 * P * 5;
+    double* dist = feat + (size_t)2 * P * 5 + (size_t)wv * LP_WAVE_DOUBLES(P);
     double* wsel = dist + P;
     double* sums = wsel + 2 * LP_MAXNB;
     int* isel = (int*)(sums + 48);
+    if (threadIdx.x == 0) sbad = 0;
     const double* ss = kp.ss_xcurv + (size_t)b * L * P * 6;
     const double* us = kp.u_ss + (size_t)b * L * P * 2;
     const double* qf = kp.qfun + (size_t)b * L * P;
@@ -109,14 +119,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
         int n = kp.time_ss[(size_t)b * L + lap] - 1;
         n = n < 1 ? 1 : (n > P - 1 ? P - 1 : n);
         nl[lapk] = n;
-        for (int e = lane; e < (n + 1) * 5; e += WAVE) {         // rows 0..n (row j+1 is the regression target of row j)
+        for (int e = threadIdx.x; e < (n + 1) * 5; e += WAVE * LP_WAVES) {   // rows 0..n (row j+1 is the regression target of row j)
             const int j = e / 5, c = e - 5 * j;
             feat[((size_t)lapk * P + j) * 5 + c] = c < 3 ? ss[((size_t)lap * P + j) * 6 + c] : us[((size_t)lap * P + j) * 2 + (c - 3)];
         }
     }
-    SYNC();
+    __syncthreads();
     int bad = 0;
-    for (int i = 0; i < N; i++) {
+    for (int i = wv; i < N; i += LP_WAVES) {
         // linearisation point: given, or the previous plan shifted by one stage (control.py:726-728)
         const int ix = kp.from_plan ? (i + 1 <= N ? i + 1 : N) : i, iu = kp.from_plan ? (i + 1 <= N - 1 ? i + 1 : N - 1) : i;
         double x0[6], u0[2];
@@ -300,11 +310,13 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
             Ci[5] = ey + dt * across - d5;
         }
     }
+    if (bad && lane == 0) atomicOr(&sbad, 1);
     // safe-set points: laps iter-1, iter-2 (control.py:625-639), n_ss_per_lap samples from `shift` after the 1-norm-nearest
+    // (one lap per wave)
     const double* xb = kp.x + (size_t)b * 6;
     double xs[6];
     for (int k = 0; k < 6; k++) xs[k] = xb[k];
-    for (int jj = 0; jj < d.n_ss_laps; jj++) {
+    for (int jj = wv; jj < d.n_ss_laps; jj += LP_WAVES) {
         const int lap = it - jj - 1;
         double best = INFINITY;
         int bj = 0x7fffffff;
@@ -326,7 +338,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_prep_kernel(const crx_lmpcprep_
             else kp.q_sel[(size_t)b * M + jj * d.n_ss_per_lap + q] = qf[(size_t)lap * P + j];
         }
     }
-    if (lane == 0) kp.status[b] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) kp.status[b] = sbad;
 }
 
 __global__ void __launch_bounds__(256) crx_lmpc_addpoint_kernel(const crx_lmpcprep_desc d, int batch, double* ss_xcurv, double* u_ss,
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(256) crx_lmpc_addpoint_kernel(const crx_lmpcpr
 }
 
 size_t crx_lmpcprep_lds_bytes(int n_points) {
-    return ((size_t)2 * n_points * 5 + n_points + 2 * LP_MAXNB + 48) * sizeof(double) + (size_t)2 * LP_MAXNB * sizeof(int);
+    return ((size_t)2 * n_points * 5 + LP_WAVES * LP_WAVE_DOUBLES(n_points)) * sizeof(double);
 }
 
 hipError_t crx_launch_lmpcprep(const crx_lmpcprep_kparams& kp, hipStream_t st) {
@@ -361,7 +374,7 @@ hipError_t crx_launch_lmpcprep(const crx_lmpcprep_kparams& kp, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set_on = dev; attr_bytes = bytes;
     }
-    hipLaunchKernelGGL(crx_lmpc_prep_kernel, dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL(crx_lmpc_prep_kernel, dim3(kp.batch), dim3(WAVE * LP_WAVES), bytes, st, kp);
     return hipGetLastError();
 }
 
