@@ -279,7 +279,7 @@ def make_game(cx, args, batch=None):
 
 def make_overtake(cx, args, batch=None):
     """SURVEY.md section 8f row 4, the row's stated purpose: closed-loop Monte-Carlo of the racing game WITH traffic -- B laps,
-    every race against two scripted cars at random gaps / speeds / lanes, both branches of LMPCRacingGame.calc_input on the
+    every race against two scripted cars at random gaps / speeds / lanes, both branches of LMPCRacingGame.calc_input (masked launches) on the
     device (crx.montecarlo.GameLaps)."""
     from crx import montecarlo, synth
     from utils import racing_env
@@ -306,7 +306,7 @@ def make_overtake(cx, args, batch=None):
     w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws)
     w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against two "
               "scripted cars each, one control step of every race per step: scene, Bezier/bounds, 3 region QPs + selection, tracking NLP (N=10, CBF rows), "
-              "12 regressions + LMPC QP, add_point, plant -- both branches computed, the race's own applied" % Bn)
+              "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
     w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch; keep steps + warmup below ~120"}
     return w
 

@@ -11,7 +11,7 @@ import numpy as np
 CRX_MAX_N = 24
 CRX_MAX_OBS = 3
 
-CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED = 0, 1, 2, 3
+CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED, CRX_SKIPPED = 0, 1, 2, 3, 4
 
 
 class IpmOpts(C.Structure):

@@ -203,9 +203,11 @@ class GameLaps:
         crx_lmpc_prep_dev, crx_lmpc_solve_dev, crx_lmpc_addpoint_dev
       crx_plant_step_wrap_dev
 
-    BOTH branches are computed for every race and the applied input, the plan hand-over (u_old, linearisation points),
-    add_point and the direction flag are taken from the branch the race is in (a wavefront per race either way; the
-    branch a race is not in costs its share of two more launches, no host round trip).  Nine libcrx launches per step."""
+    Every launch covers the whole batch; the heavy kernels of a branch (tracking NLP; regression + learning-MPC QP) are
+    MASKED launches (crx_*_masked_dev): the wavefront of a race that is in the other branch returns at once.  The cheap
+    planner front (prep, three region QPs, selection: 0.3 ms per 1024 races) runs for every race.  The applied input, the
+    plan hand-over (u_old, linearisation points), add_point and the direction flag are taken from the branch the race is
+    in; no host round trip, no compaction.  Nine libcrx launches per step."""
 
     def __init__(self, track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0,
                  lin_points, lin_input, car_s0, car_v, car_ey, N=12, N_plan=10, timestep=0.1, device=None):
@@ -256,6 +258,8 @@ class GameLaps:
         pred_e = (self.ey[:, :, None] + 0.0 * self.jdt[None, None, :]).contiguous()
         torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, pred_s, pred_e, ws=self.sws)
         self.overtake = self.sws.n_veh > 0
+        m_ot = self.overtake.to(torch.int32)                      # masked launches: every race runs its own branch's kernels only
+        m_lm = 1 - m_ot
         # ---- overtake branch
         torch_api.planner_prep_dev(self.prep, lm.xc, lm.xc, self.sws.n_veh, self.sws.veh_info, self.sws.max_dv, self.sws.obs_s, self.sws.obs_ey,
                                    self.opt_s, self.opt_ey, ws=self.pws)
@@ -263,10 +267,11 @@ class GameLaps:
                                    self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.old_flag, self.qws, self.selws)
         torch_api.track_prep_dev(self.Np, self.V, L, lm.xc, self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.selws.best_X, self.xt,
                                  self.obs_s, self.obs_e, self.lap_off, self.n_obs)
-        torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws)
+        torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws, active=m_ot)
         # ---- learning-MPC branch
-        torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws)
-        torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws)
+        torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws,
+                                active=m_lm)
+        torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws, active=m_lm)
         # ---- the branch each race is in
         ot = self.overtake
         self.u.copy_(torch.where(ot[:, None], self.tws.U[:, 0, :], lm.ws.U[:, 0, :]))

@@ -57,7 +57,8 @@ class CbfWorkspace:
         self.iters = torch.empty(batch, **i32)
 
 
-def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None):
+def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=None):
+    """crx_cbf_solve_dev; with `active` (int32 [batch], 0 = leave the problem alone) crx_cbf_solve_masked_dev."""
     N, V, B = desc.N, desc.n_obs_max, x0.shape[0]
     _chk(x0, torch.float64, (B, 6), "x0")
     _chk(xt, torch.float64, (B, N + 1, 6) if desc.per_stage_target else (B, 6), "xt")
@@ -66,9 +67,11 @@ def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None):
     _chk(lap_off, torch.float64, (B, V), "lap_off")
     _chk(n_obs, torch.int32, (B,), "n_obs")
     ws = ws or CbfWorkspace(desc, B, x0.device)
-    _call("crx_cbf_solve_dev", C.byref(desc), C.c_int(B), _ptr(x0), _ptr(xt), _ptr(obs_s), _ptr(obs_ey),
-          _ptr(lap_off), _ptr(n_obs), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost), _ptr(ws.status),
-          _ptr(ws.kkt), _ptr(ws.iters), _stream())
+    if active is not None:
+        _chk(active, torch.int32, (B,), "active")
+    _call("crx_cbf_solve_masked_dev", C.byref(desc), C.c_int(B), _ptr(active) if active is not None else None, _ptr(x0), _ptr(xt),
+          _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost),
+          _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws
 
 
@@ -134,8 +137,8 @@ class LmpcWorkspace:
         self.iters = torch.empty(batch, **i32)
 
 
-def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None):
-    """crx_lmpc_solve_dev.  n_ss must satisfy 1 <= n_ss <= desc.n_ss_max (checked here on the host copy the
+def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None, active=None):
+    """crx_lmpc_solve_dev (crx_lmpc_solve_masked_dev with `active`, int32 [batch], 0 = leave alone).  n_ss must satisfy 1 <= n_ss <= desc.n_ss_max (checked here on the host copy the
     caller keeps; the kernel indexes LDS with it)."""
     N, M, Bn = desc.N, desc.n_ss_max, x0.shape[0]
     _chk(x0, torch.float64, (Bn, 6), "x0")
@@ -147,9 +150,11 @@ def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None):
     _chk(qfun, torch.float64, (Bn, M), "qfun")
     _chk(n_ss, torch.int32, (Bn,), "n_ss")
     ws = ws or LmpcWorkspace(desc, Bn, x0.device)
-    _call("crx_lmpc_solve_dev", C.byref(desc), C.c_int(Bn), _ptr(x0), _ptr(u_old), _ptr(A), _ptr(B), _ptr(Cm),
-          _ptr(ss), _ptr(qfun), _ptr(n_ss), _ptr(ws.X), _ptr(ws.U), _ptr(ws.lam), _ptr(ws.cost), _ptr(ws.status),
-          _ptr(ws.kkt), _ptr(ws.iters), _stream())
+    if active is not None:
+        _chk(active, torch.int32, (Bn,), "active")
+    _call("crx_lmpc_solve_masked_dev", C.byref(desc), C.c_int(Bn), _ptr(active) if active is not None else None, _ptr(x0), _ptr(u_old),
+          _ptr(A), _ptr(B), _ptr(Cm), _ptr(ss), _ptr(qfun), _ptr(n_ss), _ptr(ws.X), _ptr(ws.U), _ptr(ws.lam), _ptr(ws.cost),
+          _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws
 
 
@@ -242,8 +247,9 @@ class LmpcPrepWorkspace:
         self.status = torch.empty(batch, dtype=torch.int32, device=device)
 
 
-def lmpc_prep_dev(desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan, ws=None):
-    """crx_lmpc_prep_dev: the N stage models and the safe-set selection of every race."""
+def lmpc_prep_dev(desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan, ws=None, active=None):
+    """crx_lmpc_prep_dev: the N stage models and the safe-set selection of every race (of the races with active != 0:
+    crx_lmpc_prep_masked_dev)."""
     N, P, L, Bn = desc.N, desc.n_points, desc.n_laps, x.shape[0]
     _chk(ss_xcurv, torch.float64, (Bn, L, P, 6), "ss_xcurv")
     _chk(u_ss, torch.float64, (Bn, L, P, 2), "u_ss")
@@ -255,7 +261,10 @@ def lmpc_prep_dev(desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_in
     _chk(lin_input, torch.float64, (Bn, N, 2), "lin_input")
     _chk(track, torch.float64, (desc.n_seg, 6), "track")
     ws = ws or LmpcPrepWorkspace(desc, Bn, x.device)
-    _call("crx_lmpc_prep_dev", C.byref(desc), C.c_int(Bn), _ptr(ss_xcurv), _ptr(u_ss), _ptr(qfun), _ptr(time_ss), _ptr(it), _ptr(x),
+    if active is not None:
+        _chk(active, torch.int32, (Bn,), "active")
+    _call("crx_lmpc_prep_masked_dev", C.byref(desc), C.c_int(Bn), _ptr(active) if active is not None else None, _ptr(ss_xcurv), _ptr(u_ss),
+          _ptr(qfun), _ptr(time_ss), _ptr(it), _ptr(x),
           _ptr(lin_points), _ptr(lin_input), C.c_int(int(bool(from_plan))), _ptr(track), _ptr(ws.A), _ptr(ws.B), _ptr(ws.C),
           _ptr(ws.ss), _ptr(ws.qfun), _ptr(ws.status), _stream())
     return ws

@@ -394,6 +394,12 @@ int crx_planner_solve(const crx_planner_desc* d, int batch, const double* x0, co
 int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
                       const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X, double* U,
                       double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
+    return crx_cbf_solve_masked_dev(d, batch, nullptr, x0, xt, obs_s, obs_ey, lap_off, n_obs, X, U, sigma, cost, status, kkt, iters, stream);
+}
+
+int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                             const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
+                             double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_kparams kp;
     if (int rc = fill_cbf(kp, d, batch)) return rc;
@@ -403,6 +409,7 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
         return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
     kp.x0 = x0; kp.xt = xt; kp.obs_s = obs_s; kp.obs_ey = obs_ey; kp.lap_off = lap_off; kp.n_obs = n_obs;
     kp.X = X; kp.U = U; kp.sigma = sigma; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    kp.active = active;
     return launch_solve(kp, d->n_obs_max, (hipStream_t)stream);
 }
 
@@ -730,6 +737,13 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
                        const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
                        double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
                        int32_t* iters, void* stream) {
+    return crx_lmpc_solve_masked_dev(d, batch, nullptr, x0, u_old, A, B, C, ss, qfun, n_ss, X, U, lambda, cost, status, kkt, iters, stream);
+}
+
+int crx_lmpc_solve_masked_dev(const crx_lmpc_desc* d, int batch, const int32_t* active, const double* x0, const double* u_old,
+                              const double* A, const double* B, const double* C, const double* ss, const double* qfun,
+                              const int32_t* n_ss, double* X, double* U, double* lambda, double* cost, int32_t* status,
+                              double* kkt, int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_lmpc_kparams kp;
     if (int rc = fill_lmpc(kp, d, batch)) return rc;
@@ -738,6 +752,7 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
         return fail(CRX_ERR_ARG, "NULL array argument");
     kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
     kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    kp.active = active;
     if (g_trace_rows > 0) { kp.trace = (double*)g_trace.p; kp.trace_problem = g_trace_problem; kp.trace_rows = g_trace_rows; }
     kp.poison = g_poison;
     timing_begin((hipStream_t)stream);
@@ -880,6 +895,14 @@ int crx_lmpc_prep_dev(const crx_lmpcprep_desc* d, int batch, const double* ss_xc
                       const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
                       const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
                       double* ss_sel, double* q_sel, int32_t* status, void* stream) {
+    return crx_lmpc_prep_masked_dev(d, batch, nullptr, ss_xcurv, u_ss, qfun, time_ss, iter, x, lin_points, lin_input, from_plan, track, A, B, C,
+                                    ss_sel, q_sel, status, stream);
+}
+
+int crx_lmpc_prep_masked_dev(const crx_lmpcprep_desc* d, int batch, const int32_t* active, const double* ss_xcurv, const double* u_ss,
+                             const double* qfun, const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                             const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                             double* ss_sel, double* q_sel, int32_t* status, void* stream) {
     if (int rc = ensure_init()) return rc;
     if (int rc = check_lmpcprep(d, batch)) return rc;
     if (batch == 0) return CRX_OK;
@@ -890,7 +913,7 @@ int crx_lmpc_prep_dev(const crx_lmpcprep_desc* d, int batch, const double* ss_xc
     kp.d = *d; kp.batch = batch; kp.from_plan = from_plan ? 1 : 0;
     kp.ss_xcurv = ss_xcurv; kp.u_ss = u_ss; kp.qfun = qfun; kp.time_ss = time_ss; kp.iter = iter; kp.x = x;
     kp.lin_points = lin_points; kp.lin_input = lin_input; kp.track = track;
-    kp.A = A; kp.B = B; kp.C = C; kp.ss_sel = ss_sel; kp.q_sel = q_sel; kp.status = status;
+    kp.A = A; kp.B = B; kp.C = C; kp.ss_sel = ss_sel; kp.q_sel = q_sel; kp.status = status; kp.active = active;
     hipError_t e = crx_launch_lmpcprep(kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc prep launch: %s", hipGetErrorString(e));
     return CRX_OK;

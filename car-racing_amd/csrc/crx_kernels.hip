@@ -946,6 +946,10 @@ crx_solve_kernel(const crx_kparams kp) {
     int* si = (int*)(sm + L::END_D);
     const int b = blockIdx.x, lane = threadIdx.x, N = kp.N;
     if (b >= kp.batch) return;
+    if (kp.active && kp.active[b] == 0) {   // masked launch: this problem is not part of it
+        if (lane == 0) { kp.status[b] = CRX_SKIPPED; kp.iters[b] = 0; }
+        return;
+    }
     if (kp.poison) {   // diagnostics (crx_debug_poison_lds): any read of LDS this kernel did not write turns into NaN
         for (int e = lane; e < (int)(L::BYTES / 8); e += WAVE) sm[e] = __longlong_as_double(0x7ff8dead0000beefLL);
         SYNC();

@@ -27,6 +27,7 @@ struct crx_kparams {
     double* trace;
     int trace_problem, trace_rows;
     int poison;   // diagnostics: fill the LDS slice with NaN before set-up (catches reads of stale LDS)
+    const int32_t* active;   // optional [batch]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
 };
 
 struct crx_lmpc_kparams {
@@ -41,6 +42,7 @@ struct crx_lmpc_kparams {
     double* trace;   // optional per-iteration phase cycles of ONE problem (diagnostics): trace[it][16]
     int trace_problem, trace_rows;
     int poison;      // diagnostics: fill the LDS slice with NaN before set-up
+    const int32_t* active;   // optional [batch]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
 };
 
 struct crx_select_kparams {
@@ -112,6 +114,7 @@ struct crx_lmpcprep_kparams {
     const double *x, *lin_points, *lin_input, *track;
     double *A, *B, *C, *ss_sel, *q_sel;
     int32_t* status;
+    const int32_t* active;   // optional [batch]: 0 = leave this race alone (status CRX_SKIPPED, outputs untouched)
 };
 
 #ifdef __HIPCC__

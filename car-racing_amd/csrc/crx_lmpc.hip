@@ -161,6 +161,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     extern __shared__ double sm[];
     const int pb = blockIdx.x;
     if (pb >= kp.batch) return;
+    if (kp.active && kp.active[pb] == 0) {   // masked launch: this problem is not part of it
+        if (threadIdx.x == 0) { kp.status[pb] = CRX_SKIPPED; kp.iters[pb] = 0; }
+        return;
+    }
     LCtx x;
     x.lane = threadIdx.x;
     x.N = kp.N;

@@ -101,6 +101,10 @@ __global__ void __launch_bounds__(WAVE * LP_WAVES) crx_lmpc_prep_kernel(const cr
     const crx_lmpcprep_desc& d = kp.d;
     const int b = blockIdx.x, lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     if (b >= kp.batch) return;
+    if (kp.active && kp.active[b] == 0) {   // masked launch: this race is not part of it (uniform over the workgroup)
+        if (threadIdx.x == 0) kp.status[b] = CRX_SKIPPED;
+        return;
+    }
     const int N = d.N, P = d.n_points, L = d.n_laps, M = d.n_ss_per_lap * d.n_ss_laps;
     double* feat = lsm;
     double* dist = feat + (size_t)2 * P * 5 + (size_t)wv * LP_WAVE_DOUBLES(P);

@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 110 /* 0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0) */
+#define CRX_VERSION 120 /* 0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev
+                          (0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
 #define CRX_NX 6
 #define CRX_NU 2
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
@@ -66,11 +67,12 @@ typedef enum crx_status {
     CRX_MAX_ITER = 1,      /* iteration cap or line-search failure; last iterate returned */
     CRX_INFEASIBLE = 2,    /* constraints cannot be met (incl. a bound already violated by the fixed x0), or no acceptable
                               step exists at a point that still violates them (IPOPT: local infeasibility) */
-    CRX_RESTORED = 3       /* MPC-CBF NLPs only: the solve went through its restoration phase (the step jammed on violated
+    CRX_RESTORED = 3,      /* MPC-CBF NLPs only: the solve went through its restoration phase (the step jammed on violated
                               CBF rows, or the line search failed: a crash state) and used up opts.restore_iters further
                               iterations without converging.  The returned iterate satisfies every CBF row through its
                               slacks sigma (least-violation point, zero violation) but is not optimal.  Like every status
                               != 0 it selects the reference's "use the last iterate" branch (control.py:600-603). */
+    CRX_SKIPPED = 4        /* *_masked_dev launches only: active[b] == 0, the problem was left alone (outputs untouched) */
 } crx_status;
 
 /* Interior-point options.  Defaults (crx_ipm_opts_default) restate IPOPT 3.x defaults that the
@@ -418,6 +420,11 @@ int crx_lmpc_solve_dev(const crx_lmpc_desc* d, int batch, const double* x0, cons
                        const double* B, const double* C, const double* ss, const double* qfun,
                        const int32_t* n_ss, double* X, double* U, double* lambda, double* cost,
                        int32_t* status, double* kkt, int32_t* iters, void* stream);
+/* masked launch: see crx_cbf_solve_masked_dev */
+int crx_lmpc_solve_masked_dev(const crx_lmpc_desc* d, int batch, const int32_t* active, const double* x0, const double* u_old,
+                              const double* A, const double* B, const double* C, const double* ss, const double* qfun,
+                              const int32_t* n_ss, double* X, double* U, double* lambda, double* cost, int32_t* status,
+                              double* kkt, int32_t* iters, void* stream);
 
 /*
  * Host work in front of the learning-MPC QP, on the device (second half): per race, the
@@ -463,6 +470,11 @@ int crx_lmpc_prep_dev(const crx_lmpcprep_desc* d, int batch, const double* ss_xc
                       const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
                       const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
                       double* ss_sel, double* q_sel, int32_t* status, void* stream);
+/* masked launch: see crx_cbf_solve_masked_dev (status[b] = CRX_SKIPPED for the races left alone) */
+int crx_lmpc_prep_masked_dev(const crx_lmpcprep_desc* d, int batch, const int32_t* active, const double* ss_xcurv, const double* u_ss,
+                             const double* qfun, const int32_t* time_ss, const int32_t* iter, const double* x, const double* lin_points,
+                             const double* lin_input, int from_plan, const double* track, double* A, double* B, double* C,
+                             double* ss_sel, double* q_sel, int32_t* status, void* stream);
 /* LMPCRacingGame.add_point (utils/base.py:624-629): the running lap extends the previous lap's safe set past the finish
  * line -- row time_ss[iter-1] + step + 1 of lap iter-1 becomes x + (0,0,0,0,lap_length,0) / u.  Device-resident race loops. */
 int crx_lmpc_addpoint_dev(const crx_lmpcprep_desc* d, int batch, double* ss_xcurv, double* u_ss, const int32_t* time_ss,
@@ -489,6 +501,13 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
                       const double* obs_s, const double* obs_ey, const double* lap_off,
                       const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
                       int32_t* status, double* kkt, int32_t* iters, void* stream);
+/* Masked launches (device-resident loops in which every problem of the batch takes ONE of several branches per step, e.g.
+ * LMPCRacingGame.calc_input, utils/base.py:456-583: overtake planner + tracking NLP, or learning-MPC): active [batch]
+ * int32 on the device, 0 = this problem is not part of the launch -- its wavefront returns at once, status[b] =
+ * CRX_SKIPPED, iters[b] = 0, every other output of problem b keeps its previous contents.  active == NULL: all. */
+int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                             const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
+                             double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream);
 
 /* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
  * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this. */

@@ -890,3 +890,44 @@ def test_track_prep_device(gpu):
         np.testing.assert_array_equal(os_[b].cpu().numpy(), ps[0]); np.testing.assert_array_equal(oe_[b].cpu().numpy(), pe[0])
         np.testing.assert_array_equal(lo[b].cpu().numpy(), po[0])
     assert (no.cpu().numpy() > 0).sum() > 100 and (lo.cpu().numpy() != 0).sum() > 10
+
+
+def test_masked_launches(gpu, golden_racing_game, AB):
+    """crx_*_masked_dev: problems with active == 0 are left alone (status CRX_SKIPPED, outputs untouched), the others are
+    solved exactly as by the unmasked entry points (bit-identical)."""
+    import torch
+    from crx import abi, synth, torch_api
+    A, B = AB
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)   # noqa: E731
+    # tracking NLP
+    p = synth.cfg2_mpccbf(96, N=12, seed=21, safe_start=True)
+    d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+    a = [t(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [t(p["n_obs"], torch.int32)]
+    full = torch_api.cbf_solve_dev(d, *a)
+    act = torch.from_numpy((np.arange(96) % 3 != 1).astype(np.int32)).to(dev)
+    ws = torch_api.CbfWorkspace(d, 96, dev)
+    ws.X.fill_(-7.0); ws.U.fill_(-7.0); ws.cost.fill_(-7.0)
+    torch_api.cbf_solve_dev(d, *a, ws=ws, active=act)
+    torch.cuda.synchronize()
+    on = act.cpu().numpy() != 0
+    assert (ws.status.cpu().numpy()[~on] == abi.CRX_SKIPPED).all() and (ws.iters.cpu().numpy()[~on] == 0).all()
+    assert (ws.X.cpu().numpy()[~on] == -7.0).all() and (ws.U.cpu().numpy()[~on] == -7.0).all() and (ws.cost.cpu().numpy()[~on] == -7.0).all()
+    for k in ("X", "U", "cost", "status", "iters", "kkt"):
+        np.testing.assert_array_equal(getattr(ws, k).cpu().numpy()[on], getattr(full, k).cpu().numpy()[on])
+    # learning-MPC QP
+    dl, al = helpers.lmpc_inputs(golden_racing_game)
+    n = al[0].shape[0]
+    N = dl.N
+    tl = [t(al[0]), t(al[1]), t(al[2]).reshape(n, N, 36), t(al[3]).reshape(n, N, 12), t(al[4]).reshape(n, N, 6), t(al[5]), t(al[6]),
+          torch.full((n,), al[5].shape[2], dtype=torch.int32, device=dev)]
+    fl = torch_api.lmpc_solve_dev(dl, *tl)
+    act = torch.from_numpy((np.arange(n) % 2 == 0).astype(np.int32)).to(dev)
+    wl = torch_api.LmpcWorkspace(dl, n, dev)
+    wl.X.fill_(-7.0); wl.U.fill_(-7.0)
+    torch_api.lmpc_solve_dev(dl, *tl, ws=wl, active=act)
+    torch.cuda.synchronize()
+    on = act.cpu().numpy() != 0
+    assert (wl.status.cpu().numpy()[~on] == abi.CRX_SKIPPED).all() and (wl.X.cpu().numpy()[~on] == -7.0).all()
+    for k in ("X", "U", "cost", "status", "iters"):
+        np.testing.assert_array_equal(getattr(wl, k).cpu().numpy()[on], getattr(fl, k).cpu().numpy()[on])
