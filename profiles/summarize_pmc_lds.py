@@ -23,7 +23,7 @@ def lds():
     lines = ["# rocprofv3 --pmc (separate passes, --kernel-trace only) on crx_solve_kernel; tools/gpu_pmc_lds.sh",
              "# values: mean over the full-batch launches, summed over the chip as rocprofv3 reports them.  SQ_*_CYCLES and",
              "# SQ_ACTIVE_INST_* count quad-cycles (4 clocks); GRBM_GUI_ACTIVE counts clocks summed over the 8 XCDs"]
-    for wl, title, waves in (("cfg3", "planner QPs N=12, batch 4096 (11 resident per CU since round 2)", 4096), ("cfg5", "planner QPs N=12 from raw scenarios, 65536 per launch", 65536),
+    for wl, title, waves in (("cfg3", "planner QPs N=12, batch 4096 (12 resident per CU)", 4096), ("cfg5", "planner QPs N=12 from raw scenarios, 65536 per launch", 65536),
                              ("cfg4", "tracking NLP N=20, 3 obstacles, batch 16384, SURVEY 8d draw", 16384)):
         agg = {}
         for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_lds", wl + "_*"))):
