@@ -931,3 +931,53 @@ def test_masked_launches(gpu, golden_racing_game, AB):
     assert (wl.status.cpu().numpy()[~on] == abi.CRX_SKIPPED).all() and (wl.X.cpu().numpy()[~on] == -7.0).all()
     for k in ("X", "U", "cost", "status", "iters"):
         np.testing.assert_array_equal(getattr(wl, k).cpu().numpy()[on], getattr(fl, k).cpu().numpy()[on])
+
+
+def test_zero_obstacle_nlps_incl_infeasible(gpu, orc, AB):
+    """The 0-obstacle instantiation in controller mode (control.mpc_lti form, control.py:198-248, and mpc_multi_agents
+    without vehicles in its window): 256 tracking problems on a narrow track (ey_max = 0.15) from states up to 0.14 off the
+    centre line with headings up to 1.2 rad off -- a third cannot be brought back inside the input limits.  All rows are linear, so
+    the infeasible ones end by box_certificate()'s proof; kernel and oracle must agree on every verdict and iteration
+    count, and every verdict must agree with an LP solver on the feasible set."""
+    from scipy.optimize import linprog
+    from crx import abi
+    A, B = AB
+    N, Bn = 10, 256
+    rng = np.random.default_rng(77)
+    x0 = np.zeros((Bn, 6))
+    x0[:, 0] = rng.uniform(0.8, 2.0, Bn); x0[:, 1] = rng.uniform(-0.2, 0.2, Bn); x0[:, 3] = rng.uniform(-1.2, 1.2, Bn)
+    x0[:, 4] = rng.uniform(0, 5, Bn); x0[:, 5] = rng.uniform(-0.14, 0.14, Bn)
+    xt = np.zeros((Bn, 6)); xt[:, 0] = 1.5
+    d = abi.cbf_desc(N, 0, A, B, ey_max=0.15, v_min=0.5, v_max=2.2)
+    z = np.zeros((Bn, 0, N + 1)); args = (x0, xt, z, z, np.zeros((Bn, 0)), np.zeros(Bn, dtype=np.int32))
+    rg, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+    _assert_same_verdicts("0-obstacle NLPs", rg, ro)
+    inf = rg["status"] != 0
+    assert 0.1 < inf.mean() < 0.7, inf.mean()
+    assert rg["iters"][inf].mean() < 6.0                      # proven, not diverged
+    ok = ~inf
+    assert np.abs(rg["U"][ok] - ro["U"][ok]).max() <= 2e-5 and np.abs(rg["X"][ok] - ro["X"][ok]).max() <= 2e-5
+    # LP check of every verdict: x_k = A^k x0 + sum_j A^(k-1-j) B u_j, v_min <= vx_k <= v_max, |ey_k| <= ey_max (k >= 1), u in its box
+    Ap = [np.eye(6)]
+    for _ in range(N):
+        Ap.append(A @ Ap[-1])
+    G = np.zeros((N + 1, 6, 2 * N))
+    for k in range(1, N + 1):
+        for j in range(k):
+            G[k][:, 2 * j:2 * j + 2] = Ap[k - 1 - j] @ B
+    bounds = [(-d.delta_max, d.delta_max), (-d.a_max, d.a_max)] * N
+    wrong = []
+    for b in range(Bn):
+        rows, rhs = [], []
+        for k in range(1, N + 1):
+            f = Ap[k] @ x0[b]
+            rows += [G[k][0], -G[k][0], G[k][5], -G[k][5]]
+            rhs += [d.v_max - f[0], f[0] - d.v_min, d.ey_max - f[5], f[5] + d.ey_max]
+        infeas0 = x0[b, 0] < d.v_min - 1e-8 or x0[b, 0] > d.v_max + 1e-8 or abs(x0[b, 5]) > d.ey_max + 1e-8     # quirk Q9
+        lp = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs), bounds=bounds, method="highs")
+        if bool(inf[b]) != (lp.status == 2 or infeas0):
+            lo = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs) - 1e-7, bounds=bounds, method="highs").status == 2
+            hi = linprog(np.zeros(2 * N), A_ub=np.array(rows), b_ub=np.array(rhs) + 1e-7, bounds=bounds, method="highs").status == 2
+            if lo == hi:
+                wrong.append((b, int(rg["status"][b]), int(rg["iters"][b]), int(lp.status)))
+    assert not wrong, wrong
