@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X: NLP solves/s (N=12, 6-state bicycle).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5|lmpc|races] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2_filtered|cfg3|cfg4|cfg5|lmpc|races|game|overtake] [--scaling weak|strong]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.
 
@@ -551,7 +551,8 @@ def main():
                 ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3)),
                 ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2)),
                 ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5)),
-                ("overtake", lambda: make_overtake(cx, args), min(args.steps, 60), min(args.warmup, 5))]
+                ("overtake", lambda: make_overtake(cx, args), min(args.steps, 60), min(args.warmup, 5)),
+                ("races", lambda: make_races(cx, args), min(args.steps, 30), min(args.warmup, 3))]
         out["configs"] = []
         for key, mk, st, wu in subs:
             w = mk()
