@@ -255,6 +255,7 @@ __device__ __forceinline__ double cost_value(const double* sm, const Ctx& c, dou
 // The cost is exactly quadratic along a step: f(Z + al dZ) = f + al (g'dZ) + al^2 (1/2 dZ'H dZ).  Returns the
 // directional derivative g'dZ and the curvature term qq = 1/2 dZ'H dZ in one pass, so that a line-search
 // trial costs no evaluation loop at all.
+// (returns the LANE PARTIALS of both sums: the caller reduces them together with its own, wave_sum4)
 template <int NOBS, int NMAX>
 __device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c, double& qq) {
     using L = Lay<NOBS, NMAX>;
@@ -277,8 +278,8 @@ __device__ __forceinline__ double cost_dir(const double* sm, const Ctx& c, doubl
         acc += sel(ev, t, 0.0);
         q += sel(ev, w * dv * dv + wk * dd * dd, 0.0);
     }
-    qq = wave_sum(q);
-    return wave_sum(acc);
+    qq = q;
+    return acc;
 }
 
 // row values at the iterate (al = 0): simple rows from the tables, CBF rows evaluated
@@ -1275,12 +1276,13 @@ crx_solve_kernel(const crx_kparams kp) {
                 row_step(j, ev, true, LD(L::rsc + j), jc);
             }
         }
-        rp_max = wave_max(rp_max); rd_max = wave_max(rd_max); theta = wave_sum(theta);
+        wave_max2(rp_max, rd_max);
         const double a_p = (rp_max > tau) ? tau / rp_max : 1.0;
         const double a_d = (rd_max > tau) ? tau / rd_max : 1.0;
         double cost_qq;
-        const double cost_d = cost_dir<NOBS, NMAX>(sm, c, cost_qq);
-        Dphi = wave_sum(Dphi) + cost_d;
+        double cost_d = cost_dir<NOBS, NMAX>(sm, c, cost_qq);       // lane partials
+        wave_sum4(theta, Dphi, cost_d, cost_qq);                    // four sums, one row reduction (crx_wave.h)
+        Dphi += cost_d;
         const double phi0 = f - mu * lg0.wave_total();
         if (theta_min < 0.0) {
             theta_min = 1e-4 * fmax(1.0, theta);
@@ -1326,8 +1328,7 @@ crx_solve_kernel(const crx_kparams kp) {
                     row_trial(j, ev, true, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, al), t, dt);
                 }
             }
-            const double phin = fn - mu * lg.wave_total();
-            thn = wave_sum(thn);
+            const double phin = fn - mu * lg.wave_total_with(thn);   // thn and the exponent sum share one reduction
             int okf = (thn <= theta_max) && (phin == phin);
             {   // filter (nf <= MAXF < WAVE entries: one pass, lanes past nf read entry 0 and are masked)
                 const bool iv = lane < nf;
@@ -1409,8 +1410,12 @@ crx_solve_kernel(const crx_kparams kp) {
             }
         }
         SYNC();
-        numax = wave_max(numax); th = wave_max(th);
-        nus = wave_sum(nus); cmax = wave_max(cmax); cmin = wave_min(cmin);
+        {   // four extremes, one row reduction: min = -max(-.)
+            double ncmin = -cmin;
+            wave_max4(numax, th, cmax, ncmin);
+            cmin = -ncmin;
+        }
+        nus = wave_sum(nus);
         e_p = th;
         first_order<NOBS, NMAX>(sm, si, c);
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
@@ -1616,5 +1621,32 @@ int crx_solve_resident_per_cu(int N, int nobs_template) {
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st) {
     if (sp.n_scen == 0) return hipSuccess;
     hipLaunchKernelGGL(crx_select_kernel, dim3(sp.n_scen), dim3(WAVE), 0, st, sp);
+    return hipGetLastError();
+}
+
+// diagnostics (crx_debug_wave_reduce, not in crx.h): the packed wave reductions of crx_wave.h on four 64-lane inputs.
+// out[0..3] wave_sum4, [4..7] wave_max4, [8..9] wave_sum2 of inputs 0 and 1, [10..11] wave_max2 of inputs 2 and 3,
+// [12..15] the single-value reductions (sum of 0, max of 1, min of 2, product of the mantissas of 3).
+__global__ void __launch_bounds__(WAVE) crx_debug_reduce_kernel(const double* in, double* out) {
+    const int lane = threadIdx.x;
+    double a = in[lane], b = in[64 + lane], c = in[128 + lane], d = in[192 + lane];
+    double s0 = a, s1 = b, s2 = c, s3 = d;
+    wave_sum4(s0, s1, s2, s3);
+    double m0 = a, m1 = b, m2 = c, m3 = d;
+    wave_max4(m0, m1, m2, m3);
+    double p0 = a, p1 = b;
+    wave_sum2(p0, p1);
+    double q0 = c, q1 = d;
+    wave_max2(q0, q1);
+    int ex;
+    const double r0 = wave_sum(a), r1 = wave_max(b), r2 = wave_min(c), r3 = wave_prod(frexp(fabs(d) + 1.0, &ex));
+    if (lane == 0) {
+        out[0] = s0; out[1] = s1; out[2] = s2; out[3] = s3; out[4] = m0; out[5] = m1; out[6] = m2; out[7] = m3;
+        out[8] = p0; out[9] = p1; out[10] = q0; out[11] = q1; out[12] = r0; out[13] = r1; out[14] = r2; out[15] = r3;
+    }
+}
+
+hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(crx_debug_reduce_kernel, dim3(1), dim3(WAVE), 0, st, in, out);
     return hipGetLastError();
 }

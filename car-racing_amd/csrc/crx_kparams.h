@@ -121,6 +121,7 @@ struct crx_lmpcprep_kparams {
 #include <hip/hip_runtime.h>
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
+hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
 int crx_solve_resident_per_cu(int N, int nobs_template);
 hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);

@@ -77,6 +77,46 @@ __device__ __forceinline__ double wave_min(double v) {
     return fmin(fmin(lane_f64(v, 0), lane_f64(v, 16)), fmin(lane_f64(v, 32), lane_f64(v, 48)));
 }
 
+// Packed reductions [r2]: two or four wave reductions for little more than the price of one.  A single f64 reduction
+// costs 23 VALU instructions, 12 of them the four DPP steps inside the 16-lane rows; the interior-point iteration does
+// 17 of them, ~15 % of its VALU instructions.  gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
+// alternate rows between TWO registers in one instruction, which lets several values share those four steps:
+//   swap32(a, b): a' = (a.lo32, b.lo32), b' = (a.hi32, b.hi32);  a' OP b' = rows [A A B B] (lane partials of A in rows
+//   0-1, of B in rows 2-3);  swap16(s1, s2): s1' = rows [s1.0 s2.0 s1.2 s2.2], s2' = rows [s1.1 s2.1 s1.3 s2.3];
+//   s1' OP s2' = rows [A C B D]: ONE row reduction, four readlanes.  29 instructions for four values (92), 24 for two (46).
+// All 64 lanes must be active (they are: the callers sit in wave-uniform control flow).
+__device__ __forceinline__ void swap32_f64(double& x, double& y) {
+    auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    x = __hiloint2double(hi[0], lo[0]);
+    y = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap16_f64(double& x, double& y) {
+    auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    x = __hiloint2double(hi[0], lo[0]);
+    y = __hiloint2double(hi[1], lo[1]);
+}
+#define WAVE_REDUCE4(a, b, c, d, OP)                                              \
+    do {                                                                          \
+        swap32_f64(a, b); double s1_ = OP(a, b);                                  \
+        swap32_f64(c, d); double s2_ = OP(c, d);                                  \
+        swap16_f64(s1_, s2_); double t_ = OP(s1_, s2_);                           \
+        ROW_REDUCE(t_, OP)                                                        \
+        a = lane_f64(t_, 0); c = lane_f64(t_, 16); b = lane_f64(t_, 32); d = lane_f64(t_, 48); \
+    } while (0)
+#define WAVE_REDUCE2(a, b, OP)                                                    \
+    do {                                                                          \
+        swap32_f64(a, b); double s1_ = OP(a, b), s2_ = s1_;                       \
+        swap16_f64(s1_, s2_); double t_ = OP(s1_, s2_);                           \
+        ROW_REDUCE(t_, OP)                                                        \
+        a = lane_f64(t_, 0); b = lane_f64(t_, 32);                                \
+    } while (0)
+__device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, double& d) { WAVE_REDUCE4(a, b, c, d, op_add); }
+__device__ __forceinline__ void wave_max4(double& a, double& b, double& c, double& d) { WAVE_REDUCE4(a, b, c, d, op_max); }
+__device__ __forceinline__ void wave_sum2(double& a, double& b) { WAVE_REDUCE2(a, b, op_add); }
+__device__ __forceinline__ void wave_max2(double& a, double& b) { WAVE_REDUCE2(a, b, op_max); }
+
 // sum over the wave of log(v), v > 0: mantissas multiplied, exponents added, ONE log per wave
 // (a product of <= 6*64 mantissas in [0.5,1) cannot underflow: 2^-384)
 struct LogAcc {
@@ -90,6 +130,12 @@ struct LogAcc {
     }
     __device__ __forceinline__ double wave_total() {
         return log(wave_prod(m)) + 0.6931471805599453 * wave_sum((double)e);
+    }
+    // the same with the exponent sum sharing its reduction with another sum of the caller (`other`, reduced in place)
+    __device__ __forceinline__ double wave_total_with(double& other) {
+        double ex = (double)e;
+        wave_sum2(other, ex);
+        return log(wave_prod(m)) + 0.6931471805599453 * ex;
     }
 };
 

@@ -981,3 +981,30 @@ def test_zero_obstacle_nlps_incl_infeasible(gpu, orc, AB):
             if lo == hi:
                 wrong.append((b, int(rg["status"][b]), int(rg["iters"][b]), int(lp.status)))
     assert not wrong, wrong
+
+
+def test_packed_wave_reductions(gpu):
+    """crx_wave.h wave_sum4 / wave_max4 / wave_sum2 / wave_max2 (v_permlane32_swap / v_permlane16_swap + one row reduction)
+    on random 64-lane inputs through the hidden crx_debug_wave_reduce: the maxima exact, the sums to rounding of a
+    different association, each value in ITS output slot (a transposed row map would swap slots 1 and 2)."""
+    import ctypes as C
+
+    import crx
+    L = crx.lib()
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        x = rng.normal(0, 10.0 ** rng.integers(-3, 4), (4, 64)) + np.array([[1.0], [-20.0], [300.0], [0.004]])
+        if trial == 5:
+            x = np.tile(np.arange(64.0), (4, 1)) * np.array([[1.0], [2.0], [3.0], [4.0]])     # exact sums 2016 k
+        xin = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(16)
+        assert L.crx_debug_wave_reduce(xin.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        ref_s, ref_m = x.sum(axis=1), x.max(axis=1)
+        tol = 64 * 2.3e-16 * np.abs(x).sum(axis=1)
+        assert (np.abs(out[0:4] - ref_s) <= tol).all(), (out[0:4], ref_s)
+        np.testing.assert_array_equal(out[4:8], ref_m)
+        assert (np.abs(out[8:10] - ref_s[:2]) <= tol[:2]).all()
+        np.testing.assert_array_equal(out[10:12], ref_m[2:])
+        assert abs(out[12] - ref_s[0]) <= tol[0] and out[13] == ref_m[1] and out[14] == x[2].min()
+        if trial == 5:
+            np.testing.assert_array_equal(out[0:4], 2016.0 * np.arange(1, 5))
