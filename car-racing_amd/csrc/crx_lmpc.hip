@@ -345,8 +345,11 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     ec[c6] = sel(lane < nv, pu, 0.0) - sel(lane < M, pl, 0.0);
                 }
                 ec[6] = sel(lane < M, LDS(L::lam + (lane < M ? lane : 0)), 0.0);
-#pragma unroll
-                for (int c6 = 0; c6 < 7; c6++) ec[c6] = wave_sum(ec[c6]);
+                wave_sum4(ec[0], ec[1], ec[2], ec[3]);     // seven sums in two row reductions (crx_wave.h) instead of seven
+                {
+                    double zero = 0.0;
+                    wave_sum4(ec[4], ec[5], ec[6], zero);
+                }
                 double ev = ec[6] - 1.0;
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) ev = sel(lane == c6, ec[c6] + LDS(L::xf + 6 * N + c6), ev);
@@ -373,12 +376,11 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const double ruv = fabs(LDS(L::ru + (lane < nv ? lane : 0))), rlv = fabs(LDS(L::rl + (lane < M ? lane : 0)));
                 e_d = fmax(sel(lane < nv, ruv, 0.0), sel(lane < M, rlv, 0.0));
             }
-            nus = wave_sum(nus);
-            ys = wave_sum(ys);
-            theta = wave_sum(theta);
-            e_p = wave_max(e_p);
-            e_c = wave_max(e_c);
-            e_d = wave_max(e_d);
+            {
+                double zs = 0.0, zm = 0.0;          // (all four maxima are >= 0)
+                wave_sum4(nus, ys, theta, zs);
+                wave_max4(e_p, e_c, e_d, zm);
+            }
             const double sd = fmax(100.0, (nus + ys) / (m + 7)) / 100.0, sc = fmax(100.0, nus / m) / 100.0;
             e_d /= sd;
             e_c /= sc;
@@ -593,13 +595,21 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             TICK();   // 9
             if (!ok) break;
             {
-                const double s1 = wave_sum(sel(lane < M, b2[0], 0.0)), s2 = wave_sum(sel(lane < M, b2[1], 0.0));
+                double s1 = sel(lane < M, b2[0], 0.0), s2 = sel(lane < M, b2[1], 0.0);
+                wave_sum2(s1, s2);
                 const double dy1 = (s1 + LDS(L::e + 6)) / s2;
                 const double dl = sel(lane < M, b2[0] - b2[1] * dy1, 0.0);
                 LDS(LSINK(lane < M, L::dlam + lane)) = dl;
                 double tb[6], dyx[6];
+                {
+                    double w6[6];
 #pragma unroll
-                for (int c6 = 0; c6 < 6; c6++) tb[c6] = tbx[c6] - wave_sum(Tj[c6] * dl);
+                    for (int c6 = 0; c6 < 6; c6++) w6[c6] = Tj[c6] * dl;
+                    wave_sum4(w6[0], w6[1], w6[2], w6[3]);
+                    wave_sum2(w6[4], w6[5]);
+#pragma unroll
+                    for (int c6 = 0; c6 < 6; c6++) tb[c6] = tbx[c6] - w6[c6];
+                }
 #pragma unroll
                 for (int i = 5; i >= 0; i--) {
                     double s = tb[i];
@@ -667,14 +677,11 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 qd = sel(av, (s0 + s1) * d, 0.0);
                 gdv = sel(av, gua * d, 0.0) + sel(lane < M, LDS(L::qf + j) * LDS(L::dlam + j), 0.0);
             }
-            rp_max = wave_max(rp_max);
-            rd_max = wave_max(rd_max);
-            gdv = wave_sum(gdv);
-            qd = wave_sum(qd);
-            Dphi = wave_sum(Dphi) + gdv;
-            const double a_p = rp_max > tau ? tau / rp_max : 1.0, a_d = rd_max > tau ? tau / rd_max : 1.0;
+            wave_max2(rp_max, rd_max);
             double esum = sel(lane < 7, fabs(LDS(L::e + (lane < 7 ? lane : 0))), 0.0);
-            esum = wave_sum(esum);
+            wave_sum4(gdv, qd, Dphi, esum);
+            Dphi += gdv;
+            const double a_p = rp_max > tau ? tau / rp_max : 1.0, a_d = rd_max > tau ? tau / rd_max : 1.0;
             LogAcc la0;
             LROWS(r, rv, lane, m) la0.mul(sel(rv, LDS(L::t + r), 1.0));
             const double phi0 = f - mu * la0.wave_total();
@@ -697,8 +704,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     la.mul(sel(rv, tn, 1.0));
                     thn += sel(rv, fabs(cj - tn), 0.0);
                 }
-                thn = wave_sum(thn) + (1.0 - al) * esum;
-                const double phin = fn - mu * la.wave_total();
+                const double lt = la.wave_total_with(thn);   // thn and the exponent sum share one reduction
+                thn += (1.0 - al) * esum;
+                const double phin = fn - mu * lt;
                 int okf = (thn <= theta_max) && (phin == phin);
                 for (int i = 0; i < nf && okf; i++)
                     if (!(thn < LDS(L::Fth + i) || phin < LDS(L::Fph + i))) okf = 0;
