@@ -1160,9 +1160,13 @@ crx_solve_kernel(const crx_kparams kp) {
 
     // row statistics of the current iterate: sum nu, max |c - t|, max and min of t*nu over the present rows.  Computed
     // here for the start point and afterwards inside the accept pass, which touches every row anyway.
-    double nus = 0.0, e_p = 0.0, cmax = 0.0, cmin = INFINITY;
+    // logsum_t = sum_j log t_j over the present rows, the barrier term of the merit function at the iterate: taken over
+    // from the accepted line-search trial (which computed it for exactly the slacks that become the iterate) instead of
+    // being recomputed in the row-step pass of the next iteration -- two wave reductions, a log and a frexp per row less.
+    double nus = 0.0, e_p = 0.0, cmax = 0.0, cmin = INFINITY, logsum_t = 0.0;
     auto row_stats = [&]() {
         nus = 0.0; e_p = 0.0; cmax = 0.0; cmin = INFINITY;
+        LogAcc lgs;
         for (int j = lane; j < m; j += WAVE) {
             const bool on = LD(L::rsc + j) != 0.0;
             const double t = LD(L::rt + j), nu = LD(L::rnu + j);
@@ -1170,8 +1174,10 @@ crx_solve_kernel(const crx_kparams kp) {
             e_p = fmax(e_p, on ? fabs(LD(L::rc + j) - t) : 0.0);
             cmax = fmax(cmax, on ? t * nu : 0.0);
             cmin = fmin(cmin, on ? t * nu : INFINITY);
+            lgs.mul(on ? t : 1.0);
         }
         nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
+        logsum_t = lgs.wave_total();
     };
     row_stats();
     // The interior-point loop sits inside a retry loop: when the line search finds no acceptable step the (out-of-loop,
@@ -1240,7 +1246,6 @@ crx_solve_kernel(const crx_kparams kp) {
         // ---- row steps, step lengths, merit pieces ---------------------------------------------------
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
         double rp_max = 0.0, rd_max = 0.0, theta = 0.0, Dphi = 0.0;
-        LogAcc lg0;
         // (jd = J dz of the row; shared tail of the simple-row passes and of the CBF pass)
         auto row_step = [&](int j, bool cnt, bool store, double sc, double jd) {
             const bool on = sc != 0.0;
@@ -1257,7 +1262,6 @@ crx_solve_kernel(const crx_kparams kp) {
             rd_max = fmax(rd_max, sel(cnt && on, -dnu * frcp(nu), 0.0));
             theta += sel(cnt && on, fabs(rp), 0.0);
             Dphi -= sel(cnt && on, mu * dtr, 0.0);
-            lg0.mul(sel(cnt, t, 1.0));
         };
         ROWS(j, jv, lane, m) {
             // J dz straight from the step (differencing row values would lose eps*|x|, which the
@@ -1283,14 +1287,14 @@ crx_solve_kernel(const crx_kparams kp) {
         double cost_d = cost_dir<NOBS, NMAX>(sm, c, cost_qq);       // lane partials
         wave_sum4(theta, Dphi, cost_d, cost_qq);                    // four sums, one row reduction (crx_wave.h)
         Dphi += cost_d;
-        const double phi0 = f - mu * lg0.wave_total();
+        const double phi0 = f - mu * logsum_t;
         if (theta_min < 0.0) {
             theta_min = 1e-4 * fmax(1.0, theta);
             theta_max = 1e4 * fmax(1.0, theta);
         }
         long long tc7 = CLK();
         // ---- filter line search ----------------------------------------------------------------------
-        double al = a_p, fn = f;
+        double al = a_p, fn = f, lt_acc = logsum_t;
         int acc = 0, ftype = 0;
         // switching condition al * (-Dphi)^2.3 > theta^1.1 (only consulted when theta <= theta_min)
         const bool sw_try = (theta <= theta_min) && (Dphi < 0.0);
@@ -1328,7 +1332,8 @@ crx_solve_kernel(const crx_kparams kp) {
                     row_trial(j, ev, true, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, al), t, dt);
                 }
             }
-            const double phin = fn - mu * lg.wave_total_with(thn);   // thn and the exponent sum share one reduction
+            lt_acc = lg.wave_total_with(thn);                         // thn and the exponent sum share one reduction
+            const double phin = fn - mu * lt_acc;
             int okf = (thn <= theta_max) && (phin == phin);
             {   // filter (nf <= MAXF < WAVE entries: one pass, lanes past nf read entry 0 and are masked)
                 const bool iv = lane < nf;
@@ -1375,6 +1380,7 @@ crx_solve_kernel(const crx_kparams kp) {
         }
         SYNC();
         f = fn;
+        logsum_t = lt_acc;                           // the trial slacks rtt become the slacks rt below
         // one pass over the rows: multiplier update (from the pre-step row state), new slack, row value at the new
         // iterate (simple rows exactly from Z, CBF rows evaluated), and the two divergence-test reductions
         double numax = 0.0, th = 0.0;

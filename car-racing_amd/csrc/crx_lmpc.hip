@@ -310,6 +310,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         int nf = 0, it = 0;
         status = CRX_MAX_ITER;
         f = f0;
+        // sum_j log t_j at the iterate: computed here for the start point, afterwards taken over from the accepted line-search
+        // trial (the same slacks) instead of being recomputed every iteration (crx_kernels.hip logsum_t)
+        double logsum_t;
+        {
+            LogAcc la0;
+            LROWS(r, rv, lane, m) la0.mul(sel(rv, LDS(L::t + r), 1.0));
+            logsum_t = la0.wave_total();
+        }
         // stagnation (oracle/crx_oracle_lmpc.c): 25 iterations with the barrier parameter below 1e-6 without reaching tol --
         // the iterate sits on the noise floor of a QP whose unstable local model makes 1e7-sized free responses
         int late = 0;
@@ -682,16 +690,14 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             wave_sum4(gdv, qd, Dphi, esum);
             Dphi += gdv;
             const double a_p = rp_max > tau ? tau / rp_max : 1.0, a_d = rd_max > tau ? tau / rd_max : 1.0;
-            LogAcc la0;
-            LROWS(r, rv, lane, m) la0.mul(sel(rv, LDS(L::t + r), 1.0));
-            const double phi0 = f - mu * la0.wave_total();
+            const double phi0 = f - mu * logsum_t;
             if (it == 0) {
                 theta_min = 1e-4 * fmax(1.0, theta);
                 theta_max = 1e4 * fmax(1.0, theta);
             }
             TICK();   // 11
             // ---- filter line search (all rows linear: c(v + al dv) = c + al J dv) ----
-            double al = a_p, fn = f;
+            double al = a_p, fn = f, lt = logsum_t;
             int acc = 0, ftype = 0;
             for (int ls = 0; ls < 40 && al >= 1e-10; ls++) {   // alpha_min: see crx_kernels.hip
                 fn = f + al * (gdv + 0.5 * al * qd);
@@ -704,7 +710,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     la.mul(sel(rv, tn, 1.0));
                     thn += sel(rv, fabs(cj - tn), 0.0);
                 }
-                const double lt = la.wave_total_with(thn);   // thn and the exponent sum share one reduction
+                lt = la.wave_total_with(thn);                // thn and the exponent sum share one reduction
                 thn += (1.0 - al) * esum;
                 const double phin = fn - mu * lt;
                 int okf = (thn <= theta_max) && (phin == phin);
@@ -732,6 +738,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             if (!acc) break;
             TICK();   // 12
             // ---- accept ----
+            logsum_t = lt;
             double numax = 0.0;
             LROWS(r, rv, lane, m) {
                 const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
