@@ -136,16 +136,18 @@ struct Lay {
     static constexpr int kE = kS + (NOBS ? NMAX : 0);   //        ... on ey_{k+1}
     // Riccati work.  The backward sweep runs while two arrays are dead: the row steps rdt (rewritten by the row-step pass
     // that follows the forward sweep) and the Newton step dZ beyond its first stage (rewritten by the forward sweep; the
-    // first stage receives sigma_0 at the end of the backward sweep).  P, pv, T live in the former and H in the latter
-    // wherever they fit (they do for every instantiation but H of <2,12> and <3,12>).
+    // first stage receives sigma_0 at the end of the backward sweep, after the last H is consumed).  P, pv, T live in the
+    // former and H in the latter wherever they fit (they do for every instantiation but H of <3,12>; <2,12> fits exactly:
+    // 28 412 -> 27 164 B; its residency stays at four per CU, the register file's limit: 296 registers, and a floor of two
+    // waves per SIMD would park 92 of them).
     static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
-    static constexpr bool PT_ALIAS = NX * NX + NX + NX * NZ <= MR, H_ALIAS = NZ * HS <= NMAX * NZ;
+    static constexpr bool PT_ALIAS = NX * NX + NX + NX * NZ <= MR, H_ALIAS = NZ * HS <= NV;
     static constexpr int WORK = kE + (NOBS ? NMAX : 0);
     static constexpr int P = PT_ALIAS ? rdt : WORK;
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
     static constexpr int WORK2 = PT_ALIAS ? WORK : T + NX * NZ;
-    static constexpr int H = H_ALIAS ? dZ + NZ : WORK2;      // [NZ][HS]
+    static constexpr int H = H_ALIAS ? dZ : WORK2;           // [NZ][HS]  (over dZ from its start: stage 0 of dZ is written only after the sweep)
     static constexpr int Kk = H_ALIAS ? WORK2 : H + NZ * HS; // [NMAX][NU][NX]
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
