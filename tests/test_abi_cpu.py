@@ -55,6 +55,27 @@ def test_struct_layouts_match_header(lib):
     o = abi.IpmOpts()
     lib.crx_ipm_opts_default(ctypes.byref(o))
     assert bytes(o) == bytes(abi.default_opts())
+    # every other descriptor that has a C-side initialiser (the oracle is driven through the same ctypes mirrors: a
+    # layout slip shared by both sides would be invisible to GPU-vs-oracle tests, so each mirror is pinned to the header here)
+    dbl = ctypes.c_double
+    lm = abi.LmpcDesc()
+    lib.crx_lmpc_desc_default(ctypes.byref(lm), 12, 44)
+    assert bytes(lm) == bytes(abi.lmpc_desc(12, 44))
+    pa = abi.PathDesc()
+    lib.crx_path_desc_default(ctypes.byref(pa), 10, dbl(0.6))
+    assert bytes(pa) == bytes(abi.path_desc(10, 0.6))
+    pl = abi.PlantDesc()
+    lib.crx_plant_desc_default(ctypes.byref(pl), 9, dbl(19.25))
+    assert bytes(pl) == bytes(abi.plant_desc(9, 19.25))
+    pr = abi.PrepDesc()
+    lib.crx_prep_desc_default(ctypes.byref(pr), 10, 3, 300, dbl(1.0), dbl(19.25))
+    assert bytes(pr) == bytes(abi.prep_desc(10, 3, 300, 1.0, 19.25))
+    sc = abi.SceneDesc()
+    lib.crx_scene_desc_default(ctypes.byref(sc), 10, 5, 3, dbl(19.25))
+    assert bytes(sc) == bytes(abi.scene_desc(10, 5, 3, 19.25))
+    lp = abi.LmpcPrepDesc()
+    lib.crx_lmpcprep_desc_default(ctypes.byref(lp), 12, 600, 4, 9, dbl(0.1), dbl(19.25))
+    assert bytes(lp) == bytes(abi.lmpcprep_desc(12, 600, 4, 9, 0.1, 19.25))
 
 
 def test_no_gpu_means_error_not_fallback(lib):
