@@ -7,7 +7,6 @@ make -C oracle -s
 mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
 tail -c 600 gpurun_out/final/bench_default.json; echo
-sed -i 's/for wl in cfg2 cfg2_filtered cfg3 cfg4 lmpc cfg5 races game; do/for wl in cfg2 cfg2_filtered cfg3 cfg4 lmpc cfg5 races game overtake; do/; s/\[ \$wl = game \] \&\& st=40/[ $wl = game ] \&\& st=40; [ $wl = overtake ] \&\& st=40/' tools/gpu_prof_r2.sh
 bash tools/gpu_prof_r2.sh > gpurun_out/final/prof.log 2>&1
 bash tools/gpu_pmc_r2.sh > gpurun_out/final/pmc.log 2>&1
 bash tools/gpu_pmc_lds.sh > gpurun_out/final/pmc_lds.log 2>&1
