@@ -254,7 +254,7 @@ def make_game(cx, args, batch=None):
     w = Workload()
     g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
     track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
-    w.batch = w.units = batch or 1024
+    w.batch = w.units = batch or 4096
     Bn, N = w.batch, 12
     ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1)); us = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
     qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
@@ -288,7 +288,7 @@ def make_overtake(cx, args, batch=None):
     g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
     track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
     opt = np.genfromtxt(os.path.join(ROOT, "data/optimal_traj/xcurv_l_shape.csv"), delimiter=",")
-    w.batch = w.units = batch or 1024
+    w.batch = w.units = batch or 4096
     Bn, N = w.batch, 12
     ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1)); us = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
     qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
