@@ -273,7 +273,7 @@ def make_game(cx, args, batch=None):
                                                laps.n_ss, ws=laps.ws)
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
-    w.extra = {"note": "keep steps + warmup below ~120: past the finish line the loop has no new safe set (add_trajectory is not part of it)"}
+    w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full"}
     return w
 
 
@@ -307,7 +307,7 @@ def make_overtake(cx, args, batch=None):
     w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against two "
               "scripted cars each, one control step of every race per step: scene, Bezier/bounds, 3 region QPs + selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
-    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch; keep steps + warmup below ~120"}
+    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch"}
     return w
 
 

@@ -119,9 +119,13 @@ class LmpcLaps:
         crx_lmpc_solve_dev     the learning-MPC QP                                               (control.lmpc :640-730)
         crx_lmpc_addpoint_dev  the applied (x, u) extends the previous lap's safe set            (add_point)
         crx_plant_step_wrap_dev  plant + lap bookkeeping                                         (forward_dynamics, update_memory)
+        crx_lmpc_addtraj_dev   a race that crossed the line: its logged lap becomes a safe-set lap (add_trajectory)
 
-    Four libcrx launches per step; torch owns the memory and copies u_old.  Every race carries its own safe set
-    (ss_xcurv [B, L, P, 6], u_ss [B, L, P, 2], qfun [B, L, P], time_ss [B, L]: the reference's arrays stored lap-major)."""
+    Five libcrx launches per step; torch owns the memory, copies u_old and appends the applied (x, u) to the race's lap log.
+    Every race carries its own safe set (ss_xcurv [B, L, P, 6], u_ss [B, L, P, 2], qfun [B, L, P], time_ss [B, L]: the
+    reference's arrays stored lap-major) and runs lap after lap: the lap hand-over (the reference's test script calls
+    add_trajectory between laps, tests/auto_racing_game_test.py) happens per race on the device, until the race's L laps
+    of safe-set storage are full (it then keeps racing on its last two laps)."""
 
     def __init__(self, track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
                  N=12, timestep=0.1, device=None):
@@ -150,6 +154,29 @@ class LmpcLaps:
         self.laps = torch.zeros((Bn,), **i32)
         self.xg_next, self.xc_next = torch.empty_like(self.xg), torch.empty_like(self.xc)
         self.k = 0
+        # the running lap as the simulator logs it (update_memory): states incl. the crossing one, inputs
+        self.log_x = torch.zeros((Bn, P, 6), **f64)
+        self.log_u = torch.zeros((Bn, P, 2), **f64)
+        self.log_x[:, 0] = self.xc
+        self.n_log = torch.ones((Bn,), **i32)
+        self.laps_prev = torch.zeros((Bn,), **i32)
+        self.traj_status = torch.zeros((Bn,), **i32)
+        self._ar = torch.arange(Bn, device=dev)
+        self._P = P
+
+    def log_and_handover(self, u):
+        """After the plant step: append (new state, applied input) to every race's lap log -- the crossing state with its s
+        unwrapped, like update_memory -- and hand the completed laps over to the safe set (crx_lmpc_addtraj_dev)."""
+        crossed = (self.laps > self.laps_prev).to(torch.int32)
+        self.laps_prev.copy_(self.laps)
+        xu = self.xc.clone()
+        xu[:, 4] += self.lap_length * crossed.to(torch.float64)       # (an int32 tensor times a Python float would be float32)
+        n = self.n_log.long()
+        self.log_x[self._ar, torch.clamp(n, max=self._P - 1)] = xu
+        self.log_u[self._ar, torch.clamp(n - 1, min=0, max=self._P - 1)] = u
+        self.n_log += 1
+        torch_api.lmpc_addtraj_dev(self.pdesc, crossed, self.log_x, self.log_u, self.n_log, self.ss, self.us, self.qf, self.time_ss, self.it,
+                                   self.step_no, self.xc, self.traj_status)
 
     def step(self):
         N = self.N
@@ -168,6 +195,7 @@ class LmpcLaps:
         self.u_old.copy_(self.ws.U[:, 0, :])
         self.step_no += 1
         self.k += 1
+        self.log_and_handover(self.u_old)
 
 
 def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, steps,
@@ -286,6 +314,7 @@ class GameLaps:
         lm.xg, lm.xg_next = lm.xg_next, lm.xg
         lm.xc, lm.xc_next = lm.xc_next, lm.xc
         self.t += lm.timestep
+        lm.log_and_handover(self.u)
 
 
 def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,

@@ -285,6 +285,25 @@ def lmpc_addpoint_dev(desc, ss_xcurv, u_ss, time_ss, it, step, x, u, u_stride):
           _ptr(x), _ptr(u), C.c_int(u_stride), _stream())
 
 
+def lmpc_addtraj_dev(desc, crossed, log_x, log_u, n_log, ss_xcurv, u_ss, qfun, time_ss, it, step, x, status):
+    """crx_lmpc_addtraj_dev: LMPCRacingGame.add_trajectory for the races with crossed != 0 (everything in place)."""
+    Bn, P, L = x.shape[0], desc.n_points, desc.n_laps
+    _chk(crossed, torch.int32, (Bn,), "crossed")
+    _chk(log_x, torch.float64, (Bn, P, 6), "log_x")
+    _chk(log_u, torch.float64, (Bn, P, 2), "log_u")
+    _chk(n_log, torch.int32, (Bn,), "n_log")
+    _chk(ss_xcurv, torch.float64, (Bn, L, P, 6), "ss_xcurv")
+    _chk(u_ss, torch.float64, (Bn, L, P, 2), "u_ss")
+    _chk(qfun, torch.float64, (Bn, L, P), "qfun")
+    _chk(time_ss, torch.int32, (Bn, L), "time_ss")
+    _chk(it, torch.int32, (Bn,), "iter")
+    _chk(step, torch.int32, (Bn,), "step")
+    _chk(x, torch.float64, (Bn, 6), "x")
+    _chk(status, torch.int32, (Bn,), "status")
+    _call("crx_lmpc_addtraj_dev", C.byref(desc), C.c_int(Bn), _ptr(crossed), _ptr(log_x), _ptr(log_u), _ptr(n_log), _ptr(ss_xcurv),
+          _ptr(u_ss), _ptr(qfun), _ptr(time_ss), _ptr(it), _ptr(step), _ptr(x), _ptr(status), _stream())
+
+
 class SceneWorkspace:
     def __init__(self, desc, n_scen, device):
         N1, V = desc.N + 1, desc.n_veh_max

@@ -983,6 +983,20 @@ int crx_lmpc_addpoint_dev(const crx_lmpcprep_desc* d, int batch, double* ss_xcur
     return CRX_OK;
 }
 
+int crx_lmpc_addtraj_dev(const crx_lmpcprep_desc* d, int batch, const int32_t* crossed, double* log_x, const double* log_u,
+                         int32_t* n_log, double* ss_xcurv, double* u_ss, double* qfun, int32_t* time_ss, int32_t* iter,
+                         int32_t* step, const double* x, int32_t* status, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (int rc = check_lmpcprep(d, batch)) return rc;
+    if (batch == 0) return CRX_OK;
+    if (!crossed || !log_x || !log_u || !n_log || !ss_xcurv || !u_ss || !qfun || !time_ss || !iter || !step || !x || !status)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    hipError_t e = crx_launch_lmpc_addtraj(*d, batch, crossed, log_x, log_u, n_log, ss_xcurv, u_ss, qfun, time_ss, iter, step, x, status,
+                                           (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc addtraj launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
 // ---- fused planner step ------------------------------------------------------------------------------
 int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const double* x0,
                          const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub,

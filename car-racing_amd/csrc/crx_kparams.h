@@ -122,6 +122,9 @@ struct crx_lmpcprep_kparams {
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st);
+hipError_t crx_launch_lmpc_addtraj(const crx_lmpcprep_desc& d, int batch, const int32_t* crossed, double* log_x, const double* log_u,
+                                   int32_t* n_log, double* ss_xcurv, double* u_ss, double* qfun, int32_t* time_ss, int32_t* iter,
+                                   int32_t* step, const double* x, int32_t* status, hipStream_t st);
 size_t crx_solve_lds_bytes(int N, int nobs_template);
 int crx_solve_resident_per_cu(int N, int nobs_template);
 hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);

@@ -362,6 +362,50 @@ __global__ void __launch_bounds__(256) crx_lmpc_addpoint_kernel(const crx_lmpcpr
     su[0] = u[(size_t)b * u_stride]; su[1] = u[(size_t)b * u_stride + 1];
 }
 
+// LMPCRacingGame.add_trajectory (utils/base.py:631-656) for the races that have just crossed the line: the logged lap becomes
+// lap `iter` of the race's safe set (states, inputs, cost-to-go), the counters move on, the log restarts from the wrapped
+// state.  One wavefront per race; the copies are coalesced, the cost-to-go recursion and the reference's second pass over
+// the column run on one lane in the reference's order (oracle/crx_oracle_lmpc_prep.c crx_oracle_lmpc_addtraj).
+__global__ void __launch_bounds__(WAVE) crx_lmpc_addtraj_kernel(const crx_lmpcprep_desc d, int batch, const int32_t* crossed, double* log_x,
+                                                                const double* log_u, int32_t* n_log, double* ss_xcurv, double* u_ss,
+                                                                double* qfun, int32_t* time_ss, int32_t* iter, int32_t* step,
+                                                                const double* x, int32_t* status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= batch) return;
+    if (!crossed[b]) {
+        if (lane == 0) status[b] = 0;
+        return;
+    }
+    const int P = d.n_points, L = d.n_laps, lap = iter[b];
+    int n = n_log[b] - 1;
+    n = n > P - 1 ? P - 1 : n;
+    double* lx = log_x + (size_t)b * P * 6;
+    const bool room = lap >= 0 && lap < L && n >= 1;
+    if (room) {
+        double* sx = ss_xcurv + ((size_t)b * L + lap) * P * 6;
+        double* su = u_ss + ((size_t)b * L + lap) * P * 2;
+        const double* lu = log_u + (size_t)b * P * 2;
+        for (int e = lane; e < (n + 1) * 6; e += WAVE) sx[e] = lx[e];
+        for (int e = lane; e < n * 2; e += WAVE) su[e] = lu[e];
+        if (lane == 0) {
+            double* q = qfun + ((size_t)b * L + lap) * P;
+            q[n] = 0.0;
+            for (int i = n - 1; i >= 0; i--) q[i] = lx[6 * i + 4] < d.lap_length ? q[i + 1] + 1.0 : 0.0;
+            for (int i = 0; i < P; i++)
+                if (q[i] == 0.0) q[i] = q[i > 0 ? i - 1 : P - 1] - 1.0;
+            time_ss[(size_t)b * L + lap] = n;
+        }
+    }
+    SYNC();   // (the copies above read lx[0..5]; a single wave: program order suffices)
+    if (lane < 6) lx[lane] = x[(size_t)b * 6 + lane];
+    if (lane == 0) {
+        if (room) iter[b] = lap + 1;
+        status[b] = room ? 0 : 1;
+        step[b] = 0;
+        n_log[b] = 1;
+    }
+}
+
 size_t crx_lmpcprep_lds_bytes(int n_points) {
     return ((size_t)2 * n_points * 5 + LP_WAVES * LP_WAVE_DOUBLES(n_points)) * sizeof(double);
 }
@@ -388,5 +432,14 @@ hipError_t crx_launch_lmpc_addpoint(const crx_lmpcprep_desc& d, int batch, doubl
     if (batch == 0) return hipSuccess;
     hipLaunchKernelGGL(crx_lmpc_addpoint_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, d, batch, ss_xcurv, u_ss, time_ss, iter,
                        step, x, u, u_stride);
+    return hipGetLastError();
+}
+
+hipError_t crx_launch_lmpc_addtraj(const crx_lmpcprep_desc& d, int batch, const int32_t* crossed, double* log_x, const double* log_u,
+                                   int32_t* n_log, double* ss_xcurv, double* u_ss, double* qfun, int32_t* time_ss, int32_t* iter,
+                                   int32_t* step, const double* x, int32_t* status, hipStream_t st) {
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(crx_lmpc_addtraj_kernel, dim3(batch), dim3(WAVE), 0, st, d, batch, crossed, log_x, log_u, n_log, ss_xcurv, u_ss,
+                       qfun, time_ss, iter, step, x, status);
     return hipGetLastError();
 }

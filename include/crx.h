@@ -480,6 +480,16 @@ int crx_lmpc_prep_masked_dev(const crx_lmpcprep_desc* d, int batch, const int32_
 int crx_lmpc_addpoint_dev(const crx_lmpcprep_desc* d, int batch, double* ss_xcurv, double* u_ss, const int32_t* time_ss,
                           const int32_t* iter, const int32_t* step, const double* x, const double* u, int u_stride,
                           void* stream);
+/* LMPCRacingGame.add_trajectory (utils/base.py:631-656), for the races of a device-resident loop that have just crossed the
+ * finish line (crossed[b] != 0; the others are left alone): the running lap, logged as the simulator logs it
+ * (update_memory, base.py:795-819: log_x [batch][n_points][6] with n_log[b] states, the last one the crossing state with
+ * s > lap_length; log_u [batch][n_points][2] with n_log[b] - 1 inputs), becomes lap iter[b] of the race's safe set --
+ * states, inputs, time_ss = n_log - 1, Qfun = compute_cost (lmpc_helper.py:11-23) + the reference's count-down pass over
+ * the whole column (:647-649) -- then iter[b] += 1, step[b] = 0 (time_in_iter), and the log restarts with x[b] (the wrapped
+ * state the new lap starts from), n_log[b] = 1.  status[b] = 1: the race's safe set is full (iter == n_laps), nothing stored. */
+int crx_lmpc_addtraj_dev(const crx_lmpcprep_desc* d, int batch, const int32_t* crossed, double* log_x, const double* log_u,
+                         int32_t* n_log, double* ss_xcurv, double* u_ss, double* qfun, int32_t* time_ss, int32_t* iter,
+                         int32_t* step, const double* x, int32_t* status, void* stream);
 
 /*
  * MPC-CBF NLPs.

@@ -222,3 +222,45 @@ int crx_oracle_lmpc_addpoint(const crx_lmpcprep_desc* d, int batch, double* ss_x
     }
     return CRX_OK;
 }
+
+/* LMPCRacingGame.add_trajectory (utils/base.py:631-656): the lap a race has just completed becomes lap `iter` of its safe set.
+ * log_x [batch][P][6] / log_u [batch][P][2] hold the running lap as the simulator logs it (update_memory, base.py:795-819):
+ * n_log states, the last one the crossing state with s > lap_length (unwrapped), n_log - 1 inputs.  For every race with
+ * crossed != 0:  ss[lap][0..n] = states, us[lap][0..n-1] = inputs, time_ss[lap] = n = n_log - 1,  Qfun = compute_cost
+ * (lmpc_helper.py:11-23: 0 at the last sample and past the finish line, else one more than the successor) followed by the
+ * reference's "zero means keep counting down" pass over the WHOLE column (:647-649; entry 0 would read entry -1, i.e. the
+ * last one, like numpy does),  iter += 1, step = 0 (time_in_iter), and the log restarts with x (the wrapped state the new lap
+ * starts from).  A race whose safe set is full (iter == n_laps) keeps racing without storing: status 1. */
+int crx_oracle_lmpc_addtraj(const crx_lmpcprep_desc* d, int batch, const int32_t* crossed, double* log_x, const double* log_u,
+                            int32_t* n_log, double* ss_xcurv, double* u_ss, double* qfun, int32_t* time_ss, int32_t* iter,
+                            int32_t* step, const double* x, int32_t* status) {
+    if (!d || batch < 0) return CRX_ERR_ARG;
+    const int P = d->n_points, L = d->n_laps;
+    for (int b = 0; b < batch; b++) {
+        status[b] = 0;
+        if (!crossed[b]) continue;
+        const int lap = iter[b];
+        int n = n_log[b] - 1;
+        if (n > P - 1) n = P - 1;
+        double* lx = log_x + (size_t)b * P * 6;
+        if (lap >= 0 && lap < L && n >= 1) {
+            double* sx = ss_xcurv + ((size_t)b * L + lap) * P * 6;
+            double* su = u_ss + ((size_t)b * L + lap) * P * 2;
+            double* q = qfun + ((size_t)b * L + lap) * P;
+            const double* lu = log_u + (size_t)b * P * 2;
+            for (int e = 0; e < (n + 1) * 6; e++) sx[e] = lx[e];
+            for (int e = 0; e < n * 2; e++) su[e] = lu[e];
+            time_ss[(size_t)b * L + lap] = n;
+            q[n] = 0.0;
+            for (int i = n - 1; i >= 0; i--) q[i] = lx[6 * i + 4] < d->lap_length ? q[i + 1] + 1.0 : 0.0;
+            for (int i = 0; i < P; i++)
+                if (q[i] == 0.0) q[i] = q[i > 0 ? i - 1 : P - 1] - 1.0;
+            iter[b] = lap + 1;
+        } else
+            status[b] = 1;
+        step[b] = 0;
+        for (int k = 0; k < 6; k++) lx[k] = x[(size_t)b * 6 + k];
+        n_log[b] = 1;
+    }
+    return CRX_OK;
+}

@@ -339,6 +339,55 @@ def test_batched_lmpc_laps(golden_racing_game):
         assert x[:done[b], b, 0].max() > 1.0                                       # it did accelerate beyond the 0.74 m/s of the stored laps
 
 
+def test_batched_lmpc_multi_lap(golden_racing_game):
+    """Lap after lap on the device: crx_lmpc_addtraj_dev hands every completed lap over to the race's safe set
+    (LMPCRacingGame.add_trajectory, called between laps by the reference's tests/auto_racing_game_test.py), the next lap
+    learns from it.  16 races (8 copies of the reference's scenario, 8 perturbed), 330 steps: every race completes two
+    learning-MPC laps and fills its safe set (laps 2 and 3 of 4); the stored laps are what the race drove (the first state
+    of lap 3 is the wrapped crossing state of lap 2, the cost-to-go counts down to the line); the second lap is not slower
+    than the first (it learned from it); everything stays on the track."""
+    import helpers
+    from crx import montecarlo
+
+    g = golden_racing_game
+    track = _track(1.0)
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    Bn, steps = 16, 330
+    rng = np.random.default_rng(4)
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    x0[8:, 0] += rng.uniform(-0.03, 0.03, 8); x0[8:, 5] += rng.uniform(-0.05, 0.05, 8); xg0[:, 0] = x0[:, 0]
+    tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
+    laps = montecarlo.LmpcLaps(track.point_and_tangent, track.lap_length, track.width, tile(ss), tile(us), tile(qf), tile(time_ss),
+                               np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(lin_points), tile(lin_input))
+    s_log, done = [], [[] for _ in range(Bn)]
+    import torch
+    prev = laps.laps.clone()
+    for k in range(steps):
+        laps.step()
+        cr = (laps.laps > prev).cpu().numpy(); prev = laps.laps.clone()
+        for b in np.nonzero(cr)[0]:
+            done[b].append(k + 1)
+        s_log.append(laps.xc[:, 4:6].clone())
+    torch.cuda.synchronize()
+    xy = torch.stack(s_log).cpu().numpy()
+    assert np.isfinite(xy).all() and np.abs(xy[:, :, 1]).max() <= track.width
+    it, tss = laps.it.cpu().numpy(), laps.time_ss.cpu().numpy()
+    sso, qfo = laps.ss.cpu().numpy(), laps.qf.cpu().numpy()
+    L = track.lap_length
+    for b in range(Bn):
+        assert len(done[b]) >= 2, (b, done[b])
+        t1, t2 = done[b][0], done[b][1] - done[b][0]
+        assert it[b] == 4 and tss[b, 2] == t1 and tss[b, 3] == t2, (b, it[b], tss[b], done[b])
+        assert 100 < t1 < 200 and 50 < t2 <= t1, (b, t1, t2)            # the second lap learned from the first: 150 -> ~90 steps
+        # the stored laps: start where the previous lap crossed (wrapped), end just past the line, cost-to-go counts down to it
+        assert sso[b, 2, t1, 4] > L and sso[b, 2, t1 - 1, 4] < L and sso[b, 3, t2, 4] > L
+        np.testing.assert_allclose(sso[b, 3, 0], sso[b, 2, t1] - np.array([0, 0, 0, 0, L, 0]), atol=0, rtol=0)
+        np.testing.assert_array_equal(qfo[b, 2, :t1 + 3], np.r_[np.arange(t1, 0, -1.0), 0.0, -1.0, -2.0])
+    np.testing.assert_array_equal(np.array([done[b][:2] for b in range(1, 8)]), np.array([done[0][:2]] * 7))   # copies: identical
+    t1s = np.array([done[b][0] for b in range(Bn)]); t2s = np.array([done[b][1] - done[b][0] for b in range(Bn)])
+    assert t2s.mean() <= t1s.mean() + 3, (t1s, t2s)
+
+
 def test_batched_game_laps(AB, golden_racing_game):
     """crx.montecarlo.game_laps: laps of the racing game WITH traffic, batched and device-resident -- scene -> prep -> region
     QPs -> selection -> tracking NLP in the overtake branch, regression -> LMPC QP -> add_point in the learning-MPC branch,

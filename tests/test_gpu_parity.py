@@ -1008,3 +1008,44 @@ def test_packed_wave_reductions(gpu):
         assert abs(out[12] - ref_s[0]) <= tol[0] and out[13] == ref_m[1] and out[14] == x[2].min()
         if trial == 5:
             np.testing.assert_array_equal(out[0:4], 2016.0 * np.arange(1, 5))
+
+
+def test_lmpc_addtraj_device(gpu, golden_racing_game):
+    """crx_lmpc_addtraj_dev (add_trajectory on the device, masked by `crossed`) against the oracle, which
+    tests/test_oracle_golden.py pins to the safe set the reference's own code built: everything it touches, bit for bit --
+    races that crossed, races that did not, races whose safe set is full."""
+    import ctypes as C
+
+    import torch
+
+    import oracle
+    from crx import abi, torch_api
+    from test_oracle_golden import _oracle_addtraj
+    oracle.load()
+    lib = C.CDLL(oracle._LIB)
+    g = golden_racing_game
+    Bn, P, L, Ls = 48, 600, 4, float(g["lap_length"])
+    d = abi.lmpcprep_desc(12, P, L, 9, 0.1, Ls)
+    rng = np.random.default_rng(12)
+    ss, us, qf = rng.normal(size=(Bn, L, P, 6)), rng.normal(size=(Bn, L, P, 2)), rng.normal(size=(Bn, L, P))
+    time_ss = rng.integers(100, 300, (Bn, L)).astype(np.int32)
+    it = rng.integers(2, L + 1, Bn).astype(np.int32)                    # some races are full (it == L)
+    step = rng.integers(0, 200, Bn).astype(np.int32)
+    crossed = (rng.random(Bn) < 0.6).astype(np.int32)
+    n_log = rng.integers(120, 320, Bn).astype(np.int32)
+    log_x, log_u = rng.normal(size=(Bn, P, 6)), rng.normal(size=(Bn, P, 2))
+    for b in range(Bn):                                                 # s rises along the lap and passes the line at the last sample
+        log_x[b, :n_log[b], 4] = np.linspace(0.01, Ls + 0.05, n_log[b])
+    x = rng.normal(size=(Bn, 6))
+    host = [a.copy() for a in (log_x, log_u, n_log, ss, us, qf, time_ss, it, step)]
+    st_o = _oracle_addtraj(lib, d, crossed, host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8], x)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    dv = [t(a) for a in (log_x, log_u, n_log, ss, us, qf, time_ss, it, step)]
+    st_d = torch.zeros(Bn, dtype=torch.int32, device=dev)
+    torch_api.lmpc_addtraj_dev(d, t(crossed), dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], dv[8], t(x), st_d)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st_d.cpu().numpy(), st_o)
+    for name, a, b in zip(("log_x", "log_u", "n_log", "ss", "us", "qf", "time_ss", "it", "step"), dv, host):
+        np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=name)
+    assert (st_o == 1).sum() >= 3 and ((crossed == 1) & (st_o == 0)).sum() >= 10 and (crossed == 0).sum() >= 10

@@ -347,3 +347,56 @@ def test_lmpc_noise_floor_qps_end_early(orc):
     z = np.load(os.path.join(conftest.ROOT, "tests", "golden", "lmpc_noise_floor.npz"))
     r = orc.lmpc_solve(abi.lmpc_desc(12, 44), *[z[k] for k in ("x0", "u_old", "A", "B", "C", "ss", "qfun", "n_ss")])
     assert (r["status"] != 0).all() and r["iters"].max() <= 80 and np.isfinite(r["U"]).all()
+
+
+def _oracle_addtraj(lib, d, crossed, log_x, log_u, n_log, ss, us, qf, time_ss, it, step, x):
+    import ctypes as C
+    status = np.zeros(len(crossed), dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    rc = lib.crx_oracle_lmpc_addtraj(C.byref(d), C.c_int(len(crossed)), p(crossed), p(log_x), p(log_u), p(n_log), p(ss), p(us), p(qf),
+                                     p(time_ss), p(it), p(step), p(x), p(status))
+    assert rc == 0
+    return status
+
+
+def test_lmpc_add_trajectory_vs_reference_safe_set(golden_racing_game):
+    """crx_oracle_lmpc_addtraj (LMPCRacingGame.add_trajectory, utils/base.py:631-656) against the safe set the reference's
+    own code built from its PID lap and its mpc-lti lap (tests/golden/racing_game.npz: lap0/*, lap1/* are the logged laps,
+    ss/* the arrays after both add_trajectory calls): states, inputs, time_ss and the whole cost-to-go column incl. the
+    reference's count-down pass -- exact."""
+    import ctypes as C
+
+    import oracle
+    from crx import abi
+    oracle.load()
+    lib = C.CDLL(oracle._LIB)
+    g = golden_racing_game
+    P, L = g["ss/ss0"].shape[0], g["ss/ss0"].shape[2]
+    d = abi.lmpcprep_desc(12, P, L, 9, float(g["timestep"]), float(g["lap_length"]))
+    ss, us, qf = np.zeros((1, L, P, 6)), np.zeros((1, L, P, 2)), np.zeros((1, L, P))
+    time_ss, it, step = np.zeros((1, L), dtype=np.int32), np.zeros(1, dtype=np.int32), np.full(1, 7, dtype=np.int32)
+    for lap in (0, 1):
+        xs, u = g["lap%d/xcurv" % lap], g["lap%d/u" % lap]
+        log_x, log_u = np.zeros((1, P, 6)), np.zeros((1, P, 2))
+        log_x[0, :len(xs)] = xs; log_u[0, :len(u)] = u
+        n_log = np.array([len(xs)], dtype=np.int32)
+        x_next = xs[-1] - np.array([0, 0, 0, 0, float(g["lap_length"]), 0])
+        st = _oracle_addtraj(lib, d, np.ones(1, dtype=np.int32), log_x, log_u, n_log, ss, us, qf, time_ss, it, step, x_next[None].copy())
+        assert st[0] == 0 and it[0] == lap + 1 and step[0] == 0 and n_log[0] == 1
+        np.testing.assert_array_equal(log_x[0, 0], x_next)
+        step[0] = 5
+    ref_ss = np.ascontiguousarray(g["ss/ss0"].transpose(2, 0, 1)); ref_u = np.ascontiguousarray(g["ss/u0"].transpose(2, 0, 1))
+    ref_q = np.ascontiguousarray(g["ss/Qfun0"].T)
+    for lap in (0, 1):
+        n = int(g["ss/time_ss"][lap])
+        assert time_ss[0, lap] == n == len(g["lap%d/u" % lap])
+        np.testing.assert_array_equal(ss[0, lap, :n + 1], ref_ss[lap, :n + 1])
+        np.testing.assert_array_equal(us[0, lap, :n], ref_u[lap, :n])
+        np.testing.assert_array_equal(qf[0, lap], ref_q[lap])                   # the whole column, count-down included
+    # a race that did not cross is left alone; a full safe set reports status 1 and restarts the log
+    it[0] = L
+    log_x = np.ones((1, P, 6)); n_log = np.array([40], dtype=np.int32); keep = ss.copy()
+    st = _oracle_addtraj(lib, d, np.zeros(1, dtype=np.int32), log_x, np.ones((1, P, 2)), n_log, ss, us, qf, time_ss, it, step, np.zeros((1, 6)))
+    assert st[0] == 0 and n_log[0] == 40 and (ss == keep).all()
+    st = _oracle_addtraj(lib, d, np.ones(1, dtype=np.int32), log_x, np.ones((1, P, 2)), n_log, ss, us, qf, time_ss, it, step, np.zeros((1, 6)))
+    assert st[0] == 1 and n_log[0] == 1 and it[0] == L and (ss == keep).all()
