@@ -294,18 +294,18 @@ def make_overtake(cx, args, batch=None):
     qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
     rng = np.random.default_rng(70 + cx.rank)
     x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
-    s0 = np.sort(rng.uniform(1.5, 8.0, (Bn, 2)), axis=1); s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 1.2)   # traffic close ahead: most steps overtake
-    v = rng.uniform(0.5, 0.9, (Bn, 2)); ey = rng.choice([-0.5, -0.2, 0.1, 0.4], (Bn, 2))
+    s0, v, ey = synth.multi_tests_traffic(Bn, 3, seed=70 + cx.rank)      # the reference's own random traffic (--multi-tests), 3 cars
     tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
     laps = montecarlo.GameLaps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
                                np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey, device=cx.dev)
     from crx import torch_api
-    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 2, laps.track_desc, laps.tws
-    w.kernel = "crx_solve_kernel<2>"
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 3, laps.track_desc, laps.tws
+    w.kernel = "crx_solve_kernel<3>"
     w.step = laps.step
     w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws)
-    w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against two "
-              "scripted cars each, one control step of every race per step: scene, Bezier/bounds, 3 region QPs + selection, tracking NLP (N=10, CBF rows), "
+    w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against three "
+              "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
+              "selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
     w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch"}
     return w
@@ -399,9 +399,11 @@ def measure(cx, w, steps, warmup, with_latency=True):
            "horizon": int(N), "n_obs": 0 if w.kind == "lmpc" else int(n_obs), "n_ss": int(n_obs) if w.kind == "lmpc" else 0,
            "tol": w.desc.opts.tol,
            "status_frac": {"converged": float(conv.mean()), "max_iter": float((st == 1).mean()),
-                           "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean())},
+                           "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean()),
+                           "skipped_masked": float((st == 4).mean())},
            "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
-           "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)), "iters_max": int(it.max())}
+           "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
+           "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
     if with_latency:
         cfg.update({"p50_step_latency_ms": float(np.median(lat)), "p99_step_latency_ms": float(np.percentile(lat, 99)),
                     "p50_host_call_one_control_step_ms": float(np.median(hlat)) if hlat else None})

@@ -280,7 +280,7 @@ class GameLaps:
         # scripted cars at their own clock t: s = v t + s0 (wrapped once past the line, update_memory), predictions unwrapped (quirk Q6)
         s_now = self.v * self.t + self.s0
         self.veh[:, :, 0] = self.v
-        self.veh[:, :, 4] = torch.where(s_now > L, s_now - L, s_now)
+        self.veh[:, :, 4] = s_now - L * torch.clamp(torch.ceil(s_now / L) - 1.0, min=0.0)   # update_memory: wrapped whenever s > L, lap after lap
         self.veh[:, :, 5] = self.ey
         pred_s = (self.v[:, :, None] * (self.t + self.jdt)[None, None, :] + self.s0[:, :, None]).contiguous()
         pred_e = (self.ey[:, :, None] + 0.0 * self.jdt[None, None, :]).contiguous()

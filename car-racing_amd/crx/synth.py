@@ -181,3 +181,14 @@ def cfg3_planner(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP
         ey_ub=ub.reshape(n_scen * R), N=N, V=V, n_scen=n_scen, n_veh=w["n_veh"], obs_s=w["obs_s"], obs_ey=w["obs_ey"],
         old_flag=w["old_flag"], lap_length=lap_length, raw=w,
     )
+
+
+def multi_tests_traffic(n, num_veh=3, seed=0):
+    """The scripted cars of the reference's Monte-Carlo experiment (car_racing/tests/overtake_planner_test.py:81-90,
+    `--multi-tests` / `--random-other-agents`): car i drives s(t) = 0.1 randint(0, 10) t + 3 + randint(0, 14) at the constant
+    offset ey = 0.7 - 0.1 randint(0, 14) (Python's randint is inclusive).  Returns s0, v, ey as [n, num_veh] arrays."""
+    rng = np.random.default_rng(seed)
+    v = 0.1 * rng.integers(0, 11, (n, num_veh))
+    s0 = 3.0 + rng.integers(0, 15, (n, num_veh))
+    ey = 0.7 - 0.1 * rng.integers(0, 15, (n, num_veh))
+    return s0.astype(float), v.astype(float), ey.astype(float)
