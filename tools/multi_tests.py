@@ -39,6 +39,7 @@ def main():
     prev_laps = r.lm.laps.clone()
     min_gap = torch.full((Bn,), 1e9, dtype=torch.float64, device=dev)       # min over time and cars of (ds/l)^6 + (dey/w)^6 (>= 1: no contact)
     off = torch.zeros((Bn,), dtype=torch.bool, device=dev)
+    ey_max = torch.zeros((Bn,), dtype=torch.float64, device=dev)
     ot_steps = torch.zeros((Bn,), dtype=torch.int64, device=dev)
     ahead0 = None
     torch.cuda.synchronize(); t0 = time.time()
@@ -49,6 +50,7 @@ def main():
         de = r.lm.xc[:, 5:6] - cey
         min_gap = torch.minimum(min_gap, ((ds / 0.4) ** 6 + (de / 0.2) ** 6).min(dim=1).values)
         off |= r.lm.xc[:, 5].abs() > track.width
+        ey_max = torch.maximum(ey_max, r.lm.xc[:, 5].abs())
         ot_steps += r.overtake.long()
         crossed = (r.lm.laps > prev_laps).cpu().numpy(); prev_laps = r.lm.laps.clone()
         for b in np.nonzero(crossed)[0]:
@@ -66,6 +68,7 @@ def main():
     print("steps in the overtake branch per race: p5 %d p50 %d p95 %d" % tuple(np.percentile(ot_steps.cpu().numpy(), [5, 50, 95])))
     print("contact with a car (super-ellipse (ds/0.4)^6 + (dey/0.2)^6 < 1 at some step): %d races (%.1f %%)" % ((mg < 1.0).sum(), 100 * (mg < 1.0).mean()))
     print("left the track (|ey| > %.1f at some step): %d races (%.1f %%)" % (track.width, off.sum().item(), 100 * off.float().mean().item()))
+    print("max |ey| over the run: p50 %.3f p90 %.3f p99 %.3f max %.3f" % tuple(np.percentile(ey_max.cpu().numpy(), [50, 90, 99, 100])))
     print("non-finite states: %d" % int((~torch.isfinite(r.lm.xc)).any(dim=1).sum().item()))
 
 
