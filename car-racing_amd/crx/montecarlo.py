@@ -232,8 +232,8 @@ class GameLaps:
       crx_plant_step_wrap_dev
 
     Every launch covers the whole batch; the heavy kernels of a branch (tracking NLP; regression + learning-MPC QP) are
-    MASKED launches (crx_*_masked_dev): the wavefront of a race that is in the other branch returns at once.  The cheap
-    planner front (prep, three region QPs, selection: 0.3 ms per 1024 races) runs for every race.  The applied input, the
+    MASKED launches (crx_*_masked_dev): the wavefront of a race that is in the other branch returns at once -- the region
+    QPs of the planner included; the cheap kernels around them (scene, prep, selection, tracking prep) run for every race.  The applied input, the
     plan hand-over (u_old, linearisation points), add_point and the direction flag are taken from the branch the race is
     in; no host round trip, no compaction.  Nine libcrx launches per step."""
 
@@ -292,7 +292,7 @@ class GameLaps:
         torch_api.planner_prep_dev(self.prep, lm.xc, lm.xc, self.sws.n_veh, self.sws.veh_info, self.sws.max_dv, self.sws.obs_s, self.sws.obs_ey,
                                    self.opt_s, self.opt_ey, ws=self.pws)
         torch_api.planner_plan_dev(self.plan, self.sel, self.pws.x0, self.pws.bez_s, self.pws.bez_ey, self.pws.ey_lb, self.pws.ey_ub,
-                                   self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.old_flag, self.qws, self.selws)
+                                   self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.old_flag, self.qws, self.selws, active=m_ot)
         torch_api.track_prep_dev(self.Np, self.V, L, lm.xc, self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.selws.best_X, self.xt,
                                  self.obs_s, self.obs_e, self.lap_off, self.n_obs)
         torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws, active=m_ot)

@@ -330,10 +330,13 @@ def planner_scene_dev(desc, ego_xcurv, n_all, veh_xcurv, pred_s, pred_ey, ws=Non
     return ws
 
 
-def planner_plan_dev(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag, ws, sws):
-    """crx_planner_plan_dev: all region QPs of every scenario + the selection, on one stream."""
+def planner_plan_dev(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag, ws, sws, active=None):
+    """crx_planner_plan_dev: all region QPs of every scenario + the selection, on one stream (with `active`, int32
+    [n_scen]: crx_planner_plan_masked_dev, the QPs of the scenarios with 0 are skipped)."""
     S = n_veh.shape[0]
-    _call("crx_planner_plan_dev", C.byref(desc), C.byref(sdesc), C.c_int(S), _ptr(x0), _ptr(bez_s), _ptr(bez_ey), _ptr(ey_lb), _ptr(ey_ub),
+    if active is not None:
+        _chk(active, torch.int32, (S,), "active")
+    _call("crx_planner_plan_masked_dev", C.byref(desc), C.byref(sdesc), C.c_int(S), _ptr(active), _ptr(x0), _ptr(bez_s), _ptr(bez_ey), _ptr(ey_lb), _ptr(ey_ub),
           _ptr(n_veh), _ptr(obs_s), _ptr(obs_ey), _ptr(old_flag), _ptr(ws.X), _ptr(ws.U), _ptr(ws.cost), _ptr(ws.status), _ptr(ws.kkt),
           _ptr(ws.iters), _ptr(sws.flag), _ptr(sws.sel_cost), _ptr(sws.best_X), _stream())
 

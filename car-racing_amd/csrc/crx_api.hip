@@ -368,9 +368,19 @@ void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double la
 }
 
 // ---- planner --------------------------------------------------------------------------------------
+static int planner_solve_masked(const crx_planner_desc* d, int batch, const int32_t* active, int active_div, const double* x0,
+                                const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X,
+                                double* U, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream);
+
 int crx_planner_solve_dev(const crx_planner_desc* d, int batch, const double* x0, const double* bez_s,
                           const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X, double* U,
                           double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
+    return planner_solve_masked(d, batch, nullptr, 0, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters, stream);
+}
+
+static int planner_solve_masked(const crx_planner_desc* d, int batch, const int32_t* active, int active_div, const double* x0,
+                                const double* bez_s, const double* bez_ey, const double* ey_lb, const double* ey_ub, double* X,
+                                double* U, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_kparams kp;
     if (int rc = fill_planner(kp, d, batch)) return rc;
@@ -379,6 +389,7 @@ int crx_planner_solve_dev(const crx_planner_desc* d, int batch, const double* x0
         return fail(CRX_ERR_ARG, "NULL array argument");
     kp.x0 = x0; kp.bez_s = bez_s; kp.bez_ey = bez_ey; kp.ey_lb = ey_lb; kp.ey_ub = ey_ub;
     kp.X = X; kp.U = U; kp.sigma = nullptr; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
+    kp.active = active; kp.active_div = active_div;
     return launch_solve(kp, 0, (hipStream_t)stream);
 }
 
@@ -1003,12 +1014,21 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
                          const int32_t* n_veh, const double* obs_s, const double* obs_ey, const int32_t* old_flag,
                          double* X, double* U, double* cost, int32_t* status, double* kkt, int32_t* iters,
                          int32_t* flag, double* sel_cost, double* best_X, void* stream) {
+    return crx_planner_plan_masked_dev(d, sd, n_scen, nullptr, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag, X, U, cost,
+                                       status, kkt, iters, flag, sel_cost, best_X, stream);
+}
+
+int crx_planner_plan_masked_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const int32_t* active,
+                                const double* x0, const double* bez_s, const double* bez_ey, const double* ey_lb,
+                                const double* ey_ub, const int32_t* n_veh, const double* obs_s, const double* obs_ey,
+                                const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status, double* kkt,
+                                int32_t* iters, int32_t* flag, double* sel_cost, double* best_X, void* stream) {
     if (!d || !sd) return fail(CRX_ERR_ARG, "desc is NULL");
     if (sd->N != d->N) return fail(CRX_ERR_ARG, "planner and selection horizons differ");
     if (int rc = check_select(sd, n_scen)) return rc;   // before R = n_veh_max + 1 sizes the QP launch
     const int R = sd->n_veh_max + 1;
     if ((long long)n_scen * R > 0x7fffffffLL) return fail(CRX_ERR_ARG, "n_scen * (n_veh_max + 1) overflows int");
-    if (int rc = crx_planner_solve_dev(d, n_scen * R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters, stream)) return rc;
+    if (int rc = planner_solve_masked(d, n_scen * R, active, R, x0, bez_s, bez_ey, ey_lb, ey_ub, X, U, cost, status, kkt, iters, stream)) return rc;
     return crx_select_dev(sd, n_scen, n_veh, X, obs_s, obs_ey, old_flag, flag, sel_cost, best_X, stream);
 }
 

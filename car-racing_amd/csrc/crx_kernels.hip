@@ -949,7 +949,7 @@ crx_solve_kernel(const crx_kparams kp) {
     int* si = (int*)(sm + L::END_D);
     const int b = blockIdx.x, lane = threadIdx.x, N = kp.N;
     if (b >= kp.batch) return;
-    if (kp.active && kp.active[b] == 0) {   // masked launch: this problem is not part of it
+    if (kp.active && kp.active[kp.active_div > 1 ? b / kp.active_div : b] == 0) {   // masked launch: this problem is not part of it
         if (lane == 0) { kp.status[b] = CRX_SKIPPED; kp.iters[b] = 0; }
         return;
     }

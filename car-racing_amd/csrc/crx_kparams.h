@@ -27,7 +27,8 @@ struct crx_kparams {
     double* trace;
     int trace_problem, trace_rows;
     int poison;   // diagnostics: fill the LDS slice with NaN before set-up (catches reads of stale LDS)
-    const int32_t* active;   // optional [batch]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
+    const int32_t* active;   // optional [batch / active_div]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
+    int active_div;          // problems per mask entry (planner: the regions of a scenario share one entry); 0 or 1: one each
 };
 
 struct crx_lmpc_kparams {

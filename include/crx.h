@@ -272,6 +272,14 @@ int crx_planner_plan_dev(const crx_planner_desc* d, const crx_select_desc* sd, i
                          const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status,
                          double* kkt, int32_t* iters, int32_t* flag, double* sel_cost, double* best_X,
                          void* stream);
+/* masked launch (see crx_cbf_solve_masked_dev): active [n_scen] on the device, 0 = none of this scenario's region QPs is
+ * solved (their status = CRX_SKIPPED, X / U / cost untouched); the selection still runs for every scenario and, for a
+ * skipped one, works on whatever X holds -- the caller ignores flag / best_X of the scenarios it masked out. */
+int crx_planner_plan_masked_dev(const crx_planner_desc* d, const crx_select_desc* sd, int n_scen, const int32_t* active,
+                                const double* x0, const double* bez_s, const double* bez_ey, const double* ey_lb,
+                                const double* ey_ub, const int32_t* n_veh, const double* obs_s, const double* obs_ey,
+                                const int32_t* old_flag, double* X, double* U, double* cost, int32_t* status, double* kkt,
+                                int32_t* iters, int32_t* flag, double* sel_cost, double* best_X, void* stream);
 
 /*
  * Planner host prep on the device: per scenario, the cubic Bezier reference of

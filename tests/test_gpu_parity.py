@@ -1049,3 +1049,37 @@ def test_lmpc_addtraj_device(gpu, golden_racing_game):
     for name, a, b in zip(("log_x", "log_u", "n_log", "ss", "us", "qf", "time_ss", "it", "step"), dv, host):
         np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=name)
     assert (st_o == 1).sum() >= 3 and ((crossed == 1) & (st_o == 0)).sum() >= 10 and (crossed == 0).sum() >= 10
+
+
+def test_masked_planner_plan(gpu, AB):
+    """crx_planner_plan_masked_dev: the region QPs of a masked-out scenario are skipped (status CRX_SKIPPED, X untouched),
+    the other scenarios' QPs and winners are bit-identical to the unmasked launch."""
+    import torch
+    from crx import abi, synth, torch_api
+    A, B = AB
+    n_scen, N = 96, 12
+    p = synth.cfg3_planner(n_scen, N=N, seed=31)
+    V = p["V"]; R = V + 1
+    d, sd = abi.planner_desc(N, A, B), abi.select_desc(N, V, p["lap_length"])
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)   # noqa: E731
+    qin = [t(p[k]) for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
+    sin = [t(p["n_veh"], torch.int32), t(p["obs_s"]), t(p["obs_ey"]), t(p["old_flag"], torch.int32)]
+
+    def run(active):
+        ws, sws = torch_api.PlannerWorkspace(d, n_scen * R, dev), torch_api.SelectWorkspace(sd, n_scen, dev)
+        ws.X.fill_(-7.0); ws.U.fill_(-7.0)
+        torch_api.planner_plan_dev(d, sd, *qin, *sin, ws, sws, active=active)
+        torch.cuda.synchronize()
+        return ws, sws
+
+    full, fsel = run(None)
+    act = torch.from_numpy((np.arange(n_scen) % 4 != 2).astype(np.int32)).to(dev)
+    ws, sws = run(act)
+    on = act.cpu().numpy() != 0
+    onq = np.repeat(on, R)
+    assert (ws.status.cpu().numpy()[~onq] == abi.CRX_SKIPPED).all() and (ws.X.cpu().numpy()[~onq] == -7.0).all()
+    for k in ("X", "U", "cost", "status", "iters"):
+        np.testing.assert_array_equal(getattr(ws, k).cpu().numpy()[onq], getattr(full, k).cpu().numpy()[onq], err_msg=k)
+    np.testing.assert_array_equal(sws.flag.cpu().numpy()[on], fsel.flag.cpu().numpy()[on])
+    np.testing.assert_array_equal(sws.best_X.cpu().numpy()[on], fsel.best_X.cpu().numpy()[on])
