@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof2
 wl=$1; st=$2
 mkdir -p $O
-ex=""; [ $wl = game ] && ex="--batch 1024"; [ $wl = overtake ] && ex="--batch 1024"   # the committed closed-loop profiles are per 1024 races
+ex=""
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/$wl
 rocprofv3 --kernel-trace --stats -d $O/$wl -o $wl -- python $R/bench.py --steps $st --warmup 3 --workload $wl $ex --no-cpu-baseline > $O/bench_$wl.json 2> $O/err_$wl.log

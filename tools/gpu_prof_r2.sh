@@ -6,7 +6,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg2_filtered cfg3 cfg4 lmpc cfg5 races game overtake; do
   st=50; [ $wl = cfg4 ] && st=5; [ $wl = lmpc ] && st=10; [ $wl = races ] && st=30; [ $wl = cfg5 ] && st=8; [ $wl = game ] && st=40; [ $wl = overtake ] && st=40
-  ex=""; [ $wl = game ] && ex="--batch 1024"; [ $wl = overtake ] && ex="--batch 1024"   # the committed closed-loop profiles are per 1024 races
+  ex=""
   rm -rf $O/$wl
   rocprofv3 --kernel-trace --stats -d $O/$wl -o $wl -- python $R/bench.py --steps $st --warmup 3 --workload $wl $ex --no-cpu-baseline > $O/bench_$wl.json 2> $O/err_$wl.log
   db=$(find $O/$wl -name "*.db" | head -1)
