@@ -37,7 +37,7 @@
 
 #define LMAXF 16
 
-template <int NMAX>
+template <int NMAX, bool DENSE = true>
 struct LL {
     static constexpr int NU2 = 2 * NMAX + 6 /* inputs + initial-state relaxation */, LDK = NU2 + 1, KR = NU2 + 7;
     static constexpr int MS = CRX_MAX_SS;
@@ -55,7 +55,10 @@ struct LL {
     static constexpr int srow(int k, int ey) { return 2 * (k - 1) + ey; }          // 1 <= k <= N-1
     static constexpr int srowN(int c6) { return 2 * (NMAX - 1) + c6; }              // stage N
     static constexpr int Hu = S + SROWS * NU2;                 // NU2 x NU2, row-major, stride NU2
-    static constexpr int SS = Hu + NU2 * NU2;                  // [6][MS]
+    // DENSE = false: no tracking cost (Q == 0, the reference's default, utils/base.py:353): Hu = 2 R + the dR difference
+    // stencil is diagonal + two off-diagonals and is never stored (hu_entry / hu_dot below) -- 7.2 KB less at N = 12,
+    // 38 864 -> 31 664 B = five instead of four QPs per CU
+    static constexpr int SS = Hu + (DENSE ? NU2 * NU2 : 0);    // [6][MS]
     static constexpr int qf = SS + 6 * MS;
     static constexpr int u = qf + MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
     static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS;
@@ -79,6 +82,46 @@ struct LCtx {
     int r_st, r_lam, r_el;
 };
 
+// Hu of the Q == 0 case without storing it: row a of the inputs block is [.. -2 dR .. 2 R + 2 dR (+ 2 dR) .. -2 dR ..] at
+// columns a - 2, a, a + 2 (control.py:667-681: R u^2 + dR (u_i - u_{i-1})^2), the relaxation block 2 w_x0 on its diagonal.
+__device__ __forceinline__ double hu_band_diag(const LCtx& x, const crx_lmpc_kparams& kp, int a) {
+    const int i = a >> 1, cc = a & 1;
+    const double R = cc ? kp.R[1] : kp.R[0], dR = cc ? kp.dR[1] : kp.dR[0];
+    return a < x.nu2 ? 2.0 * R + 2.0 * dR + (i + 1 < x.N ? 2.0 * dR : 0.0) : 2.0 * kp.w_x0;
+}
+template <class L, bool DENSE>
+__device__ __forceinline__ double hu_entry(const double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int a, int b) {
+    if (DENSE) return sm[L::Hu + a * L::NU2 + b];
+    const double off = (a < x.nu2 && b < x.nu2 && (b == a - 2 || b == a + 2)) ? -2.0 * ((a & 1) ? kp.dR[1] : kp.dR[0]) : 0.0;
+    return b == a ? hu_band_diag(x, kp, a) : off;
+}
+// init + (Hu v)[a] exactly as the dense two-accumulator loop forms it (s0 over the even columns starting at init, s1 over
+// the odd ones starting at 0, ascending; the zero entries contribute fma(0, v, s) = s): the three band terms of row a
+// share its parity, hence one accumulator.
+template <class L, bool DENSE>
+__device__ __forceinline__ double hu_dot(const double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int a, int voff, double init) {
+    if (DENSE) {
+        double s0 = init, s1 = 0.0;
+#pragma unroll 4
+        for (int b = 0; b < x.nv; b += 2) {
+            s0 = fma(sm[L::Hu + a * L::NU2 + b], sm[voff + b], s0);
+            s1 = fma(sm[L::Hu + a * L::NU2 + b + 1], sm[voff + b + 1], s1);
+        }
+        return s0 + s1;
+    }
+    const bool inp = a < x.nu2, even = (a & 1) == 0;
+    const int i = a >> 1;
+    const double dR2 = -2.0 * ((a & 1) ? kp.dR[1] : kp.dR[0]);
+    const double hm = (inp && i > 0) ? dR2 : 0.0, hp = (inp && i + 1 < x.N) ? dR2 : 0.0, dd = hu_band_diag(x, kp, a);
+    const double vm = sm[voff + (a >= 2 ? a - 2 : 0)], v0 = sm[voff + a], vp = sm[voff + (a + 2 < x.nv ? a + 2 : a)];
+    double acc = even ? init : 0.0;
+    acc = fma(hm, vm, acc);
+    acc = fma(dd, v0, acc);
+    acc = fma(hp, vp, acc);
+    return even ? acc + 0.0 : init + acc;
+}
+
+
 #define LDS(i) sm[(i)]
 #define LSINK(cond, off) seli((cond), (off), L::dmy)
 // all rows of the problem, uniform trip count: a lane past the last row recomputes row 0 (rv = false); pure stores rewrite
@@ -87,9 +130,9 @@ struct LCtx {
     if (const bool rv = r0_ + (lane_) < (m_); true) if (const int r = rv ? r0_ + (lane_) : 0; true)
 
 // rows c_j(v) for the current iterate; rp = c - t
-template <int NMAX>
+template <int NMAX, bool DENSE>
 __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc_kparams& kp) {
-    using L = LL<NMAX>;
+    using L = LL<NMAX, DENSE>;
     // straight-line: every lane evaluates all three row kinds on clamped indices and selects; lanes past the last row
     // recompute row 0.  The state rows sum over ALL inputs -- S[k][.][a] is zero for a >= 2k, the bound was a shortcut.
     for (int r0 = 0; r0 < x.m; r0 += WAVE) {
@@ -116,9 +159,9 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
 }
 
 // (ru, rl) = g + E'y - J'w   with w = the row array at offset `wo`
-template <int NMAX>
+template <int NMAX, bool DENSE>
 __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int wo) {
-    using L = LL<NMAX>;
+    using L = LL<NMAX, DENSE>;
     {
         const bool kv = x.lane >= 1 && x.lane < x.N;
         const int k = kv ? x.lane : 1, r = x.r_st + 3 * (k - 1);
@@ -155,9 +198,9 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
     SYNC();
 }
 
-template <int NMAX>
+template <int NMAX, bool DENSE>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
-    using L = LL<NMAX>;
+    using L = LL<NMAX, DENSE>;
     extern __shared__ double sm[];
     const int pb = blockIdx.x;
     if (pb >= kp.batch) return;
@@ -189,7 +232,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     if (lane < 6) LDS(L::xf + lane) = kp.x0[6 * pb + lane];
     const double uold0 = kp.u_old[2 * pb], uold1 = kp.u_old[2 * pb + 1];
     for (int i = lane; i < L::SROWS * L::NU2; i += WAVE) LDS(L::S + i) = 0.0;
-    for (int i = lane; i < L::NU2 * L::NU2; i += WAVE) LDS(L::Hu + i) = 0.0;
+    if (DENSE)
+        for (int i = lane; i < L::NU2 * L::NU2; i += WAVE) LDS(L::Hu + i) = 0.0;
     SYNC();
     // free response
     for (int k = 0; k < N; k++) {
@@ -207,15 +251,18 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         const int a = lane, i = a >> 1, cc = a & 1;
         const double R = cc ? kp.R[1] : kp.R[0], dR = cc ? kp.dR[1] : kp.dR[0];
         double dd = 2.0 * R + 2.0 * dR + (i + 1 < N ? 2.0 * dR : 0.0);
-        LDS(L::Hu + a * L::NU2 + a) = dd;
-        if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
-        if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
+        if (DENSE) {
+            LDS(L::Hu + a * L::NU2 + a) = dd;
+            if (i > 0) LDS(L::Hu + a * L::NU2 + a - 2) = -2.0 * dR;
+            if (i + 1 < N) LDS(L::Hu + a * L::NU2 + a + 2) = -2.0 * dR;
+        }
+        (void)dd;
         LDS(L::g0u + a) = i == 0 ? -2.0 * dR * (cc ? uold1 : uold0) : 0.0;
     } else if (lane < nu2 + 6) {
-        LDS(L::Hu + lane * L::NU2 + lane) = 2.0 * kp.w_x0;
+        if (DENSE) LDS(L::Hu + lane * L::NU2 + lane) = 2.0 * kp.w_x0;
         LDS(L::g0u + lane) = 0.0;
     }
-    if (anyQ) {
+    if (DENSE && anyQ) {   // (the launcher picks the dense instantiation whenever Q != 0)
         for (int c6 = 0; c6 < 6; c6++) {
             const double r0 = LDS(L::xf + c6) - kp.x_track[c6];
             f0 += kp.Q[c6] * r0 * r0;
@@ -251,7 +298,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     for (int r = 0; r < 6; r++) LDS(L::S + L::srowN(r) * L::NU2 + a) = nc[r];
                 }
             }
-            if (anyQ) {
+            if (DENSE && anyQ) {
                 if (col_on)
                     for (int r = 0; r < 6; r++) LDS(L::TB + r * L::NU2 + a) = nc[r];
                 SYNC();
@@ -294,7 +341,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         if (lane < 8) LDS(L::y + lane) = 0.0;
         for (int r = lane; r < m; r += WAVE) LDS(L::t + r) = 0.0;
         SYNC();
-        l_rows<NMAX>(sm, x, kp);
+        l_rows<NMAX, DENSE>(sm, x, kp);
         SYNC();
         for (int r = lane; r < m; r += WAVE) {
             LDS(L::t + r) = fmax(fabs(LDS(L::c + r)), o.slack_push);
@@ -331,17 +378,11 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
 #endif
             TICK();
             // ---- rows, gradient, equality residual ----
-            l_rows<NMAX>(sm, x, kp);
+            l_rows<NMAX, DENSE>(sm, x, kp);
             {   // gu = g0u + Hu u (lane = row); lanes past nv run row 0 and store to the sink.  Two accumulators.
                 const bool av = lane < nv;
                 const int a = av ? lane : 0;
-                double s0 = LDS(L::g0u + a), s1 = 0.0;
-#pragma unroll 4
-                for (int b = 0; b < nv; b += 2) {
-                    s0 = fma(LDS(L::Hu + a * L::NU2 + b), LDS(L::u + b), s0);
-                    s1 = fma(LDS(L::Hu + a * L::NU2 + b + 1), LDS(L::u + b + 1), s1);
-                }
-                LDS(LSINK(av, L::gu + a)) = s0 + s1;
+                LDS(LSINK(av, L::gu + a)) = hu_dot<L, DENSE>(sm, x, kp, a, L::u, LDS(L::g0u + a));
             }
             {   // e_c = x_N,c - SS_c lambd (c < 6), e_6 = 1'lambd - 1: every lane sums a strided part, one wave sum per row
                 double ec[7];
@@ -366,7 +407,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             TICK();   // 1
             // ---- error measure ----
-            l_lagr<NMAX>(sm, x, kp, L::nu);
+            l_lagr<NMAX, DENSE>(sm, x, kp, L::nu);
             double nus = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
             LROWS(r, rv, lane, m) {
                 const double tt = LDS(L::t + r), nn = LDS(L::nu + r), rr = fabs(LDS(L::rp + r));
@@ -440,7 +481,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 LDS(L::wv + r) = fma(-sg, LDS(L::rp + r), mu * ti);
             }
             SYNC();
-            l_lagr<NMAX>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
+            l_lagr<NMAX, DENSE>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
             // stage weights of the state rows for K_u
             {
                 const bool kv = lane >= 1 && lane < N;
@@ -468,7 +509,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     const double d0 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1)), d1 = LDS(L::dnu + 4 * (ad >> 1) + 2 * (ad & 1) + 1);
                     double acc[6];
 #pragma unroll
-                    for (int q = 0; q < 6; q++) acc[q] = LDS(L::Hu + a * L::NU2 + b0 + q) + sel(b0 + q == a && a < nu2, d0 + d1, 0.0);
+                    for (int q = 0; q < 6; q++) acc[q] = hu_entry<L, DENSE>(sm, x, kp, a, b0 + q) + sel(b0 + q == a && a < nu2, d0 + d1, 0.0);
                     for (int k = 1; k < N; k++) {
                         const int r0 = L::S + L::srow(k, 0) * L::NU2, r5 = L::S + L::srow(k, 1) * L::NU2;
                         const double sa0 = LDS(r0 + a), sa5 = LDS(r5 + a), w0k = LDS(L::w0 + k), w5k = LDS(L::w5 + k);
@@ -676,13 +717,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const bool av = lane < nv;
                 const int a = av ? lane : 0, j = lane < M ? lane : 0;
                 const double d = LDS(L::du + a), gua = LDS(L::gu + a);
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll 4
-                for (int b = 0; b < nv; b += 2) {
-                    s0 = fma(LDS(L::Hu + a * L::NU2 + b), LDS(L::du + b), s0);
-                    s1 = fma(LDS(L::Hu + a * L::NU2 + b + 1), LDS(L::du + b + 1), s1);
-                }
-                qd = sel(av, (s0 + s1) * d, 0.0);
+                qd = sel(av, hu_dot<L, DENSE>(sm, x, kp, a, L::du, 0.0) * d, 0.0);
                 gdv = sel(av, gua * d, 0.0) + sel(lane < M, LDS(L::qf + j) * LDS(L::dlam + j), 0.0);
             }
             wave_max2(rp_max, rd_max);
@@ -807,29 +842,45 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     }
 }
 
-template <int NMAX>
+template <int NMAX, bool DENSE>
 static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
-    const size_t bytes = LL<NMAX>::bytes(kp.n_ss_max);
-    hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(crx_lmpc_kernel<NMAX>, dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    const size_t bytes = LL<NMAX, DENSE>::bytes(kp.n_ss_max);
+    // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device
+    static int attr_set_on = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (attr_set_on != dev) {
+        hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        attr_set_on = dev;
+    }
+    hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
+}
+
+// Q == 0 (no tracking cost: the reference's LMPCRacingParam default): the instantiation that does not store Hu
+static bool lmpc_dense(const crx_lmpc_kparams& kp) {
+    for (int c = 0; c < 6; c++)
+        if (kp.Q[c] != 0.0) return true;
+    return false;
 }
 
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     if (kp.batch == 0) return hipSuccess;
-    return kp.N <= 12 ? launch_l<12>(kp, st) : launch_l<CRX_LMPC_MAX_N>(kp, st);
+    if (lmpc_dense(kp)) return kp.N <= 12 ? launch_l<12, true>(kp, st) : launch_l<CRX_LMPC_MAX_N, true>(kp, st);
+    return kp.N <= 12 ? launch_l<12, false>(kp, st) : launch_l<CRX_LMPC_MAX_N, false>(kp, st);
 }
 
-template <int NMAX>
+template <int NMAX, bool DENSE>
 static int occ_l(int n_ss_max) {
     int n = 0;
-    const size_t bytes = LL<NMAX>::bytes(n_ss_max);
-    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX>, WAVE, bytes) != hipSuccess) return -1;
+    const size_t bytes = LL<NMAX, DENSE>::bytes(n_ss_max);
+    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }
-int crx_lmpc_resident_per_cu(int N, int n_ss_max) { return N <= 12 ? occ_l<12>(n_ss_max) : occ_l<CRX_LMPC_MAX_N>(n_ss_max); }
+// (diagnostics: the Q == 0 instantiation, which is what the reference's parameters select)
+int crx_lmpc_resident_per_cu(int N, int n_ss_max) { return N <= 12 ? occ_l<12, false>(n_ss_max) : occ_l<CRX_LMPC_MAX_N, false>(n_ss_max); }
 
-size_t crx_lmpc_lds_bytes(int N, int n_ss_max) { return N <= 12 ? LL<12>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N>::bytes(n_ss_max); }
-static_assert(LL<CRX_LMPC_MAX_N>::bytes(CRX_MAX_SS) <= 160 * 1024, "LDS budget");
+size_t crx_lmpc_lds_bytes(int N, int n_ss_max) { return N <= 12 ? LL<12, false>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N, false>::bytes(n_ss_max); }
+static_assert(LL<CRX_LMPC_MAX_N, true>::bytes(CRX_MAX_SS) <= 160 * 1024, "LDS budget");
