@@ -117,3 +117,22 @@ def random_scenes(S, VA, N, lap_length, seed=0):
     pred_s = veh[:, :, 4, None] + 0.1 * j[None, None, :] * veh[:, :, 0, None]
     pred_ey = veh[:, :, 5, None] + 0.01 * np.sin(j[None, None, :] + veh[:, :, 4, None])
     return ego, n_all, veh, pred_s, pred_ey
+
+
+def thin_corridor_qps(orc, AB, eps, n_scen=128, seed=5):
+    """Planner QPs whose ey corridor is a tube of half-width eps around a trajectory known to be feasible (the solution of the
+    original QP): feasible with margin eps for eps > 0, infeasible by |eps| for eps < 0.  Returns (desc, inputs)."""
+    from crx import abi, synth
+    A, B = AB
+    N = 12
+    p = synth.cfg3_planner(n_scen, N=N, seed=seed)
+    d = abi.planner_desc(N, A, B)
+    keys = ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")
+    r0 = orc.planner_solve(d, *[p[k] for k in keys])
+    ok = np.asarray(r0["status"]) == 0
+    ey = np.asarray(r0["X"])[ok][:, :, 5]
+    q = {k: p[k][ok].copy() for k in keys}
+    q["ey_ub"] = ey[:, 0:N].max(axis=1) + eps                 # one upper bound per problem (overtake_traj_planner.py:277-324)
+    q["ey_lb"][:, 1:] = ey[:, 1:N] - eps
+    q["ey_lb"][:, 0] = np.minimum(q["ey_lb"][:, 0], ey[:, 0] - abs(eps))   # the row on the fixed x0 stays satisfied (quirk Q9)
+    return d, tuple(q[k] for k in keys)

@@ -1083,3 +1083,15 @@ def test_masked_planner_plan(gpu, AB):
         np.testing.assert_array_equal(getattr(ws, k).cpu().numpy()[onq], getattr(full, k).cpu().numpy()[onq], err_msg=k)
     np.testing.assert_array_equal(sws.flag.cpu().numpy()[on], fsel.flag.cpu().numpy()[on])
     np.testing.assert_array_equal(sws.best_X.cpu().numpy()[on], fsel.best_X.cpu().numpy()[on])
+
+
+@pytest.mark.parametrize("eps", [1e-3, 1e-8, -1e-6])
+def test_certificate_on_razor_thin_qps(gpu, orc, AB, eps):
+    """The kernel's infeasibility proof on planner QPs feasible / infeasible by a hair (tests/helpers.py thin_corridor_qps):
+    all converge for eps > 0, all are reported infeasible for eps < 0, verdict by verdict like the oracle."""
+    d, args = helpers.thin_corridor_qps(orc, AB, eps)
+    rg, ro = gpu.planner_solve(d, *args), orc.planner_solve(d, *args)
+    want = 0 if eps > 0 else 2
+    assert (rg["status"] == want).all(), np.bincount(rg["status"], minlength=3)
+    np.testing.assert_array_equal(rg["status"], np.asarray(ro["status"]))
+    assert np.abs(rg["iters"] - np.asarray(ro["iters"])).max() <= 2

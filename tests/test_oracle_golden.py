@@ -400,3 +400,19 @@ def test_lmpc_add_trajectory_vs_reference_safe_set(golden_racing_game):
     assert st[0] == 0 and n_log[0] == 40 and (ss == keep).all()
     st = _oracle_addtraj(lib, d, np.ones(1, dtype=np.int32), log_x, np.ones((1, P, 2)), n_log, ss, us, qf, time_ss, it, step, np.zeros((1, 6)))
     assert st[0] == 1 and n_log[0] == 1 and it[0] == L and (ss == keep).all()
+
+
+@pytest.mark.parametrize("eps", [1e-3, 1e-6, 1e-8])
+def test_certificate_never_fires_on_razor_thin_feasible_qps(orc, AB, eps):
+    """The infeasibility proof on planner QPs that are feasible by a hair: the ey corridor is a tube of half-width eps
+    around a known feasible trajectory.  Every one of them must converge (none may be declared infeasible)."""
+    d, args = helpers.thin_corridor_qps(orc, AB, eps)
+    r = orc.planner_solve(d, *args)
+    assert len(r["status"]) > 200 and (np.asarray(r["status"]) == 0).all(), np.bincount(np.asarray(r["status"]), minlength=3)
+
+
+def test_certificate_fires_on_qps_infeasible_by_a_hair(orc, AB):
+    """... and with the tube turned inside out by 1e-6 every one of them is infeasible, and is reported so."""
+    d, args = helpers.thin_corridor_qps(orc, AB, -1e-6)
+    r = orc.planner_solve(d, *args)
+    assert (np.asarray(r["status"]) == 2).all(), np.bincount(np.asarray(r["status"]), minlength=3)
