@@ -43,6 +43,18 @@ FP64_VALU_PEAK_GFLOPS = 78600.0  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4
 METRIC = "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency"
 
 
+def kernel_source_hash():
+    """sha256 over the sources libcrx is built from: guards numbers kept under profiles/ against a stale kernel."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "car-racing_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(kind, N, n_obs):
     """doubles in + doubles out per solve, times 8."""
     if kind == "planner":
@@ -58,11 +70,15 @@ def algorithmic_bytes(kind, N, n_obs):
 class Ctx:
     """Process-wide state of one bench invocation."""
 
-    def __init__(self):
+    def __init__(self, plumbing=False):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.dev = torch.device("cuda", self.local)
+        # --plumbing-check (tests/test_bench_plumbing.py): the multi-rank control flow of this file -- self-spawn, rendezvous,
+        # sharding, barriers, max-over-ranks timing, the collective, the JSON line -- on CPU tensors over gloo with a stand-in
+        # solver back-end, so that a typo in it cannot surface first on the driver's 8-GPU box.  Measures nothing.
+        self.plumbing = plumbing
+        self.dev = torch.device("cpu") if plumbing else torch.device("cuda", self.local)
 
     def to_dev(self, a, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -71,7 +87,8 @@ class Ctx:
     def sync_all(self):
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not self.plumbing:
+            torch.cuda.synchronize()
 
 
 class Workload:
@@ -123,7 +140,6 @@ def make_cbf(cx, key, args, batch=None, filtered=False):
     w.cpu = ("cbf", w.desc, {k: p[k] for k in keys})
     if key.startswith("cfg2"):   # all-cores CPU figure: 4096 problems of the same generator and seed (the first 256 are the batch)
         pc = synth.cfg2_mpccbf(4096, N=12, seed=2 + seed_shift, safe_start=filtered)
-        pc.update(xt=np.tile(p["xt"][:1], (4096, 1)), lap_off=np.zeros((4096, 1)), n_obs=np.full(4096, 1, dtype=np.int32))
         w.cpu = ("cbf", w.desc, {k: pc[k] for k in keys})
     import crx
     hb = crx.binding()
@@ -181,7 +197,7 @@ def make_sweep(cx, args, scaling):
         n_local = args.sweep_per_gpu
         n_total = n_local * cx.world
         raw = synth.cfg3_raw(n_local, N=12, seed=5 + 1000 * cx.rank)
-    sw = pipeline.PlannerSweep(raw, A, B, n_total, cx.dev)
+    sw = pipeline.PlannerSweep(raw, A, B, n_total, cx.dev, backend=plumbing_backend() if cx.plumbing else None)
     w.key, w.kind, w.baseline_config, w.N, w.n_obs, w.scaling = "cfg5_" + scaling, "planner", 4, 12, 0, scaling
     w.desc, w.ws = sw.desc, sw.ws
     w.batch = w.units = sw.n_local * (sw.V + 1)
@@ -193,6 +209,38 @@ def make_sweep(cx, args, scaling):
                   scaling, n_total, sw.n_local, sw.V + 1, cx.world))
     w.extra = {"scenarios_total": int(n_total), "scenarios_this_rank": int(sw.n_local), "winner_record_bytes": int(sw.exchange.rec * 8),
                "allgather_bytes_per_rank_out": int(sw.exchange.recv.numel() * 8)}
+    return w
+
+
+def plumbing_backend():
+    """--plumbing-check: the stand-in solver back-end named by CRX_BENCH_BACKEND = module:Class (tests/test_bench_plumbing.py
+    passes the one of tests/test_distributed_gloo.py); status / iteration outputs are zeroed so that measure() can read them."""
+    import importlib
+    mod, cls = os.environ["CRX_BENCH_BACKEND"].split(":")
+    be = getattr(importlib.import_module(mod), cls)()
+    inner = be.PlannerWorkspace
+
+    def zeroed(desc, batch, device):
+        ws = inner(desc, batch, device)
+        for k in ("status", "iters", "kkt", "cost", "X", "U"):
+            getattr(ws, k).zero_()
+        return ws
+
+    be.PlannerWorkspace = zeroed
+    return be
+
+
+def make_plumbing_headline(cx):
+    """--plumbing-check: a stand-in for the headline workload (no solver on CPU): same measure() path, a trivial step."""
+    w = Workload()
+    w.key, w.kind, w.N, w.n_obs, w.batch, w.units, w.kernel, w.baseline_config = "plumbing", "cbf", 12, 1, 256, 256, "none", 1
+    w.name = "plumbing check: no solver ran"
+    from crx import abi, synth
+    A, B = synth.load_AB()
+    w.desc = abi.cbf_desc(12, 1, A, B)
+    w.ws = type("WS", (), dict(status=torch.zeros(256, dtype=torch.int32), iters=torch.zeros(256, dtype=torch.int32), kkt=torch.zeros(256, dtype=torch.float64)))()
+    acc = torch.zeros(1)
+    w.step = w.solve = lambda: acc.add_(1.0)
     return w
 
 
@@ -240,7 +288,7 @@ def make_races(cx, args, batch=None):
     w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "races", "cbf", 10, 2, races.desc, races.ws
     w.kernel = "crx_solve_kernel<2>"
     w.step = races.step
-    w.solve = lambda: torch_api.cbf_solve_dev(races.desc, races.xc, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=races.ws)
+    w.solve = lambda: torch_api.cbf_solve_dev(races.desc, races.xc_next, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=races.ws)
     w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
               "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant)" % w.batch)
     return w
@@ -269,7 +317,7 @@ def make_game(cx, args, batch=None):
     w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "game", "lmpc", N, laps.desc.n_ss_max, laps.desc, laps.ws
     w.kernel = "crx_lmpc_kernel"
     w.step = laps.step
-    w.solve = lambda: torch_api.lmpc_solve_dev(laps.desc, laps.xc, laps.u_old, laps.pws.A, laps.pws.B, laps.pws.C, laps.pws.ss, laps.pws.qfun,
+    w.solve = lambda: torch_api.lmpc_solve_dev(laps.desc, laps.xc_next, laps.u_prev, laps.pws.A, laps.pws.B, laps.pws.C, laps.pws.ss, laps.pws.qfun,
                                                laps.n_ss, ws=laps.ws)
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
@@ -302,7 +350,9 @@ def make_overtake(cx, args, batch=None):
     w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 3, laps.track_desc, laps.tws
     w.kernel = "crx_solve_kernel<3>"
     w.step = laps.step
-    w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws)
+    # the tracking-NLP launch of the last step(): the state it was built for (the plant swapped xc / xc_next since) and its mask
+    w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc_next, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws,
+                                              active=laps.overtake.to(torch.int32))
     w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against three "
               "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
               "selection, tracking NLP (N=10, CBF rows), "
@@ -314,7 +364,8 @@ def make_overtake(cx, args, batch=None):
 def measure(cx, w, steps, warmup, with_latency=True):
     """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
     import crx
-    L = crx.lib()
+    L = None if cx.plumbing else crx.lib()
+    dsync = (lambda: None) if cx.plumbing else torch.cuda.synchronize
     for _ in range(warmup):
         w.step()
     cx.sync_all()
@@ -333,14 +384,6 @@ def measure(cx, w, steps, warmup, with_latency=True):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         units_all = int(t.item())
     value = units_all * steps / elapsed
-    # ---- per-launch time of the dominant kernel: HIP events recorded by libcrx on the launch stream ----
-    L.crx_set_timing(1)
-    kms = []
-    for _ in range(min(50, max(5, steps))):
-        w.solve()
-        kms.append(L.crx_last_kernel_ms())
-    L.crx_set_timing(0)
-    k_ms = float(np.mean(kms))
     allgather_ms = None
     if w.gather is not None:                           # the collective alone, same barrier / synchronize bracket
         reps = min(50, max(5, steps))
@@ -357,7 +400,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
         for _ in range(min(100, max(10, steps))):
             t1 = time.perf_counter()
             w.step()
-            torch.cuda.synchronize()
+            dsync()
             lat.append((time.perf_counter() - t1) * 1e3)
         # ONE control step as the reference's class surface issues it: host arrays in, host arrays out -- PCIe-inclusive
         if w.host_call is not None:
@@ -366,13 +409,29 @@ def measure(cx, w, steps, warmup, with_latency=True):
                 t1 = time.perf_counter()
                 w.host_call()
                 hlat.append((time.perf_counter() - t1) * 1e3)
-        w.step()
-        torch.cuda.synchronize()
+    # ---- status / iteration fields: read after one more step(), i.e. they describe a launch the workload really issues
+    w.step()
+    dsync()
     st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
+    # ---- per-launch time of the dominant kernel: HIP events recorded by libcrx on the launch stream.  solve() re-issues
+    # the dominant launch of that last step() with the same inputs and the same mask (closed-loop workloads keep the state
+    # the launch was built for)
+    kms = []
+    if cx.plumbing:
+        kms = [1.0]
+    else:
+        L.crx_set_timing(1)
+        for _ in range(min(50, max(5, steps))):
+            w.solve()
+            kms.append(L.crx_last_kernel_ms())
+        L.crx_set_timing(0)
+    k_ms = float(np.mean(kms))
     conv = st == 0
+    ran = st != 4
     N, n_obs = w.N, w.n_obs
     abytes = algorithmic_bytes(w.kind, N, n_obs)
-    achieved = abytes * w.batch / (k_ms * 1e-3) / 1e9
+    launched = int(ran.sum())                          # masked launches: the problems whose wavefront did not return at once
+    achieved = abytes * launched / (k_ms * 1e-3) / 1e9
     # analytic FP64 work: Riccati factor + solves per interior-point iteration
     nx, nu = 6 + n_obs, 2 + n_obs
     nz = nx + nu
@@ -383,25 +442,33 @@ def measure(cx, w, steps, warmup, with_latency=True):
         flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + (45 * 6 + 6 * 12 + 24 * 4) * M + 4 * (N - 1) * nu2 * nu2 / 2 \
             + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
-    L.crx_debug_lds_bytes.restype = C.c_long
     lk = 1 if w.kind == "lmpc" else 0
-    lds = int(L.crx_debug_lds_bytes(lk, int(N), int(n_obs)))
-    resident = int(L.crx_debug_resident_per_cu(lk, int(N), int(n_obs)))   # runtime: min(LDS, registers)
+    lds, resident = 1, 0
+    if not cx.plumbing:
+        L.crx_debug_lds_bytes.restype = C.c_long
+        lds = int(L.crx_debug_lds_bytes(lk, int(N), int(n_obs)))
+        resident = int(L.crx_debug_resident_per_cu(lk, int(N), int(n_obs)))   # runtime: min(LDS, registers)
     traffic = tnote = None
+    tsrc = "none: no rocprofv3 --pmc summary under profiles/ for this workload and batch"
     try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, rocprofv3 --pmc, calibrated)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
         e = pm.get(w.key.replace("cfg2_filtered", "cfg2").replace("cfg5_weak", "cfg5"))
         if e and e["batch"] == w.batch:
-            traffic, tnote = e["traffic_bytes"], pm.get("note")
+            if pm.get("kernel_source_sha256") == kernel_source_hash():
+                traffic, tnote = e["traffic_bytes"], pm.get("note")
+                tsrc = "profiles/pmc_hbm_traffic.json (kept rocprofv3 --pmc summary of an earlier run of this command, same kernel sources %s); not measured in this run" % pm.get("kernel_source_sha256")
+            else:
+                tsrc = "stale: profiles/pmc_hbm_traffic.json was measured on kernel sources %s, this build is %s" % (pm.get("kernel_source_sha256"), kernel_source_hash())
     except Exception:
         traffic = None
-    cfg = {"workload": w.name, "baseline_config": w.baseline_config, "batch_per_gpu": int(w.batch),
+    cfg = {"workload": w.name, "baseline_config": w.baseline_config, "batch_per_gpu": int(w.batch), "problems_launched": launched,
            "horizon": int(N), "n_obs": 0 if w.kind == "lmpc" else int(n_obs), "n_ss": int(n_obs) if w.kind == "lmpc" else 0,
            "tol": w.desc.opts.tol,
            "status_frac": {"converged": float(conv.mean()), "max_iter": float((st == 1).mean()),
                            "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean()),
                            "skipped_masked": float((st == 4).mean())},
-           "converged_frac": float(conv.mean()), "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
+           "converged_frac": float(conv.mean()), "converged_frac_of_launched": float(conv[ran].mean()) if ran.any() else None,
+           "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
            "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
            "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
     if with_latency:
@@ -409,10 +476,10 @@ def measure(cx, w, steps, warmup, with_latency=True):
                     "p50_host_call_one_control_step_ms": float(np.median(hlat)) if hlat else None})
     if w.extra:
         cfg.update(w.extra)
-    rec = {"key": w.key, "value": value, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+    rec = {"key": w.key, "value": value, "value_converged": value * float(conv[ran].mean()) if ran.any() else 0.0, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
            "scaling": w.scaling, "config": cfg,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "traffic_note": tnote,
                         "kernel": w.kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
                         "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
                         "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
@@ -421,6 +488,24 @@ def measure(cx, w, steps, warmup, with_latency=True):
         rec["allgather_ms"] = allgather_ms
         rec["world_size"] = dist.get_world_size() if dist.is_initialized() else 1
     return rec
+
+
+def compact(rec):
+    """One sub-config in a dozen scalars for the top-level `summary` (the driver's record keeps top-level scalars and
+    dicts but drops the `configs` array): everything DESIGN.md section 6's table quotes."""
+    c, r = rec["config"], rec["roofline"]
+    out = {"value": rec["value"], "value_converged": rec["value_converged"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+           "batch_per_gpu": c["batch_per_gpu"], "problems_launched": c["problems_launched"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
+           "converged_frac": c["converged_frac"], "infeasible_frac": c["status_frac"]["infeasible"], "restored_frac": c["status_frac"]["restored"],
+           "max_iter_frac": c["status_frac"]["max_iter"], "skipped_masked_frac": c["status_frac"]["skipped_masked"],
+           "iters_p50": c["iters_p50"], "iters_p90": c["iters_p90"], "iters_max": c["iters_max"], "roofline_frac": r["frac"],
+           "achieved_GBps": r["achieved"], "traffic": r["traffic"], "resident_per_cu": r["resident_problems_per_cu"]}
+    for k in ("p50_step_latency_ms", "p50_host_call_one_control_step_ms"):
+        if c.get(k) is not None:
+            out[k] = c[k]
+    if "allgather_ms" in rec:
+        out["allgather_ms"] = rec["allgather_ms"]
+    return out
 
 
 def cpu_baseline(w):
@@ -432,7 +517,15 @@ def cpu_baseline(w):
 
     orc = oracle.load()
     kind, desc, p = w.cpu
-    cores = oracle.threads()
+    host_threads = oracle.threads()                  # omp_get_max_threads(): the HOST's cores, not what this container may use
+    quota = None
+    try:   # cgroup v2 CPU quota of the box, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        quota = None
+    affinity = len(os.sched_getaffinity(0))
+    cores = max(1, min(host_threads, affinity, int(np.ceil(quota)) if quota else host_threads))   # threads actually used
 
     def run(n):
         a = tuple(v[:n] for v in p.values())
@@ -453,13 +546,7 @@ def cpu_baseline(w):
     v1, r1, e1 = timed(min(n, 256), 8.0)
     oracle.set_threads(cores)
     vall, rall, eall = timed(n, 10.0)
-    quota = None
-    try:   # cgroup v2 CPU quota of the box, if any: omp_get_max_threads() counts the host's cores, not what the container may use
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q == "max" else float(q) / float(per)
-    except Exception:
-        quota = None
-    out = {"value": vall, "unit": "solves/s", "cores": cores, "cpu_quota_cores": quota, "affinity_cores": len(os.sched_getaffinity(0)),
+    out = {"value": vall, "unit": "solves/s", "cores": cores, "cpu_quota_cores": quota, "affinity_cores": affinity, "host_threads": host_threads,
            "speedup_vs_one_thread": vall / v1, "kind": "port",
            "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (rall, n, eall),
            "one_thread": {"value": v1, "cores": 1, "sample": "%d repetitions of the first %d problems, %.1f s wall" % (r1, min(n, 256), e1)}}
@@ -507,44 +594,60 @@ def main():
     ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
+    ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
+                    help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
-    cx = Ctx()
+    cx = Ctx(plumbing=args.plumbing_check)
     if args.gpus != cx.world:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, cx.world), file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(cx.local)
-    if cx.world > 1 or args.force_collective:
+    if args.plumbing_check:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
-
-    import crx
-    crx.init(cx.local)
+        if cx.world > 1:
+            dist.init_process_group("gloo", rank=cx.rank, world_size=cx.world)
+    else:
+        if not torch.cuda.is_available():
+            print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(cx.local)
+        if cx.world > 1 or (args.force_collective and args.collective == "torch"):
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
+        import crx
+        crx.init(cx.local)
+    from crx import dist as cdist
+    cdist.COLLECTIVE = args.collective
     if args.force_collective:
-        from crx import dist as cdist
         cdist.FORCE_COLLECTIVE = True
     b = args.batch or None
     make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
             "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}
-    head = make[args.workload or "cfg2"]()
-    rec = measure(cx, head, args.steps, args.warmup)
-    out = {"metric": METRIC, "value": rec["value"], "unit": "solves/s", "n_gpus": cx.world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None, "dtype": "f64",
-           "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"]}
+    head = make_plumbing_headline(cx) if args.plumbing_check else make[args.workload or "cfg2"]()
+    rec = measure(cx, head, args.steps, args.warmup, with_latency=not args.plumbing_check)
+    out = {"metric": METRIC, "value": rec["value"], "value_converged": rec["value_converged"], "unit": "solves/s", "n_gpus": cx.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "summary": {head.key: compact(rec)}, "config": rec["config"],
+           "roofline": rec["roofline"]}
     for k in ("allgather_ms", "world_size"):
         if k in rec:
             out[k] = rec[k]
     if cx.rank == 0 and not args.no_cpu_baseline and head.cpu is not None:
         out["cpu_baseline"] = cpu_baseline(head)
-    if args.workload is None and not args.no_sub_configs:
+    if args.plumbing_check:
+        out["configs"] = []
+        for key, sc in (("cfg5_weak", "weak"), ("cfg5_strong", "strong")):
+            r = measure(cx, make_sweep(cx, args, sc), 2, 1, with_latency=False)
+            out["configs"].append(r)
+            out["summary"][key] = compact(r)
+    elif args.workload is None and not args.no_sub_configs:
         # every other single-GPU BASELINE config in the same driver-timed run; slow configs get fewer steps (stated)
         subs = [("cfg2_filtered", lambda: make_cbf(cx, "cfg2_filtered", args, None, filtered=True), args.steps, args.warmup),
                 ("cfg3", lambda: make_planner(cx, args), args.steps, args.warmup),
@@ -558,9 +661,13 @@ def main():
         out["configs"] = []
         for key, mk, st, wu in subs:
             w = mk()
-            out["configs"].append(measure(cx, w, st, wu, with_latency=key in ("cfg3", "cfg4", "lmpc")))
+            r = measure(cx, w, st, wu, with_latency=key in ("cfg3", "cfg4", "lmpc"))
+            out["configs"].append(r)
+            out["summary"][key] = compact(r)
             del w
             torch.cuda.empty_cache()
+    if not args.plumbing_check:
+        cdist.CrxComm.destroy()
     if dist.is_initialized():
         dist.destroy_process_group()
     if cx.rank == 0:

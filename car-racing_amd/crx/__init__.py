@@ -11,7 +11,8 @@ import os
 from . import abi, hostprep  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrx.so")
+# CRX_LIB: another build of the same library (A/B measurements of kernel variants, tools/ab_*.sh); default: the in-tree build
+LIB_PATH = os.environ.get("CRX_LIB") or os.path.join(_HERE, "libcrx.so")
 _state = {"lib": None, "binding": None, "device": None}
 
 

@@ -368,8 +368,9 @@ class Binding:
         )
         return out
 
-    def lmpc_prep(self, desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan=False):
-        """crx_lmpc_prep: stage models + safe-set selection.  ss_xcurv (Bn,L,P,6), u_ss (Bn,L,P,2), qfun (Bn,L,P)."""
+    def lmpc_prep(self, desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan=False, seed=None):
+        """crx_lmpc_prep: stage models + safe-set selection.  ss_xcurv (Bn,L,P,6), u_ss (Bn,L,P,2), qfun (Bn,L,P).
+        A, B, C are in/out (a singular stage keeps its three regression rows): `seed` = (A, B, C) to start from, else zeros."""
         N, P, L, M = desc.N, desc.n_points, desc.n_laps, desc.n_ss_per_lap * desc.n_ss_laps
         x = np.ascontiguousarray(x, dtype=_D)
         Bn = x.shape[0]
@@ -379,6 +380,8 @@ class Binding:
         track = _in(track, _D, (desc.n_seg, 6))
         out = dict(A=np.zeros((Bn, N, 6, 6)), B=np.zeros((Bn, N, 6, 2)), C=np.zeros((Bn, N, 6)), ss=np.zeros((Bn, 6, M)),
                    qfun=np.zeros((Bn, M)), status=np.zeros(Bn, dtype=_I))
+        if seed is not None:
+            out["A"], out["B"], out["C"] = (_in(a, _D, out[k].shape).copy() for k, a in zip("ABC", seed))
         getattr(self.lib, self.prefix + "lmpc_prep").restype = C.c_int
         self._call("lmpc_prep", C.byref(desc), C.c_int(Bn), _p(ss_xcurv), _p(u_ss), _p(qfun), _p(time_ss), _p(it), _p(x),
                    _p(lin_points), _p(lin_input), C.c_int(int(bool(from_plan))), _p(track), _p(out["A"]), _p(out["B"]),

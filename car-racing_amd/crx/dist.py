@@ -8,6 +8,44 @@ import torch.distributed as dist
 
 # bench.py --force-collective: issue the all-gather through the backend even with one rank (RCCL plumbing check on a 1-GPU box)
 FORCE_COLLECTIVE = False
+# "torch": torch.distributed's all_gather_into_tensor (backend nccl = RCCL on the GPU box, gloo in the CPU tests);
+# "crx":   crx_allgather_winners_dev, the same exchange issued on RCCL by libcrx itself (include/crx.h) -- what a C caller
+#          of the library uses; torch.distributed then only carries the 128-byte communicator id to the ranks
+COLLECTIVE = "torch"
+
+
+class CrxComm:
+    """libcrx's own RCCL communicator (crx_comm_*), one per process.  The rendezvous is the caller's business: here the id
+    travels through torch.distributed's object broadcast when there is a process group, and nowhere when world == 1."""
+    _ready = False
+
+    @classmethod
+    def ensure(cls):
+        import ctypes as C
+
+        from . import binding, lib
+        if cls._ready:
+            return
+        binding()
+        L = lib()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0 and L.crx_comm_get_unique_id(buf) != 0:
+            raise RuntimeError("crx_comm_get_unique_id: " + (L.crx_last_error() or b"").decode())
+        ids = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        if L.crx_comm_init_rank(C.create_string_buffer(ids[0], 128), C.c_int(world), C.c_int(rank)) != 0:
+            raise RuntimeError("crx_comm_init_rank: " + (L.crx_last_error() or b"").decode())
+        cls._ready = True
+
+    @classmethod
+    def destroy(cls):
+        from . import lib
+        if cls._ready:
+            lib().crx_comm_destroy()
+            cls._ready = False
 
 
 def shard_bounds(n_items, rank, world):
@@ -44,6 +82,24 @@ class WinnerExchange:
         n = self.sizes[self.rank]
         if flag.shape[0] != n or best_X.shape[0] != n:
             raise ValueError("rank %d holds %d winners, its shard of %d over %d ranks is %d" % (self.rank, flag.shape[0], self.n_total, self.world, n))
+        if COLLECTIVE == "crx" and (self.world > 1 or FORCE_COLLECTIVE):
+            # pack + ncclAllGather inside libcrx, on torch's current stream (the winners never pass through torch ops)
+            import ctypes as C
+
+            from . import lib
+            from .torch_api import _ptr, _stream
+            CrxComm.ensure()
+            fl = flag.to(torch.int32).contiguous()
+            bx = best_X.contiguous()
+            if lib().crx_allgather_winners_dev(C.c_int(n), C.c_int(self.n_max), C.c_int(self.shape_X[0] - 1), _ptr(fl), _ptr(bx), _ptr(self.send),
+                                               _ptr(self.recv), _stream()) != 0:
+                raise RuntimeError("crx_allgather_winners_dev: " + (lib().crx_last_error() or b"").decode())
+            if self.even:
+                allrec = self.recv
+            else:
+                out = self.recv.view(self.world, self.n_max, self.rec)
+                allrec = torch.cat([out[r, : self.sizes[r]] for r in range(self.world)], dim=0)
+            return allrec[:, 0].to(torch.int32), allrec[:, 1:].reshape(-1, *self.shape_X)
         self.send[:n, 0] = flag
         self.send[:n, 1:] = best_X.reshape(n, self.rec - 1)
         if self.world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVE):

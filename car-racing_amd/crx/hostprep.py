@@ -115,3 +115,9 @@ def tracking_targets(x, traj_xcurv, N, dt_ref=0.1):
     xt[:, 0] = x[0]
     xt[:, 5] = interp_clipped(traj_xcurv[:, 4], traj_xcurv[:, 5], s)
     return xt
+
+
+def tracking_targets_batch(x, traj_xcurv, N, dt_ref=0.1):
+    """tracking_targets for a batch: x [B,6], traj_xcurv [B,M,6] -> xt [B,N+1,6]."""
+    x = np.asarray(x, dtype=float)
+    return np.stack([tracking_targets(x[b], traj_xcurv[b], N, dt_ref) for b in range(x.shape[0])])

@@ -18,13 +18,32 @@ from . import abi, torch_api
 _LAP_TRUNC = torch.trunc
 
 
+class _Noise:
+    """The plant's process noise (utils/base.py:929-939) for the batched loops: standard-normal draws from a torch generator
+    on the device, one [B, 3] tensor per control step; clipping and scaling happen in crx_plant_step_noise_dev.  seed None =
+    zero noise (the `--zero-noise` runs of the reference's scripts; the reference's default is noise ON)."""
+
+    def __init__(self, seed, device):
+        self.gen = None
+        if seed is not None:
+            self.gen = torch.Generator(device=device)
+            self.gen.manual_seed(int(seed))
+        self.device = device
+
+    def draw(self, batch):
+        if self.gen is None:
+            return None
+        return torch.randn((batch, 3), generator=self.gen, dtype=torch.float64, device=self.device)
+
+
 class MpccbfRaces:
     """State of B races on the device; step() advances all of them by one control step."""
 
     def __init__(self, track_table, lap_length, track_width, A, B, xcurv0, xglob0, car_s0, car_v, car_ey,
-                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None):
+                 vt=0.8, eyt=0.0, N=10, alpha=0.8, timestep=0.1, device=None, noise_seed=None):
         dev = torch.device(device if device is not None else "cuda")
         f64 = dict(dtype=torch.float64, device=dev)
+        self.noise = _Noise(noise_seed, dev)
         self.xc = torch.as_tensor(np.ascontiguousarray(xcurv0), **f64).clone()
         self.xg = torch.as_tensor(np.ascontiguousarray(xglob0), **f64).clone()
         self.s0, self.v, self.ey = (torch.as_tensor(np.ascontiguousarray(a), **f64) for a in (car_s0, car_v, car_ey))
@@ -55,7 +74,8 @@ class MpccbfRaces:
                                self.obs_s, self.obs_e, self.lap_off, self.n_obs)
         torch_api.cbf_solve_dev(self.desc, self.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.ws)
         # the plant reads u_0 of every race straight out of the solver's U [B][N][2]
-        torch_api.plant_step_wrap_dev(self.pdesc, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps)
+        torch_api.plant_step_wrap_dev(self.pdesc, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
+                                      noise_z=self.noise.draw(self.batch))
         self.xg, self.xg_next = self.xg_next, self.xg
         self.xc, self.xc_next = self.xc_next, self.xc
         self.u = self.ws.U[:, 0, :]
@@ -128,10 +148,11 @@ class LmpcLaps:
     of safe-set storage are full (it then keeps racing on its last two laps)."""
 
     def __init__(self, track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
-                 N=12, timestep=0.1, device=None):
+                 N=12, timestep=0.1, device=None, noise_seed=None):
         dev = torch.device(device if device is not None else "cuda")
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
+        self.noise = _Noise(noise_seed, dev)
 
         def t(a, kw):
             return torch.as_tensor(np.ascontiguousarray(a), **kw).clone()
@@ -150,6 +171,7 @@ class LmpcLaps:
         self.ws = torch_api.LmpcWorkspace(self.desc, Bn, dev)
         self.n_ss = torch.full((Bn,), self.desc.n_ss_max, **i32)
         self.u_old = torch.zeros((Bn, 2), **f64)
+        self.u_prev = torch.zeros((Bn, 2), **f64)     # u_old of the last QP launch (bench.py re-issues that launch to time it)
         self.step_no = torch.zeros((Bn,), **i32)
         self.laps = torch.zeros((Bn,), **i32)
         self.xg_next, self.xc_next = torch.empty_like(self.xg), torch.empty_like(self.xc)
@@ -189,9 +211,11 @@ class LmpcLaps:
         torch_api.lmpc_solve_dev(self.desc, self.xc, self.u_old, self.pws.A, self.pws.B, self.pws.C, self.pws.ss, self.pws.qfun, self.n_ss,
                                  ws=self.ws)
         torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.step_no, self.xc, self.ws.U, 2 * N)
-        torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps)
+        torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
+                                      noise_z=self.noise.draw(self.batch))
         self.xg, self.xg_next = self.xg_next, self.xg
         self.xc, self.xc_next = self.xc_next, self.xc
+        self.u_prev.copy_(self.u_old)
         self.u_old.copy_(self.ws.U[:, 0, :])
         self.step_no += 1
         self.k += 1
@@ -199,11 +223,11 @@ class LmpcLaps:
 
 
 def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, steps,
-              N=12, timestep=0.1, device=None):
+              N=12, timestep=0.1, device=None, noise_seed=None):
     """Run `steps` control steps of B learning-MPC laps; returns host logs xcurv [steps+1, B, 6], u [steps, B, 2], status [steps, B]
     (QP status), prep_status [steps, B] (singular regression), laps [B]."""
     r = LmpcLaps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, N=N,
-                 timestep=timestep, device=device)
+                 timestep=timestep, device=device, noise_seed=noise_seed)
     log_x, log_u, log_st, log_ps = [r.xc.clone()], [], [], []
     for _ in range(steps):
         r.step()
@@ -238,9 +262,9 @@ class GameLaps:
     in; no host round trip, no compaction.  Nine libcrx launches per step."""
 
     def __init__(self, track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0,
-                 lin_points, lin_input, car_s0, car_v, car_ey, N=12, N_plan=10, timestep=0.1, device=None):
+                 lin_points, lin_input, car_s0, car_v, car_ey, N=12, N_plan=10, timestep=0.1, device=None, noise_seed=None):
         self.lm = LmpcLaps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
-                           N=N, timestep=timestep, device=device)
+                           N=N, timestep=timestep, device=device, noise_seed=noise_seed)
         lm = self.lm
         dev = lm.xc.device
         f64 = dict(dtype=torch.float64, device=dev)
@@ -304,13 +328,14 @@ class GameLaps:
         ot = self.overtake
         self.u.copy_(torch.where(ot[:, None], self.tws.U[:, 0, :], lm.ws.U[:, 0, :]))
         torch_api.lmpc_addpoint_dev(lm.pdesc, lm.ss, lm.us, lm.time_ss, lm.it, torch.where(ot, self.neg, lm.step_no), lm.xc, self.u, 2)
+        lm.u_prev.copy_(lm.u_old)
         lm.u_old.copy_(torch.where(ot[:, None], lm.u_old, lm.ws.U[:, 0, :]))
         X, U = lm.ws.X, lm.ws.U
         self.lin_points.copy_(torch.where(ot[:, None, None], self.lin_points, torch.cat((X[:, 1:], X[:, -1:]), dim=1)))
         self.lin_input.copy_(torch.where(ot[:, None, None], self.lin_input, torch.cat((U[:, 1:], U[:, -1:]), dim=1)))
         lm.step_no += (~ot).to(torch.int32)
         self.old_flag.copy_(torch.where(ot, self.selws.flag, torch.full_like(self.old_flag, -1)))
-        torch_api.plant_step_wrap_dev(lm.plant, lm.tab, lm.xg, lm.xc, self.u, 2, lm.xg_next, lm.xc_next, lm.laps)
+        torch_api.plant_step_wrap_dev(lm.plant, lm.tab, lm.xg, lm.xc, self.u, 2, lm.xg_next, lm.xc_next, lm.laps, noise_z=lm.noise.draw(lm.batch))
         lm.xg, lm.xg_next = lm.xg_next, lm.xg
         lm.xc, lm.xc_next = lm.xc_next, lm.xc
         self.t += lm.timestep
@@ -318,11 +343,11 @@ class GameLaps:
 
 
 def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
-              car_s0, car_v, car_ey, steps, device=None):
+              car_s0, car_v, car_ey, steps, device=None, noise_seed=None):
     """Run `steps` control steps of B racing-game laps with scripted traffic.  Host logs: xcurv [steps+1, B, 6], u [steps, B, 2],
     overtake [steps, B] (which branch), flag [steps, B] (direction flag, -1 in the LMPC branch), cars_s [steps, B, V], laps [B]."""
     r = GameLaps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
-                 car_s0, car_v, car_ey, device=device)
+                 car_s0, car_v, car_ey, device=device, noise_seed=noise_seed)
     lx, lu, lo, lf, lc = [r.lm.xc.clone()], [], [], [], []
     for _ in range(steps):
         lc.append((r.v * r.t + r.s0).clone())

@@ -66,8 +66,37 @@ def _lanes(rng, shape):
     return 0.7 - 0.1 * rng.integers(0, 15, size=shape)  # mirrors overtake_planner_test.py:81-82
 
 
-def cfg2_mpccbf(batch=256, N=12, seed=2, n_obs=1, safe_start=True):
-    """MPC-CBF NLP batch: one obstacle inside the +-2*vx window (control.py:520-522)."""
+def _lap_some(x0, lapped_frac, seed):
+    """Put a fraction of the egos one lap ahead of the traffic (raw s in [lap, 2 lap): the state control.mpccbf sees on
+    the step the ego crosses the line before utils/base.py:809 resets it, or when the caller counts s cumulatively).
+    The window test works on wrapped distances (control.py:499-523) so the same obstacles stay in; their CBF rows get
+    lap_off = lap_length for `diffs` and NONE for `diffs_next` (quirk Q1, control.py:539-542)."""
+    if lapped_frac <= 0.0:
+        return x0
+    rng = np.random.default_rng(np.random.PCG64(1000 + seed))
+    x0 = x0.copy()
+    x0[rng.uniform(size=x0.shape[0]) < lapped_frac, 4] += LAP_L_SHAPE
+    return x0
+
+
+def _through_window(p, n_obs, lap_length):
+    """What control.mpccbf / mpc_multi_agents do with the cars before building rows (control.py:499-523 / :293-309): the
+    +-2 vx window on lap-wrapped distances decides which cars become obstacles, in dict order, and fixes their lap offsets.
+    The product's host prep (hostprep.cbf_window / pack_obstacles) is used, as by control.mpccbf's mirror; the parity of
+    that prep with the reference's own rows on these very draws is pinned by tests/golden/cfg{2,4}_draw.npz."""
+    from . import hostprep
+
+    keep, lap_off = hostprep.cbf_window(p["x0"], p["obs_s"][:, :, 0], lap_length)
+    ps, pe, po, n = hostprep.pack_obstacles(keep, p["obs_s"], p["obs_ey"], lap_off, n_obs)
+    p.update(obs_s=ps, obs_ey=pe, lap_off=po, n_obs=n)
+    return p
+
+
+def cfg2_mpccbf(batch=256, N=12, seed=2, n_obs=1, safe_start=True, lapped_frac=0.0, lap_length=LAP_L_SHAPE):
+    """MPC-CBF NLP batch: one car drawn inside +-1.5 vx of the ego; the reference's window test
+    (control.py:520-522) then decides whether it enters the NLP (a car drawn across the start line does not).
+    `cars` [batch, n_obs, 3] = (s0, v, ey) of the scripted cars s(t) = v t + s0 -- the raw scenario the reference-side
+    fixture generator (tests/golden/tools/make_golden.py draws) replays through the reference's own code."""
     rng = np.random.default_rng(np.random.PCG64(seed))
     j = np.arange(N + 1)
 
@@ -78,18 +107,22 @@ def cfg2_mpccbf(batch=256, N=12, seed=2, n_obs=1, safe_start=True):
         ey_o = _lanes(rng, (n, n_obs))
         obs_s = s_o[:, :, None] + 0.1 * j[None, None, :] * v_o[:, :, None]
         obs_ey = np.repeat(ey_o[:, :, None], N + 1, axis=2)
-        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey)
+        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey, cars=np.stack([s_o, v_o, ey_o], axis=2))
 
     p = _resample_unsafe(gen, batch, 0.2) if safe_start else gen(batch)
+    p["x0"] = _lap_some(p["x0"], lapped_frac, seed)
     xt = np.tile(np.array([0.8, 0, 0, 0, 0, 0.0]), (batch, 1))
-    p.update(xt=xt, lap_off=np.zeros((batch, n_obs)), n_obs=np.full(batch, n_obs, dtype=np.int32),
-             N=N, alpha=0.8, margin=0.2)
+    p = _through_window(p, n_obs, lap_length)
+    p.update(xt=xt, N=N, alpha=0.8, margin=0.2, lap_length=lap_length)
     return p
 
 
-def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True):
+def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True, lapped_frac=0.0, lap_length=LAP_L_SHAPE):
     """mpc_multi_agents-form NLP (control.py:251-473): per-stage ey target, alpha 0.6, margin 0.15,
-    three obstacles ahead in the planner's front window (planner_helper.py:231-236)."""
+    three cars ahead in the planner's front window (planner_helper.py:231-236); the controller's own +-2 vx window
+    (control.py:293-309) then keeps the ones that become obstacles.  `traj` [batch, N+1, 6] is the planner-output-like
+    target trajectory handed to the controller (`target_traj_xcurv`): nodes at s0 + 0.1 j vx0, so that the reference's
+    clipped interpolation (control.py:373-382) returns the node values."""
     rng = np.random.default_rng(np.random.PCG64(seed))
     j = np.arange(N + 1)
 
@@ -101,19 +134,24 @@ def cfg4_tracking_cbf(batch=16384, N=20, seed=4, n_obs=3, safe_start=True):
         ey_o = _lanes(rng, (n, n_obs))
         obs_s = s_o[:, :, None] + 0.1 * j[None, None, :] * v_o[:, :, None]
         obs_ey = np.repeat(ey_o[:, :, None], N + 1, axis=2)
-        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey)
+        return dict(x0=x0, obs_s=obs_s, obs_ey=obs_ey, cars=np.stack([s_o, v_o, ey_o], axis=2))
 
     p = _resample_unsafe(gen, batch, 0.15) if safe_start else gen(batch)
+    p["x0"] = _lap_some(p["x0"], lapped_frac, seed)
     x0 = p["x0"]
     # target: smooth lateral move from the current ey to a random lane over the horizon
     ey_goal = _lanes(rng, (batch,))
     w = (j / N)[None, :]
     blend = 3 * w ** 2 - 2 * w ** 3
-    xt = np.zeros((batch, N + 1, 6))
-    xt[:, :, 0] = x0[:, 0, None]
-    xt[:, :, 5] = x0[:, 5, None] * (1 - blend) + ey_goal[:, None] * blend
-    p.update(xt=xt, lap_off=np.zeros((batch, n_obs)), n_obs=np.full(batch, n_obs, dtype=np.int32),
-             N=N, alpha=0.6, margin=0.15)
+    traj = np.zeros((batch, N + 1, 6))
+    traj[:, :, 0] = x0[:, 0, None]
+    traj[:, :, 4] = x0[:, 4, None] + 0.1 * j[None, :] * x0[:, 0, None]
+    traj[:, :, 5] = x0[:, 5, None] * (1 - blend) + ey_goal[:, None] * blend
+    from . import hostprep
+
+    xt = hostprep.tracking_targets_batch(x0, traj, N)
+    p = _through_window(p, n_obs, lap_length)
+    p.update(xt=xt, traj=traj, N=N, alpha=0.6, margin=0.15, lap_length=lap_length)
     return p
 
 
@@ -152,7 +190,8 @@ def cfg3_raw(n_scen=1024, N=12, seed=3, V=3, track_width=1.0, lap_length=LAP_L_S
     obs_s = s_o[rows, order][:, :, None] + 0.1 * j[None, None, :] * v_o[rows, order][:, :, None]
     obs_ey = np.repeat(ey_o[rows, order][:, :, None], N + 1, axis=2)
     return dict(
-        x=x, veh_info=np.stack([s_o, ey_o, ey_o], axis=2), max_dv=dv.max(axis=1), obs_s=obs_s, obs_ey=obs_ey,
+        x=x, veh_info=np.stack([s_o, ey_o, ey_o], axis=2), cars=np.stack([s_o, v_o, ey_o], axis=2), max_dv=dv.max(axis=1),
+        obs_s=obs_s, obs_ey=obs_ey,
         n_veh=np.full(n_scen, V, dtype=np.int32), opt_s=np.ascontiguousarray(opt[:, 4]),
         opt_ey=np.ascontiguousarray(opt[:, 5]), opt=opt, N=N, V=V, n_scen=n_scen, track_width=track_width,
         lap_length=lap_length, old_flag=rng.integers(-1, R, n_scen).astype(np.int32),

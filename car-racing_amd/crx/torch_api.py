@@ -217,9 +217,10 @@ def cbf_prep_dev(N, lap_length, t, dt, xcurv, car_s0, car_v, car_ey, obs_s, obs_
           _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _stream())
 
 
-def plant_step_wrap_dev(desc, track, xglob, xcurv, u, u_stride, xglob_next, xcurv_next, laps):
+def plant_step_wrap_dev(desc, track, xglob, xcurv, u, u_stride, xglob_next, xcurv_next, laps, noise_z=None):
     """crx_plant_step_wrap_dev: plant step + lap bookkeeping; `u` may be a strided view's base tensor (u_stride doubles
-    between vehicles, e.g. the U output of cbf_solve_dev with u_stride = 2 N)."""
+    between vehicles, e.g. the U output of cbf_solve_dev with u_stride = 2 N).  noise_z [B,3]: standard-normal draws for the
+    reference's bounded process noise (utils/base.py:929-939; crx_plant_step_noise_dev), None = zero noise."""
     Bn = xglob.shape[0]
     _chk(track, torch.float64, (desc.n_seg, 6), "track")
     _chk(xglob, torch.float64, (Bn, 6), "xglob")
@@ -229,8 +230,10 @@ def plant_step_wrap_dev(desc, track, xglob, xcurv, u, u_stride, xglob_next, xcur
     _chk(laps, torch.int32, (Bn,), "laps")
     if not u.is_cuda or u.dtype != torch.float64 or not u.is_contiguous() or u.numel() < (Bn - 1) * u_stride + 2:
         raise ValueError("u: expected a contiguous cuda float64 tensor holding %d inputs at stride %d" % (Bn, u_stride))
-    _call("crx_plant_step_wrap_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
-          C.c_int(u_stride), _ptr(xglob_next), _ptr(xcurv_next), _ptr(laps), _stream())
+    if noise_z is not None:
+        _chk(noise_z, torch.float64, (Bn, 3), "noise_z")
+    _call("crx_plant_step_noise_dev", C.byref(desc), C.c_int(Bn), _ptr(track), _ptr(xglob), _ptr(xcurv), _ptr(u),
+          C.c_int(u_stride), _ptr(noise_z), _ptr(xglob_next), _ptr(xcurv_next), _ptr(laps), _stream())
 
 
 class LmpcPrepWorkspace:
@@ -239,12 +242,14 @@ class LmpcPrepWorkspace:
     def __init__(self, desc, batch, device):
         N, M = desc.N, desc.n_ss_per_lap * desc.n_ss_laps
         f64 = dict(dtype=torch.float64, device=device)
-        self.A = torch.empty((batch, N, 36), **f64)
-        self.B = torch.empty((batch, N, 12), **f64)
-        self.C = torch.empty((batch, N, 6), **f64)
-        self.ss = torch.empty((batch, 6, M), **f64)
-        self.qfun = torch.empty((batch, M), **f64)
-        self.status = torch.empty(batch, dtype=torch.int32, device=device)
+        # A, B, C are in/out: the kernel leaves the three regression rows of a singular stage (status 1) and everything of a
+        # masked-out race untouched, so they start defined (zeros), never as uninitialised memory that could reach the QP
+        self.A = torch.zeros((batch, N, 36), **f64)
+        self.B = torch.zeros((batch, N, 12), **f64)
+        self.C = torch.zeros((batch, N, 6), **f64)
+        self.ss = torch.zeros((batch, 6, M), **f64)
+        self.qfun = torch.zeros((batch, M), **f64)
+        self.status = torch.zeros(batch, dtype=torch.int32, device=device)
 
 
 def lmpc_prep_dev(desc, ss_xcurv, u_ss, qfun, time_ss, it, x, lin_points, lin_input, track, from_plan, ws=None, active=None):
@@ -333,7 +338,26 @@ def planner_scene_dev(desc, ego_xcurv, n_all, veh_xcurv, pred_s, pred_ey, ws=Non
 def planner_plan_dev(desc, sdesc, x0, bez_s, bez_ey, ey_lb, ey_ub, n_veh, obs_s, obs_ey, old_flag, ws, sws, active=None):
     """crx_planner_plan_dev: all region QPs of every scenario + the selection, on one stream (with `active`, int32
     [n_scen]: crx_planner_plan_masked_dev, the QPs of the scenarios with 0 are skipped)."""
-    S = n_veh.shape[0]
+    S, N, V = n_veh.shape[0], desc.N, sdesc.n_veh_max
+    R = V + 1
+    _chk(x0, torch.float64, (S * R, 6), "x0")
+    _chk(bez_s, torch.float64, (S * R, N + 1), "bez_s")
+    _chk(bez_ey, torch.float64, (S * R, N + 1), "bez_ey")
+    _chk(ey_lb, torch.float64, (S * R, N), "ey_lb")
+    _chk(ey_ub, torch.float64, (S * R,), "ey_ub")
+    _chk(n_veh, torch.int32, (S,), "n_veh")
+    _chk(obs_s, torch.float64, (S, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (S, V, N + 1), "obs_ey")
+    _chk(old_flag, torch.int32, (S,), "old_flag")
+    _chk(ws.X, torch.float64, (S * R, N + 1, 6), "ws.X")
+    _chk(ws.U, torch.float64, (S * R, N, 2), "ws.U")
+    for name in ("cost", "kkt"):
+        _chk(getattr(ws, name), torch.float64, (S * R,), "ws." + name)
+    for name in ("status", "iters"):
+        _chk(getattr(ws, name), torch.int32, (S * R,), "ws." + name)
+    _chk(sws.flag, torch.int32, (S,), "sws.flag")
+    _chk(sws.sel_cost, torch.float64, (S, R), "sws.sel_cost")
+    _chk(sws.best_X, torch.float64, (S, N + 1, 6), "sws.best_X")
     if active is not None:
         _chk(active, torch.int32, (S,), "active")
     _call("crx_planner_plan_masked_dev", C.byref(desc), C.byref(sdesc), C.c_int(S), _ptr(active), _ptr(x0), _ptr(bez_s), _ptr(bez_ey), _ptr(ey_lb), _ptr(ey_ub),

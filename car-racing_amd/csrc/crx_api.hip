@@ -9,8 +9,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <mutex>
 #include <vector>
+
+#include <rccl/rccl.h>   // types only: the entry points are resolved at run time (rccl_bind), libcrx does not link librccl
 
 #include "crx_kparams.h"
 
@@ -605,7 +609,7 @@ int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, 
     if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
     crx_plant_kparams pk;
     pk.d = *d; pk.batch = batch; pk.u_stride = 2; pk.wrap = 0; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
-    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = nullptr;
+    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = nullptr; pk.noise_z = nullptr;
     hipError_t e = crx_launch_plant(pk, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "plant launch: %s", hipGetErrorString(e));
     return CRX_OK;
@@ -613,6 +617,12 @@ int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, 
 
 int crx_plant_step_wrap_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
                             const double* u, int u_stride, double* xglob_next, double* xcurv_next, int32_t* laps, void* stream) {
+    return crx_plant_step_noise_dev(d, batch, track, xglob, xcurv, u, u_stride, nullptr, xglob_next, xcurv_next, laps, stream);
+}
+
+int crx_plant_step_noise_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                             const double* u, int u_stride, const double* noise_z, double* xglob_next, double* xcurv_next,
+                             int32_t* laps, void* stream) {
     if (int rc = ensure_init()) return rc;
     if (int rc = check_plant(d, batch)) return rc;
     if (u_stride < 2) return fail(CRX_ERR_ARG, "u_stride < 2");
@@ -620,7 +630,7 @@ int crx_plant_step_wrap_dev(const crx_plant_desc* d, int batch, const double* tr
     if (!track || !xglob || !xcurv || !u || !xglob_next || !xcurv_next) return fail(CRX_ERR_ARG, "NULL array argument");
     crx_plant_kparams pk;
     pk.d = *d; pk.batch = batch; pk.u_stride = u_stride; pk.wrap = 1; pk.track = track; pk.xglob = xglob; pk.xcurv = xcurv; pk.u = u;
-    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = laps;
+    pk.xglob_next = xglob_next; pk.xcurv_next = xcurv_next; pk.laps = laps; pk.noise_z = noise_z;
     hipError_t e = crx_launch_plant(pk, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "plant launch: %s", hipGetErrorString(e));
     return CRX_OK;
@@ -978,6 +988,11 @@ int crx_lmpc_prep(const crx_lmpcprep_desc* d, int batch, const double* ss_xcurv,
     double* dA = sg.out(A, Bn * N * 36); double* dB = sg.out(B, Bn * N * 12); double* dC = sg.out(C, Bn * N * 6);
     double* dsel = sg.out(ss_sel, Bn * 6 * M); double* dq = sg.out(q_sel, Bn * M); int32_t* dst = sg.out(status, Bn);
     if (int rc = sg.up(g_stream)) return rc;
+    // A, B, C are in/out: a singular stage leaves its three regression rows untouched (include/crx.h), so the staging copies
+    // start from the caller's arrays, not from whatever an earlier call left in the staging buffer
+    HIP_TRY(hipMemcpyAsync(dA, A, Bn * N * 36 * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dB, B, Bn * N * 12 * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dC, C, Bn * N * 6 * sizeof(double), hipMemcpyHostToDevice, g_stream));
     if (int rc = crx_lmpc_prep_dev(d, batch, dss, dus, dqf, dts, dit, dx, dlp, dli, from_plan, dtr, dA, dB, dC, dsel, dq, dst, g_stream)) return rc;
     return sg.down(g_stream);
 }
@@ -1070,6 +1085,115 @@ int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n
     if (int rc = crx_planner_plan_dev(d, sd, n_scen, dx0, dbs, dbe, dlb, dub, dnv, dos, doe, dof, dX, dU, dc, ds, dk, di,
                                       dfl, dsc, dbX, g_stream)) return rc;
     return sg.down(g_stream);
+}
+
+}  // extern "C"
+
+// ---- multi-GPU: the ONE collective of the planner sweep, on RCCL directly ----------------------------------------
+// One process per GPU; the caller owns the rendezvous (it carries the 128-byte id from rank 0 to the others by whatever
+// it has: MPI, a file, torch.distributed's store).  RCCL is resolved at run time: if the process already holds a librccl
+// (PyTorch-ROCm bundles one under the SONAME librccl.so.1) that copy is used -- two RCCL instances in one process would
+// each build their own topology and IPC state -- otherwise /opt/rocm's is loaded.  libcrx therefore has no link-time
+// dependency on RCCL, and single-GPU users never load it.
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_world = 0, g_rank = -1;
+
+int rccl_bind() {
+    if (g_rccl.AllGather) return CRX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;     // a copy the process already holds
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(CRX_ERR_HIP, "RCCL not found (librccl.so.1): %s", dlerror());
+    g_rccl.h = h;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    auto ag = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GetErrorString || !ag)
+        return fail(CRX_ERR_HIP, "librccl lacks an expected entry point");
+    g_rccl.AllGather = ag;
+    return CRX_OK;
+}
+#define RCCL_TRY(expr)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) return fail(CRX_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+// winner record = [flag as double, X (N+1)*6]: 79 doubles = 632 B at N = 12; rows past n_local are zero
+__global__ void __launch_bounds__(256) crx_pack_winners_kernel(int n_local, int n_max, int rec, const int32_t* flag, const double* best_X,
+                                                               double* send) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_max * rec) return;
+    const size_t s = i / rec;
+    const int c = (int)(i - s * rec);
+    double v = 0.0;
+    if (s < (size_t)n_local) v = c == 0 ? (double)flag[s] : best_X[s * (rec - 1) + (c - 1)];
+    send[i] = v;
+}
+}  // namespace
+
+extern "C" {
+
+int crx_comm_get_unique_id(void* id) {
+    if (!id) return fail(CRX_ERR_ARG, "id is NULL");
+    if (int rc = ensure_init()) return rc;
+    if (int rc = rccl_bind()) return rc;
+    static_assert(sizeof(ncclUniqueId) == CRX_COMM_ID_BYTES, "id size");
+    RCCL_TRY(g_rccl.GetUniqueId((ncclUniqueId*)id));
+    return CRX_OK;
+}
+
+int crx_comm_init_rank(const void* id, int world, int rank) {
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(CRX_ERR_ARG, "bad communicator arguments (world %d, rank %d)", world, rank);
+    if (int rc = ensure_init()) return rc;
+    if (int rc = rccl_bind()) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_comm) return fail(CRX_ERR_ARG, "communicator already initialised (crx_comm_destroy first)");
+    HIP_TRY(hipSetDevice(g_device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    RCCL_TRY(g_rccl.CommInitRank(&g_comm, world, uid, rank));
+    g_world = world; g_rank = rank;
+    return CRX_OK;
+}
+
+int crx_comm_world(void) { return g_comm ? g_world : 0; }
+int crx_comm_rank(void) { return g_comm ? g_rank : -1; }
+
+int crx_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm) return CRX_OK;
+    RCCL_TRY(g_rccl.CommDestroy(g_comm));
+    g_comm = nullptr; g_world = 0; g_rank = -1;
+    return CRX_OK;
+}
+
+int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const double* best_X, double* send, double* recv,
+                              void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (!g_comm) return fail(CRX_ERR_ARG, "no communicator (crx_comm_init_rank)");
+    if (n_local < 0 || n_max < n_local || N < 1 || N > CRX_MAX_N) return fail(CRX_ERR_ARG, "bad sizes (n_local %d, n_max %d, N %d)", n_local, n_max, N);
+    if (n_max == 0) return CRX_OK;
+    if (!send || !recv || (n_local > 0 && (!flag || !best_X))) return fail(CRX_ERR_ARG, "NULL array argument");
+    const int rec = 1 + (N + 1) * 6;
+    const size_t cnt = (size_t)n_max * rec;
+    hipLaunchKernelGGL(crx_pack_winners_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_local, n_max, rec, flag,
+                       best_X, send);
+    HIP_TRY(hipGetLastError());
+    RCCL_TRY(g_rccl.AllGather(send, recv, cnt, ncclFloat64, g_comm, (hipStream_t)stream));
+    return CRX_OK;
 }
 
 }  // extern "C"

@@ -33,6 +33,15 @@
 #include "crx_kparams.h"
 #include "crx_wave.h"
 
+#ifndef CRX_OPAQUE_LANE
+#define CRX_OPAQUE_LANE 1 /* make EXTRA=-DCRX_OPAQUE_LANE=0: round-2 behaviour (lane maps hoisted out of the interior-point loop) */
+#endif
+#ifndef CRX_W2_FLOOR
+#define CRX_W2_FLOOR 0 /* 1: pin <2,12> at two waves per SIMD (256 registers, 76 B of scratch) = 6 instead of 4 problems per CU */
+#endif
+#ifndef CRX_SLIM
+#define CRX_SLIM 1 /* make EXTRA=-DCRX_SLIM=0: the full LDS layout for every instantiation (A/B builds, tools/ab_slim.sh) */
+#endif
 #define MAXF 12 /* filter entries (reset at every barrier update; when full, further entries are dropped) */
 
 // a^p for p in 0..8, straight-line: p is wave-uniform (the CBF degree 2/4/6/8, degree-1, degree-2), so every select
@@ -121,13 +130,22 @@ struct Lay {
     static constexpr int rc = rnu + MR;
     static constexpr int rdt = rc + MR;
     static constexpr int rtt = rdt + MR;             // trial slack / 1/t (dnu is recomputed at accept: -w + Sigma (rp - dt))
-    static constexpr int rsig = rtt + MR;            // Sigma = nu/t
-    static constexpr int rw = rsig + MR;             // w = nu - mu/t + Sigma*(c - t)
-    static constexpr int rsc = rw + MR;              // row scale (0 = row absent)
-    static constexpr int rb = rsc + MR;              // simple rows: bound (their sign lives in the riv table)
-    static constexpr int G = rb + MR;                // [NMAX][NO][4] CBF curvatures at the iterate: d2/ds2, d2/dey2 of the "next" term, then
-                                                     // of the "current" term (the gradients go straight into Jc)
-    static constexpr int Hd = G + NMAX * NOBS * 4;   // [NV] stage Hessian diagonal
+    // SLIM layout [r3] (the 3-obstacle instantiations: BASELINE configs[3], N = 20): four problems per CU need <= 40 960 B
+    // and the full layout is 52 560 B.  Whatever is a pure function of other LDS contents is recomputed where it is used
+    // -- Sigma and w from (t, nu, c, mu), the bound of a simple row from its slot, the presence of a simple row from its
+    // table entry, the rows of a coordinate and the triangle map from arithmetic -- and the curvature table G shares the
+    // storage of the feedback gains Kk (G lives from first_order to assemble_newton, Kk from the backward to the forward
+    // sweep).  Same operations on the same operands in the same order: results identical to the full layout bit for bit.
+    static constexpr bool SLIM = CRX_SLIM && NOBS == 3 && NMAX == 20;   // the other 3-obstacle instantiations are register-bound at 4 per CU either way
+    static constexpr int MRS = SLIM ? 0 : MR;        // length of the per-row arrays a slim layout does without
+    static constexpr int rsig = rtt + MR;            // Sigma = nu/t                               (full layout only)
+    static constexpr int rw = rsig + MRS;            // w = nu - mu/t + Sigma*(c - t)              (full layout only)
+    static constexpr int rsc = rw + MRS;             // row scale (0 = row absent)                 (full layout only)
+    static constexpr int csc = rsc + MRS;            // slim: [NMAX][NO] scales of the CBF rows (0 = absent); simple rows: presence = RIV_SIMPLE
+    static constexpr int rb = csc + (SLIM ? NMAX * NOBS : 0);   // simple rows: bound (their sign lives in the riv table)   (full layout only)
+    static constexpr int Gpos = rb + MRS;            // [NMAX][NO][4] CBF curvatures at the iterate: d2/ds2, d2/dey2 of the "next" term, then
+                                                     // of the "current" term (the gradients go straight into Jc); slim: over Kk, see G below
+    static constexpr int Hd = Gpos + (SLIM ? 0 : NMAX * NOBS * 4);   // [NV] stage Hessian diagonal
     static constexpr int hg = Hd + NV;               // [NV] Newton gradient
     static constexpr int ga = hg;                    // Lagrangian gradient / reduced form: SAME storage -- assemble_newton turns ga[e]
                                                      // into hg[e] in place, and nothing reads ga again before first_order rebuilds it
@@ -149,6 +167,8 @@ struct Lay {
     static constexpr int WORK2 = PT_ALIAS ? WORK : T + NX * NZ;
     static constexpr int H = H_ALIAS ? dZ : WORK2;           // [NZ][HS]  (over dZ from its start: stage 0 of dZ is written only after the sweep)
     static constexpr int Kk = H_ALIAS ? WORK2 : H + NZ * HS; // [NMAX][NU][NX]
+    static constexpr int G = SLIM ? Kk : Gpos;
+    static_assert(NMAX * NOBS * 4 <= NMAX * NU * NX, "G fits inside Kk");
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
     static constexpr int Fph = Fth + MAXF;
@@ -157,7 +177,7 @@ struct Lay {
     static constexpr int END_D = dmy + 2;
     // int tables (stored after the doubles)
     static constexpr int triH = 0;                   // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
-    static constexpr int END_I = triH + (NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2);
+    static constexpr int END_I = triH + ((NZ * NZ <= WAVE || SLIM) ? 0 : NZ * (NZ + 1) / 2);   // slim: tri_decode()
     static constexpr int SH_OFF = (END_I + 1) & ~1;  // in ints, from si
     // 16-bit tables (after the ints; SH16())
     static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
@@ -169,8 +189,9 @@ struct Lay {
     using vrow_t = std::conditional_t<(MR <= 127), signed char, short>;
     static constexpr int vlo = 0;                    // [NV]
     static constexpr int vhi = vlo + NV;             // [NV]
-    static constexpr int END_V = vhi + NV;
+    static constexpr int END_V = SLIM ? 0 : vhi + NV;   // slim: coord_rows() computes them
     static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)SH_OFF * 4 + (size_t)END_S16 * 2 + (((size_t)END_V * sizeof(vrow_t) + 7) & ~(size_t)7);
+    static_assert(!SLIM || BYTES <= 40960, "the slim layout exists to fit four problems per CU (160 KB / 4)");
 };
 
 // problem context kept in registers (all wave-uniform)
@@ -178,7 +199,82 @@ struct Ctx {
     int N, lane, nobs, m;
     double lin_sN, cconst, wsig, alpha, om, cm, rLs, rWs;
     int degree;
+    double b_d, b_a, b_vlo, b_vhi, b_e;   // delta_max, a_max, v_min, v_max, ey_max: the bounds of the simple rows (slim layout: row_bound())
 };
+
+// ---- accessors that hide the two layouts ---------------------------------------------------------------------------
+// scale of row j (0 = row absent)
+template <class L>
+__device__ __forceinline__ double row_scale(const double* sm, const int* si, int j, int N) {
+    if constexpr (L::SLIM) {
+        const bool cbf = j < N * L::NR && j % L::NR >= 8 + L::NO;
+        const int k = j / L::NR, ob = j - k * L::NR - 8 - L::NO;
+        const double cs = sm[L::csc + seli(cbf, k * L::NO + ob, 0)];
+        return sel(cbf, cs, sel((RIVT(si, j) & RIV_SIMPLE) != 0, 1.0, 0.0));
+    } else {
+        return sm[L::rsc + j];
+    }
+}
+// scale of the CBF row (k, ob)
+template <class L>
+__device__ __forceinline__ double cbf_scale(const double* sm, int k, int ob) {
+    if constexpr (L::SLIM) return sm[L::csc + k * L::NO + ob];
+    else return sm[L::rsc + k * L::NR + 8 + L::NO + ob];
+}
+// bound of the simple row j (what set-up stores in rb: 0 for rows that are absent or not table-driven)
+template <class L>
+__device__ __forceinline__ double row_bound(const double* sm, const Ctx& c, int j) {
+    if constexpr (L::SLIM) {
+        const int r = j < c.N * L::NR ? j % L::NR : 8;
+        const double ub = sel(r < 2, c.b_d, c.b_a) * sel((r & 1) != 0, 1.0, -1.0);
+        const double xb = sel(r == 4, c.b_vlo, sel(r == 5, c.b_vhi, sel(r == 6, -c.b_e, c.b_e)));
+        return sel(r < 4, ub, sel(r < 8, xb, 0.0));
+    } else {
+        return sm[L::rb + j];
+    }
+}
+// Sigma = nu/t and w = nu - mu/t + Sigma (c - t) of row j: stored by assemble_newton (full layout) or recomputed from the
+// row state with the same expressions (slim).  rti = 1/t as assemble_newton computed it (frcp(t)).
+template <class L>
+__device__ __forceinline__ void row_sig_w(const double* sm, int j, bool on, double mu, double t, double nu, double rti, double cj,
+                                          double& sig, double& w) {
+    if constexpr (L::SLIM) {
+        const double sg = nu * rti;
+        sig = sel(on, sg, 0.0);
+        w = sel(on, nu - mu * rti + sg * (cj - t), 0.0);
+    } else {
+        sig = sm[L::rsig + j];
+        w = sm[L::rw + j];
+    }
+}
+// rows that bound stage coordinate e = (k, a) from below / above (-1: none)
+template <class L>
+__device__ __forceinline__ void coord_rows(const int* si, const Ctx& c, int e, int k, int a, int& rl, int& rh) {
+    if constexpr (L::SLIM) {
+        constexpr int NX = L::NX, NR = L::NR;
+        const int N = c.N;
+        const bool isx = a < 6, iss0 = a >= 6 && a < NX, isu = a >= NX && a < NX + 2;
+        const bool xb = isx && k >= 1 && (a == 0 || a == 5);
+        int jl = seli(xb, (k - 1) * NR + seli(a == 0, 4, 6), -1);
+        jl = seli(iss0 && k == 0, N * NR + (a - 6), jl);
+        jl = seli(isu && k < N, k * NR + 2 * (a - NX), jl);
+        jl = seli(a >= NX + 2 && k < N, k * NR + 8 + (a - NX - 2), jl);
+        const int jh = seli(xb || (isu && k < N), jl + 1, -1);
+        // presence (absent obstacle slots, infinite bounds) is what the row table says
+        rl = seli(jl >= 0 && (RIVT(si, seli(jl >= 0, jl, 0)) & RIV_SIMPLE) != 0, jl, -1);
+        rh = seli(jh >= 0 && (RIVT(si, seli(jh >= 0, jh, 0)) & RIV_SIMPLE) != 0, jh, -1);
+    } else {
+        rl = VROW(si)[L::vlo + e];
+        rh = VROW(si)[L::vhi + e];
+    }
+}
+// entry e of the packed lower triangle -> (row, column)
+__device__ __forceinline__ void tri_decode(int e, int& r, int& a) {
+    int q = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    q += ((q + 1) * (q + 2) / 2 <= e) ? 1 : 0;
+    q -= (q * (q + 1) / 2 > e) ? 1 : 0;
+    r = q; a = e - q * (q + 1) / 2;
+}
 
 #define LD(off) sm[(off)]
 
@@ -289,9 +385,9 @@ template <int NOBS, int NMAX>
 __device__ __forceinline__ void eval_rows(double* sm, const int* si, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     for (int j = c.lane; j < c.m; j += WAVE) {
-        const double sc = LD(L::rsc + j);
+        const double sc = row_scale<L>(sm, si, j, c.N);
         const int pk = RIVT(si, j);
-        double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
+        double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - row_bound<L>(sm, c, j));
         if (NOBS && j < c.N * L::NR) {
             const int k = j / L::NR, r = j - k * L::NR;
             if (r >= 8 + NOBS && sc != 0.0) v = sc * cbf_value<NOBS, NMAX>(sm, c, k, r - 8 - NOBS, 0.0);
@@ -325,7 +421,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
             const double p2sc = ipow_d(dsc, q - 2), p2ec = ipow_d(dec, q - 2);
             const double gsn = qd * p2sn * dsn * c.rLs, gen = qd * p2en * den * c.rWs;
             const double gsc = qd * p2sc * dsc * c.rLs, gec = qd * p2ec * dec * c.rWs;
-            const double d = LD(L::rsc + k * L::NR + 8 + NOBS + o);
+            const double d = cbf_scale<L>(sm, k, o);
             double m4[L::NZ], m5[L::NZ];
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) { m4[a] = LD(L::M + 4 * L::NZ + a); m5[a] = LD(L::M + 5 * L::NZ + a); }
@@ -359,7 +455,8 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
         double g = w2 * (LD(L::Z + e) - ref);
         g += (k == N && a == 4) ? c.lin_sN : 0.0;
         g += sig_on ? c.wsig : 0.0;
-        const int rl = VROW(si)[L::vlo + e], rh = VROW(si)[L::vhi + e];
+        int rl, rh;
+        coord_rows<L>(si, c, e, k, a, rl, rh);
         const double nl = LD(L::rnu + (rl >= 0 ? rl : 0)), nh = LD(L::rnu + (rh >= 0 ? rh : 0));
         g -= sel(rl >= 0, nl, 0.0);
         g += sel(rh >= 0, nh, 0.0);
@@ -481,12 +578,14 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         (void)jv;
         const double t = LD(L::rt + j), nu = LD(L::rnu + j);
         const double rti = frcp(t);
-        const double sig = nu * rti;
-        const bool on = LD(L::rsc + j) != 0.0;
         LD(L::rtt + j) = rti;                       // 1/t for the row-step pass (rtt is free until the line search)
-        LD(L::rsig + j) = sel(on, sig, 0.0);
-        const double cj = LD(L::rc + j);
-        LD(L::rw + j) = sel(on, nu - mu * rti + sig * (cj - t), 0.0);
+        if constexpr (!L::SLIM) {
+            const double sig = nu * rti;
+            const bool on = LD(L::rsc + j) != 0.0;
+            LD(L::rsig + j) = sel(on, sig, 0.0);
+            const double cj = LD(L::rc + j);
+            LD(L::rw + j) = sel(on, nu - mu * rti + sig * (cj - t), 0.0);
+        }
     }
     SYNC();
     COORDS(e, ev, c.lane, N * L::NZ + L::NX) {   // stage N has states only (127 entries at N=12, 1 obstacle: two passes, not three)
@@ -498,9 +597,16 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         double h = sel(isx || isu, 2.0 * cw, 0.0);
         // absent obstacle: pin its sigma_0 (state copy at k = 0) and sigma_{k+1} (input copy)
         h += ((iss0 && k == 0 && o >= c.nobs) || (iss1 && o >= c.nobs)) ? 1.0 : 0.0;
-        const int rl = VROW(si)[L::vlo + e], rh = VROW(si)[L::vhi + e];
+        int rl, rh;
+        coord_rows<L>(si, c, e, k, a, rl, rh);
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
-        const double sgl = LD(L::rsig + il), sgh = LD(L::rsig + ih), wl = LD(L::rw + il), wh = LD(L::rw + ih);
+        double sgl, sgh, wl, wh;
+        if constexpr (L::SLIM) {   // a row found by coord_rows is present
+            row_sig_w<L>(sm, il, true, mu, LD(L::rt + il), LD(L::rnu + il), LD(L::rtt + il), LD(L::rc + il), sgl, wl);
+            row_sig_w<L>(sm, ih, true, mu, LD(L::rt + ih), LD(L::rnu + ih), LD(L::rtt + ih), LD(L::rc + ih), sgh, wh);
+        } else {
+            sgl = LD(L::rsig + il); sgh = LD(L::rsig + ih); wl = LD(L::rw + il); wh = LD(L::rw + ih);
+        }
         h += sel(rl >= 0, sgl, 0.0) + sel(rh >= 0, sgh, 0.0);
         g += sel(rl >= 0, wl, 0.0) - sel(rh >= 0, wh, 0.0);
         if (NOBS) {
@@ -508,9 +614,13 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 #pragma unroll
             for (int ob = 0; ob < NOBS; ob++) {
                 const int j = kk * L::NR + 8 + NOBS + ob;
-                const double jca = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a), rwj = LD(L::rw + j);
+                const double csj = cbf_scale<L>(sm, kk, ob);
+                const double jca = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a);
+                double rsj_, rwj;
+                row_sig_w<L>(sm, j, csj != 0.0, mu, LD(L::rt + j), LD(L::rnu + j), LD(L::rtt + j), LD(L::rc + j), rsj_, rwj);
+                (void)rsj_;
                 g += sel(k < N, jca * rwj, 0.0);
-                const double cur = LD(L::rnu + j) * LD(L::rsc + j) * c.om * LD(L::G + (kk * L::NO + ob) * 4 + (a == 4 ? 2 : 3));
+                const double cur = LD(L::rnu + j) * csj * c.om * LD(L::G + (kk * L::NO + ob) * 4 + (a == 4 ? 2 : 3));
                 h += sel(k < N && (a == 4 || a == 5), cur, 0.0);
             }
         }
@@ -524,7 +634,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 #pragma unroll
         for (int o = 0; o < NOBS; o++) {
             const int j = k * L::NR + 8 + NOBS + o;
-            const double nd = LD(L::rnu + j) * LD(L::rsc + j);
+            const double nd = LD(L::rnu + j) * cbf_scale<L>(sm, k, o);
             ks -= nd * LD(L::G + (k * L::NO + o) * 4 + 0);
             ke -= nd * LD(L::G + (k * L::NO + o) * 4 + 1);
         }
@@ -572,6 +682,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const int e0 = lane + q * WAVE;
         const int e = e0 < NTRI ? e0 : 0;
         if (FULL) { hr[q] = e / NZ; ha[q] = e - hr[q] * NZ; }
+        else if constexpr (L::SLIM) tri_decode(e, hr[q], ha[q]);
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
         hst[q] = SINK(e0 < NTRI, L::H + hr[q] * HS + ha[q]);
         hst2[q] = SINK(!FULL && e0 < NTRI, L::H + ha[q] * HS + hr[q]);
@@ -678,7 +789,14 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
             if (NOBS) {
 #pragma unroll
-                for (int o = 0; o < NOBS; o++) rs[o] = LD(L::rsig + k * L::NR + 8 + NOBS + o);
+                for (int o = 0; o < NOBS; o++) {
+                    if constexpr (L::SLIM) {   // Sigma of the CBF row (k, o): nu / t, 0 for an absent row
+                        const int j = k * L::NR + 8 + NOBS + o;
+                        rs[o] = sel(LD(L::csc + k * L::NO + o) != 0.0, LD(L::rnu + j) * LD(L::rtt + j), 0.0);
+                    } else {
+                        rs[o] = LD(L::rsig + k * L::NR + 8 + NOBS + o);
+                    }
+                }
             }
             double hvs = LD(L::hg + k * NZ + lz), mz[NX], pvv[NX];
 #pragma unroll
@@ -899,7 +1017,7 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
         double snext = LD(L::Z + N * NZ + 6 + ob);                       // sigma_N
         for (int i = N - 1; i >= 0; i--) {
             const int j = i * NR + 8 + NOBS + ob;
-            const double G = LD(L::rdt + j), push = slack_push / LD(L::rsc + j);
+            const double G = LD(L::rdt + j), push = slack_push / cbf_scale<L>(sm, i, ob);
             const double need = (snext - G + push) / c.om;
             double si = LD(L::Z + i * NZ + 6 + ob);
             if (need > si) {
@@ -937,7 +1055,7 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
 #define CRX_PLANNER_WAVES 3
 #endif
 template <int NOBS, int NMAX> struct MinWaves {
-    static constexpr int v = (NOBS == 1 && NMAX == 12) ? 2 : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
+    static constexpr int v = ((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? 2 : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
 };
 
 template <int NOBS, int NMAX>
@@ -962,6 +1080,7 @@ crx_solve_kernel(const crx_kparams kp) {
     const int m = c.m;
     c.alpha = kp.alpha; c.om = 1.0 - kp.alpha; c.cm = 1.0 + kp.margin; c.rLs = 1.0 / kp.l_sum; c.rWs = 1.0 / kp.w_sum;
     c.degree = kp.degree; c.wsig = kp.w_slack; c.lin_sN = 0.0; c.cconst = 0.0;
+    c.b_d = kp.delta_max; c.b_a = kp.a_max; c.b_vlo = kp.v_min; c.b_vhi = kp.v_max; c.b_e = kp.ey_max;
 
     // ---- (3) set-up: one coalesced pass over this problem's inputs -----------------------------------
     for (int e = lane; e < NX * NZ; e += WAVE) {
@@ -973,7 +1092,10 @@ crx_solve_kernel(const crx_kparams kp) {
         } else if (a == NX + 2 + (i - 6)) v = 1.0;
         LD(L::M + e) = v;
     }
-    for (int e = lane; e < (N + 1) * NZ; e += WAVE) { LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0; VROW(si)[L::vlo + e] = -1; VROW(si)[L::vhi + e] = -1; }
+    for (int e = lane; e < (N + 1) * NZ; e += WAVE) {
+        LD(L::Z + e) = 0.0; LD(L::dZ + e) = 0.0;
+        if constexpr (!L::SLIM) { VROW(si)[L::vlo + e] = -1; VROW(si)[L::vhi + e] = -1; }
+    }
     if (lane < 16) {
         double v = 0.0;
         if (lane < 6) v = kp.wq[lane];
@@ -981,7 +1103,7 @@ crx_solve_kernel(const crx_kparams kp) {
         LD(L::cst + lane) = v;
     }
     {   // index tables of the Riccati sweep (decoded once; the sweep itself is branch-free)
-        constexpr int NTRI = NZ * NZ <= WAVE ? 0 : NZ * (NZ + 1) / 2;   // table only when H needs the triangle form
+        constexpr int NTRI = (NZ * NZ <= WAVE || L::SLIM) ? 0 : NZ * (NZ + 1) / 2;   // table only when H needs the triangle form (slim: tri_decode)
         for (int e = lane; e < NTRI; e += WAVE) {
             int r = 0;
             while ((r + 1) * (r + 2) / 2 <= e) r++;
@@ -1081,17 +1203,24 @@ crx_solve_kernel(const crx_kparams kp) {
                 on = ((r - 8 - NOBS) < c.nobs) ? 1.0 : 0.0;
             }
         }
-        if (simple && on != 0.0) {
-            if (sg > 0.0) VROW(si)[L::vlo + iv] = (typename L::vrow_t)j; else VROW(si)[L::vhi + iv] = (typename L::vrow_t)j;
+        if constexpr (!L::SLIM) {
+            if (simple && on != 0.0) {
+                if (sg > 0.0) VROW(si)[L::vlo + iv] = (typename L::vrow_t)j; else VROW(si)[L::vhi + iv] = (typename L::vrow_t)j;
+            }
         }
         if (on == 0.0 || !simple) { sg = 0.0; bd = 0.0; iv = 0; }
         SH16(si)[L::riv + j] = (unsigned short)(iv | (sg != 0.0 ? RIV_SIMPLE : 0) | (sg < 0.0 ? RIV_NEG : 0));
-        LD(L::rb + j) = bd;
-        LD(L::rsc + j) = on;
+        if constexpr (L::SLIM) {
+            if (!simple) { const int k = j / NR; LD(L::csc + k * L::NO + (j - k * NR - 8 - NOBS)) = on; }
+        } else {
+            LD(L::rb + j) = bd;
+            LD(L::rsc + j) = on;
+            LD(L::rsig + j) = 0.0; LD(L::rw + j) = 0.0;
+        }
         LD(L::rnu + j) = on;       // multiplier start 1 (0 for absent rows)
         LD(L::rt + j) = 1.0;
         LD(L::rc + j) = 1.0;
-        LD(L::rdt + j) = 0.0; LD(L::rsig + j) = 0.0; LD(L::rw + j) = 0.0; LD(L::rtt + j) = 1.0;
+        LD(L::rdt + j) = 0.0; LD(L::rtt + j) = 1.0;
     }
     SYNC();
     // starting point: u = 0, sigma = 0, x by roll-out
@@ -1119,7 +1248,7 @@ crx_solve_kernel(const crx_kparams kp) {
                     gm = fmax(gm, fabs(c.om * q * ipow_d(dsc, q - 1) * c.rLs));
                     gm = fmax(gm, fabs(c.om * q * ipow_d(dec, q - 1) * c.rWs));
                 }
-                LD(L::rsc + k * NR + 8 + NOBS + o) = fmin(1.0, kp.opts.grad_scale_max / gm);
+                LD(L::SLIM ? L::csc + k * L::NO + o : L::rsc + k * NR + 8 + NOBS + o) = fmin(1.0, kp.opts.grad_scale_max / gm);
             }
         }
         SYNC();
@@ -1127,7 +1256,7 @@ crx_solve_kernel(const crx_kparams kp) {
     eval_rows<NOBS, NMAX>(sm, si, c);
     SYNC();
     for (int j = lane; j < m; j += WAVE)
-        if (LD(L::rsc + j) != 0.0) LD(L::rt + j) = fmax(fabs(LD(L::rc + j)), kp.opts.slack_push);
+        if (row_scale<L>(sm, si, j, N) != 0.0) LD(L::rt + j) = fmax(fabs(LD(L::rc + j)), kp.opts.slack_push);
     // multiplier start on simple-bound rows: the reduced cost gradient that pushes against the bound
     for (int j = lane; j < m; j += WAVE) { LD(L::rtt + j) = LD(L::rnu + j); LD(L::rnu + j) = 0.0; }
     SYNC();
@@ -1155,7 +1284,7 @@ crx_solve_kernel(const crx_kparams kp) {
     double f = cost_value<NOBS, NMAX>(sm, c, 0.0);
     int nf = 0, status = 1, it = 0;
     double mact = 0.0;
-    for (int j = lane; j < m; j += WAVE) mact += (LD(L::rsc + j) != 0.0) ? 1.0 : 0.0;
+    for (int j = lane; j < m; j += WAVE) mact += (row_scale<L>(sm, si, j, N) != 0.0) ? 1.0 : 0.0;
     mact = wave_sum(mact);
     const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1170,7 +1299,7 @@ crx_solve_kernel(const crx_kparams kp) {
         nus = 0.0; e_p = 0.0; cmax = 0.0; cmin = INFINITY;
         LogAcc lgs;
         for (int j = lane; j < m; j += WAVE) {
-            const bool on = LD(L::rsc + j) != 0.0;
+            const bool on = row_scale<L>(sm, si, j, N) != 0.0;
             const double t = LD(L::rt + j), nu = LD(L::rnu + j);
             nus += nu;
             e_p = fmax(e_p, on ? fabs(LD(L::rc + j) - t) : 0.0);
@@ -1202,6 +1331,16 @@ crx_solve_kernel(const crx_kparams kp) {
 
     for (;; it++) {
         long long tc0 = CLK();
+#if CRX_OPAQUE_LANE
+        // [r3] The lane index is made opaque once per iteration: everything the phases derive from it (which entry a lane
+        // owns, LDS addresses, the selects of the row / coordinate passes) is then recomputed inside the iteration instead of
+        // being hoisted out of the interior-point loop and kept alive across it -- integer work that the idle issue slots of
+        // a latency-bound wave absorb, against 40..140 registers: <0,12> 168 VGPRs + 116 B of scratch -> 160 and none (the
+        // parked dwords were x6..10 the algorithmic HBM traffic of the planner launches), <1,12> 256 + 28 B -> 208,
+        // <2,12> 345 -> 277, <3,20> 476 -> 332.
+        asm volatile("" : "+v"(c.lane));
+        const int lane = c.lane;   // shadows the kernel's `lane` inside the loop body
+#endif
         // ---- KKT error -----------------------------------------------------------------------------
         double e_c = cmax;
         const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
@@ -1252,7 +1391,8 @@ crx_solve_kernel(const crx_kparams kp) {
         auto row_step = [&](int j, bool cnt, bool store, double sc, double jd) {
             const bool on = sc != 0.0;
             const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j);
-            const double rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
+            double rwj, rsj;
+            row_sig_w<L>(sm, j, on, mu, t, nu, rti, rcj, rsj, rwj);
             ROW_LOADS_DONE();
             const double rp = rcj - t;
             const double dt = sel(on, jd + rp, 0.0);
@@ -1270,7 +1410,7 @@ crx_solve_kernel(const crx_kparams kp) {
             // multiplier update amplifies by Sigma = nu/t ~ 1e10..1e13)
             const bool simple = !ROW_IS_CBF(j, N);
             const int pk = RIVT(si, j);
-            const double sc = LD(L::rsc + j), jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
+            const double sc = row_scale<L>(sm, si, j, N), jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
             row_step(j, jv && simple, simple, sc, jd);
         }
         if (NOBS) {
@@ -1279,7 +1419,7 @@ crx_solve_kernel(const crx_kparams kp) {
                 double jc = 0.0;
 #pragma unroll
                 for (int a = 0; a < NZ; a++) jc += J[a] * LD(L::dZ + k * NZ + a);
-                row_step(j, ev, true, LD(L::rsc + j), jc);
+                row_step(j, ev, true, cbf_scale<L>(sm, k, ob), jc);
             }
         }
         wave_max2(rp_max, rd_max);
@@ -1324,13 +1464,13 @@ crx_solve_kernel(const crx_kparams kp) {
             };
             ROWS(j, jv, lane, m) {
                 const bool simple = !ROW_IS_CBF(j, N);
-                const double sc = LD(L::rsc + j), t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
+                const double sc = row_scale<L>(sm, si, j, N), t = LD(L::rt + j), dt = LD(L::rdt + j), cj = LD(L::rc + j);
                 ROW_LOADS_DONE();
                 row_trial(j, jv && simple, simple, sc, cj + al * (dt - (cj - t)), t, dt);   // linear rows: exact
             }
             if (NOBS) {
                 CBF_ROWS(j, k, ob, ev, lane, N) {   // evaluated at Z + al dZ
-                    const double sc = LD(L::rsc + j), t = LD(L::rt + j), dt = LD(L::rdt + j);
+                    const double sc = cbf_scale<L>(sm, k, ob), t = LD(L::rt + j), dt = LD(L::rdt + j);
                     row_trial(j, ev, true, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, al), t, dt);
                 }
             }
@@ -1389,8 +1529,10 @@ crx_solve_kernel(const crx_kparams kp) {
         nus = 0.0; cmax = 0.0; cmin = INFINITY;
         auto row_accept = [&](int j, bool own, double sc, double v) {   // own: this lane is the one that updates row j
             const bool on = sc != 0.0, cnt = own && on;
-            const double tn = LD(L::rtt + j), rcj = LD(L::rc + j), rtj = LD(L::rt + j), rwj = LD(L::rw + j), rsj = LD(L::rsig + j);
+            const double tn = LD(L::rtt + j), rcj = LD(L::rc + j), rtj = LD(L::rt + j);
             const double rdj = LD(L::rdt + j), rnj = LD(L::rnu + j);
+            double rwj, rsj;   // (slim: 1/t is recomputed -- rtt holds the trial slack by now; frcp(t) returns what assemble_newton stored)
+            row_sig_w<L>(sm, j, on, mu, rtj, rnj, L::SLIM ? frcp(rtj) : 0.0, rcj, rsj, rwj);
             ROW_LOADS_DONE();
             const double mut = mu * frcp(tn);
             const double rp = rcj - rtj;                       // dnu as in the row-step pass (rc, rt, rw, rsig still hold that state)
@@ -1408,12 +1550,12 @@ crx_solve_kernel(const crx_kparams kp) {
         };
         ROWS(j, jv, lane, m) {
             const int pk = RIVT(si, j);
-            const double sc = LD(L::rsc + j), v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
+            const double sc = row_scale<L>(sm, si, j, N), v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - row_bound<L>(sm, c, j));
             row_accept(j, jv && !ROW_IS_CBF(j, N), sc, v);
         }
         if (NOBS) {
             CBF_ROWS(j, k, ob, ev, lane, N) {
-                const double sc = LD(L::rsc + j);
+                const double sc = cbf_scale<L>(sm, k, ob);
                 row_accept(j, ev, sc, sc * cbf_value<NOBS, NMAX>(sm, c, k, ob, 0.0));
             }
         }
@@ -1443,7 +1585,7 @@ crx_solve_kernel(const crx_kparams kp) {
             const bool cbf = ROW_IS_CBF(j, N);
             const int r = j < N * NR ? j % NR : 8;              // rows N*NR.. are the sigma_0 bounds
             const bool sig = NOBS && (j >= N * NR || (r >= 8 && r < 8 + NOBS));
-            if ((cbf || sig) && LD(L::rsc + j) != 0.0) {
+            if ((cbf || sig) && row_scale<L>(sm, si, j, N) != 0.0) {
                 const double t = fmax(fabs(LD(L::rc + j)), o.slack_push);
                 LD(L::rt + j) = t;
                 LD(L::rnu + j) = fmin(fmax(o.mu_init / t, 1e-8), 1e8);
@@ -1462,6 +1604,8 @@ crx_solve_kernel(const crx_kparams kp) {
         // jammed, but nothing to restore (the violated rows are not CBF rows): stop looking for jams and redo this
         // iteration -- same state, same step, accepted this time (the oracle simply goes on to accept it)
         jam_on = 0; jam = 0;
+        // (slim layout: the curvature table G shares its storage with the feedback gains the abandoned sweep has just written)
+        if constexpr (L::SLIM) first_order<NOBS, NMAX>(sm, si, c);
         continue;
     }
     // no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still violated there

@@ -79,6 +79,7 @@ struct crx_plant_kparams {
     const double *track, *xglob, *xcurv, *u;
     double *xglob_next, *xcurv_next;
     int32_t* laps;
+    const double* noise_z;   // optional [batch][3] standard-normal draws: the bounded process noise of base.py:929-939
 };
 
 struct crx_cbfprep_kparams {

@@ -105,14 +105,37 @@ __global__ void __launch_bounds__(WAVE) crx_scene_kernel(const crx_scene_kparams
     const double L = d.lap_length, s_e = wrap_above(ego[4], L);
     // vehicles of interest, in dict order (get_overtake_flag :29-42 -> check_ego_agent_distance planner_helper.py:218-266)
     int idx[CRX_MAX_OBS], nv = 0, over = 0;
+    unsigned long long hits = 0ull;
+    int nh = 0;
     for (int v = 0; v < na; v++) {
         const double dv = fabs(ego[0] - vx_[6 * v]);
         const double s_a = wrap_above(vx_[6 * v + 4], L);
         const double ahead = d.safety_factor * d.veh_length + d.prediction_factor * dv, behind = 1.0 * d.veh_length;
         const bool hit = (s_a - s_e <= ahead && s_a >= s_e) || (s_a + L - s_e <= ahead && s_a + L >= s_e) ||
                          (s_e - s_a <= behind && s_a <= s_e) || (s_e + L - s_a <= behind && s_a <= s_e + L);
-        if (hit) { if (nv < V) idx[nv++] = v; else over++; }
+        if (hit) { hits |= 1ull << v; nh++; }
     }
+    // More vehicles of interest than the n_veh_max slots (the reference has no limit): keep the n_veh_max NEAREST along the
+    // track (distance on the closed lap, ties to the earlier one), in dict order -- the policy of hostprep.pack_obstacles on the
+    // controller side; `overflow` counts the dropped ones.
+    if (nh > V) {
+        unsigned long long keep = 0ull;
+        for (int k = 0; k < V; k++) {
+            int best = -1;
+            double bd = 0.0;
+            for (int v = 0; v < na; v++) {
+                if (!((hits >> v) & 1ull) || ((keep >> v) & 1ull)) continue;
+                const double g = wrap_above(vx_[6 * v + 4], L) - s_e;
+                const double dist = fmin(fabs(g), fmin(fabs(g + L), fabs(g - L)));
+                if (best < 0 || dist < bd) { best = v; bd = dist; }
+            }
+            keep |= 1ull << best;
+        }
+        over = nh - V;
+        hits = keep;
+    }
+    for (int v = 0; v < na; v++)
+        if ((hits >> v) & 1ull) idx[nv++] = v;
     // partial "sort" (:66-76, quirk Q3): a new vehicle goes to the FRONT if its ey >= the current first one's, else to the back
     int ord[CRX_MAX_OBS];
     for (int k = 0; k < nv; k++) {
@@ -274,6 +297,14 @@ __global__ void __launch_bounds__(256) crx_plant_kernel(const crx_plant_kparams 
     double* g = pk.xglob_next + 6 * (size_t)b;
     double* c = pk.xcurv_next + 6 * (size_t)b;
     g[0] = vx; g[1] = vy; g[2] = wz; g[3] = psi; g[4] = X; g[5] = Y;
+    if (pk.noise_z) {
+        // bounded process noise (utils/base.py:929-939): clip(z sigma, +-lim), HALF of it added to the curvilinear velocities
+        // only -- the global-frame copy stays clean (the next step reads its velocities from xcurv, vehicle_dynamics.py:17-19)
+        const double* z = pk.noise_z + 3 * (size_t)b;
+        vx += 0.5 * fmax(-0.05, fmin(z[0] * 0.01, 0.05));
+        vy += 0.5 * fmax(-0.1, fmin(z[1] * 0.01, 0.1));
+        wz += 0.5 * fmax(-0.05, fmin(z[2] * 0.005, 0.05));
+    }
     c[0] = vx; c[1] = vy; c[2] = wz; c[3] = epsi; c[4] = s; c[5] = ey;
 }
 

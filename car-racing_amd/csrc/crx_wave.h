@@ -85,6 +85,12 @@ __device__ __forceinline__ double wave_min(double v) {
 //   0-1, of B in rows 2-3);  swap16(s1, s2): s1' = rows [s1.0 s2.0 s1.2 s2.2], s2' = rows [s1.1 s2.1 s1.3 s2.3];
 //   s1' OP s2' = rows [A C B D]: ONE row reduction, four readlanes.  29 instructions for four values (92), 24 for two (46).
 // All 64 lanes must be active (they are: the callers sit in wave-uniform control flow).
+// gfx950 (MI355X, CDNA4) ONLY: these two instructions do not exist on gfx942 and older.  libcrx is written for this one
+// target (no multi-arch fallback paths by design); another --offload-arch stops here with a readable message instead of
+// an "unknown builtin" deep inside the solver.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libcrx targets gfx950 (MI355X / CDNA4) only: crx_wave.h uses v_permlane32_swap / v_permlane16_swap (build with ARCH=gfx950)"
+#endif
 __device__ __forceinline__ void swap32_f64(double& x, double& y) {
     auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
     auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);

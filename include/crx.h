@@ -317,7 +317,9 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
  *   n_all     [S]            vehicles in the scenario besides the ego, 0..n_all_max, in the reference's dict order
  *   veh_xcurv [S][VA][6]     their current states;  pred_s, pred_ey [S][VA][N+1]  their predictions (get_trajectory_nsteps rows 4, 5)
  *   n_veh [S]                out: vehicles of interest (the planner runs iff > 0);  overflow [S]: of-interest vehicles beyond
- *                            n_veh_max that were dropped (the reference has no limit; libcrx plans around at most CRX_MAX_OBS)
+ *                            n_veh_max that were dropped (the reference has no limit; libcrx plans around at most CRX_MAX_OBS).
+ *                            On overflow the n_veh_max vehicles NEAREST to the ego along the closed lap are kept (ties to the
+ *                            earlier one), in dict order -- the closest car is never the one dropped.
  *   order [S][V]             out: vehicle index (0..n_all-1) of sorted vehicle k, -1 beyond n_veh
  *   veh_info [S][V][3], max_dv [S], obs_s, obs_ey [S][V][N+1]   out
  */
@@ -344,8 +346,12 @@ int crx_planner_scene_dev(const crx_scene_desc* d, int n_scen, const double* ego
  * One control step of the plant for a batch of vehicles: n_sub explicit Euler
  * sub-steps of the dynamic bicycle with Pacejka tyres (system/vehicle_dynamics.py:4-49) in global and
  * curvilinear coordinates, the curvature looked up from the track table at every sub-step
- * (racing_env.py:225-246), exactly DynamicBicycleModel.forward_dynamics with zero noise (base.py:897-942;
- * the bounded process noise :930-939 is host RNG and stays with the caller).
+ * (racing_env.py:225-246), exactly DynamicBicycleModel.forward_dynamics (base.py:897-942).  The reference's bounded
+ * process noise (:929-939; ON by default, car_racing/tests/overtake_planner_test.py:41-42 makes zero-noise opt-in) is
+ * applied by crx_plant_step_noise_dev from standard-normal draws the CALLER supplies (its RNG, its seed):
+ *   noise_z [batch][3] or NULL   z ~ N(0,1) per vehicle for (vx, vy, wz); the kernel forms clip(0.01 z0, +-0.05),
+ *                                clip(0.01 z1, +-0.1), clip(0.005 z2, +-0.05) and adds HALF of each to the curvilinear
+ *                                velocities only (xglob_next keeps the noise-free ones, as the reference does).  NULL = zero noise.
  *   track [n_seg][6] rows (x, y, psi, s_start, length, curvature);  xglob, xcurv [batch][6];  u [batch][2]
  * crx_plant_step_wrap_dev additionally applies the lap bookkeeping of ModelBase.update_memory (base.py:795-819):
  * s > lap_length -> s -= lap_length, laps[b] += 1 (laps may be NULL).  u_stride = doubles between the inputs of
@@ -354,6 +360,9 @@ int crx_planner_scene_dev(const crx_scene_desc* d, int n_scen, const double* ego
 int crx_plant_step_wrap_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
                             const double* xcurv, const double* u, int u_stride, double* xglob_next, double* xcurv_next,
                             int32_t* laps, void* stream);
+int crx_plant_step_noise_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
+                             const double* xcurv, const double* u, int u_stride, const double* noise_z, double* xglob_next,
+                             double* xcurv_next, int32_t* laps, void* stream);
 int crx_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
                    const double* u, double* xglob_next, double* xcurv_next);
 int crx_plant_step_dev(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
@@ -526,6 +535,28 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
 int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
                              const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
                              double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream);
+
+/*
+ * Multi-GPU: problems are independent and a planner sweep is sharded by scenario, so the path has
+ * exactly ONE exchange step -- an all-gather of the fixed-size winner records {flag, X[N+1][6]} (1 + 6(N+1) doubles =
+ * 632 B at N = 12) -- issued on RCCL (ncclAllGather over xGMI).  One process per GPU.  The caller owns the rendezvous:
+ * rank 0 calls crx_comm_get_unique_id and carries the CRX_COMM_ID_BYTES bytes to the other ranks by whatever it has (MPI,
+ * a file, torch.distributed's store); every rank then calls crx_comm_init_rank on the device it gave crx_init (collective:
+ * returns when all ranks arrived).  RCCL is resolved at run time (a copy the process already holds, e.g. PyTorch's, else
+ * /opt/rocm's); libcrx does not link it.
+ *   crx_allgather_winners_dev  packs this rank's n_local winners (flag [n_local] int32, best_X [n_local][N+1][6] -- the
+ *       outputs of crx_select / crx_planner_plan) into send [n_max][rec] (rows past n_local zero: ragged shards are
+ *       padded to the largest, n_max, which every rank derives from (n_total, world) alone) and gathers every rank's
+ *       block into recv [world][n_max][rec], in rank order, on `stream`.  rec = 1 + 6 (N + 1), record = [flag, X].
+ */
+#define CRX_COMM_ID_BYTES 128
+int crx_comm_get_unique_id(void* id /* [CRX_COMM_ID_BYTES] */);
+int crx_comm_init_rank(const void* id, int world, int rank);
+int crx_comm_world(void);   /* 0 without a communicator */
+int crx_comm_rank(void);    /* -1 without a communicator */
+int crx_comm_destroy(void);
+int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const double* best_X, double* send,
+                              double* recv, void* stream);
 
 /* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
  * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this. */

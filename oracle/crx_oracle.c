@@ -387,6 +387,10 @@ static int thread_ws(work_t** w, ocp_t** p) {
 #include <stdio.h>
 static int g_verbose = 0;
 void crx_oracle_set_verbose(int v) { g_verbose = v; }
+/* experiment knobs (tools/tail_knobs.py): 0 JAM_ALPHA, 1 JAM_COUNT, 2 STALL_ITERS, 3 CRAWL_ALPHA, 4 CRAWL_COUNT (0 = off),
+ * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off) */
+static double g_knob[8] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0};
+void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 8) g_knob[i] = v; }
 
 /* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
  * its restoration phase).  What jams on crash states (ego inside, or about to enter, an obstacle's unsafe set) is the
@@ -484,9 +488,10 @@ static void ipm_solve(work_t* w, result_t* res) {
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0;
-    enum { JAM_COUNT = 5, STALL_ITERS = 50 };
-    const double JAM_ALPHA = 1e-3;
+    const int JAM_COUNT = (int)g_knob[1], STALL_ITERS = (int)g_knob[2];
+    const double JAM_ALPHA = g_knob[0];
     int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
+    int crawl = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     for (it = 0;; it++) {
         /* residuals */
@@ -655,11 +660,16 @@ static void ipm_solve(work_t* w, result_t* res) {
          * slacks of violated CBF rows are collapsing and every step is cut to nothing (IPOPT's alpha < alpha_min test
          * sends it to restoration from the same situation) */
         if (acc && jam_on && al < JAM_ALPHA && e_p > o->tol) jam++; else jam = 0;
+        /* crawl: CRAWL_COUNT accepted steps in a row cut below CRAWL_ALPHA by the fraction-to-the-boundary rule while still infeasible */
+        if (g_knob[4] > 0) {
+            if (acc && jam_on && al < g_knob[3] && e_p > 1e-6) crawl++; else crawl = 0;
+            if (crawl >= (int)g_knob[4]) { jam = JAM_COUNT; crawl = 0; }
+        }
         /* stall: STALL_ITERS iterations without a restoration and still infeasible -- the same crawl with steps just above
          * JAM_ALPHA; healthy problems are done (p99 16 iterations, max 30 on the BASELINE draws) or at least feasible by then */
         if (acc && jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
         if (!acc || jam >= JAM_COUNT) {
-            if (o->restore_iters >= 0 && n_restore < 2 && restore_slacks(w, o->mu_init)) {
+            if (o->restore_iters >= 0 && n_restore < (int)g_knob[5] && restore_slacks(w, o->mu_init)) {
                 if (g_verbose) fprintf(stderr, "      RESTORE (acc %d jam %d)\n", acc, jam);
                 if (n_restore++ == 0) it_limit = it + 1 + o->restore_iters;
                 mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0; jam = 0;
@@ -717,6 +727,32 @@ void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
     o->grad_scale_max = 100.0;
 }
 
+/* The region QP of generate_traj_per_region as the canonical stage-structured problem (line numbers into
+ * planning/overtake_traj_planner.py). */
+static void fill_planner(ocp_t* p, const crx_planner_desc* d, const double* xb, const double* bs, const double* be,
+                         const double* ey_lb_b, double ey_ub_b) {
+    const int N = d->N;
+    memset(p, 0, sizeof(*p));
+    p->N = N; p->nobs = 0; p->linear_rows = 1;
+    memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
+    memcpy(p->x0, xb, sizeof(p->x0));
+    p->wq[4] = d->w_ref; p->wq[5] = d->w_ref;                     /* :333-334 */
+    for (int j = 0; j <= N; j++) {
+        double st = clip(xb[4] + 1.0 * j * xb[0] * d->dt_ref, bs[0], bs[N]);   /* :330-331 */
+        p->xr[j][4] = st;
+        p->xr[j][5] = interp_lin(bs, be, N + 1, st);                            /* :332 */
+    }
+    p->lin[N][4] = -d->w_prog; p->cconst = d->w_prog * xb[4];      /* :328 */
+    for (int k = 0; k < N; k++) p->wc[k] = (k >= 1 && k <= N - 2) ? d->w_dey : 0.0; /* :325-327 */
+    p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;            /* :280-281 */
+    p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                    /* :283-284 */
+    for (int k = 0; k <= N; k++) {
+        p->vlo[k] = -HUGE_VAL; p->vhi[k] = (k >= 1) ? d->vx_max : HUGE_VAL;   /* :276 */
+        if (k < N) { p->elo[k] = ey_lb_b[k]; p->ehi[k] = ey_ub_b; } /* :277-324 */
+        else { p->elo[k] = -HUGE_VAL; p->ehi[k] = HUGE_VAL; }
+    }
+}
+
 int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double* x0,
                              const double* bez_s, const double* bez_ey, const double* ey_lb,
                              const double* ey_ub, double* X, double* U, double* cost,
@@ -733,26 +769,8 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
         const double* xb = x0 + 6 * b;
         const double* bs = bez_s + (size_t)(N + 1) * b;
         const double* be = bez_ey + (size_t)(N + 1) * b;
-        memset(p, 0, sizeof(*p));
-        p->N = N; p->nobs = 0; p->linear_rows = 1;
-        memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
-        memcpy(p->x0, xb, sizeof(p->x0));
-        p->wq[4] = d->w_ref; p->wq[5] = d->w_ref;                     /* :333-334 */
-        for (int j = 0; j <= N; j++) {
-            double st = clip(xb[4] + 1.0 * j * xb[0] * d->dt_ref, bs[0], bs[N]);   /* :330-331 */
-            p->xr[j][4] = st;
-            p->xr[j][5] = interp_lin(bs, be, N + 1, st);                            /* :332 */
-        }
-        p->lin[N][4] = -d->w_prog; p->cconst = d->w_prog * xb[4];      /* :328 */
-        for (int k = 0; k < N; k++) p->wc[k] = (k >= 1 && k <= N - 2) ? d->w_dey : 0.0; /* :325-327 */
-        p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;            /* :280-281 */
-        p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                    /* :283-284 */
+        fill_planner(p, d, xb, bs, be, ey_lb + (size_t)N * b, ey_ub[b]);
         int infeas0 = 0;
-        for (int k = 0; k <= N; k++) {
-            p->vlo[k] = -HUGE_VAL; p->vhi[k] = (k >= 1) ? d->vx_max : HUGE_VAL;   /* :276 */
-            if (k < N) { p->elo[k] = ey_lb[(size_t)N * b + k]; p->ehi[k] = ey_ub[b]; } /* :277-324 */
-            else { p->elo[k] = -HUGE_VAL; p->ehi[k] = HUGE_VAL; }
-        }
         /* rows on the fixed x0 are constants: feasible -> inert, violated -> IPOPT cannot succeed */
         if (xb[5] < p->elo[0] - d->opts.tol || xb[5] > p->ehi[0] + d->opts.tol) infeas0 = 1;
         result_t r;
@@ -785,6 +803,35 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
     return CRX_OK;
 }
 
+/* control.mpccbf / control.mpc_multi_agents as the canonical stage-structured problem (line numbers into
+ * control/control.py).  xt_b: [6] or, with per_stage_target, [N+1][6]; obstacle arrays: this problem's [V][N+1] block. */
+static void fill_cbf(ocp_t* p, const crx_cbf_desc* d, const double* xb, const double* xt_b, const double* obs_s_b,
+                     const double* obs_ey_b, const double* lap_off_b, int nobs) {
+    const int N = d->N, V = d->n_obs_max;
+    memset(p, 0, sizeof(*p));
+    p->N = N; p->nobs = nobs; p->linear_rows = (V == 0);
+    memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
+    memcpy(p->x0, xb, sizeof(p->x0));
+    memcpy(p->wq, d->Q, sizeof(p->wq));                            /* :588-591 */
+    for (int k = 0; k <= N; k++)
+        memcpy(p->xr[k], d->per_stage_target ? xt_b + (size_t)k * 6 : xt_b,
+               sizeof(double) * 6);
+    p->wr[0] = d->R[0]; p->wr[1] = d->R[1];                        /* :578-579 */
+    p->wsig = d->w_slack;                                          /* :560,562 */
+    p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;           /* :572-573 */
+    p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                   /* :575-576 */
+    for (int k = 0; k <= N; k++) {                                 /* :582-586 */
+        p->vlo[k] = d->v_min; p->vhi[k] = d->v_max; p->elo[k] = -d->ey_max; p->ehi[k] = d->ey_max;
+    }
+    for (int o = 0; o < p->nobs; o++) {
+        memcpy(p->obs_s[o], obs_s_b + (size_t)o * (N + 1), sizeof(double) * (N + 1));
+        memcpy(p->obs_ey[o], obs_ey_b + (size_t)o * (N + 1), sizeof(double) * (N + 1));
+        p->lap_off[o] = lap_off_b[o];
+    }
+    p->alpha = d->alpha; p->cm = 1.0 + d->margin; p->Ls = d->l_sum; p->Ws = d->w_sum;
+    p->degree = d->degree;
+}
+
 int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
                          const double* obs_s, const double* obs_ey, const double* lap_off,
                          const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
@@ -804,28 +851,8 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
     for (int b = 0; b < batch; b++) {
         if (!have_ws) { status[b] = CRX_MAX_ITER; continue; }
         const double* xb = x0 + 6 * b;
-        memset(p, 0, sizeof(*p));
-        p->N = N; p->nobs = n_obs ? n_obs[b] : V; p->linear_rows = (V == 0);
-        memcpy(p->A, d->A, sizeof(p->A)); memcpy(p->B, d->B, sizeof(p->B));
-        memcpy(p->x0, xb, sizeof(p->x0));
-        memcpy(p->wq, d->Q, sizeof(p->wq));                            /* :588-591 */
-        for (int k = 0; k <= N; k++)
-            memcpy(p->xr[k], d->per_stage_target ? xt + ((size_t)(N + 1) * b + k) * 6 : xt + 6 * b,
-                   sizeof(double) * 6);
-        p->wr[0] = d->R[0]; p->wr[1] = d->R[1];                        /* :578-579 */
-        p->wsig = d->w_slack;                                          /* :560,562 */
-        p->ulo[0] = -d->delta_max; p->uhi[0] = d->delta_max;           /* :572-573 */
-        p->ulo[1] = -d->a_max; p->uhi[1] = d->a_max;                   /* :575-576 */
-        for (int k = 0; k <= N; k++) {                                 /* :582-586 */
-            p->vlo[k] = d->v_min; p->vhi[k] = d->v_max; p->elo[k] = -d->ey_max; p->ehi[k] = d->ey_max;
-        }
-        for (int o = 0; o < p->nobs; o++) {
-            memcpy(p->obs_s[o], obs_s + ((size_t)V * b + o) * (N + 1), sizeof(double) * (N + 1));
-            memcpy(p->obs_ey[o], obs_ey + ((size_t)V * b + o) * (N + 1), sizeof(double) * (N + 1));
-            p->lap_off[o] = lap_off[(size_t)V * b + o];
-        }
-        p->alpha = d->alpha; p->cm = 1.0 + d->margin; p->Ls = d->l_sum; p->Ws = d->w_sum;
-        p->degree = d->degree;
+        fill_cbf(p, d, xb, d->per_stage_target ? xt + (size_t)(N + 1) * 6 * b : xt + 6 * b, obs_s + (size_t)V * (N + 1) * b,
+                 obs_ey + (size_t)V * (N + 1) * b, lap_off + (size_t)V * b, n_obs ? n_obs[b] : V);
         int infeas0 = (xb[0] < d->v_min - d->opts.tol || xb[0] > d->v_max + d->opts.tol ||
                        xb[5] < -d->ey_max - d->opts.tol || xb[5] > d->ey_max + d->opts.tol); /* Q9 */
         result_t r;
@@ -841,6 +868,62 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
         cost[b] = r.cost; status[b] = r.status; kkt[b] = r.kkt; iters[b] = r.iters;
     }
     }
+    return CRX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Problem-row probes (tests only): evaluate the problem this file builds from C-ABI inputs at a caller-chosen point
+ * (inputs U, slacks sigma; states by the roll-out), so that tests can compare cost and rows with what the
+ * reference's own code built for the same scenario (tests/golden/cfg*_draw.npz hold the reference's values at the
+ * same point), independently of any solve.
+ *   cost      the objective
+ *   cbf_rows  [n_obs_max][N]   UNSCALED values of  h_{i+1} - h_i + alpha h_i  (control.py:559), 0 for absent obstacles
+ *   box       [4][N+1][... ] -> flat: ulo[2], uhi[2], then vlo[N+1], vhi[N+1], elo[N+1], ehi[N+1] (+-inf = absent)
+ *   X         [N+1][6] the rolled-out states
+ * ---------------------------------------------------------------------------------------------- */
+static void probe_common(work_t* w, ocp_t* p, const crx_ipm_opts* o, const double* U, const double* sigma, int V,
+                         double* cost, double* cbf_rows, double* box, double* X) {
+    const int N = p->N;
+    setup(w, p, o);
+    for (int k = 0; k < N; k++) { w->v[iu(w, k)] = U[2 * k]; w->v[iu(w, k) + 1] = U[2 * k + 1]; }
+    for (int ob = 0; ob < p->nobs; ob++)
+        for (int k = 0; k <= N; k++) w->v[isig(w, k, ob)] = sigma[(size_t)ob * (N + 1) + k];
+    unpack(w, w->v);
+    *cost = cost_value(w);
+    if (cbf_rows) {
+        for (int i = 0; i < V * N; i++) cbf_rows[i] = 0.0;
+        for (int j = 0; j < w->m; j++)
+            if (w->row[j].kind == ROW_CBF) cbf_rows[(size_t)w->row[j].o * N + w->row[j].k] = row_value(w, j);
+    }
+    double* b = box;
+    for (int i = 0; i < 2; i++) *b++ = p->ulo[i];
+    for (int i = 0; i < 2; i++) *b++ = p->uhi[i];
+    for (int k = 0; k <= N; k++) *b++ = p->vlo[k];
+    for (int k = 0; k <= N; k++) *b++ = p->vhi[k];
+    for (int k = 0; k <= N; k++) *b++ = p->elo[k];
+    for (int k = 0; k <= N; k++) *b++ = p->ehi[k];
+    memcpy(X, w->x, sizeof(double) * 6 * (N + 1));
+}
+
+int crx_oracle_cbf_probe(const crx_cbf_desc* d, const double* x0, const double* xt, const double* obs_s,
+                         const double* obs_ey, const double* lap_off, int n_obs, const double* U, const double* sigma,
+                         double* cost, double* cbf_rows, double* box, double* X) {
+    if (!d || d->N < 2 || d->N > MAXN || d->n_obs_max < 0 || d->n_obs_max > MAXO || n_obs < 0 || n_obs > d->n_obs_max)
+        return CRX_ERR_ARG;
+    work_t* w; ocp_t* p;
+    if (!thread_ws(&w, &p)) return CRX_ERR_ARG;
+    fill_cbf(p, d, x0, xt, obs_s, obs_ey, lap_off, n_obs);
+    probe_common(w, p, &d->opts, U, sigma, d->n_obs_max, cost, cbf_rows, box, X);
+    return CRX_OK;
+}
+
+int crx_oracle_planner_probe(const crx_planner_desc* d, const double* x0, const double* bez_s, const double* bez_ey,
+                             const double* ey_lb, double ey_ub, const double* U, double* cost, double* box, double* X) {
+    if (!d || d->N < 2 || d->N > MAXN) return CRX_ERR_ARG;
+    work_t* w; ocp_t* p;
+    if (!thread_ws(&w, &p)) return CRX_ERR_ARG;
+    fill_planner(p, d, x0, bez_s, bez_ey, ey_lb, ey_ub);
+    probe_common(w, p, &d->opts, U, NULL, 0, cost, NULL, box, X);
     return CRX_OK;
 }
 
@@ -869,7 +952,10 @@ int crx_oracle_planner_scene(const crx_scene_desc* d, int n_scen, const double* 
         if (na < 0 || na > VA) return CRX_ERR_ARG;
         double s_e = ego[4];
         while (s_e > L) s_e -= L;                                                    /* planner_helper.py:222-223 */
-        int idx[MAXO], nv = 0, over = 0;
+        int idx[MAXO], nv = 0, over = 0, nh = 0;
+        char hit_[64] = {0}, keep_[64] = {0};
+        double gap_[64];
+        if (VA > 64) return CRX_ERR_ARG;
         for (int v = 0; v < na; v++) {
             const double dv = fabs(ego[0] - vx[6 * v]);
             double s_a = vx[6 * v + 4];
@@ -877,8 +963,22 @@ int crx_oracle_planner_scene(const crx_scene_desc* d, int n_scen, const double* 
             const double ahead = d->safety_factor * d->veh_length + d->prediction_factor * dv, behind = 1.0 * d->veh_length;
             const int hit = (s_a - s_e <= ahead && s_a >= s_e) || (s_a + L - s_e <= ahead && s_a + L >= s_e) ||
                             (s_e - s_a <= behind && s_a <= s_e) || (s_e + L - s_a <= behind && s_a <= s_e + L);
-            if (hit) { if (nv < V) idx[nv++] = v; else over++; }
+            const double g = s_a - s_e;
+            gap_[v] = fmin(fabs(g), fmin(fabs(g + L), fabs(g - L)));
+            if (hit) { hit_[v] = 1; nh++; }
         }
+        if (nh > V) {   /* more vehicles of interest than slots (the reference has no limit): the V nearest, in dict order */
+            for (int k = 0; k < V; k++) {
+                int best = -1;
+                for (int v = 0; v < na; v++)
+                    if (hit_[v] && !keep_[v] && (best < 0 || gap_[v] < gap_[best])) best = v;
+                keep_[best] = 1;
+            }
+            over = nh - V;
+            memcpy(hit_, keep_, sizeof(hit_));
+        }
+        for (int v = 0; v < na; v++)
+            if (hit_[v]) idx[nv++] = v;
         int ord[MAXO];
         for (int k = 0; k < nv; k++) {                                                /* overtake_traj_planner.py:70-76 */
             const double e = vx[6 * idx[k] + 5];
@@ -954,8 +1054,17 @@ int crx_oracle_select(const crx_select_desc* d, int n_scen, const int32_t* n_veh
  * with lo <= s <= hi).  Pinned by tests/golden/harness.npz (single steps and a PID closed loop recorded
  * from the reference).
  * ---------------------------------------------------------------------------------------------- */
+int crx_oracle_plant_step_noise(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                                const double* u, const double* noise_z, double* xglob_next, double* xcurv_next);
 int crx_oracle_plant_step(const crx_plant_desc* d, int batch, const double* track, const double* xglob,
                           const double* xcurv, const double* u, double* xglob_next, double* xcurv_next) {
+    return crx_oracle_plant_step_noise(d, batch, track, xglob, xcurv, u, NULL, xglob_next, xcurv_next);
+}
+
+/* ... with the bounded process noise of utils/base.py:929-939 from caller-supplied standard-normal draws noise_z [batch][3]
+ * (np.random.randn() in the reference, in the order vx, vy, wz); NULL = zero noise */
+int crx_oracle_plant_step_noise(const crx_plant_desc* d, int batch, const double* track, const double* xglob, const double* xcurv,
+                                const double* u, const double* noise_z, double* xglob_next, double* xcurv_next) {
     if (!d || batch < 0 || d->n_seg < 1) return CRX_ERR_ARG;
     for (int b = 0; b < batch; b++) {
         double vx = xcurv[6 * b], vy = xcurv[6 * b + 1], wz = xcurv[6 * b + 2];
@@ -986,6 +1095,12 @@ int crx_oracle_plant_step(const crx_plant_desc* d, int batch, const double* trac
         double* g = xglob_next + 6 * (size_t)b;
         double* c = xcurv_next + 6 * (size_t)b;
         g[0] = vx; g[1] = vy; g[2] = wz; g[3] = psi; g[4] = X; g[5] = Y;
+        if (noise_z) {   /* :929-939: clipped, HALF added, curvilinear copy only */
+            const double* z = noise_z + 3 * (size_t)b;
+            vx += 0.5 * fmax(-0.05, fmin(z[0] * 0.01, 0.05));
+            vy += 0.5 * fmax(-0.1, fmin(z[1] * 0.01, 0.1));
+            wz += 0.5 * fmax(-0.05, fmin(z[2] * 0.005, 0.05));
+        }
         c[0] = vx; c[1] = vy; c[2] = wz; c[3] = epsi; c[4] = s; c[5] = ey;
     }
     return CRX_OK;

@@ -136,3 +136,45 @@ def thin_corridor_qps(orc, AB, eps, n_scen=128, seed=5):
     q["ey_lb"][:, 1:] = ey[:, 1:N] - eps
     q["ey_lb"][:, 0] = np.minimum(q["ey_lb"][:, 0], ey[:, 0] - abs(eps))   # the row on the fixed x0 stays satisfied (quirk Q9)
     return d, tuple(q[k] for k in keys)
+
+
+# ---- row probes of the oracle (oracle/crx_oracle.c crx_oracle_cbf_probe / crx_oracle_planner_probe) ------------------------
+def _dp(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def oracle_cbf_probe(orc, d, x0, xt, obs_s, obs_ey, lap_off, n_obs, U, sigma):
+    """The cost, the UNSCALED CBF row values [n_obs_max][N], the variable boxes and the rolled-out states of the problem the
+    oracle builds from one problem's C-ABI inputs, at the point (U [N][2], sigma [n_obs][N+1])."""
+    import ctypes as C
+    N, V = d.N, d.n_obs_max
+    f64 = np.float64
+    x0, xt, U = (np.ascontiguousarray(a, dtype=f64) for a in (x0, xt, U))
+    obs_s, obs_ey, lap_off = (np.ascontiguousarray(a, dtype=f64).reshape(max(V, 1), -1) for a in (obs_s, obs_ey, lap_off))
+    sig = np.zeros((max(V, 1), N + 1))
+    sig[:n_obs] = np.asarray(sigma, dtype=f64).reshape(n_obs, N + 1)
+    cost = C.c_double(0.0)
+    rows, box, X = np.zeros((max(V, 1), N)), np.zeros(4 + 4 * (N + 1)), np.zeros((N + 1, 6))
+    fn = orc.lib.crx_oracle_cbf_probe
+    fn.restype = C.c_int
+    rc = fn(C.byref(d), _dp(x0), _dp(xt), _dp(obs_s), _dp(obs_ey), _dp(lap_off), C.c_int(int(n_obs)), _dp(U), _dp(sig), C.byref(cost),
+            _dp(rows), _dp(box), _dp(X))
+    assert rc == 0, rc
+    b = box[4:].reshape(4, N + 1)
+    return dict(cost=cost.value, cbf=rows[:n_obs], ulo=box[0:2], uhi=box[2:4], vlo=b[0], vhi=b[1], elo=b[2], ehi=b[3], X=X)
+
+
+def oracle_planner_probe(orc, d, x0, bez_s, bez_ey, ey_lb, ey_ub, U):
+    import ctypes as C
+    N = d.N
+    f64 = np.float64
+    x0, bez_s, bez_ey, ey_lb, U = (np.ascontiguousarray(a, dtype=f64) for a in (x0, bez_s, bez_ey, ey_lb, U))
+    cost = C.c_double(0.0)
+    box, X = np.zeros(4 + 4 * (N + 1)), np.zeros((N + 1, 6))
+    fn = orc.lib.crx_oracle_planner_probe
+    fn.restype = C.c_int
+    rc = fn(C.byref(d), _dp(x0), _dp(bez_s), _dp(bez_ey), _dp(ey_lb), C.c_double(float(ey_ub)), _dp(U), C.byref(cost), _dp(box), _dp(X))
+    assert rc == 0, rc
+    b = box[4:].reshape(4, N + 1)
+    return dict(cost=cost.value, ulo=box[0:2], uhi=box[2:4], vlo=b[0], vhi=b[1], elo=b[2], ehi=b[3], X=X)

@@ -1,0 +1,278 @@
+"""The BASELINE draws bench.py times, tied to the reference's OWN problem construction.
+
+tests/golden/cfg{2,3,4}_draw.npz (tests/golden/tools/make_draws.py) replay the synthetic scenarios of crx/synth.py through
+the reference's unmodified control.mpccbf / mpc_multi_agents / OvertakeTrajPlanner.get_local_traj under the recording CasADi
+stand-in.  Three-way checks, CPU side here (the `-m gpu` twins are in tests/test_gpu_parity.py):
+
+  rows      cost, variable boxes and CBF row values of the reference's recorded problem at a seeded point == the rows
+            oracle/crx_oracle.c builds from the arrays the PRODUCT's host prep (crx/synth.py + crx/hostprep.py, the path
+            bench.py takes) makes of the same raw scenario -- for every problem, crash states included, no solve involved;
+  prep      obstacles that enter the NLP, their predictions, Bezier polylines, sorted vehicles == the reference's;
+  solutions oracle == certified KKT point of the reference-built problem (third solver, or the oracle's own point put
+            through the solver-agnostic certificate on the reference's recorded graph: `how`), direction flags exact;
+  classes   every problem the oracle does not converge on is classified: `third solver finds no KKT point either` /
+            `a KKT point exists (solvable; the oracle / kernel stop for latency or by their restoration budget)`.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+import helpers
+
+LAP = 19.22957795362994
+
+
+def _load(name):
+    path = os.path.join(conftest.GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(name + " not generated")
+    return np.load(path, allow_pickle=False)
+
+
+def _group(z, g):
+    return {k[len(g) + 1:]: z[k] for k in z.files if k.startswith(g + "/")}
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def cbf_batch(kind, lapped):
+    from crx import synth
+    if kind == "cfg2":
+        return synth.cfg2_mpccbf(256, N=12, seed=2, safe_start=False, lapped_frac=0.25 if lapped else 0.0)
+    return synth.cfg4_tracking_cbf(256, N=20, seed=4, safe_start=False, lapped_frac=0.25 if lapped else 0.0)
+
+
+def cbf_desc(kind, A, B, tol=1e-8):
+    from crx import abi
+    if kind == "cfg2":
+        d = abi.cbf_desc(12, 1, A, B, alpha=0.8, margin=0.2)
+    else:
+        d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    d.opts.tol = tol
+    return d
+
+
+KEYS = ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")
+
+
+@pytest.mark.parametrize("kind,group", [("cfg2", "draw"), ("cfg2", "lapped"), ("cfg4", "draw"), ("cfg4", "lapped")])
+def test_cbf_rows_and_prep_match_reference(orc, AB, kind, group):
+    """synth + hostprep build the reference's rows (module docstring: rows, prep)."""
+    from crx import hostprep
+    A, B = AB
+    g = _group(_load(kind + "_draw.npz"), group)
+    p = cbf_batch(kind, group == "lapped")
+    d = cbf_desc(kind, A, B)
+    N, V = d.N, d.n_obs_max
+    assert len(g["index"]) >= (16 if group == "lapped" else 48) or os.environ.get("CRX_DRAW_PARTIAL")
+    n_lapped = 0
+    for r, b in enumerate(g["index"]):
+        b = int(b)
+        tag = "%s/%s #%d" % (kind, group, b)
+        # the fixture replayed exactly what synth draws today
+        np.testing.assert_array_equal(p["x0"][b], g["x0"][r], err_msg=tag)
+        np.testing.assert_array_equal(p["cars"][b], g["cars"][r], err_msg=tag)
+        n = int(g["n_obs_ref"][r])
+        assert int(p["n_obs"][b]) == n, tag                                   # the window test kept the same cars ...
+        keep, off = hostprep.cbf_window(p["x0"][b:b + 1], g["cars"][r][None, :, 0], LAP)
+        kept = np.nonzero(keep[0])[0]
+        assert len(kept) == n, tag
+        # ... and their predictions are what the reference's vehicle model returned (sympy s(t) = v t + s0 vs numpy)
+        np.testing.assert_allclose(p["obs_s"][b, :n], g["obs_pred"][r][kept, 4, :], rtol=0, atol=2e-14, err_msg=tag)
+        np.testing.assert_allclose(p["obs_ey"][b, :n], g["obs_pred"][r][kept, 5, :], rtol=0, atol=1e-15, err_msg=tag)
+        n_lapped += bool(np.any(p["lap_off"][b, :n] != 0.0))
+        # rows at the probe point
+        U, sig = g["probe_U"][r], g["probe_sigma"][r][:n]
+        pr = helpers.oracle_cbf_probe(orc, d, p["x0"][b], p["xt"][b], p["obs_s"][b], p["obs_ey"][b], p["lap_off"][b], n, U, sig)
+        assert g["probe_eq"][r] <= 1e-12, tag                                # dynamics + x0 rows vanish on the roll-out: same A, B, x0
+        assert _rel(pr["cost"], g["probe_f"][r]) <= 1e-12, (tag, pr["cost"], g["probe_f"][r])
+        ref_rows = g["probe_cbf"][r][:n]
+        assert (_rel(pr["cbf"], ref_rows) <= 1e-9).all(), (tag, np.abs(pr["cbf"] - ref_rows).max())
+        # boxes: inputs, vx and ey of every stage (the reference also states them on the fixed x0), sigma >= 0
+        # (the fixture recovers a bound as -(c(z) - a z) / a from the recorded row: exact up to the rounding of that expression)
+        bx = dict(rtol=0, atol=4e-15, err_msg=tag)
+        for c in range(2):
+            np.testing.assert_allclose(g["box_u_lo"][r][:, c], pr["ulo"][c], **bx)
+            np.testing.assert_allclose(g["box_u_hi"][r][:, c], pr["uhi"][c], **bx)
+        np.testing.assert_allclose(g["box_x_lo"][r][:, 0], pr["vlo"], **bx)
+        np.testing.assert_allclose(g["box_x_hi"][r][:, 0], pr["vhi"], **bx)
+        np.testing.assert_allclose(g["box_x_lo"][r][:, 5], pr["elo"], **bx)
+        np.testing.assert_allclose(g["box_x_hi"][r][:, 5], pr["ehi"], **bx)
+        assert np.isinf(g["box_x_lo"][r][:, 1:5]).all() and np.isinf(g["box_x_hi"][r][:, 1:5]).all(), tag
+        assert (np.abs(g["box_sig_lo"][r][:n]) <= 4e-15).all(), tag
+    if group == "lapped":
+        assert n_lapped >= len(g["index"]) // 2, "the lapped draw must exercise lap_off != 0 (quirk Q1)"
+
+
+def _solve_and_compare(binding, orc, AB, kind, group, tol, T):
+    """Shared by the CPU (oracle) and GPU (libcrx) versions.  Returns the classification table."""
+    A, B = AB
+    g = _group(_load(kind + "_draw.npz"), group)
+    p = cbf_batch(kind, group == "lapped")
+    d = cbf_desc(kind, A, B, tol)
+    idx = g["index"].astype(int)
+    res = binding.cbf_solve(d, *[p[k][idx] for k in KEYS])
+    N = d.N
+    how = g["how"] if "how" in g else np.where(g["success"], 0, np.where(g["retry_certified"], 1, -1))
+    table = dict(converged_certified=0, converged_uncertified=0, stopped_solvable=0, stopped_unsolved=0, other_kkt_point=0)
+    worst = dict(x=0.0, xw=0.0, u=0.0, f=0.0)
+    loose = []
+    for r, b in enumerate(idx):
+        tag = "%s/%s #%d how %d status %d iters %d" % (kind, group, b, how[r], res["status"][r], res["iters"][r])
+        conv, cert = res["status"][r] == 0, how[r] >= 0
+        table["converged_certified" if conv and cert else "converged_uncertified" if conv else "stopped_solvable" if cert else "stopped_unsolved"] += 1
+        if not (conv and cert):
+            continue
+        n = int(g["n_obs_ref"][r])
+        fg = g["cert"][r][0]
+        df = abs(res["cost"][r] - fg) / max(1.0, abs(fg))
+        # non-convex rows: the point must be the certified one unless it is another KKT point that is no worse
+        if df > T["f"] and res["cost"][r] < fg:
+            table["other_kkt_point"] += 1
+            continue                                                          # a better local minimum than the third solver's: allowed
+        assert df <= T["f"], (tag, res["cost"][r], fg)
+        dX, dU = np.abs(res["X"][r] - g["X"][r]), np.abs(res["U"][r] - g["U"][r])
+        scale = max(1.0, abs(fg) * 1e-6)                                      # crash states: costs 1e8..1e12, slacks 1e4..1e8
+        # cost-weighted states of both NLPs: vx, ey (Q = diag(10,0,0,4|5,0,40|50): s carries no cost and is only as sharp as x)
+        Tl = T.get("loose", T)
+        assert dX.max() <= Tl["x"] * scale and dX[:, [0, 5]].max() <= Tl["xw"] * scale, (tag, dX.max(), dX[:, [0, 5]].max())
+        assert dU.max() <= Tl["u"] * scale, (tag, dU.max())
+        if not (dX.max() <= T["x"] * scale and dX[:, [0, 5]].max() <= T["xw"] * scale and dU.max() <= T["u"] * scale):
+            loose.append(tag)
+        if n:
+            ds = np.abs(res["sigma"][r][:n] - g["sigma"][r][:n])
+            assert (ds <= 1e-6 * np.maximum(1.0, np.abs(g["sigma"][r][:n]))).all(), (tag, ds.max())
+        for k, v in (("x", dX.max()), ("xw", dX[:, [0, 5]].max()), ("u", dU.max()), ("f", df)):
+            worst[k] = max(worst[k], v / (scale if k != "f" else 1.0))
+    return table, worst, res, g, how
+
+
+# tol 1e-11 on both sides: 252 of the 256 + 32 cfg2 problems that have a certified point agree to x 4e-7 / u 6e-6 (vx, ey 5e-7);
+# ONE (#131) sits on a weakly determined direction and agrees to 1.8e-5 only (cost to 1e-11) -- `loose` bounds every problem,
+# the strict set all but `n_loose` of them.  Four more (#6, #33, #95, #163) end at a DIFFERENT KKT point of lower cost than the
+# third solver's from the same zero start (non-convex NLP): listed by the test, not compared.
+TIGHT = dict(tol=1e-11, x=1e-6, u=1e-5, f=1e-9, xw=1e-6, loose=dict(x=5e-5, u=5e-5, xw=2e-6), n_loose=2)
+# tol 1e-8 against points solved to 1e-11: on problems with an ACTIVE CBF row (most of these draws; few of the hand-made
+# goldens) the barrier perturbation mu ~ 1e-9 moves vx / ey by up to ~3e-5 (the row's gradient is 1e2..1e9)
+DEFAULT = dict(tol=1e-8, x=5e-4, u=2e-3, f=1e-7, xw=1e-4)
+
+
+@pytest.mark.parametrize("T", [DEFAULT, TIGHT], ids=["tol1e-8", "tol1e-11"])
+@pytest.mark.parametrize("kind,group", [("cfg2", "draw"), ("cfg2", "lapped"), ("cfg4", "draw"), ("cfg4", "lapped")])
+def test_oracle_solutions_on_reference_built_draws(orc, AB, kind, group, T):
+    table, worst, res, g, how = _solve_and_compare(orc, orc, AB, kind, group, T["tol"], T)
+    print("\n%s/%s tol %g: %s worst %s" % (kind, group, T["tol"], table, {k: "%.1e" % v for k, v in worst.items()}))
+    n = len(how)
+    assert table["converged_certified"] >= 0.8 * n, table
+    # every converged solve must be backed by a certificate on the reference's graph (how = 3 certifies the oracle's own
+    # tol-1e-11 point there); a converged, uncertified one would mean the oracle solves a different problem
+    assert table["converged_uncertified"] <= (0 if T["tol"] <= 1e-10 else max(1, n // 50)), table
+
+
+def test_headline_non_converged_are_classified(orc, AB):
+    """BENCH's headline batch (cfg2, 256 problems, SURVEY 8d draw, unfiltered): every problem that does not end CONVERGED at the
+    product's default options is classified by what is known about the reference-built problem."""
+    T = DEFAULT
+    table, worst, res, g, how = _solve_and_compare(orc, orc, AB, "cfg2", "draw", T["tol"], T)
+    st = res["status"]
+    stopped = np.nonzero(st != 0)[0]
+    lines = []
+    for r in stopped:
+        lines.append("#%d status %d iters %d: %s" % (int(g["index"][r]), st[r], res["iters"][r],
+                     {-1: "no KKT point known (third solver, 4 random starts and the oracle at 1e-11 all fail)", 0: "KKT point exists (third solver, zero start)",
+                      1: "KKT point exists (third solver, 1000 iterations)", 2: "KKT point exists (third solver, random start)",
+                      3: "KKT point exists (oracle at tol 1e-11, certified on the reference's graph)"}[int(how[r])]))
+    print("\nheadline batch: %d of %d not converged\n  " % (len(stopped), len(st)) + "\n  ".join(lines))
+    assert len(st) == 256
+    assert len(stopped) <= 16, len(stopped)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg3: the overtake planner
+# ---------------------------------------------------------------------------------------------------------------------
+def planner_batch():
+    from crx import synth
+    return synth.cfg3_planner(1024, N=12, seed=3)
+
+
+def test_planner_prep_and_rows_match_reference(orc, AB):
+    from crx import abi
+    A, B = AB
+    g = _group(_load("cfg3_draw.npz"), "draw")
+    p = planner_batch()
+    N, V, R = 12, 3, 4
+    d = abi.planner_desc(N, A, B)
+    n = len(g["index"])
+    assert n >= 48 or os.environ.get("CRX_DRAW_PARTIAL")
+    assert g["overtake_flag"].all() and (g["n_interest"] == V).all() and (g["n_veh_ref"] == V).all()   # synth's cars are all of interest
+    for r, b in enumerate(g["index"].astype(int)):
+        tag = "cfg3 #%d" % b
+        np.testing.assert_array_equal(p["raw"]["x"][b], g["x"][r], err_msg=tag)
+        np.testing.assert_array_equal(p["raw"]["cars"][b], g["cars"][r], err_msg=tag)
+        assert int(p["old_flag"][b]) == int(g["old_flag"][r])
+        # sorted vehicles (quirk Q3) and their predictions
+        from crx import synth
+        order = synth.partial_sort_order(g["cars"][r][None, :, 2])[0]
+        np.testing.assert_array_equal(order, g["sorted_idx"][r], err_msg=tag)
+        np.testing.assert_allclose(p["obs_s"][b], g["obs_pred"][r][:, 4, :], rtol=0, atol=2e-14, err_msg=tag)
+        np.testing.assert_allclose(p["obs_ey"][b], g["obs_pred"][r][:, 5, :], rtol=0, atol=1e-15, err_msg=tag)
+        sl = slice(b * R, (b + 1) * R)
+        # Bezier polylines of every region (planner_helper through the mirror)
+        np.testing.assert_allclose(p["bez_s"][sl], g["bezier"][r][:, :, 0], rtol=0, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(p["bez_ey"][sl], g["bezier"][r][:, :, 1], rtol=0, atol=1e-12, err_msg=tag)
+        for reg in range(R):
+            q = b * R + reg
+            # boxes of the reference's rows: ey_k in [max over its (<= 3) lower-bound rows, w - 0.1] for k < N, vx_k <= 5 for k >= 1
+            lo, hi = g["region_box_x_lo"][r][reg], g["region_box_x_hi"][r][reg]
+            np.testing.assert_allclose(lo[:N, 5], p["ey_lb"][q], rtol=0, atol=1e-14, err_msg=tag)
+            assert (np.abs(hi[:N, 5] - p["ey_ub"][q]) <= 4e-15).all() and np.isinf(lo[N, 5]) and np.isinf(hi[N, 5]), tag
+            assert (np.abs(hi[1:, 0] - d.vx_max) <= 4e-15).all() and np.isinf(hi[0, 0]) and np.isinf(lo[:, 0]).all(), tag
+            assert (np.abs(g["region_box_u_lo"][r][reg] - [-d.delta_max, -d.a_max]) <= 4e-15).all(), tag
+            assert (np.abs(g["region_box_u_hi"][r][reg] - [d.delta_max, d.a_max]) <= 4e-15).all(), tag
+            pr = helpers.oracle_planner_probe(orc, d, p["x0"][q], p["bez_s"][q], p["bez_ey"][q], p["ey_lb"][q], p["ey_ub"][q], g["region_probe_U"][r][reg])
+            assert _rel(pr["cost"], g["region_probe_f"][r][reg]) <= 1e-11, (tag, reg, pr["cost"], g["region_probe_f"][r][reg])
+
+
+def _planner_compare(binding, orc, AB, T):
+    from crx import abi
+    A, B = AB
+    g = _group(_load("cfg3_draw.npz"), "draw")
+    p = planner_batch()
+    N, V, R = 12, 3, 4
+    idx = g["index"].astype(int)
+    rows = np.concatenate([np.arange(b * R, (b + 1) * R) for b in idx])
+    d = abi.planner_desc(N, A, B)
+    d.opts.tol = T["tol"]
+    res = binding.planner_solve(d, *[p[k][rows] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")])
+    ok_ref = g["region_success"].reshape(-1)
+    st = res["status"]
+    # verdicts: the reference's QP is infeasible (HiGHS) <=> status != 0 -> fall-back trajectory, exactly
+    np.testing.assert_array_equal(st == 0, ok_ref)
+    Xg = g["region_X"].reshape(-1, N + 1, 6)
+    dX = np.abs(res["X"] - Xg)
+    assert dX[~ok_ref].max() <= 1e-12                                         # closed-form fall-backs (:365-374)
+    # the QP weights only s and ey (and the progress term): those, and vx, are sharp; vy, wz, epsi are determined through
+    # the dynamics alone (reduced Hessian cond 6.7e6) -- worst of the 129 feasible regions 5.3e-4 at tol 1e-8, 6.7e-6 at 1e-11
+    px, pxw = (1e-3, 1e-5) if T["tol"] > 1e-10 else (1e-5, 1e-7)
+    assert dX[ok_ref].max() <= px and dX[ok_ref][:, :, [0, 4, 5]].max() <= pxw, (dX[ok_ref].max(), dX[ok_ref][:, :, [0, 4, 5]].max())
+    fg = g["region_cert"].reshape(-1, 6)[:, 0]
+    assert (_rel(res["cost"][ok_ref], fg[ok_ref]) <= T["f"]).all()
+    # selection (a2): direction flag and winning trajectory, from the solver's own X
+    sd = abi.select_desc(N, V, LAP)
+    n = len(idx)
+    sel = orc.select(sd, p["n_veh"][idx], res["X"].reshape(n, R, N + 1, 6), p["obs_s"][idx], p["obs_ey"][idx], p["old_flag"][idx])
+    np.testing.assert_array_equal(sel["flag"], g["direction_flag"])
+    np.testing.assert_allclose(sel["best_X"], g["traj_xcurv"], rtol=0, atol=px)
+    np.testing.assert_allclose(sel["best_X"][:, :, [0, 4, 5]], g["traj_xcurv"][:, :, [0, 4, 5]], rtol=0, atol=pxw)
+    return res, g
+
+
+@pytest.mark.parametrize("T", [DEFAULT, TIGHT], ids=["tol1e-8", "tol1e-11"])
+def test_oracle_planner_on_reference_built_draw(orc, AB, T):
+    res, g = _planner_compare(orc, orc, AB, T)
+    ok = g["region_success"].reshape(-1)
+    assert ok.sum() >= 0.3 * len(ok) and (~ok).sum() >= 0.2 * len(ok)        # the BASELINE draw: ~41 % infeasible regions

@@ -225,6 +225,12 @@ def test_scene_oracle_vs_mirror_and_reference(orc, golden_planner):
         e = mk(ego[s])
         hit = [v for v in range(n_all[s]) if ph.check_ego_agent_distance(e, mk(veh[s, v]), par, L)]
         keep = hit[:V]
+        if len(hit) > V:    # overflow policy (the reference has no limit): the V nearest along the closed lap, in dict order
+            def gap(v):
+                se, sa = ego[s, 4], veh[s, v, 4]
+                se, sa = (se - L if se > L else se), (sa - L if sa > L else sa)
+                return min(abs(sa - se), abs(sa - se + L), abs(sa - se - L))
+            keep = sorted(sorted(hit, key=lambda v: (gap(v), v))[:V])
         assert r["n_veh"][s] == len(keep) and r["overflow"][s] == len(hit) - len(keep), s
         seen_over += len(hit) > V
         seen_empty += len(hit) == 0

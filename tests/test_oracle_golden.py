@@ -416,3 +416,32 @@ def test_certificate_fires_on_qps_infeasible_by_a_hair(orc, AB):
     d, args = helpers.thin_corridor_qps(orc, AB, -1e-6)
     r = orc.planner_solve(d, *args)
     assert (np.asarray(r["status"]) == 2).all(), np.bincount(np.asarray(r["status"]), minlength=3)
+
+
+def test_plant_step_with_process_noise(orc):
+    """crx_oracle_plant_step_noise against the reference's own DynamicBicycleModel.forward_dynamics WITH its bounded process
+    noise (utils/base.py:929-939; tests/golden/plant_noise.npz, make_draws.py plant_noise): same standard-normal draws in,
+    same state out -- half of the clipped noise on the curvilinear velocities, none on the global-frame copy."""
+    import ctypes as C
+    import os
+
+    import conftest
+    from crx import abi
+
+    g = np.load(os.path.join(conftest.GOLDEN, "plant_noise.npz"))
+    n = len(g["seed"])
+    d = abi.plant_desc(g["table"].shape[0], float(g["lap_length"]))
+    xg, xc = np.zeros((n, 6)), np.zeros((n, 6))
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (g["table"], g["xglob"], g["xcurv"], g["u"], g["z"])]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    fn = orc.lib.crx_oracle_plant_step_noise
+    fn.restype = C.c_int
+    assert fn(C.byref(d), C.c_int(n), *[p(a) for a in arrs], p(xg), p(xc)) == 0
+    np.testing.assert_allclose(xc, g["xcurv_next"], rtol=0, atol=2e-13)
+    np.testing.assert_allclose(xg, g["xglob_next"], rtol=0, atol=2e-13)
+    clipped = np.abs(g["z"] * np.array([0.01, 0.01, 0.005])) > np.array([0.05, 0.1, 0.05])
+    assert clipped.sum() >= 3 and (~clipped).sum() >= 30                      # both sides of every clip are exercised
+    assert np.abs(xc[:, :3] - xg[:, :3]).max() > 1e-3                          # the noise is there, on xcurv only
+    # zero noise = the plain step
+    r0 = orc.plant_step(d, g["table"], g["xglob"], g["xcurv"], g["u"])
+    np.testing.assert_array_equal(r0["xglob"], xg)

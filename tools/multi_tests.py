@@ -2,7 +2,9 @@
 random scripted cars, one after the other) as ONE batched, device-resident run: B races x `steps` control steps of
 crx.montecarlo.GameLaps against crx.synth.multi_tests_traffic.  Prints what such a sweep is run for: lap times of the
 learning-MPC laps, overtakes, contacts, races that left the track.
-usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3]"""
+The plant runs WITH the reference's bounded process noise (utils/base.py:929-939), as the reference's script does unless
+--zero-noise is given (overtake_planner_test.py:41-42): crx_plant_step_noise_dev, draws from a seeded torch generator.
+usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3] [noise_seed=1 | none]"""
 import os
 import sys
 import time
@@ -21,6 +23,7 @@ def main():
     Bn = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     V = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    seed = None if (len(sys.argv) > 4 and sys.argv[4].lower() in ("none", "zero")) else (int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     A, B = synth.load_AB()
     g = np.load(os.path.join(ROOT, "tests", "golden", "racing_game.npz"))
     track = racing_env.ClosedTrack(np.genfromtxt(os.path.join(ROOT, "data/track_layout/l_shape.csv"), delimiter=","), track_width=1.0)
@@ -32,7 +35,7 @@ def main():
     s0, v, ey = synth.multi_tests_traffic(Bn, V, seed=1)
     tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
     r = montecarlo.GameLaps(track.point_and_tangent, L, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
-                            np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey)
+                            np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey, noise_seed=seed)
     dev = r.lm.xc.device
     cs0, cv, cey = (torch.as_tensor(a, device=dev) for a in (s0, v, ey))
     lap_steps = [[] for _ in range(Bn)]
@@ -59,7 +62,8 @@ def main():
     laps = np.array([len(x) for x in lap_steps])
     first = np.array([x[0] for x in lap_steps if len(x) >= 1]); second = np.array([x[1] - x[0] for x in lap_steps if len(x) >= 2])
     mg = min_gap.cpu().numpy()
-    print("%d races x %d steps against %d random cars each: %.2f s wall = %.3g race-steps/s" % (Bn, steps, V, wall, Bn * steps / wall))
+    print("%d races x %d steps against %d random cars each, process noise %s: %.2f s wall = %.3g race-steps/s" % (
+        Bn, steps, V, "ON (seed %d)" % seed if seed is not None else "off", wall, Bn * steps / wall))
     print("laps completed per race: %s" % dict(zip(*np.unique(laps, return_counts=True))))
     if len(first):
         print("first learning-MPC lap : steps p5 %d p50 %d p95 %d" % tuple(np.percentile(first, [5, 50, 95])))
