@@ -329,7 +329,8 @@ def second_pass(kind, group, rows_npz, p, build):
         f0, g0, ce0, Je, ci0, Ji0 = opti.eval_all(np.zeros(opti.nvar))
         Z = np.linalg.svd(Je)[2][Je.shape[0]:].T
         zp = np.linalg.lstsq(Je, -ce0, rcond=None)[0]
-        for attempt in range(4):
+        # cfg4 (N = 20: ~2 minutes per third-solver run): no random starts, the oracle's point is the only second-pass candidate
+        for attempt in range(4 if kind == "cfg2" else 0):
             U0 = rng.uniform(-1.0, 1.0, (N, 2)) * np.array([0.5, 1.0])
             X0 = np.zeros((N + 1, 6)); X0[0] = g["x0"][r]
             for k in range(N):

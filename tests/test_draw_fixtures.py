@@ -68,7 +68,7 @@ def test_cbf_rows_and_prep_match_reference(orc, AB, kind, group):
     p = cbf_batch(kind, group == "lapped")
     d = cbf_desc(kind, A, B)
     N, V = d.N, d.n_obs_max
-    assert len(g["index"]) >= (16 if group == "lapped" else 48) or os.environ.get("CRX_DRAW_PARTIAL")
+    assert len(g["index"]) >= (12 if group == "lapped" else 48) or os.environ.get("CRX_DRAW_PARTIAL")
     n_lapped = 0
     for r, b in enumerate(g["index"]):
         b = int(b)
@@ -108,9 +108,16 @@ def test_cbf_rows_and_prep_match_reference(orc, AB, kind, group):
         assert n_lapped >= len(g["index"]) // 2, "the lapped draw must exercise lap_off != 0 (quirk Q1)"
 
 
+# cfg4 (N = 20, three obstacles, reduced Hessian cond 1e8): measured worst over the 48 + 12 problems -- tol 1e-8: x 2.9e-4, vx/ey 3e-6,
+# u 1.8e-4, cost 3.2e-7; tol 1e-11: x 5.2e-6, vx/ey 2.5e-6, u 4.2e-5, cost 1.8e-9
+TOL4 = {1e-8: dict(x=5e-4, u=2e-3, f=1e-6, xw=1e-4), 1e-11: dict(x=2e-5, u=1e-4, f=5e-9, xw=5e-6)}
+
+
 def _solve_and_compare(binding, orc, AB, kind, group, tol, T):
     """Shared by the CPU (oracle) and GPU (libcrx) versions.  Returns the classification table."""
     A, B = AB
+    if kind == "cfg4":
+        T = dict(tol=tol, n_loose=0, **TOL4[tol])
     g = _group(_load(kind + "_draw.npz"), group)
     p = cbf_batch(kind, group == "lapped")
     d = cbf_desc(kind, A, B, tol)
