@@ -358,6 +358,8 @@ def make_overtake(cx, args, batch=None):
               "selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
     w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch"}
+    # the scene stage keeps at most CRX_MAX_OBS vehicles of interest per race (the nearest): how often were there more?
+    w.post = lambda: {"scene_overflow_races": int((laps.overflow_seen > 0).sum().item())}
     return w
 
 
@@ -476,6 +478,8 @@ def measure(cx, w, steps, warmup, with_latency=True):
                     "p50_host_call_one_control_step_ms": float(np.median(hlat)) if hlat else None})
     if w.extra:
         cfg.update(w.extra)
+    if getattr(w, "post", None):
+        cfg.update(w.post())
     rec = {"key": w.key, "value": value, "value_converged": value * float(conv[ran].mean()) if ran.any() else 0.0, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
            "scaling": w.scaling, "config": cfg,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

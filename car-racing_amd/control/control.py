@@ -41,8 +41,9 @@ def _predictions(vehicles, names, time, timestep, n, realtime_flag):
     return out
 
 
-def _solve_cbf(desc, x, xt, preds, lap_length):
-    """Window filter (:499-523), lap offsets (:538-540, quirk Q1) and one batched crx call of size 1."""
+def _solve_cbf(desc, x, xt, preds, lap_length, dims=None):
+    """Window filter (:499-523), lap offsets (:538-540, quirk Q1) and one batched crx call of size 1.  dims: (l_sum, w_sum) per
+    entry of `preds` when the obstacle vehicles differ in size (:529-535), None = the descriptor's pair."""
     N = desc.N
     V = len(preds)
     obs_s = np.zeros((1, max(V, 1), N + 1))
@@ -55,6 +56,10 @@ def _solve_cbf(desc, x, xt, preds, lap_length):
     else:
         keep, lap_off = np.zeros((1, 0), dtype=bool), np.zeros((1, 0))
     nmax = desc.n_obs_max
+    if nmax and dims is not None:
+        ps, pe, po, n, pd = hostprep.pack_obstacles(keep, obs_s[:, :V], obs_ey[:, :V], lap_off, nmax, ego_s=x[:, 4],
+                                                    dims=np.asarray(dims, dtype=float).reshape(1, V, 2))
+        return crx.cbf_solve(desc, x, xt, ps, pe, po, n, obs_dims=pd)
     ps, pe, po, n = hostprep.pack_obstacles(keep, obs_s[:, :V], obs_ey[:, :V], lap_off, nmax, ego_s=x[:, 4]) if nmax else (
         np.zeros((1, 0, N + 1)), np.zeros((1, 0, N + 1)), np.zeros((1, 0)), np.zeros(1, dtype=np.int32))
     return crx.cbf_solve(desc, x, xt, ps, pe, po, n)
@@ -85,10 +90,12 @@ def mpccbf(xcurv, xtarget, mpc_cbf_param, vehicles, agent_name, lap_length, time
         x1 = np.asarray(xcurv, dtype=float).reshape(1, X_DIM)
         keep, _ = hostprep.cbf_window(x1, np.array([[p[4, 0] for p in preds]]), lap_length)
         preds = [p for p, k in zip(preds, keep[0]) if k]
+        others = [n for n, k in zip(others, keep[0]) if k]
     ego, first = vehicles[agent_name], (vehicles[others[0]] if others else vehicles[agent_name])
-    # the reference takes (l, w) per obstacle (control.py:529-535); the C ABI carries one (l_sum, w_sum) per call
-    if any((vehicles[n].param.length, vehicles[n].param.width) != (first.param.length, first.param.width) for n in others):
-        raise ValueError("mpccbf: libcrx needs all obstacle vehicles to share one length and width (crx_cbf_desc.l_sum / w_sum)")
+    # (l, w) per obstacle (control.py:529-535): crx_cbf_solve_dims when the cars differ, the descriptor's pair when they do not
+    same = all((vehicles[n].param.length, vehicles[n].param.width) == (first.param.length, first.param.width) for n in others)
+    dims = None if same else [(ego.param.length / 2 + vehicles[n].param.length / 2, ego.param.width / 2 + vehicles[n].param.width / 2)
+                              for n in others]
     desc = abi.cbf_desc(
         N, min(len(preds), _N_OBS_MAX), mpc_cbf_param.matrix_A, mpc_cbf_param.matrix_B,
         Q=np.diag(mpc_cbf_param.matrix_Q), R=np.diag(mpc_cbf_param.matrix_R), alpha=mpc_cbf_param.alpha,
@@ -96,7 +103,7 @@ def mpccbf(xcurv, xtarget, mpc_cbf_param, vehicles, agent_name, lap_length, time
         v_min=system_param.v_min, v_max=system_param.v_max,
         l_sum=ego.param.length / 2 + first.param.length / 2, w_sum=ego.param.width / 2 + first.param.width / 2)
     xt = np.asarray(xtarget, dtype=float).reshape(1, X_DIM)
-    r = _solve_cbf(desc, xcurv, xt, preds, lap_length)
+    r = _solve_cbf(desc, xcurv, xt, preds, lap_length, dims=dims)
     if r["status"][0] != abi.CRX_CONVERGED:
         print("solver failed.")  # the reference then uses the last iterate (:600-603); so do we
     print("solver time: {}".format((datetime.datetime.now() - start).total_seconds()))

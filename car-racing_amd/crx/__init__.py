@@ -65,8 +65,8 @@ def planner_solve(desc, x0, bez_s, bez_ey, ey_lb, ey_ub):
     return binding().planner_solve(desc, x0, bez_s, bez_ey, ey_lb, ey_ub)
 
 
-def cbf_solve(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs):
-    return binding().cbf_solve(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs)
+def cbf_solve(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims=None):
+    return binding().cbf_solve(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims)
 
 
 def select(desc, n_veh, X, obs_s, obs_ey, old_flag):

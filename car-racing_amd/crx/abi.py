@@ -276,7 +276,8 @@ class Binding:
         )
         return out
 
-    def cbf_solve(self, desc, x0, xt, obs_s, obs_ey, lap_off, n_obs):
+    def cbf_solve(self, desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims=None):
+        """crx_cbf_solve; with obs_dims (Bn, V, 2) = (l_agent + l_obs, w_agent + w_obs) per obstacle slot: crx_cbf_solve_dims."""
         N, V = desc.N, desc.n_obs_max
         x0 = np.ascontiguousarray(x0, dtype=_D)
         Bn = x0.shape[0]
@@ -291,6 +292,14 @@ class Binding:
             cost=np.zeros(Bn), status=np.zeros(Bn, dtype=_I), kkt=np.zeros(Bn),
             iters=np.zeros(Bn, dtype=_I),
         )
+        if obs_dims is not None:
+            obs_dims = _in(obs_dims, _D, (Bn, V, 2))
+            self._call(
+                "cbf_solve_dims", C.byref(desc), C.c_int(Bn), _p(x0), _p(xt), _p(obs_s), _p(obs_ey),
+                _p(lap_off), _p(n_obs), _p(obs_dims), _p(out["X"]), _p(out["U"]), _p(out["sigma"]), _p(out["cost"]),
+                _p(out["status"]), _p(out["kkt"]), _p(out["iters"]),
+            )
+            return out
         self._call(
             "cbf_solve", C.byref(desc), C.c_int(Bn), _p(x0), _p(xt), _p(obs_s), _p(obs_ey),
             _p(lap_off), _p(n_obs), _p(out["X"]), _p(out["U"]), _p(out["sigma"]), _p(out["cost"]),

@@ -68,13 +68,15 @@ def cbf_window(x_raw, obs_pred_s0, lap_length, safety_time=2.0):
     return keep, lap_off
 
 
-def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max, ego_s=None):
-    """Compact the kept obstacles to the front (dict order of the reference's obs_infos) and pad."""
+def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max, ego_s=None, dims=None):
+    """Compact the kept obstacles to the front (dict order of the reference's obs_infos) and pad.  With `dims` [B, V, 2]
+    (l_agent + l_obs, w_agent + w_obs of every vehicle, control.py:529-535) a fifth array follows: the dims of the kept ones."""
     B, V, L = obs_s.shape
     out_s = np.zeros((B, n_obs_max, L))
     out_e = np.zeros((B, n_obs_max, L))
     out_off = np.zeros((B, n_obs_max))
     n = np.zeros(B, dtype=np.int32)
+    out_d = np.ones((B, n_obs_max, 2)) if dims is not None else None
     for b in range(B):
         idx = np.nonzero(keep[b])[0]
         if len(idx) > n_obs_max:
@@ -91,6 +93,10 @@ def pack_obstacles(keep, obs_s, obs_ey, lap_off, n_obs_max, ego_s=None):
         out_s[b, : len(idx)] = obs_s[b, idx]
         out_e[b, : len(idx)] = obs_ey[b, idx]
         out_off[b, : len(idx)] = lap_off[b, idx]
+        if dims is not None:
+            out_d[b, : len(idx)] = np.asarray(dims)[b, idx]
+    if dims is not None:
+        return out_s, out_e, out_off, n, out_d
     return out_s, out_e, out_off, n
 
 

@@ -185,10 +185,20 @@ class LmpcLaps:
         self.traj_status = torch.zeros((Bn,), **i32)
         self._ar = torch.arange(Bn, device=dev)
         self._P = P
+        self.u = torch.zeros((Bn, 2), **f64)              # the input applied in the last step
+        self.addpoint_step = torch.zeros((Bn,), **i32)
+        self.crossed = torch.zeros((Bn,), **i32)
 
     def log_and_handover(self, u):
         """After the plant step: append (new state, applied input) to every race's lap log -- the crossing state with its s
-        unwrapped, like update_memory -- and hand the completed laps over to the safe set (crx_lmpc_addtraj_dev)."""
+        unwrapped, like update_memory -- (crx_game_log_dev) and hand the completed laps over to the safe set
+        (crx_lmpc_addtraj_dev)."""
+        torch_api.game_log_dev(self.lap_length, self.xc, u, self.laps, self.laps_prev, self.log_x, self.log_u, self.n_log, self.crossed)
+        torch_api.lmpc_addtraj_dev(self.pdesc, self.crossed, self.log_x, self.log_u, self.n_log, self.ss, self.us, self.qf, self.time_ss, self.it,
+                                   self.step_no, self.xc, self.traj_status)
+
+    def log_and_handover_torch(self, u):
+        """log_and_handover written as element-wise torch ops (round 2; kept as an independent restatement for the tests)."""
         crossed = (self.laps > self.laps_prev).to(torch.int32)
         self.laps_prev.copy_(self.laps)
         xu = self.xc.clone()
@@ -200,7 +210,10 @@ class LmpcLaps:
         torch_api.lmpc_addtraj_dev(self.pdesc, crossed, self.log_x, self.log_u, self.n_log, self.ss, self.us, self.qf, self.time_ss, self.it,
                                    self.step_no, self.xc, self.traj_status)
 
-    def step(self):
+    def step(self, torch_glue=False):
+        """One control step of every race: six libcrx launches (regression, QP, commit, add_point, plant, log) + the lap hand-over.
+        torch_glue = True: the bookkeeping as element-wise torch ops instead of crx_game_commit_dev / crx_game_log_dev (round 2's
+        formulation, kept for the tests: both must produce the same bits)."""
         N = self.N
         if self.k == 0:     # first call of the lap: linearisation points handed over by the previous controller (utils/base.py:651-653)
             torch_api.lmpc_prep_dev(self.pdesc, self.ss, self.us, self.qf, self.time_ss, self.it, self.xc, self.lin_points, self.lin_input,
@@ -210,16 +223,29 @@ class LmpcLaps:
                                     self.tab, True, ws=self.pws)
         torch_api.lmpc_solve_dev(self.desc, self.xc, self.u_old, self.pws.A, self.pws.B, self.pws.C, self.pws.ss, self.pws.qfun, self.n_ss,
                                  ws=self.ws)
-        torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.step_no, self.xc, self.ws.U, 2 * N)
-        torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
+        if torch_glue:
+            torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.step_no, self.xc, self.ws.U, 2 * N)
+            torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
+                                          noise_z=self.noise.draw(self.batch))
+            self.xg, self.xg_next = self.xg_next, self.xg
+            self.xc, self.xc_next = self.xc_next, self.xc
+            self.u_prev.copy_(self.u_old)
+            self.u_old.copy_(self.ws.U[:, 0, :])
+            self.u.copy_(self.u_old)
+            self.step_no += 1
+            self.k += 1
+            self.log_and_handover_torch(self.u_old)
+            return
+        # applied input, plan hand-over (u_old; lin_points / lin_input are the shifted plan), step counter: one launch
+        torch_api.game_commit_dev(N, N, None, None, self.ws.X, self.ws.U, None, self.u, self.u_old, self.u_prev, self.lin_points, self.lin_input,
+                                  self.step_no, self.addpoint_step, None)
+        torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.addpoint_step, self.xc, self.u, 2)
+        torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.u, 2, self.xg_next, self.xc_next, self.laps,
                                       noise_z=self.noise.draw(self.batch))
         self.xg, self.xg_next = self.xg_next, self.xg
         self.xc, self.xc_next = self.xc_next, self.xc
-        self.u_prev.copy_(self.u_old)
-        self.u_old.copy_(self.ws.U[:, 0, :])
-        self.step_no += 1
         self.k += 1
-        self.log_and_handover(self.u_old)
+        self.log_and_handover(self.u)
 
 
 def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, steps,
@@ -297,21 +323,32 @@ class GameLaps:
         self.lin_points, self.lin_input = lm.lin_points.clone(), lm.lin_input.clone()
         self.neg = torch.full((Bn,), -(1 << 20), **i32)
         self.overtake = torch.zeros((Bn,), dtype=torch.bool, device=dev)
+        self.m_ot, self.m_lm = torch.zeros((Bn,), **i32), torch.zeros((Bn,), **i32)
+        self.pred_s, self.pred_e = torch.zeros((Bn, VA, N_plan + 1), **f64), torch.zeros((Bn, VA, N_plan + 1), **f64)
+        self.overflow_seen = torch.zeros((Bn,), **i32)    # scene overflow (more vehicles of interest than slots), accumulated
         self.t = 0.0
 
     def step(self):
+        """One control step of every race: thirteen libcrx launches (traffic, scene, masks, prep, plan = QPs + selection, track
+        prep, tracking NLP, regression, learning-MPC QP, commit, add_point, plant, log) + the lap hand-over."""
         lm, L, N = self.lm, self.L, self.lm.N
-        # scripted cars at their own clock t: s = v t + s0 (wrapped once past the line, update_memory), predictions unwrapped (quirk Q6)
-        s_now = self.v * self.t + self.s0
-        self.veh[:, :, 0] = self.v
-        self.veh[:, :, 4] = s_now - L * torch.clamp(torch.ceil(s_now / L) - 1.0, min=0.0)   # update_memory: wrapped whenever s > L, lap after lap
-        self.veh[:, :, 5] = self.ey
-        pred_s = (self.v[:, :, None] * (self.t + self.jdt)[None, None, :] + self.s0[:, :, None]).contiguous()
-        pred_e = (self.ey[:, :, None] + 0.0 * self.jdt[None, None, :]).contiguous()
-        torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, pred_s, pred_e, ws=self.sws)
-        self.overtake = self.sws.n_veh > 0
-        m_ot = self.overtake.to(torch.int32)                      # masked launches: every race runs its own branch's kernels only
-        m_lm = 1 - m_ot
+        torch_api.game_traffic_dev(self.Np, L, self.t, lm.timestep, self.s0, self.v, self.ey, self.veh, self.pred_s, self.pred_e)
+        torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, self.pred_s, self.pred_e, ws=self.sws)
+        torch_api.game_masks_dev(self.sws.n_veh, self.m_ot, self.m_lm, overflow=self.sws.overflow, overflow_seen=self.overflow_seen)
+        self.overtake = self.m_ot                                  # int32 mask; bool(overtake[b]) = race b is in the overtake branch
+        self._branches(self.m_ot, self.m_lm)
+        torch_api.game_commit_dev(N, self.Np, self.m_ot, self.tws.U, lm.ws.X, lm.ws.U, self.selws.flag, self.u, lm.u_old, lm.u_prev,
+                                  self.lin_points, self.lin_input, lm.step_no, lm.addpoint_step, self.old_flag)
+        torch_api.lmpc_addpoint_dev(lm.pdesc, lm.ss, lm.us, lm.time_ss, lm.it, lm.addpoint_step, lm.xc, self.u, 2)
+        torch_api.plant_step_wrap_dev(lm.plant, lm.tab, lm.xg, lm.xc, self.u, 2, lm.xg_next, lm.xc_next, lm.laps, noise_z=lm.noise.draw(lm.batch))
+        lm.xg, lm.xg_next = lm.xg_next, lm.xg
+        lm.xc, lm.xc_next = lm.xc_next, lm.xc
+        self.t += lm.timestep
+        lm.log_and_handover(self.u)
+
+    def _branches(self, m_ot, m_lm):
+        """The solver launches of both branches (masked: every race runs its own branch's kernels only)."""
+        lm, L = self.lm, self.L
         # ---- overtake branch
         torch_api.planner_prep_dev(self.prep, lm.xc, lm.xc, self.sws.n_veh, self.sws.veh_info, self.sws.max_dv, self.sws.obs_s, self.sws.obs_ey,
                                    self.opt_s, self.opt_ey, ws=self.pws)
@@ -324,6 +361,23 @@ class GameLaps:
         torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws,
                                 active=m_lm)
         torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws, active=m_lm)
+
+    def step_torch(self):
+        """The same control step with the bookkeeping written as element-wise torch ops (round 2's formulation, ~40 small launches;
+        kept as an independent restatement for the tests: step() must produce the same bits)."""
+        lm, L, N = self.lm, self.L, self.lm.N
+        # scripted cars at their own clock t: s = v t + s0 (wrapped once past the line, update_memory), predictions unwrapped (quirk Q6)
+        s_now = self.v * self.t + self.s0
+        self.veh[:, :, 0] = self.v
+        self.veh[:, :, 4] = s_now - L * torch.clamp(torch.ceil(s_now / L) - 1.0, min=0.0)   # update_memory: wrapped whenever s > L, lap after lap
+        self.veh[:, :, 5] = self.ey
+        pred_s = (self.v[:, :, None] * (self.t + self.jdt)[None, None, :] + self.s0[:, :, None]).contiguous()
+        pred_e = (self.ey[:, :, None] + 0.0 * self.jdt[None, None, :]).contiguous()
+        torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, pred_s, pred_e, ws=self.sws)
+        self.overtake = self.sws.n_veh > 0
+        m_ot = self.overtake.to(torch.int32)                      # masked launches: every race runs its own branch's kernels only
+        m_lm = 1 - m_ot
+        self._branches(m_ot, m_lm)
         # ---- the branch each race is in
         ot = self.overtake
         self.u.copy_(torch.where(ot[:, None], self.tws.U[:, 0, :], lm.ws.U[:, 0, :]))
@@ -339,7 +393,7 @@ class GameLaps:
         lm.xg, lm.xg_next = lm.xg_next, lm.xg
         lm.xc, lm.xc_next = lm.xc_next, lm.xc
         self.t += lm.timestep
-        lm.log_and_handover(self.u)
+        lm.log_and_handover_torch(self.u)
 
 
 def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input,
@@ -352,6 +406,6 @@ def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u
     for _ in range(steps):
         lc.append((r.v * r.t + r.s0).clone())
         r.step()
-        lx.append(r.lm.xc.clone()); lu.append(r.u.clone()); lo.append(r.overtake.clone()); lf.append(r.old_flag.clone())
+        lx.append(r.lm.xc.clone()); lu.append(r.u.clone()); lo.append(r.overtake.clone().bool()); lf.append(r.old_flag.clone())
     return dict(xcurv=torch.stack(lx).cpu().numpy(), u=torch.stack(lu).cpu().numpy(), overtake=torch.stack(lo).cpu().numpy(),
                 flag=torch.stack(lf).cpu().numpy(), cars_s=torch.stack(lc).cpu().numpy(), laps=r.lm.laps.cpu().numpy())

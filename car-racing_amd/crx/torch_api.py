@@ -57,8 +57,9 @@ class CbfWorkspace:
         self.iters = torch.empty(batch, **i32)
 
 
-def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=None):
-    """crx_cbf_solve_dev; with `active` (int32 [batch], 0 = leave the problem alone) crx_cbf_solve_masked_dev."""
+def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=None, obs_dims=None):
+    """crx_cbf_solve_dev; with `active` (int32 [batch], 0 = leave the problem alone) crx_cbf_solve_masked_dev; with `obs_dims`
+    ([batch, n_obs_max, 2]: l_agent + l_obs, w_agent + w_obs per obstacle slot) crx_cbf_solve_dims_dev."""
     N, V, B = desc.N, desc.n_obs_max, x0.shape[0]
     _chk(x0, torch.float64, (B, 6), "x0")
     _chk(xt, torch.float64, (B, N + 1, 6) if desc.per_stage_target else (B, 6), "xt")
@@ -69,8 +70,10 @@ def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=N
     ws = ws or CbfWorkspace(desc, B, x0.device)
     if active is not None:
         _chk(active, torch.int32, (B,), "active")
-    _call("crx_cbf_solve_masked_dev", C.byref(desc), C.c_int(B), _ptr(active) if active is not None else None, _ptr(x0), _ptr(xt),
-          _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost),
+    if obs_dims is not None:
+        _chk(obs_dims, torch.float64, (B, V, 2), "obs_dims")
+    _call("crx_cbf_solve_dims_dev", C.byref(desc), C.c_int(B), _ptr(active) if active is not None else None, _ptr(x0), _ptr(xt),
+          _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _ptr(obs_dims), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost),
           _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws
 
@@ -379,3 +382,53 @@ def track_prep_dev(N, V, lap_length, x, n_veh, obs_s_in, obs_ey_in, traj, xt, ob
     _call("crx_track_prep_dev", C.c_int(N), C.c_int(V), C.c_double(lap_length), C.c_double(safety_time), C.c_double(dt_ref), C.c_int(Bn),
           _ptr(x), _ptr(n_veh), _ptr(obs_s_in), _ptr(obs_ey_in), _ptr(traj), _ptr(xt), _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs),
           _stream())
+
+
+# ---- device-resident racing-game loop: bookkeeping between the solver launches (include/crx.h crx_game_*) ----------------------
+def game_traffic_dev(N, lap_length, t, dt, car_s0, car_v, car_ey, veh_xcurv, pred_s, pred_ey):
+    Bn, VA = car_s0.shape
+    for name, a in (("car_s0", car_s0), ("car_v", car_v), ("car_ey", car_ey)):
+        _chk(a, torch.float64, (Bn, VA), name)
+    _chk(veh_xcurv, torch.float64, (Bn, VA, 6), "veh_xcurv")
+    _chk(pred_s, torch.float64, (Bn, VA, N + 1), "pred_s")
+    _chk(pred_ey, torch.float64, (Bn, VA, N + 1), "pred_ey")
+    _call("crx_game_traffic_dev", C.c_int(N), C.c_int(Bn), C.c_int(VA), C.c_double(lap_length), C.c_double(t), C.c_double(dt), _ptr(car_s0),
+          _ptr(car_v), _ptr(car_ey), _ptr(veh_xcurv), _ptr(pred_s), _ptr(pred_ey), _stream())
+
+
+def game_masks_dev(n_veh, m_overtake, m_lmpc, overflow=None, overflow_seen=None):
+    Bn = n_veh.shape[0]
+    for name, a in (("n_veh", n_veh), ("m_overtake", m_overtake), ("m_lmpc", m_lmpc)) + ((("overflow", overflow), ("overflow_seen", overflow_seen)) if overflow is not None else ()):
+        _chk(a, torch.int32, (Bn,), name)
+    _call("crx_game_masks_dev", C.c_int(Bn), _ptr(n_veh), _ptr(overflow), _ptr(m_overtake), _ptr(m_lmpc), _ptr(overflow_seen), _stream())
+
+
+def game_commit_dev(N, Np, overtake, U_track, X_lmpc, U_lmpc, flag, u, u_old, u_prev, lin_points, lin_input, step_no, addpoint_step, old_flag):
+    Bn = u.shape[0]
+    _chk(X_lmpc, torch.float64, (Bn, N + 1, 6), "X_lmpc")
+    _chk(U_lmpc, torch.float64, (Bn, N, 2), "U_lmpc")
+    for name, a in (("u", u), ("u_old", u_old), ("u_prev", u_prev)):
+        _chk(a, torch.float64, (Bn, 2), name)
+    _chk(lin_points, torch.float64, (Bn, N + 1, 6), "lin_points")
+    _chk(lin_input, torch.float64, (Bn, N, 2), "lin_input")
+    _chk(step_no, torch.int32, (Bn,), "step_no")
+    _chk(addpoint_step, torch.int32, (Bn,), "addpoint_step")
+    if overtake is not None:
+        _chk(overtake, torch.int32, (Bn,), "overtake")
+        _chk(U_track, torch.float64, (Bn, Np, 2), "U_track")
+        _chk(flag, torch.int32, (Bn,), "flag")
+        _chk(old_flag, torch.int32, (Bn,), "old_flag")
+    _call("crx_game_commit_dev", C.c_int(N), C.c_int(Np), C.c_int(Bn), _ptr(overtake), _ptr(U_track), _ptr(X_lmpc), _ptr(U_lmpc), _ptr(flag),
+          _ptr(u), _ptr(u_old), _ptr(u_prev), _ptr(lin_points), _ptr(lin_input), _ptr(step_no), _ptr(addpoint_step), _ptr(old_flag), _stream())
+
+
+def game_log_dev(lap_length, xcurv, u, laps, laps_prev, log_x, log_u, n_log, crossed):
+    Bn, P = log_x.shape[0], log_x.shape[1]
+    _chk(xcurv, torch.float64, (Bn, 6), "xcurv")
+    _chk(u, torch.float64, (Bn, 2), "u")
+    for name, a in (("laps", laps), ("laps_prev", laps_prev), ("n_log", n_log), ("crossed", crossed)):
+        _chk(a, torch.int32, (Bn,), name)
+    _chk(log_x, torch.float64, (Bn, P, 6), "log_x")
+    _chk(log_u, torch.float64, (Bn, P, 2), "log_u")
+    _call("crx_game_log_dev", C.c_int(Bn), C.c_int(P), C.c_double(lap_length), _ptr(xcurv), _ptr(u), _ptr(laps), _ptr(laps_prev), _ptr(log_x),
+          _ptr(log_u), _ptr(n_log), _ptr(crossed), _stream())

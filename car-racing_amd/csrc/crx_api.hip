@@ -432,6 +432,13 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
 int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
                              const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
                              double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
+    return crx_cbf_solve_dims_dev(d, batch, active, x0, xt, obs_s, obs_ey, lap_off, n_obs, nullptr, X, U, sigma, cost, status, kkt, iters, stream);
+}
+
+int crx_cbf_solve_dims_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                           const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs,
+                           const double* obs_dims, double* X, double* U, double* sigma, double* cost, int32_t* status, double* kkt,
+                           int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_kparams kp;
     if (int rc = fill_cbf(kp, d, batch)) return rc;
@@ -441,12 +448,18 @@ int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* ac
         return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
     kp.x0 = x0; kp.xt = xt; kp.obs_s = obs_s; kp.obs_ey = obs_ey; kp.lap_off = lap_off; kp.n_obs = n_obs;
     kp.X = X; kp.U = U; kp.sigma = sigma; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
-    kp.active = active;
+    kp.active = active; kp.obs_dims = d->n_obs_max > 0 ? obs_dims : nullptr;
     return launch_solve(kp, d->n_obs_max, (hipStream_t)stream);
 }
 
 int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
                   const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X, double* U,
+                  double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters) {
+    return crx_cbf_solve_dims(d, batch, x0, xt, obs_s, obs_ey, lap_off, n_obs, nullptr, X, U, sigma, cost, status, kkt, iters);
+}
+
+int crx_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
+                  const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, double* X, double* U,
                   double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters) {
     if (int rc = ensure_init()) return rc;
     crx_kparams chk;
@@ -458,20 +471,26 @@ int crx_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const doub
         if (!obs_s || !obs_ey || !lap_off || !n_obs || !sigma) return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
         for (size_t b = 0; b < B; b++)
             if (n_obs[b] < 0 || n_obs[b] > (int)V) return fail(CRX_ERR_ARG, "n_obs[%zu]=%d outside [0,%zu]", b, n_obs[b], V);
+        if (obs_dims)
+            for (size_t b = 0; b < B; b++)
+                for (int o = 0; o < n_obs[b]; o++)
+                    if (!(obs_dims[(b * V + o) * 2] > 0.0) || !(obs_dims[(b * V + o) * 2 + 1] > 0.0))
+                        return fail(CRX_ERR_ARG, "obs_dims[%zu][%d] must be positive", b, o);
     }
     std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g_device));
     const size_t n_x0 = B * 6, n_xt = d->per_stage_target ? B * (N + 1) * 6 : B * 6, n_ob = B * V * (N + 1), n_lo = B * V;
     const size_t n_X = B * (N + 1) * 6, n_U = B * N * 2;
     Stage sg;
-    if (int rc = sg.reserve((n_x0 + n_xt + 2 * n_ob + n_lo) * 8 + B * 4, (n_X + n_U + n_ob + 2 * B) * 8 + 2 * B * 4)) return rc;
+    if (int rc = sg.reserve((n_x0 + n_xt + 2 * n_ob + 3 * n_lo) * 8 + B * 4, (n_X + n_U + n_ob + 2 * B) * 8 + 2 * B * 4)) return rc;
     double* dx0 = sg.in(x0, n_x0); double* dxt = sg.in(xt, n_xt);
     double* dos = sg.in(obs_s, n_ob); double* doe = sg.in(obs_ey, n_ob); double* dlo = sg.in(lap_off, n_lo);
+    double* ddm = (obs_dims && V > 0) ? sg.in(obs_dims, 2 * n_lo) : nullptr;
     int32_t* dno = sg.in(V > 0 ? n_obs : (const int32_t*)nullptr, B);
     double* dX = sg.out(X, n_X); double* dU = sg.out(U, n_U); double* dsg = sg.out(sigma, n_ob);
     double* dc = sg.out(cost, B); double* dk = sg.out(kkt, B); int32_t* ds = sg.out(status, B); int32_t* di = sg.out(iters, B);
     if (int rc = sg.up(g_stream)) return rc;
-    if (int rc = crx_cbf_solve_dev(d, batch, dx0, dxt, dos, doe, dlo, dno, dX, dU, dsg, dc, ds, dk, di, g_stream)) return rc;
+    if (int rc = crx_cbf_solve_dims_dev(d, batch, nullptr, dx0, dxt, dos, doe, dlo, dno, ddm, dX, dU, dsg, dc, ds, dk, di, g_stream)) return rc;
     return sg.down(g_stream);
 }
 
@@ -1085,6 +1104,75 @@ int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n
     if (int rc = crx_planner_plan_dev(d, sd, n_scen, dx0, dbs, dbe, dlb, dub, dnv, dos, doe, dof, dX, dU, dc, ds, dk, di,
                                       dfl, dsc, dbX, g_stream)) return rc;
     return sg.down(g_stream);
+}
+
+}  // extern "C"
+
+// ---- device-resident racing-game loop: bookkeeping between the solver launches ----------------------------------
+extern "C" {
+
+int crx_game_traffic_dev(int N, int batch, int n_cars, double lap_length, double t, double dt, const double* car_s0, const double* car_v,
+                         const double* car_ey, double* veh_xcurv, double* pred_s, double* pred_ey, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (N < 1 || N > CRX_MAX_N || batch < 0 || n_cars < 0 || !(lap_length > 0.0)) return fail(CRX_ERR_ARG, "bad game traffic dimensions");
+    if (batch == 0 || n_cars == 0) return CRX_OK;
+    if (!car_s0 || !car_v || !car_ey || !veh_xcurv || !pred_s || !pred_ey) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_game_kparams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.Np = N; gp.batch = batch; gp.n_cars = n_cars; gp.lap_length = lap_length; gp.t = t; gp.dt = dt;
+    gp.car_s0 = car_s0; gp.car_v = car_v; gp.car_ey = car_ey; gp.veh_xcurv = veh_xcurv; gp.pred_s = pred_s; gp.pred_ey = pred_ey;
+    hipError_t e = crx_launch_game(0, gp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "game traffic launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_game_masks_dev(int batch, const int32_t* n_veh, const int32_t* overflow, int32_t* m_overtake, int32_t* m_lmpc,
+                       int32_t* overflow_seen, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (batch < 0) return fail(CRX_ERR_ARG, "batch < 0");
+    if (batch == 0) return CRX_OK;
+    if (!n_veh || !m_overtake || !m_lmpc) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_game_kparams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.batch = batch; gp.n_veh = n_veh; gp.m_overtake = m_overtake; gp.m_lmpc = m_lmpc;
+    if (overflow && overflow_seen) { gp.overflow = overflow; gp.overflow_seen = overflow_seen; }
+    hipError_t e = crx_launch_game(1, gp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "game masks launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_game_commit_dev(int N, int Np, int batch, const int32_t* overtake, const double* U_track, const double* X_lmpc,
+                        const double* U_lmpc, const int32_t* flag, double* u, double* u_old, double* u_prev, double* lin_points,
+                        double* lin_input, int32_t* step_no, int32_t* addpoint_step, int32_t* old_flag, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (N < 1 || N > CRX_MAX_N || batch < 0 || (overtake && (Np < 1 || Np > CRX_MAX_N))) return fail(CRX_ERR_ARG, "bad game commit dimensions");
+    if (batch == 0) return CRX_OK;
+    if (!X_lmpc || !U_lmpc || !u || !u_old || !u_prev || !lin_points || !lin_input || !step_no || !addpoint_step)
+        return fail(CRX_ERR_ARG, "NULL array argument");
+    if (overtake && (!U_track || (old_flag && !flag))) return fail(CRX_ERR_ARG, "NULL overtake-branch array");
+    crx_game_kparams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.N = N; gp.Np = Np; gp.batch = batch; gp.overtake = overtake; gp.U_track = U_track; gp.X_lmpc = X_lmpc; gp.U_lmpc = U_lmpc;
+    gp.flag = flag; gp.u = u; gp.u_old = u_old; gp.u_prev = u_prev; gp.lin_points = lin_points; gp.lin_input = lin_input;
+    gp.step_no = step_no; gp.addpoint_step = addpoint_step; gp.old_flag = old_flag;
+    hipError_t e = crx_launch_game(2, gp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "game commit launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_game_log_dev(int batch, int n_points, double lap_length, const double* xcurv, const double* u, const int32_t* laps,
+                     int32_t* laps_prev, double* log_x, double* log_u, int32_t* n_log, int32_t* crossed, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (batch < 0 || n_points < 2) return fail(CRX_ERR_ARG, "bad game log dimensions");
+    if (batch == 0) return CRX_OK;
+    if (!xcurv || !u || !laps || !laps_prev || !log_x || !log_u || !n_log || !crossed) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_game_kparams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.batch = batch; gp.n_points = n_points; gp.lap_length = lap_length; gp.xcurv = xcurv; gp.u = (double*)u; gp.laps = laps;
+    gp.laps_prev = laps_prev; gp.log_x = log_x; gp.log_u = log_u; gp.n_log = n_log; gp.crossed = crossed;
+    hipError_t e = crx_launch_game(3, gp, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "game log launch: %s", hipGetErrorString(e));
+    return CRX_OK;
 }
 
 }  // extern "C"

@@ -172,8 +172,8 @@ struct Lay {
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
     static constexpr int Fph = Fth + MAXF;
-    static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 12.. lap_off
-    static constexpr int dmy = cst + 16;             // sink of the address-predicated stores (lanes without an entry write here)
+    static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 12.. lap_off, 16.. 1/l_sum per obstacle, 16+NOBS.. 1/w_sum per obstacle
+    static constexpr int dmy = cst + 16 + 2 * NOBS;  // sink of the address-predicated stores (lanes without an entry write here)
     static constexpr int END_D = dmy + 2;
     // int tables (stored after the doubles)
     static constexpr int triH = 0;                   // [NZ(NZ+1)/2] packed (r << 8 | a) of the lower triangle of H
@@ -197,7 +197,7 @@ struct Lay {
 // problem context kept in registers (all wave-uniform)
 struct Ctx {
     int N, lane, nobs, m;
-    double lin_sN, cconst, wsig, alpha, om, cm, rLs, rWs;
+    double lin_sN, cconst, wsig, alpha, om, cm;
     int degree;
     double b_d, b_a, b_vlo, b_vhi, b_e;   // delta_max, a_max, v_min, v_max, ey_max: the bounds of the simple rows (slim layout: row_bound())
 };
@@ -299,10 +299,12 @@ __device__ __forceinline__ void cbf_dist(const double* sm, const Ctx& c, int k, 
     const double ec = LD(L::Z + k * L::NZ + 5) + al * LD(L::dZ + k * L::NZ + 5);
     const double sn = LD(L::Z + (k + 1) * L::NZ + 4) + al * LD(L::dZ + (k + 1) * L::NZ + 4);
     const double en = LD(L::Z + (k + 1) * L::NZ + 5) + al * LD(L::dZ + (k + 1) * L::NZ + 5);
-    dsc = (sc - LD(L::obs_s + o * N1 + k) - LD(L::cst + 12 + o)) * c.rLs;  // lap-corrected (control.py:539-540)
-    dec = (ec - LD(L::obs_e + o * N1 + k)) * c.rWs;
-    dsn = (sn - LD(L::obs_s + o * N1 + k + 1)) * c.rLs;                    // NOT corrected (control.py:542, quirk Q1)
-    den = (en - LD(L::obs_e + o * N1 + k + 1)) * c.rWs;
+    // 1 / (l_agent + l_obs), 1 / (w_agent + w_obs) of THIS obstacle (control.py:529-535 takes them per obstacle)
+    const double rLs = LD(L::cst + 16 + o), rWs = LD(L::cst + 16 + L::NO + o);
+    dsc = (sc - LD(L::obs_s + o * N1 + k) - LD(L::cst + 12 + o)) * rLs;  // lap-corrected (control.py:539-540)
+    dec = (ec - LD(L::obs_e + o * N1 + k)) * rWs;
+    dsn = (sn - LD(L::obs_s + o * N1 + k + 1)) * rLs;                    // NOT corrected (control.py:542, quirk Q1)
+    den = (en - LD(L::obs_e + o * N1 + k + 1)) * rWs;
 }
 
 template <int NOBS, int NMAX>
@@ -419,14 +421,15 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
             const double qd = (double)q, qq = (double)(q * (q - 1));
             const double p2sn = ipow_d(dsn, q - 2), p2en = ipow_d(den, q - 2);
             const double p2sc = ipow_d(dsc, q - 2), p2ec = ipow_d(dec, q - 2);
-            const double gsn = qd * p2sn * dsn * c.rLs, gen = qd * p2en * den * c.rWs;
-            const double gsc = qd * p2sc * dsc * c.rLs, gec = qd * p2ec * dec * c.rWs;
+            const double rLs = LD(L::cst + 16 + o), rWs = LD(L::cst + 16 + L::NO + o);
+            const double gsn = qd * p2sn * dsn * rLs, gen = qd * p2en * den * rWs;
+            const double gsc = qd * p2sc * dsc * rLs, gec = qd * p2ec * dec * rWs;
             const double d = cbf_scale<L>(sm, k, o);
             double m4[L::NZ], m5[L::NZ];
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) { m4[a] = LD(L::M + 4 * L::NZ + a); m5[a] = LD(L::M + 5 * L::NZ + a); }
-            G[0] = sel(here, qq * p2sn * c.rLs * c.rLs, 0.0); G[1] = sel(here, qq * p2en * c.rWs * c.rWs, 0.0);
-            G[2] = sel(here, qq * p2sc * c.rLs * c.rLs, 0.0); G[3] = sel(here, qq * p2ec * c.rWs * c.rWs, 0.0);
+            G[0] = sel(here, qq * p2sn * rLs * rLs, 0.0); G[1] = sel(here, qq * p2en * rWs * rWs, 0.0);
+            G[2] = sel(here, qq * p2sc * rLs * rLs, 0.0); G[3] = sel(here, qq * p2ec * rWs * rWs, 0.0);
             // every entry composed in registers and stored once (no read-modify-write round trips through LDS)
 #pragma unroll
             for (int a = 0; a < L::NZ; a++) {
@@ -1078,7 +1081,7 @@ crx_solve_kernel(const crx_kparams kp) {
     Ctx c;
     c.N = N; c.lane = lane; c.m = N * NR + NOBS; c.nobs = 0;
     const int m = c.m;
-    c.alpha = kp.alpha; c.om = 1.0 - kp.alpha; c.cm = 1.0 + kp.margin; c.rLs = 1.0 / kp.l_sum; c.rWs = 1.0 / kp.w_sum;
+    c.alpha = kp.alpha; c.om = 1.0 - kp.alpha; c.cm = 1.0 + kp.margin;
     c.degree = kp.degree; c.wsig = kp.w_slack; c.lin_sN = 0.0; c.cconst = 0.0;
     c.b_d = kp.delta_max; c.b_a = kp.a_max; c.b_vlo = kp.v_min; c.b_vhi = kp.v_max; c.b_e = kp.ey_max;
 
@@ -1158,7 +1161,15 @@ crx_solve_kernel(const crx_kparams kp) {
                 LD(L::obs_s + e) = on ? kp.obs_s[((size_t)b * kp.n_obs_max) * (N + 1) + e] : 0.0;
                 LD(L::obs_e + e) = on ? kp.obs_ey[((size_t)b * kp.n_obs_max) * (N + 1) + e] : 0.0;
             }
-            if (lane < NOBS) LD(L::cst + 12 + lane) = lane < c.nobs ? kp.lap_off[(size_t)b * kp.n_obs_max + lane] : 0.0;
+            if (lane < NOBS) {
+                LD(L::cst + 12 + lane) = lane < c.nobs ? kp.lap_off[(size_t)b * kp.n_obs_max + lane] : 0.0;
+                // obstacle dimensions: per problem and obstacle slot if the caller gave them, else the descriptor's pair
+                const bool own = kp.obs_dims != nullptr && lane < c.nobs;
+                const double ls = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2] : kp.l_sum;
+                const double ws = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2 + 1] : kp.w_sum;
+                LD(L::cst + 16 + lane) = 1.0 / ls;
+                LD(L::cst + 16 + NOBS + lane) = 1.0 / ws;
+            }
         }
         const double v0 = LD(L::Z + 0), e0 = LD(L::Z + 5);
         if (v0 < kp.v_min - kp.opts.tol || v0 > kp.v_max + kp.opts.tol || e0 < -kp.ey_max - kp.opts.tol ||
@@ -1242,11 +1253,12 @@ crx_solve_kernel(const crx_kparams kp) {
                 cbf_dist<NOBS, NMAX>(sm, c, k, o, 0.0, dsc, dec, dsn, den);
                 const int q = c.degree;
                 double gm = 1.0;
-                gm = fmax(gm, fabs(q * ipow_d(dsn, q - 1) * c.rLs));
-                gm = fmax(gm, fabs(q * ipow_d(den, q - 1) * c.rWs));
+                const double rLs = LD(L::cst + 16 + o), rWs = LD(L::cst + 16 + NOBS + o);
+                gm = fmax(gm, fabs(q * ipow_d(dsn, q - 1) * rLs));
+                gm = fmax(gm, fabs(q * ipow_d(den, q - 1) * rWs));
                 if (k > 0) {
-                    gm = fmax(gm, fabs(c.om * q * ipow_d(dsc, q - 1) * c.rLs));
-                    gm = fmax(gm, fabs(c.om * q * ipow_d(dec, q - 1) * c.rWs));
+                    gm = fmax(gm, fabs(c.om * q * ipow_d(dsc, q - 1) * rLs));
+                    gm = fmax(gm, fabs(c.om * q * ipow_d(dec, q - 1) * rWs));
                 }
                 LD(L::SLIM ? L::csc + k * L::NO + o : L::rsc + k * NR + 8 + NOBS + o) = fmin(1.0, kp.opts.grad_scale_max / gm);
             }
@@ -1332,13 +1344,16 @@ crx_solve_kernel(const crx_kparams kp) {
     for (;; it++) {
         long long tc0 = CLK();
 #if CRX_OPAQUE_LANE
-        // [r3] The lane index is made opaque once per iteration: everything the phases derive from it (which entry a lane
-        // owns, LDS addresses, the selects of the row / coordinate passes) is then recomputed inside the iteration instead of
-        // being hoisted out of the interior-point loop and kept alive across it -- integer work that the idle issue slots of
-        // a latency-bound wave absorb, against 40..140 registers: <0,12> 168 VGPRs + 116 B of scratch -> 160 and none (the
-        // parked dwords were x6..10 the algorithmic HBM traffic of the planner launches), <1,12> 256 + 28 B -> 208,
-        // <2,12> 345 -> 277, <3,20> 476 -> 332.
-        asm volatile("" : "+v"(c.lane));
+        // [r3] Planner instantiations: the lane index is made opaque once per iteration, so that everything the phases derive
+        // from it (which entry a lane owns, LDS addresses, the selects of the row / coordinate passes) is recomputed inside
+        // the iteration instead of being hoisted out of the interior-point loop and kept alive across it.  <0,12>: 168 VGPRs +
+        // 116 B of scratch per lane -> 160 and NO scratch (the parked dwords were x6..10 the algorithmic HBM traffic of the
+        // planner launches); cfg3 +4.7 %, cfg5 +1.7 % (tools/gpu_round3_a.sh).  The obstacle instantiations run one wave per
+        // SIMD and are bound by instruction ISSUE (one instruction per four clocks and wave: profiles/r03_pmc_issue.txt); the
+        // recomputation is ~19 % more VALU instructions there and costs 4..5 % (cfg2, cfg4, races) although it frees 40..140
+        // registers -- they keep the hoisted maps.  (With the barrier, the full-layout 3-obstacle instantiations also produced
+        // a kernel that faults on MI355X / ROCm 7.0.2 -- not understood; found by the GPU suite, tools/gpu_round3_b.sh.)
+        if (NOBS == 0) asm volatile("" : "+v"(c.lane));
         const int lane = c.lane;   // shadows the kernel's `lane` inside the loop body
 #endif
         // ---- KKT error -----------------------------------------------------------------------------

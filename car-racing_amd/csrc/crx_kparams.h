@@ -20,6 +20,7 @@ struct crx_kparams {
     // cbf inputs
     const double *xt, *obs_s, *obs_ey, *lap_off;
     const int32_t* n_obs;
+    const double* obs_dims;  // optional [batch][n_obs_max][2]: (l_agent + l_obs, w_agent + w_obs) per obstacle slot; NULL: l_sum, w_sum
     // outputs
     double *X, *U, *sigma, *cost, *kkt;
     int32_t *status, *iters;
@@ -131,6 +132,30 @@ size_t crx_solve_lds_bytes(int N, int nobs_template);
 int crx_solve_resident_per_cu(int N, int nobs_template);
 hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);
 hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
+
+// device-resident racing-game loop: the bookkeeping between the solver launches (crx.montecarlo.GameLaps / LmpcLaps)
+struct crx_game_kparams {
+    int N, Np, batch, n_cars, n_points;
+    double lap_length, t, dt;
+    // traffic
+    const double *car_s0, *car_v, *car_ey;
+    double *veh_xcurv, *pred_s, *pred_ey;
+    // masks
+    const int32_t *n_veh, *overflow;
+    int32_t *m_overtake, *m_lmpc, *overflow_seen;
+    // commit
+    const int32_t* overtake;
+    const double *U_track, *X_lmpc, *U_lmpc;
+    const int32_t* flag;
+    double *u, *u_old, *u_prev, *lin_points, *lin_input;
+    int32_t *step_no, *addpoint_step, *old_flag;
+    // log
+    const double* xcurv;
+    const int32_t* laps;
+    int32_t *laps_prev, *n_log, *crossed;
+    double *log_x, *log_u;
+};
+hipError_t crx_launch_game(int which, const crx_game_kparams& gp, hipStream_t st);
 hipError_t crx_launch_plant(const crx_plant_kparams& pk, hipStream_t st);
 hipError_t crx_launch_prep(const crx_prep_kparams& pp, hipStream_t st);
 hipError_t crx_launch_scene(const crx_scene_kparams& sp, hipStream_t st);

@@ -514,3 +514,106 @@ hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st) {
     hipLaunchKernelGGL(crx_path_kernel, dim3(pp.batch), dim3(WAVE), 0, st, pp);
     return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident racing-game loop (crx.montecarlo.GameLaps): the bookkeeping of
+// LMPCRacingGame.calc_input (utils/base.py:456-583) and of the simulator (racing/offboard.py:114-131, base.py:780-819)
+// between the solver launches, one thread per race (or per race and car).  Round 2 did this with ~40 element-wise torch
+// launches per control step; these four kernels are the same assignments in the same order.
+// ------------------------------------------------------------------------------------------------
+// scripted cars at their own clock t (NoDynamicsModel, base.py:847-890): s = v t + s0 wrapped once past the line like
+// update_memory keeps it (base.py:795-819), predictions v (t + j dt) + s0 unwrapped (get_trajectory_nsteps: quirk Q6)
+__global__ void __launch_bounds__(256) crx_game_traffic_kernel(const crx_game_kparams gp) {
+#pragma clang fp contract(off)   // multiply, then add, as the element-wise formulation this replaces did (and NumPy does)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= gp.batch * gp.n_cars) return;
+    const double v = gp.car_v[i], s0 = gp.car_s0[i], ey = gp.car_ey[i], L = gp.lap_length;
+    const double s_now = v * gp.t + s0;
+    double* x = gp.veh_xcurv + (size_t)6 * i;
+    x[0] = v; x[1] = 0.0; x[2] = 0.0; x[3] = 0.0;
+    x[4] = s_now - L * fmax(ceil(s_now / L) - 1.0, 0.0);
+    x[5] = ey;
+    const int N1 = gp.Np + 1;
+    for (int j = 0; j < N1; j++) {
+        gp.pred_s[(size_t)i * N1 + j] = v * (gp.t + (double)j * gp.dt) + s0;
+        gp.pred_ey[(size_t)i * N1 + j] = ey + 0.0 * ((double)j * gp.dt);
+    }
+}
+
+// which branch a race takes this step (utils/base.py:463-467: vehicles of interest -> overtake planner + tracking NLP, none ->
+// learning MPC), as the `active` masks of the masked launches
+__global__ void __launch_bounds__(256) crx_game_masks_kernel(const crx_game_kparams gp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gp.batch) return;
+    const int ot = gp.n_veh[b] > 0 ? 1 : 0;
+    gp.m_overtake[b] = ot;
+    gp.m_lmpc[b] = 1 - ot;
+    if (gp.overflow_seen) gp.overflow_seen[b] += gp.overflow[b];
+}
+
+// after the solves: the input the race applies, the learning MPC's hand-over of its plan (u_old, linearisation points shifted
+// by one stage with the last one repeated: control.py:726-728 / utils/base.py:504-515), the step counter of add_point and the
+// direction flag (utils/base.py:546-551) -- each from the branch the race is in; the other branch's state is left alone
+__global__ void __launch_bounds__(256) crx_game_commit_kernel(const crx_game_kparams gp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gp.batch) return;
+    const int N = gp.N;
+    const bool ot = gp.overtake && gp.overtake[b] != 0;
+    const double* Ul = gp.U_lmpc + (size_t)b * N * 2;
+    const double* Xl = gp.X_lmpc + (size_t)b * (N + 1) * 6;
+    const double u0 = ot ? gp.U_track[(size_t)b * gp.Np * 2] : Ul[0], u1 = ot ? gp.U_track[(size_t)b * gp.Np * 2 + 1] : Ul[1];
+    gp.u[2 * b] = u0; gp.u[2 * b + 1] = u1;
+    gp.u_prev[2 * b] = gp.u_old[2 * b]; gp.u_prev[2 * b + 1] = gp.u_old[2 * b + 1];
+    gp.addpoint_step[b] = ot ? -(1 << 20) : gp.step_no[b];
+    if (gp.old_flag) gp.old_flag[b] = ot ? gp.flag[b] : -1;
+    if (!ot) {
+        gp.u_old[2 * b] = Ul[0]; gp.u_old[2 * b + 1] = Ul[1];
+        double* lp = gp.lin_points + (size_t)b * (N + 1) * 6;
+        double* li = gp.lin_input + (size_t)b * N * 2;
+        for (int k = 0; k <= N; k++) {
+            const int ks = k < N ? k + 1 : N;
+            for (int c = 0; c < 6; c++) lp[6 * k + c] = Xl[6 * ks + c];
+        }
+        for (int k = 0; k < N; k++) {
+            const int ks = k < N - 1 ? k + 1 : N - 1;
+            li[2 * k] = Ul[2 * ks]; li[2 * k + 1] = Ul[2 * ks + 1];
+        }
+        gp.step_no[b] += 1;
+    }
+}
+
+// after the plant: the lap log the simulator keeps (ModelBase.update_memory: the new state -- the one that crossed the line
+// with its s unwrapped -- and the applied input) and which races have just completed a lap (-> crx_lmpc_addtraj_dev)
+__global__ void __launch_bounds__(256) crx_game_log_kernel(const crx_game_kparams gp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gp.batch) return;
+    const int P = gp.n_points;
+    const int cr = gp.laps[b] > gp.laps_prev[b] ? 1 : 0;
+    gp.laps_prev[b] = gp.laps[b];
+    gp.crossed[b] = cr;
+    const int n = gp.n_log[b];
+    const int ix = n < P - 1 ? n : P - 1;
+    int iu = n - 1; iu = iu < 0 ? 0 : (iu > P - 1 ? P - 1 : iu);
+    const double* x = gp.xcurv + (size_t)6 * b;
+    double* lx = gp.log_x + ((size_t)b * P + ix) * 6;
+    for (int c = 0; c < 6; c++) lx[c] = x[c];
+    lx[4] = x[4] + gp.lap_length * (double)cr;
+    double* lu = gp.log_u + ((size_t)b * P + iu) * 2;
+    lu[0] = gp.u[2 * b]; lu[1] = gp.u[2 * b + 1];
+    gp.n_log[b] = n + 1;
+}
+
+hipError_t crx_launch_game(int which, const crx_game_kparams& gp, hipStream_t st) {
+    if (gp.batch == 0) return hipSuccess;
+    const int n = which == 0 ? gp.batch * gp.n_cars : gp.batch;
+    if (n == 0) return hipSuccess;
+    const dim3 grid((n + 255) / 256), block(256);
+    switch (which) {
+        case 0: hipLaunchKernelGGL(crx_game_traffic_kernel, grid, block, 0, st, gp); break;
+        case 1: hipLaunchKernelGGL(crx_game_masks_kernel, grid, block, 0, st, gp); break;
+        case 2: hipLaunchKernelGGL(crx_game_commit_kernel, grid, block, 0, st, gp); break;
+        default: hipLaunchKernelGGL(crx_game_log_kernel, grid, block, 0, st, gp); break;
+    }
+    return hipGetLastError();
+}

@@ -125,7 +125,7 @@ typedef struct crx_cbf_desc {
     double ey_max;         /* track.width (control.py:585-586) */
     double alpha;          /* 0.8 mpc_cbf_param.alpha / 0.6 literal (control.py:285) */
     double margin;         /* 0.2 (control.py:527) / 0.15 (:311) */
-    double l_sum;          /* l_agent + l_obs (control.py:532-535) = 0.4 */
+    double l_sum;          /* l_agent + l_obs (control.py:532-535) = 0.4; per-obstacle values: crx_cbf_solve_dims */
     double w_sum;          /* w_agent + w_obs = 0.2 */
     double w_slack;        /* 1e4 (control.py:560,562) */
     crx_ipm_opts opts;
@@ -528,6 +528,17 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
                       const double* obs_s, const double* obs_ey, const double* lap_off,
                       const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
                       int32_t* status, double* kkt, int32_t* iters, void* stream);
+/* Per-obstacle dimensions.  The reference takes (l_obs, w_obs) from every obstacle vehicle's own CarParam (control.py:529-535);
+ * crx_cbf_desc carries ONE pair (l_sum, w_sum) for the common case of identical cars.  obs_dims [batch][n_obs_max][2] =
+ * (l_agent + l_obs, w_agent + w_obs) of every obstacle slot of every problem overrides it (slots >= n_obs[b] are not read);
+ * NULL = the descriptor's pair for all.  `active` as in the masked launch below (NULL: all). */
+int crx_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
+                       const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, double* X,
+                       double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters);
+int crx_cbf_solve_dims_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                           const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs,
+                           const double* obs_dims, double* X, double* U, double* sigma, double* cost, int32_t* status, double* kkt,
+                           int32_t* iters, void* stream);
 /* Masked launches (device-resident loops in which every problem of the batch takes ONE of several branches per step, e.g.
  * LMPCRacingGame.calc_input, utils/base.py:456-583: overtake planner + tracking NLP, or learning-MPC): active [batch]
  * int32 on the device, 0 = this problem is not part of the launch -- its wavefront returns at once, status[b] =
@@ -535,6 +546,40 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
 int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
                              const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
                              double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream);
+
+/*
+ * Device-resident racing-game loop: the bookkeeping of LMPCRacingGame.calc_input (utils/base.py:456-583)
+ * and of the simulator between the solver launches, so that a control step of B races is a fixed sequence of libcrx launches with
+ * nothing returning to the host (crx.montecarlo.GameLaps: traffic -> scene -> masks -> prep -> plan -> track prep -> tracking NLP |
+ * regression -> learning-MPC QP -> commit -> add_point -> plant -> log -> add_trajectory).
+ *   crx_game_traffic_dev  scripted cars s(t) = v t + s0, ey(t) = ey (NoDynamicsModel, base.py:847-890) at their clock t: states
+ *                         veh_xcurv [B][n_cars][6] (s wrapped once past the line like update_memory keeps it) and predictions
+ *                         pred_s, pred_ey [B][n_cars][N+1] at t + j dt (unwrapped: quirk Q6) -- the inputs of crx_planner_scene_dev
+ *   crx_game_masks_dev    m_overtake = (n_veh > 0), m_lmpc = 1 - m_overtake: the `active` masks of the masked launches; with
+ *                         overflow / overflow_seen (both may be NULL) the scene stage's dropped-vehicle counts are accumulated
+ *                         per race, so that a sweep can report whether the n_veh_max slots ever were too few
+ *   crx_game_commit_dev   after the solves, per race from the branch it is in (overtake == NULL: every race drives by learning MPC):
+ *                         u [B][2] the input to apply (u_0 of the tracking NLP U_track [B][Np][2] or of the learning-MPC QP
+ *                         U_lmpc [B][N][2]); u_prev <- u_old; learning-MPC branch only: u_old <- u_0, lin_points [B][N+1][6] /
+ *                         lin_input [B][N][2] <- the plan X_lmpc / U_lmpc shifted by one stage, last stage repeated
+ *                         (control.py:726-728), step_no += 1; addpoint_step = the step index crx_lmpc_addpoint_dev takes (negative in
+ *                         the overtake branch: no point is added, utils/base.py:546-551); old_flag <- flag or -1 (may be NULL)
+ *   crx_game_log_dev      after the plant: crossed [B] = lap counter advanced; the new state (s unwrapped if it crossed) and the
+ *                         applied input appended to the race's lap log log_x [B][n_points][6], log_u [B][n_points][2], n_log += 1
+ *                         (ModelBase.update_memory) -- the inputs of crx_lmpc_addtraj_dev
+ * A race keeps n_laps laps of safe set (crx_lmpcprep_desc.n_laps); when they are full crx_lmpc_addtraj_dev reports status 1 and the
+ * race goes on racing on its last two laps (the reference allocates for the number of laps it is asked to run, utils/base.py:631-656).
+ */
+int crx_game_traffic_dev(int N, int batch, int n_cars, double lap_length, double t, double dt, const double* car_s0,
+                         const double* car_v, const double* car_ey, double* veh_xcurv, double* pred_s, double* pred_ey,
+                         void* stream);
+int crx_game_masks_dev(int batch, const int32_t* n_veh, const int32_t* overflow, int32_t* m_overtake, int32_t* m_lmpc,
+                       int32_t* overflow_seen, void* stream);
+int crx_game_commit_dev(int N, int Np, int batch, const int32_t* overtake, const double* U_track, const double* X_lmpc,
+                        const double* U_lmpc, const int32_t* flag, double* u, double* u_old, double* u_prev, double* lin_points,
+                        double* lin_input, int32_t* step_no, int32_t* addpoint_step, int32_t* old_flag, void* stream);
+int crx_game_log_dev(int batch, int n_points, double lap_length, const double* xcurv, const double* u, const int32_t* laps,
+                     int32_t* laps_prev, double* log_x, double* log_u, int32_t* n_log, int32_t* crossed, void* stream);
 
 /*
  * Multi-GPU: problems are independent and a planner sweep is sharded by scenario, so the path has

@@ -66,7 +66,7 @@ typedef struct {
     double ulo[2], uhi[2];
     double vlo[MAXN + 1], vhi[MAXN + 1], elo[MAXN + 1], ehi[MAXN + 1]; /* +-HUGE_VAL = absent */
     double obs_s[MAXO][MAXN + 1], obs_ey[MAXO][MAXN + 1], lap_off[MAXO];
-    double alpha, cm, Ls, Ws;
+    double alpha, cm, Ls[MAXO], Ws[MAXO];   /* l_agent + l_obs, w_agent + w_obs per obstacle (control.py:529-535) */
     int degree;
     int linear_rows;              /* every row is linear in v (no obstacle slot in the descriptor): box_certificate() applies */
 } ocp_t;
@@ -147,10 +147,10 @@ static double cost_value(const work_t* w) {
  *   c = g_next(x_{i+1}) - sigma_{i+1} - (1-alpha) (g_cur(x_i) - sigma_i) - alpha*(1+margin)      */
 static inline void cbf_terms(const ocp_t* p, const double x[][6], int o, int i, double* dsc,
                              double* dec, double* dsn, double* den) {
-    *dsc = (x[i][4] - p->obs_s[o][i] - p->lap_off[o]) / p->Ls;     /* lap-corrected (:539-540) */
-    *dec = (x[i][5] - p->obs_ey[o][i]) / p->Ws;
-    *dsn = (x[i + 1][4] - p->obs_s[o][i + 1]) / p->Ls;             /* NOT lap-corrected (:542) */
-    *den = (x[i + 1][5] - p->obs_ey[o][i + 1]) / p->Ws;
+    *dsc = (x[i][4] - p->obs_s[o][i] - p->lap_off[o]) / p->Ls[o];     /* lap-corrected (:539-540) */
+    *dec = (x[i][5] - p->obs_ey[o][i]) / p->Ws[o];
+    *dsn = (x[i + 1][4] - p->obs_s[o][i + 1]) / p->Ls[o];             /* NOT lap-corrected (:542) */
+    *den = (x[i + 1][5] - p->obs_ey[o][i + 1]) / p->Ws[o];
 }
 
 static double row_value(const work_t* w, int j) {
@@ -193,8 +193,8 @@ static void row_jac(const work_t* w, int j, double* out) {
             double dsc, dec, dsn, den;
             int i = r->k, q = p->degree;
             cbf_terms(p, w->x, r->o, i, &dsc, &dec, &dsn, &den);
-            double gsn = q * ipow(dsn, q - 1) / p->Ls, gen = q * ipow(den, q - 1) / p->Ws;
-            double gsc = q * ipow(dsc, q - 1) / p->Ls, gec = q * ipow(dec, q - 1) / p->Ws;
+            double gsn = q * ipow(dsn, q - 1) / p->Ls[r->o], gen = q * ipow(den, q - 1) / p->Ws[r->o];
+            double gsc = q * ipow(dsc, q - 1) / p->Ls[r->o], gec = q * ipow(dec, q - 1) / p->Ws[r->o];
             double om = 1.0 - p->alpha;
             for (int a = 0; a < n; a++)
                 out[a] = gsn * w->Sx[i + 1][4][a] + gen * w->Sx[i + 1][5][a] -
@@ -356,11 +356,12 @@ static void scale_rows(work_t* w) {
         cbf_terms(p, w->x, w->row[j].o, w->row[j].k, &dsc, &dec, &dsn, &den);
         double gm = 1.0; /* |d/d sigma_{i+1}| */
         double v;
-        v = fabs(q * ipow(dsn, q - 1) / p->Ls); if (v > gm) gm = v;
-        v = fabs(q * ipow(den, q - 1) / p->Ws); if (v > gm) gm = v;
+        const double Ls = p->Ls[w->row[j].o], Ws = p->Ws[w->row[j].o];
+        v = fabs(q * ipow(dsn, q - 1) / Ls); if (v > gm) gm = v;
+        v = fabs(q * ipow(den, q - 1) / Ws); if (v > gm) gm = v;
         if (w->row[j].k > 0) { /* x_0 is not a variable */
-            v = fabs((1.0 - p->alpha) * q * ipow(dsc, q - 1) / p->Ls); if (v > gm) gm = v;
-            v = fabs((1.0 - p->alpha) * q * ipow(dec, q - 1) / p->Ws); if (v > gm) gm = v;
+            v = fabs((1.0 - p->alpha) * q * ipow(dsc, q - 1) / Ls); if (v > gm) gm = v;
+            v = fabs((1.0 - p->alpha) * q * ipow(dec, q - 1) / Ws); if (v > gm) gm = v;
         }
         w->d[j] = fmin(1.0, w->o->grad_scale_max / gm);
     }
@@ -545,10 +546,10 @@ static void ipm_solve(work_t* w, result_t* res) {
             double dsc, dec, dsn, den;
             cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
             double wn = w->nu[j] * w->d[j];
-            double hsn = q * (q - 1) * ipow(dsn, q - 2) / (p->Ls * p->Ls);
-            double hen = q * (q - 1) * ipow(den, q - 2) / (p->Ws * p->Ws);
-            double hsc = q * (q - 1) * ipow(dsc, q - 2) / (p->Ls * p->Ls);
-            double hec = q * (q - 1) * ipow(dec, q - 2) / (p->Ws * p->Ws);
+            double hsn = q * (q - 1) * ipow(dsn, q - 2) / (p->Ls[ob] * p->Ls[ob]);
+            double hen = q * (q - 1) * ipow(den, q - 2) / (p->Ws[ob] * p->Ws[ob]);
+            double hsc = q * (q - 1) * ipow(dsc, q - 2) / (p->Ls[ob] * p->Ls[ob]);
+            double hec = q * (q - 1) * ipow(dec, q - 2) / (p->Ws[ob] * p->Ws[ob]);
             double om = 1.0 - p->alpha;
             /* W -= nu * hess c */
             for (int a = 0; a < n; a++)
@@ -806,7 +807,7 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
 /* control.mpccbf / control.mpc_multi_agents as the canonical stage-structured problem (line numbers into
  * control/control.py).  xt_b: [6] or, with per_stage_target, [N+1][6]; obstacle arrays: this problem's [V][N+1] block. */
 static void fill_cbf(ocp_t* p, const crx_cbf_desc* d, const double* xb, const double* xt_b, const double* obs_s_b,
-                     const double* obs_ey_b, const double* lap_off_b, int nobs) {
+                     const double* obs_ey_b, const double* lap_off_b, int nobs, const double* dims_b) {
     const int N = d->N, V = d->n_obs_max;
     memset(p, 0, sizeof(*p));
     p->N = N; p->nobs = nobs; p->linear_rows = (V == 0);
@@ -828,14 +829,29 @@ static void fill_cbf(ocp_t* p, const crx_cbf_desc* d, const double* xb, const do
         memcpy(p->obs_ey[o], obs_ey_b + (size_t)o * (N + 1), sizeof(double) * (N + 1));
         p->lap_off[o] = lap_off_b[o];
     }
-    p->alpha = d->alpha; p->cm = 1.0 + d->margin; p->Ls = d->l_sum; p->Ws = d->w_sum;
+    p->alpha = d->alpha; p->cm = 1.0 + d->margin;
+    for (int o = 0; o < MAXO; o++) {   /* :529-535: per obstacle when the caller gives them */
+        p->Ls[o] = (dims_b && o < nobs) ? dims_b[2 * o] : d->l_sum;
+        p->Ws[o] = (dims_b && o < nobs) ? dims_b[2 * o + 1] : d->w_sum;
+    }
     p->degree = d->degree;
 }
 
+int crx_oracle_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
+                              const double* obs_s, const double* obs_ey, const double* lap_off,
+                              const int32_t* n_obs, const double* obs_dims, double* X, double* U, double* sigma, double* cost,
+                              int32_t* status, double* kkt, int32_t* iters);
 int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
                          const double* obs_s, const double* obs_ey, const double* lap_off,
                          const int32_t* n_obs, double* X, double* U, double* sigma, double* cost,
                          int32_t* status, double* kkt, int32_t* iters) {
+    return crx_oracle_cbf_solve_dims(d, batch, x0, xt, obs_s, obs_ey, lap_off, n_obs, NULL, X, U, sigma, cost, status, kkt, iters);
+}
+
+int crx_oracle_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const double* xt,
+                              const double* obs_s, const double* obs_ey, const double* lap_off,
+                              const int32_t* n_obs, const double* obs_dims, double* X, double* U, double* sigma, double* cost,
+                              int32_t* status, double* kkt, int32_t* iters) {
     if (!d || d->N < 2 || d->N > MAXN || batch < 0 || d->n_obs_max < 0 || d->n_obs_max > MAXO ||
         (d->degree & 1) || d->degree < 2)
         return CRX_ERR_ARG;
@@ -852,7 +868,7 @@ int crx_oracle_cbf_solve(const crx_cbf_desc* d, int batch, const double* x0, con
         if (!have_ws) { status[b] = CRX_MAX_ITER; continue; }
         const double* xb = x0 + 6 * b;
         fill_cbf(p, d, xb, d->per_stage_target ? xt + (size_t)(N + 1) * 6 * b : xt + 6 * b, obs_s + (size_t)V * (N + 1) * b,
-                 obs_ey + (size_t)V * (N + 1) * b, lap_off + (size_t)V * b, n_obs ? n_obs[b] : V);
+                 obs_ey + (size_t)V * (N + 1) * b, lap_off + (size_t)V * b, n_obs ? n_obs[b] : V, obs_dims ? obs_dims + (size_t)2 * V * b : NULL);
         int infeas0 = (xb[0] < d->v_min - d->opts.tol || xb[0] > d->v_max + d->opts.tol ||
                        xb[5] < -d->ey_max - d->opts.tol || xb[5] > d->ey_max + d->opts.tol); /* Q9 */
         result_t r;
@@ -906,13 +922,13 @@ static void probe_common(work_t* w, ocp_t* p, const crx_ipm_opts* o, const doubl
 }
 
 int crx_oracle_cbf_probe(const crx_cbf_desc* d, const double* x0, const double* xt, const double* obs_s,
-                         const double* obs_ey, const double* lap_off, int n_obs, const double* U, const double* sigma,
-                         double* cost, double* cbf_rows, double* box, double* X) {
+                         const double* obs_ey, const double* lap_off, int n_obs, const double* obs_dims, const double* U,
+                         const double* sigma, double* cost, double* cbf_rows, double* box, double* X) {
     if (!d || d->N < 2 || d->N > MAXN || d->n_obs_max < 0 || d->n_obs_max > MAXO || n_obs < 0 || n_obs > d->n_obs_max)
         return CRX_ERR_ARG;
     work_t* w; ocp_t* p;
     if (!thread_ws(&w, &p)) return CRX_ERR_ARG;
-    fill_cbf(p, d, x0, xt, obs_s, obs_ey, lap_off, n_obs);
+    fill_cbf(p, d, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims);
     probe_common(w, p, &d->opts, U, sigma, d->n_obs_max, cost, cbf_rows, box, X);
     return CRX_OK;
 }

@@ -1,7 +1,7 @@
 """profiles/<round>_pmc_hbm_traffic.txt + profiles/pmc_hbm_traffic.json from the rocprofv3 --pmc passes of tools/gpu_pmc_r2.sh
-(csv output under gpurun_out/pmc2/), corrected with the calibration of tools/gpu_calib.sh (profiles/pmc_calibration.json):
+(csv output under gpurun_out/pmc3/ -- round 3: tools/gpu_round3_d.sh), corrected with the calibration of tools/gpu_calib.sh (profiles/pmc_calibration.json):
 FETCH_SIZE under-counts an 8 B/lane coalesced stream by the measured factor, WRITE_SIZE counts whole 64 B lines.
-Usage: python profiles/summarize_pmc.py [round-prefix, default r02]"""
+Usage: python profiles/summarize_pmc.py [round-prefix, default r03] [csv directory under gpurun_out/]"""
 import collections
 import csv
 import glob
@@ -10,7 +10,8 @@ import os
 import sys
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-PRE = sys.argv[1] if len(sys.argv) > 1 else "r02"
+PRE = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = sys.argv[2] if len(sys.argv) > 2 else ("pmc2" if PRE == "r02" else "pmc3")   # directory under gpurun_out/ holding the csv output
 # workload -> (kernel name fragment, problems per full launch, algorithmic bytes per problem in / out)
 WL = {"cfg2": ("crx_solve_kernel", 256, 39 * 8, 118 * 8), "cfg3": ("crx_solve_kernel", 4096, 57 * 8, 93 * 8),
       "cfg4": ("crx_solve_kernel", 16384, 162 * 8, 232 * 8), "cfg5": ("crx_solve_kernel", 65536, 57 * 8, 93 * 8)}
@@ -39,7 +40,7 @@ def main():
     for wl, (frag, n, b_in, b_out) in WL.items():
         v = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            f = glob.glob(os.path.join(ROOT, "gpurun_out", "pmc2", "%s_%s" % (wl, ctr), "**", "*counter_collection.csv"), recursive=True)
+            f = glob.glob(os.path.join(ROOT, "gpurun_out", SRC, "%s_%s" % (wl, ctr), "**", "*counter_collection.csv"), recursive=True)
             v[ctr] = rows(f[0], frag, n * 64)[ctr] if f else []
         F, W = v["FETCH_SIZE"], v["WRITE_SIZE"]
         if not F or not W:
@@ -53,6 +54,13 @@ def main():
                          rd + wr, (rd + wr) / ((b_in + b_out) * n), (b_in + b_out) * n))
         js[wl] = {"batch": n, "fetch_kib": round(fm, 1), "write_kib": round(wm, 1), "traffic_bytes": round(rd + wr),
                   "traffic_bytes_uncalibrated": round((fm + wm) * 1024), "algorithmic_bytes": (b_in + b_out) * n}
+    # the kernel sources these numbers were measured on (written by the GPU script next to the csv files): bench.py reports the
+    # traffic only while the sources are unchanged
+    try:
+        js["kernel_source_sha256"] = open(os.path.join(ROOT, "gpurun_out", SRC, "source_hash.txt")).read().strip()
+    except Exception:
+        js["kernel_source_sha256"] = None
+    lines.append("# kernel sources: sha256[:16] = %s (bench.py kernel_source_hash())" % js["kernel_source_sha256"])
     lines.append("# FETCH_SIZE of a launch that reads no data at all (tools/ubench/fetch_calib write8): %.1f KiB -- the floor every launch pays." % fixed_kib)
     open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.txt" % PRE), "w").write("\n".join(lines) + "\n")
     json.dump(js, open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json"), "w"), indent=1)

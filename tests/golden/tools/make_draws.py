@@ -385,6 +385,32 @@ def upgrade(kind):
     np.savez_compressed(path, **z)
 
 
+def gen_dims(n=16):
+    """control.mpccbf with obstacle vehicles of UNEQUAL size (control.py:529-535 takes l_obs, w_obs from every obstacle's own
+    CarParam): the first n problems of the cfg2 draw with a second car added beside the first, both with random dimensions.
+    -> tests/golden/cfg2_dims.npz (same fields as cfg2_draw.npz + car_dims)."""
+    p = synth.cfg2_mpccbf(256, N=12, seed=2, safe_start=False)
+    rng = np.random.default_rng(21)
+    rows = []
+    for b in range(n):
+        x0 = p["x0"][b]
+        c1 = tuple(p["cars"][b, 0])
+        c2 = (c1[0] + rng.uniform(0.6, 1.4), float(rng.uniform(0.1, 0.9)), float(0.7 - 0.1 * rng.integers(0, 15)))
+        cars = [c1, c2]
+        dims = [(float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.15, 0.35))) for _ in cars]
+        r = mg.mpccbf_case(x0, cars, N=12, alpha=0.8, vt=0.8, car_dims=dims)
+        opti, z, info = mg.RECORDS[-1]
+        n_obs = int(r["n_obs_in_problem"])
+        row = dict(index=b, x0=x0, cars=np.array(cars), car_dims=np.array(dims), n_obs_ref=n_obs, obs_pred=r["obs_pred"], u_returned=r["u_returned"],
+                   X=r["X"], U=r["U"], sigma=np.asarray(r["sigma"]).reshape(n_obs, 13), cert=r["cert"])
+        row.update(probe(opti, 12, n_obs, x0, 7500 + b))
+        _classified(row, opti, info, z, 12, n_obs)
+        rows.append(row)
+        print("dims %2d/%d n_obs %d success %s iters %d retry %s" % (b + 1, n, n_obs, row["success"], row["ipm_iters"], row["retry_certified"]), flush=True)
+    out = {"draw/" + k: v for k, v in _stack(rows).items()}
+    np.savez_compressed(os.path.join(mg.OUT, "cfg2_dims.npz"), **out)
+
+
 def gen_plant_noise(n=24):
     """DynamicBicycleModel.forward_dynamics (utils/base.py:897-942) WITH its process noise on random states: the reference's
     own step under np.random.seed(k), the three standard-normal draws it consumed, and the state it returned."""
@@ -450,6 +476,9 @@ mg.planner_case = _planner_case_with_probes
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    if which[0] == "dims":
+        gen_dims()
+        sys.exit(0)
     if which[0] == "plant_noise":
         gen_plant_noise()
         sys.exit(0)

@@ -179,8 +179,9 @@ def cert_fields(info):
 # -------------------------------------------------------------------------------------------------
 # mpccbf (control.py:476-607)
 # -------------------------------------------------------------------------------------------------
-def mpccbf_case(x0, cars, N=10, alpha=0.8, vt=0.8, width=1.0, time=0.0):
-    """cars: list of (s0, v, ey) for NoDynamicsModel obstacles s(t) = v t + s0, ey(t) = ey."""
+def mpccbf_case(x0, cars, N=10, alpha=0.8, vt=0.8, width=1.0, time=0.0, car_dims=None):
+    """cars: list of (s0, v, ey) for NoDynamicsModel obstacles s(t) = v t + s0, ey(t) = ey; car_dims: (length, width) per car
+    (default CarParam(): 0.4 x 0.2)."""
     track = make_track(width)
     ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(), system_param=base.SystemParam())
     ego.set_zero_noise()
@@ -197,7 +198,7 @@ def mpccbf_case(x0, cars, N=10, alpha=0.8, vt=0.8, width=1.0, time=0.0):
     sim.add_vehicle(ego)
     ego.ctrl_policy.set_racing_sim(sim)
     for i, (s0, v, ey) in enumerate(cars):
-        c = offboard.NoDynamicsModel(name="car%d" % (i + 1), param=base.CarParam())
+        c = offboard.NoDynamicsModel(name="car%d" % (i + 1), param=base.CarParam() if car_dims is None else base.CarParam(length=car_dims[i][0], width=car_dims[i][1]))
         c.set_track(track)
         c.set_state_curvilinear_func(T, v * T + s0, ey + 0.0 * T)
         sim.add_vehicle(c)

@@ -144,7 +144,7 @@ def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def oracle_cbf_probe(orc, d, x0, xt, obs_s, obs_ey, lap_off, n_obs, U, sigma):
+def oracle_cbf_probe(orc, d, x0, xt, obs_s, obs_ey, lap_off, n_obs, U, sigma, obs_dims=None):
     """The cost, the UNSCALED CBF row values [n_obs_max][N], the variable boxes and the rolled-out states of the problem the
     oracle builds from one problem's C-ABI inputs, at the point (U [N][2], sigma [n_obs][N+1])."""
     import ctypes as C
@@ -158,7 +158,8 @@ def oracle_cbf_probe(orc, d, x0, xt, obs_s, obs_ey, lap_off, n_obs, U, sigma):
     rows, box, X = np.zeros((max(V, 1), N)), np.zeros(4 + 4 * (N + 1)), np.zeros((N + 1, 6))
     fn = orc.lib.crx_oracle_cbf_probe
     fn.restype = C.c_int
-    rc = fn(C.byref(d), _dp(x0), _dp(xt), _dp(obs_s), _dp(obs_ey), _dp(lap_off), C.c_int(int(n_obs)), _dp(U), _dp(sig), C.byref(cost),
+    dims = None if obs_dims is None else np.ascontiguousarray(obs_dims, dtype=f64).reshape(max(V, 1), 2)
+    rc = fn(C.byref(d), _dp(x0), _dp(xt), _dp(obs_s), _dp(obs_ey), _dp(lap_off), C.c_int(int(n_obs)), _dp(dims) if dims is not None else None, _dp(U), _dp(sig), C.byref(cost),
             _dp(rows), _dp(box), _dp(X))
     assert rc == 0, rc
     b = box[4:].reshape(4, N + 1)

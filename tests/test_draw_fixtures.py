@@ -283,3 +283,69 @@ def test_oracle_planner_on_reference_built_draw(orc, AB, T):
     res, g = _planner_compare(orc, orc, AB, T)
     ok = g["region_success"].reshape(-1)
     assert ok.sum() >= 0.3 * len(ok) and (~ok).sum() >= 0.2 * len(ok)        # the BASELINE draw: ~41 % infeasible regions
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# obstacle vehicles of unequal size (control.py:529-535): crx_cbf_solve_dims
+# ---------------------------------------------------------------------------------------------------------------------
+def dims_batch():
+    """The scenarios of tests/golden/cfg2_dims.npz through the PRODUCT's host prep: window test, packing, per-obstacle
+    (l_agent + l_obs, w_agent + w_obs) following the kept cars."""
+    from crx import hostprep
+    g = _group(_load("cfg2_dims.npz"), "draw")
+    n, N = len(g["index"]), 12
+    j = np.arange(N + 1)
+    cars, cd = g["cars"], g["car_dims"]
+    obs_s = cars[:, :, 0, None] + 0.1 * j[None, None, :] * cars[:, :, 1, None]
+    obs_ey = np.repeat(cars[:, :, 2, None], N + 1, axis=2)
+    keep, lap_off = hostprep.cbf_window(g["x0"], obs_s[:, :, 0], LAP)
+    dims = np.stack([0.2 + 0.5 * cd[:, :, 0], 0.1 + 0.5 * cd[:, :, 1]], axis=2)          # ego: CarParam() = 0.4 x 0.2
+    ps, pe, po, nn, pd = hostprep.pack_obstacles(keep, obs_s, obs_ey, lap_off, 2, dims=dims)
+    xt = np.tile(np.array([0.8, 0, 0, 0, 0, 0.0]), (n, 1))
+    return g, dict(x0=g["x0"], xt=xt, obs_s=ps, obs_ey=pe, lap_off=po, n_obs=nn, obs_dims=pd)
+
+
+def _dims_compare(binding, orc, AB, T):
+    from crx import abi
+    A, B = AB
+    g, p = dims_batch()
+    d = abi.cbf_desc(12, 2, A, B, alpha=0.8, margin=0.2)
+    d.opts.tol = T["tol"]
+    res = binding.cbf_solve(d, *[p[k] for k in KEYS], obs_dims=p["obs_dims"])
+    plain = binding.cbf_solve(d, *[p[k] for k in KEYS])                                  # the descriptor's single pair: a different problem
+    n_cmp = n_diff = 0
+    for r in range(len(g["index"])):
+        if not (bool(g["certified"][r]) and res["status"][r] == 0):
+            continue
+        fg = g["cert"][r][0]
+        if abs(res["cost"][r] - fg) / max(1.0, abs(fg)) > T["f"] and res["cost"][r] < fg:
+            continue
+        n_cmp += 1
+        scale = max(1.0, abs(fg) * 1e-6)
+        Tl = T.get("loose", T)
+        assert abs(res["cost"][r] - fg) / max(1.0, abs(fg)) <= T["f"], (r, res["cost"][r], fg)
+        assert np.abs(res["X"][r] - g["X"][r]).max() <= Tl["x"] * scale and np.abs(res["U"][r] - g["U"][r]).max() <= Tl["u"] * scale, r
+        n_diff += np.abs(plain["X"][r] - g["X"][r]).max() > 1e-4
+    assert n_cmp >= 10 and n_diff >= 3, (n_cmp, n_diff)    # ... and the sizes matter: with one common pair the answers differ
+    return res
+
+
+def test_unequal_cars_rows_and_solutions(orc, AB):
+    """Rows: cost / CBF rows of the reference's recorded problem (two obstacle cars of different, random sizes) == the oracle's rows
+    with per-obstacle dims; solutions: oracle == certified KKT points."""
+    from crx import abi
+    A, B = AB
+    g, p = dims_batch()
+    d = abi.cbf_desc(12, 2, A, B, alpha=0.8, margin=0.2)
+    seen2 = 0
+    for r in range(len(g["index"])):
+        n = int(g["n_obs_ref"][r])
+        assert int(p["n_obs"][r]) == n, r
+        seen2 += n == 2
+        pr = helpers.oracle_cbf_probe(orc, d, p["x0"][r], p["xt"][r], p["obs_s"][r], p["obs_ey"][r], p["lap_off"][r], n, g["probe_U"][r],
+                                      g["probe_sigma"][r][:n], obs_dims=p["obs_dims"][r])
+        assert _rel(pr["cost"], g["probe_f"][r]) <= 1e-12, r
+        assert (_rel(pr["cbf"], g["probe_cbf"][r][:n]) <= 1e-9).all(), (r, pr["cbf"], g["probe_cbf"][r][:n])
+    assert seen2 >= 8
+    for T in (DEFAULT, TIGHT):
+        _dims_compare(orc, orc, AB, T)

@@ -464,3 +464,59 @@ def test_batched_game_laps(AB, golden_racing_game):
     # (c) random traffic
     assert np.abs(x[:, :, 5]).max() <= 1.3 * track.width
     assert (r["laps"] >= 1).mean() >= 0.8, r["laps"]
+
+
+def test_fused_game_bookkeeping_equals_torch_glue(AB, golden_racing_game):
+    """crx_game_traffic_dev / crx_game_masks_dev / crx_game_commit_dev / crx_game_log_dev (round 3: the bookkeeping of the batched
+    racing-game loop in four small kernels) against the element-wise torch formulation they replace (GameLaps.step_torch,
+    LmpcLaps.step(torch_glue=True)): same assignments in the same order, so the two loops must agree BIT FOR BIT -- states, inputs,
+    direction flags, safe sets, lap logs -- over a lap and a half, lap hand-over and both branches included; with and without the
+    plant's process noise (same seed, same draws)."""
+    import torch
+
+    import helpers
+    import scenarios
+    from crx import montecarlo
+
+    A, B = AB
+    g = golden_racing_game
+    track = _track(1.0)
+    opt = scenarios.table("optimal_traj", "xcurv_l_shape")
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    Bn, steps = 96, 260
+    rng = np.random.default_rng(33)
+    s0 = 3.0 + rng.integers(0, 15, (Bn, 3)).astype(float); v = 0.1 * rng.integers(0, 11, (Bn, 3)); ey = 0.7 - 0.1 * rng.integers(0, 15, (Bn, 3))
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    x0[:, 0] += rng.uniform(-0.03, 0.03, Bn); xg0[:, 0] = x0[:, 0]
+    tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
+
+    def make(seed):
+        return montecarlo.GameLaps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
+                                   np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(lin_points), tile(lin_input), s0, v, ey, noise_seed=seed)
+
+    for seed in (None, 5):
+        a, b = make(seed), make(seed)
+        n_ot = 0
+        for k in range(steps):
+            a.step(); b.step_torch()
+            n_ot += int(b.overtake.sum())
+            if k % 20 == 19 or k == steps - 1:
+                for name in ("xc", "xg", "u_old", "step_no", "laps", "n_log", "it", "time_ss"):
+                    assert torch.equal(getattr(a.lm, name), getattr(b.lm, name)), (seed, k, name)
+                assert torch.equal(a.u, b.u) and torch.equal(a.old_flag, b.old_flag) and torch.equal(a.overtake.bool(), b.overtake), (seed, k)
+                assert torch.equal(a.lin_points, b.lin_points) and torch.equal(a.lin_input, b.lin_input), (seed, k)
+        assert torch.equal(a.lm.ss, b.lm.ss) and torch.equal(a.lm.us, b.lm.us) and torch.equal(a.lm.qf, b.lm.qf)
+        assert torch.equal(a.lm.log_x, b.lm.log_x) and torch.equal(a.lm.log_u, b.lm.log_u)
+        assert int((a.lm.laps >= 1).sum()) >= Bn // 2 and 0.1 <= n_ot / (Bn * steps) <= 0.9      # laps were handed over, both branches ran
+        assert int(a.overflow_seen.sum()) == 0                                                   # three cars, three slots
+    # the learning-MPC laps alone
+    def lm(seed):
+        return montecarlo.LmpcLaps(track.point_and_tangent, track.lap_length, track.width, tile(ss), tile(us), tile(qf), tile(time_ss),
+                                   np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(lin_points), tile(lin_input), noise_seed=seed)
+    for seed in (None, 7):
+        a, b = lm(seed), lm(seed)
+        for k in range(200):
+            a.step(); b.step(torch_glue=True)
+        for name in ("xc", "xg", "u_old", "u", "step_no", "laps", "n_log", "it", "time_ss", "ss", "us", "qf", "log_x", "log_u"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (seed, name)
+        assert int((a.laps >= 1).sum()) >= Bn // 2
