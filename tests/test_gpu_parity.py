@@ -1239,3 +1239,36 @@ def test_allgather_winners_c_abi_one_rank(gpu):
         cdist.COLLECTIVE, cdist.FORCE_COLLECTIVE = "torch", False
         cdist.CrxComm.destroy()
     assert L.crx_comm_world() == 0
+
+
+@pytest.mark.parametrize("T", ["default", "tight"])
+def test_unequal_obstacle_sizes(gpu, orc, AB, T):
+    """crx_cbf_solve_dims: obstacle vehicles of different sizes (control.py:529-535 reads every obstacle's own CarParam) -- libcrx
+    against the certified KKT points of the problems the reference built for two cars of random dimensions (tests/golden/cfg2_dims.npz)
+    and against the oracle; the device entry point with per-problem dims equals the host one."""
+    import torch
+
+    import test_draw_fixtures as tdf
+    from crx import abi, torch_api
+
+    Tt = tdf.DEFAULT if T == "default" else tdf.TIGHT
+    rg = tdf._dims_compare(gpu, orc, AB, Tt)
+    A, B = AB
+    g, p = tdf.dims_batch()
+    d = abi.cbf_desc(12, 2, A, B, alpha=0.8, margin=0.2)
+    d.opts.tol = Tt["tol"]
+    ro = orc.cbf_solve(d, *[p[k] for k in tdf.KEYS], obs_dims=p["obs_dims"])
+    d.opts.restore_iters = -1
+    g0 = gpu.cbf_solve(d, *[p[k] for k in tdf.KEYS], obs_dims=p["obs_dims"])
+    o0 = orc.cbf_solve(d, *[p[k] for k in tdf.KEYS], obs_dims=p["obs_dims"])
+    _assert_same_verdicts("unequal cars, no restoration", g0, o0, tol=Tt["tol"], max_tight_stall=2)
+    touched = frozenset(np.nonzero((g0["status"] != rg["status"]) | (g0["iters"] != rg["iters"]) | (o0["status"] != ro["status"]) | (o0["iters"] != ro["iters"]))[0].tolist())
+    _assert_same_verdicts("unequal cars", rg, ro, tol=Tt["tol"], restored=touched, max_restored_verdict=2, max_tight_stall=2)
+    # device entry point
+    d.opts.restore_iters = 25
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)   # noqa: E731
+    ws = torch_api.cbf_solve_dev(d, t(p["x0"]), t(p["xt"]), t(p["obs_s"]), t(p["obs_ey"]), t(p["lap_off"]), t(p["n_obs"], torch.int32), obs_dims=t(p["obs_dims"]))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ws.X.cpu().numpy(), rg["X"])
+    np.testing.assert_array_equal(ws.status.cpu().numpy(), rg["status"])
