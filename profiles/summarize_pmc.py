@@ -32,11 +32,11 @@ def main():
     fixed_kib = cal["big_write/FETCH_SIZE"]["counter_kib"]   # FETCH_SIZE of a launch that reads nothing: kernarg + code of a tiny kernel
     lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only), bench.py --workload <wl>",
              "# counter unit KiB.  Calibration on a known byte count in this kernel's access pattern (one wave per record, 8 B per lane;",
-             "# profiles/%s_pmc_calibration.txt): FETCH_SIZE x 1024 x %.3f = bytes read, WRITE_SIZE x 1024 x %.3f = bytes written." % (PRE, f_read, f_write),
+             "# profiles/r02_pmc_calibration.txt): FETCH_SIZE x 1024 x %.3f = bytes read, WRITE_SIZE x 1024 x %.3f = bytes written." % (f_read, f_write),
              "# The algorithmic bytes are the per-problem inputs / outputs of SURVEY.md section 8d; everything fetched beyond them is",
              "# instruction fetch (the solver kernel is ~150-300 KB of code, fetched once per XCD L2) and partial cache lines."]
     js = {"note": "HBM bytes per full-batch launch of the solver kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on a known "
-                  "byte count in the kernel's own access pattern (profiles/%s_pmc_calibration.txt): traffic_bytes = FETCH*1024*%.3f + WRITE*1024*%.3f" % (PRE, f_read, f_write)}
+                  XX}
     for wl, (frag, n, b_in, b_out) in WL.items():
         v = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
