@@ -36,7 +36,7 @@ def main():
              "# The algorithmic bytes are the per-problem inputs / outputs of SURVEY.md section 8d; everything fetched beyond them is",
              "# instruction fetch (the solver kernel is ~150-300 KB of code, fetched once per XCD L2) and partial cache lines."]
     js = {"note": "HBM bytes per full-batch launch of the solver kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on a known "
-                  XX}
+                  "byte count in the kernel's own access pattern (profiles/r02_pmc_calibration.txt): traffic_bytes = FETCH*1024*%.3f + WRITE*1024*%.3f" % (f_read, f_write)}
     for wl, (frag, n, b_in, b_out) in WL.items():
         v = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
