@@ -326,6 +326,9 @@ class GameLaps:
         self.m_ot, self.m_lm = torch.zeros((Bn,), **i32), torch.zeros((Bn,), **i32)
         self.pred_s, self.pred_e = torch.zeros((Bn, VA, N_plan + 1), **f64), torch.zeros((Bn, VA, N_plan + 1), **f64)
         self.overflow_seen = torch.zeros((Bn,), **i32)    # scene overflow (more vehicles of interest than slots), accumulated
+        # the two branches of a step are independent until the commit: their kernels go to two HIP streams and overlap (the
+        # masked launches of a branch leave part of the chip idle: a third of the races plan and track, the rest regress and solve)
+        self.s_ot, self.s_lm = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         self.t = 0.0
 
     def step(self):
@@ -336,7 +339,7 @@ class GameLaps:
         torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, self.pred_s, self.pred_e, ws=self.sws)
         torch_api.game_masks_dev(self.sws.n_veh, self.m_ot, self.m_lm, overflow=self.sws.overflow, overflow_seen=self.overflow_seen)
         self.overtake = self.m_ot                                  # int32 mask; bool(overtake[b]) = race b is in the overtake branch
-        self._branches(self.m_ot, self.m_lm)
+        self._branches(self.m_ot, self.m_lm, overlap=True)
         torch_api.game_commit_dev(N, self.Np, self.m_ot, self.tws.U, lm.ws.X, lm.ws.U, self.selws.flag, self.u, lm.u_old, lm.u_prev,
                                   self.lin_points, self.lin_input, lm.step_no, lm.addpoint_step, self.old_flag)
         torch_api.lmpc_addpoint_dev(lm.pdesc, lm.ss, lm.us, lm.time_ss, lm.it, lm.addpoint_step, lm.xc, self.u, 2)
@@ -346,10 +349,23 @@ class GameLaps:
         self.t += lm.timestep
         lm.log_and_handover(self.u)
 
-    def _branches(self, m_ot, m_lm):
-        """The solver launches of both branches (masked: every race runs its own branch's kernels only)."""
+    def _branches(self, m_ot, m_lm, overlap=False):
+        """The solver launches of both branches (masked: every race runs its own branch's kernels only); overlap: each branch
+        on its own stream, forked from and joined to the current one."""
+        if overlap:
+            cur = torch.cuda.current_stream(self.lm.xc.device)
+            self.s_ot.wait_stream(cur); self.s_lm.wait_stream(cur)
+            with torch.cuda.stream(self.s_ot):
+                self._branch_overtake(m_ot)
+            with torch.cuda.stream(self.s_lm):
+                self._branch_lmpc(m_lm)
+            cur.wait_stream(self.s_ot); cur.wait_stream(self.s_lm)
+        else:
+            self._branch_overtake(m_ot)
+            self._branch_lmpc(m_lm)
+
+    def _branch_overtake(self, m_ot):
         lm, L = self.lm, self.L
-        # ---- overtake branch
         torch_api.planner_prep_dev(self.prep, lm.xc, lm.xc, self.sws.n_veh, self.sws.veh_info, self.sws.max_dv, self.sws.obs_s, self.sws.obs_ey,
                                    self.opt_s, self.opt_ey, ws=self.pws)
         torch_api.planner_plan_dev(self.plan, self.sel, self.pws.x0, self.pws.bez_s, self.pws.bez_ey, self.pws.ey_lb, self.pws.ey_ub,
@@ -357,7 +373,9 @@ class GameLaps:
         torch_api.track_prep_dev(self.Np, self.V, L, lm.xc, self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.selws.best_X, self.xt,
                                  self.obs_s, self.obs_e, self.lap_off, self.n_obs)
         torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws, active=m_ot)
-        # ---- learning-MPC branch
+
+    def _branch_lmpc(self, m_lm):
+        lm = self.lm
         torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws,
                                 active=m_lm)
         torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws, active=m_lm)

@@ -556,30 +556,29 @@ __global__ void __launch_bounds__(256) crx_game_masks_kernel(const crx_game_kpar
 // by one stage with the last one repeated: control.py:726-728 / utils/base.py:504-515), the step counter of add_point and the
 // direction flag (utils/base.py:546-551) -- each from the branch the race is in; the other branch's state is left alone
 __global__ void __launch_bounds__(256) crx_game_commit_kernel(const crx_game_kparams gp) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= gp.batch) return;
-    const int N = gp.N;
+    // one thread per (race, element of the plan hand-over): E = 6 (N + 1) + 2 N elements; thread 0 of a race also does its scalars
+    const int N = gp.N, EX = 6 * (N + 1), E = EX + 2 * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)gp.batch * E) return;
+    const int b = (int)(i / E), e = (int)(i - (size_t)b * E);
     const bool ot = gp.overtake && gp.overtake[b] != 0;
     const double* Ul = gp.U_lmpc + (size_t)b * N * 2;
     const double* Xl = gp.X_lmpc + (size_t)b * (N + 1) * 6;
-    const double u0 = ot ? gp.U_track[(size_t)b * gp.Np * 2] : Ul[0], u1 = ot ? gp.U_track[(size_t)b * gp.Np * 2 + 1] : Ul[1];
-    gp.u[2 * b] = u0; gp.u[2 * b + 1] = u1;
-    gp.u_prev[2 * b] = gp.u_old[2 * b]; gp.u_prev[2 * b + 1] = gp.u_old[2 * b + 1];
-    gp.addpoint_step[b] = ot ? -(1 << 20) : gp.step_no[b];
-    if (gp.old_flag) gp.old_flag[b] = ot ? gp.flag[b] : -1;
-    if (!ot) {
-        gp.u_old[2 * b] = Ul[0]; gp.u_old[2 * b + 1] = Ul[1];
-        double* lp = gp.lin_points + (size_t)b * (N + 1) * 6;
-        double* li = gp.lin_input + (size_t)b * N * 2;
-        for (int k = 0; k <= N; k++) {
-            const int ks = k < N ? k + 1 : N;
-            for (int c = 0; c < 6; c++) lp[6 * k + c] = Xl[6 * ks + c];
-        }
-        for (int k = 0; k < N; k++) {
-            const int ks = k < N - 1 ? k + 1 : N - 1;
-            li[2 * k] = Ul[2 * ks]; li[2 * k + 1] = Ul[2 * ks + 1];
-        }
-        gp.step_no[b] += 1;
+    if (e == 0) {
+        const double u0 = ot ? gp.U_track[(size_t)b * gp.Np * 2] : Ul[0], u1 = ot ? gp.U_track[(size_t)b * gp.Np * 2 + 1] : Ul[1];
+        gp.u[2 * b] = u0; gp.u[2 * b + 1] = u1;
+        gp.u_prev[2 * b] = gp.u_old[2 * b]; gp.u_prev[2 * b + 1] = gp.u_old[2 * b + 1];
+        gp.addpoint_step[b] = ot ? -(1 << 20) : gp.step_no[b];
+        if (gp.old_flag) gp.old_flag[b] = ot ? gp.flag[b] : -1;
+        if (!ot) { gp.u_old[2 * b] = Ul[0]; gp.u_old[2 * b + 1] = Ul[1]; gp.step_no[b] += 1; }
+    }
+    if (ot) return;
+    if (e < EX) {                       // lin_points[k] <- X[k + 1], the last stage repeated
+        const int k = e / 6, c = e - 6 * k, ks = k < N ? k + 1 : N;
+        gp.lin_points[(size_t)b * EX + e] = Xl[6 * ks + c];
+    } else {                            // lin_input[k] <- U[k + 1], the last stage repeated
+        const int q = e - EX, k = q >> 1, c = q & 1, ks = k < N - 1 ? k + 1 : N - 1;
+        gp.lin_input[(size_t)b * 2 * N + q] = Ul[2 * ks + c];
     }
 }
 
@@ -606,9 +605,9 @@ __global__ void __launch_bounds__(256) crx_game_log_kernel(const crx_game_kparam
 
 hipError_t crx_launch_game(int which, const crx_game_kparams& gp, hipStream_t st) {
     if (gp.batch == 0) return hipSuccess;
-    const int n = which == 0 ? gp.batch * gp.n_cars : gp.batch;
+    const long long n = which == 0 ? (long long)gp.batch * gp.n_cars : (which == 2 ? (long long)gp.batch * (8 * gp.N + 6) : gp.batch);
     if (n == 0) return hipSuccess;
-    const dim3 grid((n + 255) / 256), block(256);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     switch (which) {
         case 0: hipLaunchKernelGGL(crx_game_traffic_kernel, grid, block, 0, st, gp); break;
         case 1: hipLaunchKernelGGL(crx_game_masks_kernel, grid, block, 0, st, gp); break;

@@ -472,7 +472,7 @@ static void ipm_solve(work_t* w, result_t* res) {
     for (int j = 0; j < m; j++) {
         /* slack start: inside the bound by at least slack_push, and for a violated row as large
          * as the violation so that the first fraction-to-the-boundary step is O(1/2), not O(push) */
-        w->t[j] = fmax(fabs(w->c[j]), o->slack_push);
+        w->t[j] = g_knob[7] != 0.0 ? fmax(w->c[j], o->slack_push * g_knob[7]) : fmax(fabs(w->c[j]), o->slack_push);
         w->nu[j] = 1.0;
         /* simple-bound rows: start the multiplier at the cost gradient that pushes against the
          * bound (dual-feasible start for the 1e4-weighted CBF slacks; IPOPT starts all at 1) */
