@@ -44,14 +44,14 @@ METRIC = "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency"
 
 
 def kernel_source_hash():
-    """sha256 over the sources libcrx is built from: guards numbers kept under profiles/ against a stale kernel."""
-    import glob
+    """sha256 over the sources the SOLVER kernel is built from (crx_kernels.hip, crx_wave.h, the Makefile's flags): guards the
+    rocprofv3 numbers kept under profiles/ (HBM traffic of crx_solve_kernel) against a kernel that changed since."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "car-racing_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ("crx_kernels.hip", "crx_wave.h", "Makefile"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -7,7 +7,7 @@ mkdir -p $O $R/gpurun_out/pmc3 $R/gpurun_out/prof3
 make -C oracle -s
 ( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -v "^  File\|^Extension\|^$" | tail -25 ) > $O/pytest_gpu.log
 grep -h "passed\|failed" $O/pytest_gpu.log | tail -2
-python -c "import bench; print(bench.kernel_source_hash())" > $R/gpurun_out/pmc3/source_hash.txt
+python -c "import bench; print(bench.kernel_source_hash())" > $R/gpurun_out/pmc3/source_hash.txt   # sha over crx_kernels.hip, crx_wave.h, Makefile
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python - <<PY
 import json
