@@ -44,8 +44,10 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 120 /* 0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev
-                          (0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
+#define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
+                          crx_comm_* / crx_allgather_winners_dev (RCCL); additions only, every 0.1.2 entry point unchanged
+                          (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
+                           0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
 #define CRX_NX 6
 #define CRX_NU 2
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
@@ -604,7 +606,9 @@ int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag
                               double* recv, void* stream);
 
 /* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
- * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this. */
+ * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this.
+ * PROCESS-GLOBAL and unsynchronised (one switch, one pair of events): a measurement aid for one stream at a time -- two
+ * threads or streams timing concurrently overwrite each other's events.  Leave it off outside measurements. */
 void crx_set_timing(int enable);
 double crx_last_kernel_ms(void);
 
