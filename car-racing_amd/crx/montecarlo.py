@@ -251,7 +251,8 @@ class LmpcLaps:
 def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, steps,
               N=12, timestep=0.1, device=None, noise_seed=None):
     """Run `steps` control steps of B learning-MPC laps; returns host logs xcurv [steps+1, B, 6], u [steps, B, 2], status [steps, B]
-    (QP status), prep_status [steps, B] (singular regression), laps [B]."""
+    (QP status), prep_status [steps, B] (singular regression: the stage keeps its previous / zero model rows), laps [B],
+    traj_status [B] (lap hand-over: 1 = safe-set storage full)."""
     r = LmpcLaps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_ss, it, xcurv0, xglob0, lin_points, lin_input, N=N,
                  timestep=timestep, device=device, noise_seed=noise_seed)
     log_x, log_u, log_st, log_ps = [r.xc.clone()], [], [], []
@@ -262,7 +263,8 @@ def lmpc_laps(track_table, lap_length, track_width, ss_xcurv, u_ss, qfun, time_s
         log_st.append(r.ws.status.clone())
         log_ps.append(r.pws.status.clone())
     return dict(xcurv=torch.stack(log_x).cpu().numpy(), u=torch.stack(log_u).cpu().numpy(), status=torch.stack(log_st).cpu().numpy(),
-                prep_status=torch.stack(log_ps).cpu().numpy(), laps=r.laps.cpu().numpy())
+                prep_status=torch.stack(log_ps).cpu().numpy(), laps=r.laps.cpu().numpy(),
+                traj_status=r.traj_status.cpu().numpy())   # 1: the race's n_laps of safe-set storage were full at its last hand-over
 
 
 class GameLaps:
@@ -426,4 +428,5 @@ def game_laps(track_table, lap_length, track_width, A, B, opt_xcurv, ss_xcurv, u
         r.step()
         lx.append(r.lm.xc.clone()); lu.append(r.u.clone()); lo.append(r.overtake.clone().bool()); lf.append(r.old_flag.clone())
     return dict(xcurv=torch.stack(lx).cpu().numpy(), u=torch.stack(lu).cpu().numpy(), overtake=torch.stack(lo).cpu().numpy(),
-                flag=torch.stack(lf).cpu().numpy(), cars_s=torch.stack(lc).cpu().numpy(), laps=r.lm.laps.cpu().numpy())
+                flag=torch.stack(lf).cpu().numpy(), cars_s=torch.stack(lc).cpu().numpy(), laps=r.lm.laps.cpu().numpy(),
+                traj_status=r.lm.traj_status.cpu().numpy(), scene_overflow=r.overflow_seen.cpu().numpy())
