@@ -389,7 +389,9 @@ static int thread_ws(work_t** w, ocp_t** p) {
 static int g_verbose = 0;
 void crx_oracle_set_verbose(int v) { g_verbose = v; }
 /* experiment knobs (tools/tail_knobs.py): 0 JAM_ALPHA, 1 JAM_COUNT, 2 STALL_ITERS, 3 CRAWL_ALPHA, 4 CRAWL_COUNT (0 = off),
- * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off) */
+ * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
+ * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1).  Defaults = the shipped algorithm;
+ * the kernel has no such knobs. */
 static double g_knob[8] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0};
 void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 8) g_knob[i] = v; }
 
@@ -494,6 +496,13 @@ static void ipm_solve(work_t* w, result_t* res) {
     int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
     int crawl = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
+    if (g_knob[6] >= 0.0 && o->restore_iters >= 0) {   /* experiment: slacks first -- restore before the first iteration when a
+                                                          CBF row of a stage <= knob is violated at the start point */
+        int viol = 0;
+        for (int j = 0; j < m; j++)
+            if (w->row[j].kind == ROW_CBF && w->row[j].k <= (int)g_knob[6] && w->c[j] < 0.0) viol = 1;
+        if (viol && restore_slacks(w, o->mu_init)) { n_restore = 1; it_limit = 1 + o->restore_iters; first = 1; }
+    }
     for (it = 0;; it++) {
         /* residuals */
         double nus = 0.0;
