@@ -48,5 +48,6 @@ print("""Reading.  A single-wave workgroup owns a SIMD's issue slot once every f
 (<1,12>) instructions = 60 k / 40 k clocks of pure issue, which is 70..90 % of the iteration time of a lone wave (89.7 k / 41 k clocks,
 profiles/r02_phase_cycles.txt).  They are bound by the INSTRUCTION COUNT, not by latency, LDS or the instruction cache (hit rate
 99.98 %).  With 3 -> 4 such waves per CU (slim layout) every wave still has its own SIMD, but the LDS pipe is shared: the time parked
-on s_waitcnt grows from 26 % to 28 % of a longer residency and the launch is no faster (25.1 ms -> 24.9 ms) although 33 % more
-problems are in flight.  The planner instantiation (3 waves per SIMD) interleaves waves on a SIMD and is bound by the VALU pipe.""")
+on s_waitcnt grows from 26 % to 28 % of a longer residency and the launch gains 10 % (27.3 ms -> 24.75 ms, same draw and session:
+tools/gpu_round3_f.sh) although 33 % more problems are in flight.  (The slim-layout pass above was taken on the build that also
+recomputed the lane maps in <3,20> -- 18.2 k instructions per iteration; the shipped build keeps them hoisted there.)  The planner instantiation (3 waves per SIMD) interleaves waves on a SIMD and is bound by the VALU pipe.""")
