@@ -29,6 +29,12 @@ import subprocess
 import sys
 import time
 
+# The HIP runtime multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
+# queue serialise.  The closed-loop workloads use up to six streams (two sub-batches, each with its two branch streams): with 4
+# queues their overlap is partly lost (overtake 3.97 ms per step), with 8 it is there (3.25 ms; tools/gpu_round3_i.sh).  Must be set
+# before the runtime initialises; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "car-racing_amd")):
     if _p not in sys.path:
@@ -110,6 +116,29 @@ class Workload:
 
     def solve(self):
         raise NotImplementedError
+
+
+class CatWs:
+    """status / iters / kkt of K concurrent sub-batches as one (crx.montecarlo.Concurrent)."""
+
+    def __init__(self, conc, get):
+        self.conc, self.get = conc, get
+
+    status = property(lambda self: self.conc.cat(lambda p: self.get(p).status))
+    iters = property(lambda self: self.conc.cat(lambda p: self.get(p).iters))
+    kkt = property(lambda self: self.conc.cat(lambda p: self.get(p).kkt))
+
+
+def sub_batches(n, k):
+    """k contiguous slices of range(n), sizes differing by at most one."""
+    k = max(1, min(int(k), n))
+    base, rem = divmod(n, k)
+    out, lo = [], 0
+    for i in range(k):
+        hi = lo + base + (1 if i < rem else 0)
+        out.append(slice(lo, hi))
+        lo = hi
+    return out
 
 
 def make_cbf(cx, key, args, batch=None, filtered=False):
@@ -281,16 +310,19 @@ def make_races(cx, args, batch=None):
     rng = np.random.default_rng(50 + cx.rank)
     s0 = np.sort(rng.uniform(3.0, 17.0, (w.batch, 2)), axis=1)
     s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
-    races = montecarlo.MpccbfRaces(track.point_and_tangent, track.lap_length, track.width, A, B, np.zeros((w.batch, 6)),
-                                   np.zeros((w.batch, 6)), s0, rng.uniform(0.1, 0.4, (w.batch, 2)),
-                                   rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (w.batch, 2)), vt=0.8, N=10, device=cx.dev)
+    cv, ce = rng.uniform(0.1, 0.4, (w.batch, 2)), rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (w.batch, 2))
+    parts = [montecarlo.MpccbfRaces(track.point_and_tangent, track.lap_length, track.width, A, B, np.zeros((sl.stop - sl.start, 6)),
+                                    np.zeros((sl.stop - sl.start, 6)), s0[sl], cv[sl], ce[sl], vt=0.8, N=10, device=cx.dev)
+             for sl in sub_batches(w.batch, args.race_streams)]
+    conc = montecarlo.Concurrent(parts, cx.dev)
     from crx import torch_api
-    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "races", "cbf", 10, 2, races.desc, races.ws
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "races", "cbf", 10, 2, parts[0].desc, CatWs(conc, lambda p: p.ws)
     w.kernel = "crx_solve_kernel<2>"
-    w.step = races.step
-    w.solve = lambda: torch_api.cbf_solve_dev(races.desc, races.xc_next, races.xt, races.obs_s, races.obs_e, races.lap_off, races.n_obs, ws=races.ws)
+    w.step = conc.step
+    w.solve_parts = [(lambda r=r: torch_api.cbf_solve_dev(r.desc, r.xc_next, r.xt, r.obs_s, r.obs_e, r.lap_off, r.n_obs, ws=r.ws)) for r in parts]
     w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
-              "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant)" % w.batch)
+              "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant); %d sub-batches on %d HIP streams" % (w.batch, len(parts), len(parts)))
+    w.extra = {"race_streams": len(parts)}
     return w
 
 
@@ -309,19 +341,25 @@ def make_game(cx, args, batch=None):
     rng = np.random.default_rng(60 + cx.rank)
     x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
     x0[:, 0] += rng.uniform(-0.03, 0.03, Bn); x0[:, 5] += rng.uniform(-0.05, 0.05, Bn); xg0[:, 0] = x0[:, 0]
-    laps = montecarlo.LmpcLaps(track.point_and_tangent, track.lap_length, track.width, np.tile(ss[None], (Bn, 1, 1, 1)),
-                               np.tile(us[None], (Bn, 1, 1, 1)), np.tile(qf[None], (Bn, 1, 1)), np.tile(time_ss[None], (Bn, 1)),
-                               np.full(Bn, 2, dtype=np.int32), x0, xg0, np.tile(ss[0, 1:N + 2][None], (Bn, 1, 1)),
-                               np.tile(us[0, 1:N + 1][None], (Bn, 1, 1)), N=N, device=cx.dev)
+    def part(sl):
+        n = sl.stop - sl.start
+        return montecarlo.LmpcLaps(track.point_and_tangent, track.lap_length, track.width, np.tile(ss[None], (n, 1, 1, 1)),
+                                   np.tile(us[None], (n, 1, 1, 1)), np.tile(qf[None], (n, 1, 1)), np.tile(time_ss[None], (n, 1)),
+                                   np.full(n, 2, dtype=np.int32), x0[sl], xg0[sl], np.tile(ss[0, 1:N + 2][None], (n, 1, 1)),
+                                   np.tile(us[0, 1:N + 1][None], (n, 1, 1)), N=N, device=cx.dev)
+
+    parts = [part(sl) for sl in sub_batches(Bn, args.race_streams)]
+    conc = montecarlo.Concurrent(parts, cx.dev)
     from crx import torch_api
-    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "game", "lmpc", N, laps.desc.n_ss_max, laps.desc, laps.ws
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "game", "lmpc", N, parts[0].desc.n_ss_max, parts[0].desc, CatWs(conc, lambda p: p.ws)
     w.kernel = "crx_lmpc_kernel"
-    w.step = laps.step
-    w.solve = lambda: torch_api.lmpc_solve_dev(laps.desc, laps.xc_next, laps.u_prev, laps.pws.A, laps.pws.B, laps.pws.C, laps.pws.ss, laps.pws.qfun,
-                                               laps.n_ss, ws=laps.ws)
+    w.step = conc.step
+    w.solve_parts = [(lambda l=l: torch_api.lmpc_solve_dev(l.desc, l.xc_next, l.u_prev, l.pws.A, l.pws.B, l.pws.C, l.pws.ss, l.pws.qfun, l.n_ss, ws=l.ws))
+                     for l in parts]
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
-    w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full"}
+    w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full",
+               "race_streams": len(parts)}
     return w
 
 
@@ -344,22 +382,28 @@ def make_overtake(cx, args, batch=None):
     x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
     s0, v, ey = synth.multi_tests_traffic(Bn, 3, seed=70 + cx.rank)      # the reference's own random traffic (--multi-tests), 3 cars
     tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
-    laps = montecarlo.GameLaps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
-                               np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey, device=cx.dev)
+    def part(sl):
+        n = sl.stop - sl.start
+        tl = lambda a: np.tile(a[None], (n,) + (1,) * a.ndim)   # noqa: E731
+        return montecarlo.GameLaps(track.point_and_tangent, track.lap_length, track.width, A, B, opt, tl(ss), tl(us), tl(qf), tl(time_ss),
+                                   np.full(n, 2, dtype=np.int32), x0[sl], xg0[sl], tl(ss[0, 1:N + 2]), tl(us[0, 1:N + 1]), s0[sl], v[sl], ey[sl], device=cx.dev)
+
+    parts = [part(sl) for sl in sub_batches(Bn, args.race_streams)]
+    conc = montecarlo.Concurrent(parts, cx.dev)
     from crx import torch_api
-    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 3, laps.track_desc, laps.tws
+    w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "overtake", "cbf_tracking", 10, 3, parts[0].track_desc, CatWs(conc, lambda p: p.tws)
     w.kernel = "crx_solve_kernel<3>"
-    w.step = laps.step
+    w.step = conc.step
     # the tracking-NLP launch of the last step(): the state it was built for (the plant swapped xc / xc_next since) and its mask
-    w.solve = lambda: torch_api.cbf_solve_dev(laps.track_desc, laps.lm.xc_next, laps.xt, laps.obs_s, laps.obs_e, laps.lap_off, laps.n_obs, ws=laps.tws,
-                                              active=laps.overtake.to(torch.int32))
+    w.solve_parts = [(lambda g=g: torch_api.cbf_solve_dev(g.track_desc, g.lm.xc_next, g.xt, g.obs_s, g.obs_e, g.lap_off, g.n_obs, ws=g.tws,
+                                                          active=g.overtake.to(torch.int32))) for g in parts]
     w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against three "
               "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
               "selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
-    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch"}
+    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch", "race_streams": len(parts)}
     # the scene stage keeps at most CRX_MAX_OBS vehicles of interest per race (the nearest): how often were there more?
-    w.post = lambda: {"scene_overflow_races": int((laps.overflow_seen > 0).sum().item())}
+    w.post = lambda: {"scene_overflow_races": int(sum((g.overflow_seen > 0).sum().item() for g in parts))}
     return w
 
 
@@ -424,8 +468,15 @@ def measure(cx, w, steps, warmup, with_latency=True):
     else:
         L.crx_set_timing(1)
         for _ in range(min(50, max(5, steps))):
-            w.solve()
-            kms.append(L.crx_last_kernel_ms())
+            if getattr(w, "solve_parts", None):     # concurrent sub-batches: the launches of one step, timed one after the other
+                t_ms = 0.0
+                for f in w.solve_parts:
+                    f()
+                    t_ms += L.crx_last_kernel_ms()
+                kms.append(t_ms)
+            else:
+                w.solve()
+                kms.append(L.crx_last_kernel_ms())
         L.crx_set_timing(0)
     k_ms = float(np.mean(kms))
     conv = st == 0
@@ -598,6 +649,8 @@ def main():
     ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
+    ap.add_argument("--race-streams", type=int, default=2,
+                    help="closed-loop workloads (races, game, overtake): independent sub-batches of the races on this many HIP streams (1 = one batch)")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")

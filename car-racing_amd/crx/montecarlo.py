@@ -36,6 +36,44 @@ class _Noise:
         return torch.randn((batch, 3), generator=self.gen, dtype=torch.float64, device=self.device)
 
 
+class Concurrent:
+    """K independent sub-batches of races stepping on K HIP streams.  Races do not interact, so a batch can be cut anywhere; what
+    the cut buys is OVERLAP: the streams free-run (no join per step), a sub-batch's plant (100 serial Euler sub-steps per vehicle:
+    ~0.2 ms on 64 wavefronts, 6 % of the chip) and the straggler tail of its solver launch run while the next sub-batch's solver
+    launch occupies the other CUs.  Every race computes exactly what it computes in one big batch (bit-identical).  `parts` are
+    MpccbfRaces / LmpcLaps / GameLaps objects over disjoint slices of the races; step() issues one control step of every part and
+    returns without waiting; call torch.cuda.synchronize() (or sync()) before reading results.
+    Streams only overlap when they sit on different HARDWARE queues: the HIP runtime multiplexes a process's streams onto
+    GPU_MAX_HW_QUEUES of them (default 4) and streams sharing one serialise.  Two sub-batches of GameLaps are six streams: set
+    GPU_MAX_HW_QUEUES=8 in the environment before the runtime initialises (bench.py does).  Measured, 4096 races per step
+    (tools/gpu_round3_i.sh): races 0.784 -> 0.687 ms, learning-MPC laps 3.82 -> 3.31 ms, racing game 3.56 -> 3.25 ms with two
+    sub-batches and 8 queues; with 4 queues the racing game LOSES (3.97 ms: its two branch streams collide)."""
+
+    def __init__(self, parts, device=None):
+        self.parts = list(parts)
+        dev = torch.device(device if device is not None else "cuda")
+        self.device = dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.parts]
+        cur = torch.cuda.current_stream(dev)
+        for st in self.streams:            # whatever set the parts up on the caller's stream comes first
+            st.wait_stream(cur)
+
+    def step(self):
+        for part, st in zip(self.parts, self.streams):
+            with torch.cuda.stream(st):
+                part.step()
+
+    def sync(self):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def cat(self, get):
+        """Concatenate a per-race tensor of every part (after sync()): get(part) -> tensor [B_part, ...]."""
+        self.sync()
+        return torch.cat([get(p) for p in self.parts], dim=0)
+
+
 class MpccbfRaces:
     """State of B races on the device; step() advances all of them by one control step."""
 

@@ -520,3 +520,54 @@ def test_fused_game_bookkeeping_equals_torch_glue(AB, golden_racing_game):
         for name in ("xc", "xg", "u_old", "u", "step_no", "laps", "n_log", "it", "time_ss", "ss", "us", "qf", "log_x", "log_u"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (seed, name)
         assert int((a.laps >= 1).sum()) >= Bn // 2
+
+
+def test_concurrent_sub_batches_are_bit_identical(AB, golden_racing_game):
+    """crx.montecarlo.Concurrent: K independent sub-batches of races free-running on K HIP streams (what bench.py's closed-loop
+    workloads use to overlap one sub-batch's plant and solver tail with the next one's solver launch).  Races do not interact: every
+    race must compute exactly what it computes in one big batch -- MPC-CBF races and racing games with traffic (whose two branches
+    already sit on two streams of their own)."""
+    import torch
+
+    import helpers
+    import scenarios
+    from crx import montecarlo
+
+    A, B = AB
+    track = _track(1.0)
+    tab, L = track.point_and_tangent, track.lap_length
+    rng = np.random.default_rng(9)
+    m = 192
+    s0 = np.sort(rng.uniform(3.0, 17.0, (m, 2)), axis=1); s0[:, 1] = np.maximum(s0[:, 1], s0[:, 0] + 2.0)
+    v = rng.uniform(0.1, 0.4, (m, 2)); ey = rng.choice([-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], (m, 2))
+    z = np.zeros((m, 6))
+    whole = montecarlo.MpccbfRaces(tab, L, track.width, A, B, z, z, s0, v, ey, vt=0.8, N=10)
+    cuts = [slice(0, 64), slice(64, 150), slice(150, 192)]
+    conc = montecarlo.Concurrent([montecarlo.MpccbfRaces(tab, L, track.width, A, B, z[c], z[c], s0[c], v[c], ey[c], vt=0.8, N=10) for c in cuts])
+    for _ in range(120):
+        whole.step(); conc.step()
+    torch.cuda.synchronize()
+    assert torch.equal(conc.cat(lambda p: p.xc), whole.xc) and torch.equal(conc.cat(lambda p: p.laps), whole.laps)
+    assert torch.equal(conc.cat(lambda p: p.ws.iters), whole.ws.iters)
+    # racing game with traffic
+    g = golden_racing_game
+    opt = scenarios.table("optimal_traj", "xcurv_l_shape")
+    d, ss, us, qf, time_ss, lin_points, lin_input = helpers.lmpc_lap_setup(g, track)
+    Bn = 64
+    c0 = 3.0 + rng.integers(0, 15, (Bn, 3)).astype(float); cv = 0.1 * rng.integers(0, 11, (Bn, 3)); ce = 0.7 - 0.1 * rng.integers(0, 15, (Bn, 3))
+    x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
+    x0[:, 0] += rng.uniform(-0.03, 0.03, Bn); xg0[:, 0] = x0[:, 0]
+
+    def game(sl):
+        n = sl.stop - sl.start
+        tl = lambda a: np.tile(a[None], (n,) + (1,) * a.ndim)   # noqa: E731
+        return montecarlo.GameLaps(tab, L, track.width, A, B, opt, tl(ss), tl(us), tl(qf), tl(time_ss), np.full(n, 2, dtype=np.int32), x0[sl], xg0[sl],
+                                   tl(lin_points), tl(lin_input), c0[sl], cv[sl], ce[sl])
+
+    whole, conc = game(slice(0, Bn)), montecarlo.Concurrent([game(slice(0, 40)), game(slice(40, Bn))])
+    for _ in range(180):
+        whole.step(); conc.step()
+    torch.cuda.synchronize()
+    assert torch.equal(conc.cat(lambda p: p.lm.xc), whole.lm.xc) and torch.equal(conc.cat(lambda p: p.old_flag), whole.old_flag)
+    assert torch.equal(conc.cat(lambda p: p.lm.ss), whole.lm.ss) and torch.equal(conc.cat(lambda p: p.lm.laps), whole.lm.laps)
+    assert int((whole.lm.laps >= 1).sum()) >= Bn // 3

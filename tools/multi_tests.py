@@ -11,6 +11,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises: GameLaps' two branch streams need their own hardware queues
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "car-racing_amd")):
     sys.path.insert(0, p)
