@@ -164,7 +164,12 @@ def make_cbf(cx, key, args, batch=None, filtered=False):
     w.extra = {"scenario_filter": bool(filtered)}
     t_in = [cx.to_dev(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [cx.to_dev(p["n_obs"], torch.int32)]
     w.ws = torch_api.CbfWorkspace(w.desc, w.batch, cx.dev)
-    w.step = w.solve = lambda: torch_api.cbf_solve_dev(w.desc, *t_in, ws=w.ws)
+    # dispatch order (include/crx.h): computed inside the timed step, one more launch -- from the iteration counts of the previous
+    # step (what a receding-horizon loop has) or, with no previous solve, from the start barrier of every problem
+    obuf = torch.empty(w.batch, dtype=torch.int32, device=cx.dev)
+    order = {"index": lambda: None, "longest_first": lambda: torch_api.longest_first(w.ws.iters, out=obuf),
+             "start_barrier": lambda: torch_api.cbf_order_dev(w.desc, t_in[0], t_in[2], t_in[3], t_in[4], t_in[5], out=obuf)}[args.dispatch]
+    w.step = w.solve = lambda: torch_api.cbf_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
     keys = ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")
     w.cpu = ("cbf", w.desc, {k: p[k] for k in keys})
     if key.startswith("cfg2"):   # all-cores CPU figure: 4096 problems of the same generator and seed (the first 256 are the batch)
@@ -291,7 +296,9 @@ def make_lmpc(cx, args, batch=None):
     t_in = [cx.to_dev(p[k]) for k in keys] + [cx.to_dev(p["n_ss"], torch.int32)]
     w.ws = torch_api.LmpcWorkspace(w.desc, w.batch, cx.dev)
     w.kernel = "crx_lmpc_kernel"
-    w.step = w.solve = lambda: torch_api.lmpc_solve_dev(w.desc, *t_in, ws=w.ws)
+    obuf = torch.empty(w.batch, dtype=torch.int32, device=cx.dev)
+    order = (lambda: torch_api.longest_first(w.ws.iters, out=obuf)) if args.dispatch == "longest_first" else (lambda: None)
+    w.step = w.solve = lambda: torch_api.lmpc_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
     w.name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, w.batch)
     w.cpu = ("lmpc", w.desc, {k: p[k] for k in keys + ("n_ss",)})
     hb = crx.binding()
@@ -319,7 +326,10 @@ def make_races(cx, args, batch=None):
     w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "races", "cbf", 10, 2, parts[0].desc, CatWs(conc, lambda p: p.ws)
     w.kernel = "crx_solve_kernel<2>"
     w.step = conc.step
-    w.solve_parts = [(lambda r=r: torch_api.cbf_solve_dev(r.desc, r.xc_next, r.xt, r.obs_s, r.obs_e, r.lap_off, r.n_obs, ws=r.ws)) for r in parts]
+    for r in parts:
+        r.dispatch = args.dispatch
+    w.solve_parts = [(lambda r=r: torch_api.cbf_solve_dev(r.desc, r.xc_next, r.xt, r.obs_s, r.obs_e, r.lap_off, r.n_obs, ws=r.ws,
+                                                          order=montecarlo._order(r, r.ws.iters))) for r in parts]
     w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
               "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant); %d sub-batches on %d HIP streams" % (w.batch, len(parts), len(parts)))
     w.extra = {"race_streams": len(parts)}
@@ -354,8 +364,10 @@ def make_game(cx, args, batch=None):
     w.key, w.kind, w.N, w.n_obs, w.desc, w.ws = "game", "lmpc", N, parts[0].desc.n_ss_max, parts[0].desc, CatWs(conc, lambda p: p.ws)
     w.kernel = "crx_lmpc_kernel"
     w.step = conc.step
-    w.solve_parts = [(lambda l=l: torch_api.lmpc_solve_dev(l.desc, l.xc_next, l.u_prev, l.pws.A, l.pws.B, l.pws.C, l.pws.ss, l.pws.qfun, l.n_ss, ws=l.ws))
-                     for l in parts]
+    for l in parts:
+        l.dispatch = args.dispatch
+    w.solve_parts = [(lambda l=l: torch_api.lmpc_solve_dev(l.desc, l.xc_next, l.u_prev, l.pws.A, l.pws.B, l.pws.C, l.pws.ss, l.pws.qfun, l.n_ss, ws=l.ws,
+                                                           order=montecarlo._order(l, l.ws.iters))) for l in parts]
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
     w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full",
@@ -395,8 +407,11 @@ def make_overtake(cx, args, batch=None):
     w.kernel = "crx_solve_kernel<3>"
     w.step = conc.step
     # the tracking-NLP launch of the last step(): the state it was built for (the plant swapped xc / xc_next since) and its mask
+    for g in parts:
+        g.dispatch = args.dispatch
     w.solve_parts = [(lambda g=g: torch_api.cbf_solve_dev(g.track_desc, g.lm.xc_next, g.xt, g.obs_s, g.obs_e, g.lap_off, g.n_obs, ws=g.tws,
-                                                          active=g.overtake.to(torch.int32))) for g in parts]
+                                                          active=g.overtake.to(torch.int32), order=montecarlo._order(g, g.tws.iters, g.overtake)))
+                     for g in parts]
     w.name = ("racing game with traffic (tests/auto_racing_game_test.py lap 4 / overtake_planner_test.py --multi-tests): %d races per GPU against three "
               "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
               "selection, tracking NLP (N=10, CBF rows), "
@@ -651,6 +666,10 @@ def main():
                     help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
     ap.add_argument("--race-streams", type=int, default=2,
                     help="closed-loop workloads (races, game, overtake): independent sub-batches of the races on this many HIP streams (1 = one batch)")
+    ap.add_argument("--dispatch", default="index", choices=["index", "longest_first", "start_barrier"],
+                    help="workgroup -> problem mapping of the solver launches (crx_*_solve_ordered_dev): launch order; the problems whose "
+                         "previous solve took most iterations first (crx_order_longest_first_dev); cfg2 / cfg4 only: smallest start barrier "
+                         "first, no previous solve needed (crx_cbf_order_dev).  The order kernel is part of the timed step")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
@@ -688,6 +707,8 @@ def main():
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
             "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}
     head = make_plumbing_headline(cx) if args.plumbing_check else make[args.workload or "cfg2"]()
+    if head.kind != "planner" and not args.plumbing_check:   # the planner QPs are uniform (7..15 iterations): nothing to reorder
+        head.extra = dict(head.extra or {}, dispatch=args.dispatch)
     rec = measure(cx, head, args.steps, args.warmup, with_latency=not args.plumbing_check)
     out = {"metric": METRIC, "value": rec["value"], "value_converged": rec["value_converged"], "unit": "solves/s", "n_gpus": cx.world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],

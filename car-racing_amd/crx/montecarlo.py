@@ -36,6 +36,14 @@ class _Noise:
         return torch.randn((batch, 3), generator=self.gen, dtype=torch.float64, device=self.device)
 
 
+def _order(obj, iters, active=None):
+    """Dispatch order of the next solver launch (include/crx.h, "Dispatch order"): obj.dispatch = "longest_first" lists the races
+    whose previous solve took most iterations first (and the masked-out ones last); "index" (default) = launch order."""
+    if getattr(obj, "dispatch", "index") != "longest_first":
+        return None
+    return torch_api.longest_first(iters, active)
+
+
 class Concurrent:
     """K independent sub-batches of races stepping on K HIP streams.  Races do not interact, so a batch can be cut anywhere; what
     the cut buys is OVERLAP: the streams free-run (no join per step), a sub-batch's plant (100 serial Euler sub-steps per vehicle:
@@ -110,7 +118,8 @@ class MpccbfRaces:
         N = self.N
         torch_api.cbf_prep_dev(N, self.lap_length, self.t, self.timestep, self.xc, self.s0, self.v, self.ey,
                                self.obs_s, self.obs_e, self.lap_off, self.n_obs)
-        torch_api.cbf_solve_dev(self.desc, self.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.ws)
+        torch_api.cbf_solve_dev(self.desc, self.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.ws,
+                                order=_order(self, self.ws.iters))
         # the plant reads u_0 of every race straight out of the solver's U [B][N][2]
         torch_api.plant_step_wrap_dev(self.pdesc, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
                                       noise_z=self.noise.draw(self.batch))
@@ -260,7 +269,7 @@ class LmpcLaps:
             torch_api.lmpc_prep_dev(self.pdesc, self.ss, self.us, self.qf, self.time_ss, self.it, self.xc, self.ws.X, self.ws.U,
                                     self.tab, True, ws=self.pws)
         torch_api.lmpc_solve_dev(self.desc, self.xc, self.u_old, self.pws.A, self.pws.B, self.pws.C, self.pws.ss, self.pws.qfun, self.n_ss,
-                                 ws=self.ws)
+                                 ws=self.ws, order=_order(self, self.ws.iters))
         if torch_glue:
             torch_api.lmpc_addpoint_dev(self.pdesc, self.ss, self.us, self.time_ss, self.it, self.step_no, self.xc, self.ws.U, 2 * N)
             torch_api.plant_step_wrap_dev(self.plant, self.tab, self.xg, self.xc, self.ws.U, 2 * N, self.xg_next, self.xc_next, self.laps,
@@ -412,13 +421,15 @@ class GameLaps:
                                    self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.old_flag, self.qws, self.selws, active=m_ot)
         torch_api.track_prep_dev(self.Np, self.V, L, lm.xc, self.sws.n_veh, self.sws.obs_s, self.sws.obs_ey, self.selws.best_X, self.xt,
                                  self.obs_s, self.obs_e, self.lap_off, self.n_obs)
-        torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws, active=m_ot)
+        torch_api.cbf_solve_dev(self.track_desc, lm.xc, self.xt, self.obs_s, self.obs_e, self.lap_off, self.n_obs, ws=self.tws, active=m_ot,
+                                order=_order(self, self.tws.iters, m_ot))
 
     def _branch_lmpc(self, m_lm):
         lm = self.lm
         torch_api.lmpc_prep_dev(lm.pdesc, lm.ss, lm.us, lm.qf, lm.time_ss, lm.it, lm.xc, self.lin_points, self.lin_input, lm.tab, False, ws=lm.pws,
                                 active=m_lm)
-        torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws, active=m_lm)
+        torch_api.lmpc_solve_dev(lm.desc, lm.xc, lm.u_old, lm.pws.A, lm.pws.B, lm.pws.C, lm.pws.ss, lm.pws.qfun, lm.n_ss, ws=lm.ws, active=m_lm,
+                                 order=_order(self, lm.ws.iters, m_lm))
 
     def step_torch(self):
         """The same control step with the bookkeeping written as element-wise torch ops (round 2's formulation, ~40 small launches;

@@ -54,12 +54,46 @@ class CbfWorkspace:
         self.cost = torch.empty(batch, **f64)
         self.kkt = torch.empty(batch, **f64)
         self.status = torch.empty(batch, **i32)
-        self.iters = torch.empty(batch, **i32)
+        self.iters = torch.zeros(batch, **i32)
 
 
-def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=None, obs_dims=None):
-    """crx_cbf_solve_dev; with `active` (int32 [batch], 0 = leave the problem alone) crx_cbf_solve_masked_dev; with `obs_dims`
-    ([batch, n_obs_max, 2]: l_agent + l_obs, w_agent + w_obs per obstacle slot) crx_cbf_solve_dims_dev."""
+def longest_first(iters, active=None, out=None):
+    """crx_order_longest_first_dev: dispatch order for the next launch from the iteration counts of the previous one (int32 [batch]
+    on the device): the problems that took longest start first, masked-out ones (active == 0) last (include/crx.h, "Dispatch
+    order").  Stable: equal counts keep index order."""
+    Bn = iters.shape[0]
+    _chk(iters, torch.int32, (Bn,), "iters")
+    if active is not None:
+        _chk(active, torch.int32, (Bn,), "active")
+    order = out if out is not None else torch.empty(Bn, dtype=torch.int32, device=iters.device)
+    _chk(order, torch.int32, (Bn,), "order")
+    _call("crx_order_longest_first_dev", C.c_int(Bn), _ptr(iters), _ptr(active), _ptr(order), _stream())
+    return order
+
+
+def cbf_order_dev(desc, x0, obs_s, obs_ey, lap_off, n_obs, obs_dims=None, active=None, out=None):
+    """crx_cbf_order_dev: dispatch order of a CBF-NLP launch with no previous solve to go by -- smallest start barrier first."""
+    N, V, Bn = desc.N, desc.n_obs_max, x0.shape[0]
+    _chk(x0, torch.float64, (Bn, 6), "x0")
+    _chk(obs_s, torch.float64, (Bn, V, N + 1), "obs_s")
+    _chk(obs_ey, torch.float64, (Bn, V, N + 1), "obs_ey")
+    _chk(lap_off, torch.float64, (Bn, V), "lap_off")
+    _chk(n_obs, torch.int32, (Bn,), "n_obs")
+    if obs_dims is not None:
+        _chk(obs_dims, torch.float64, (Bn, V, 2), "obs_dims")
+    if active is not None:
+        _chk(active, torch.int32, (Bn,), "active")
+    order = out if out is not None else torch.empty(Bn, dtype=torch.int32, device=x0.device)
+    _chk(order, torch.int32, (Bn,), "order")
+    _call("crx_cbf_order_dev", C.byref(desc), C.c_int(Bn), _ptr(active), _ptr(x0), _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs),
+          _ptr(obs_dims), _ptr(order), _stream())
+    return order
+
+
+def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=None, obs_dims=None, order=None):
+    """crx_cbf_solve_ordered_dev, the superset entry point: `active` (int32 [batch], 0 = leave the problem alone), `obs_dims`
+    ([batch, n_obs_max, 2]: l_agent + l_obs, w_agent + w_obs per obstacle slot), `order` (int32 [batch] permutation: workgroup i
+    solves problem order[i]; see longest_first) -- each optional."""
     N, V, B = desc.N, desc.n_obs_max, x0.shape[0]
     _chk(x0, torch.float64, (B, 6), "x0")
     _chk(xt, torch.float64, (B, N + 1, 6) if desc.per_stage_target else (B, 6), "xt")
@@ -72,7 +106,10 @@ def cbf_solve_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, ws=None, active=N
         _chk(active, torch.int32, (B,), "active")
     if obs_dims is not None:
         _chk(obs_dims, torch.float64, (B, V, 2), "obs_dims")
-    _call("crx_cbf_solve_dims_dev", C.byref(desc), C.c_int(B), _ptr(active) if active is not None else None, _ptr(x0), _ptr(xt),
+    if order is not None:
+        _chk(order, torch.int32, (B,), "order")
+    _call("crx_cbf_solve_ordered_dev", C.byref(desc), C.c_int(B), _ptr(active) if active is not None else None,
+          _ptr(order) if order is not None else None, _ptr(x0), _ptr(xt),
           _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs), _ptr(obs_dims), _ptr(ws.X), _ptr(ws.U), _ptr(ws.sigma), _ptr(ws.cost),
           _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws
@@ -137,11 +174,11 @@ class LmpcWorkspace:
         self.cost = torch.empty(batch, **f64)
         self.kkt = torch.empty(batch, **f64)
         self.status = torch.empty(batch, **i32)
-        self.iters = torch.empty(batch, **i32)
+        self.iters = torch.zeros(batch, **i32)
 
 
-def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None, active=None):
-    """crx_lmpc_solve_dev (crx_lmpc_solve_masked_dev with `active`, int32 [batch], 0 = leave alone).  n_ss must satisfy 1 <= n_ss <= desc.n_ss_max (checked here on the host copy the
+def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None, active=None, order=None):
+    """crx_lmpc_solve_ordered_dev (`active`, int32 [batch], 0 = leave alone; `order`, int32 [batch] dispatch permutation; both optional).  n_ss must satisfy 1 <= n_ss <= desc.n_ss_max (checked here on the host copy the
     caller keeps; the kernel indexes LDS with it)."""
     N, M, Bn = desc.N, desc.n_ss_max, x0.shape[0]
     _chk(x0, torch.float64, (Bn, 6), "x0")
@@ -155,7 +192,10 @@ def lmpc_solve_dev(desc, x0, u_old, A, B, Cm, ss, qfun, n_ss, ws=None, active=No
     ws = ws or LmpcWorkspace(desc, Bn, x0.device)
     if active is not None:
         _chk(active, torch.int32, (Bn,), "active")
-    _call("crx_lmpc_solve_masked_dev", C.byref(desc), C.c_int(Bn), _ptr(active) if active is not None else None, _ptr(x0), _ptr(u_old),
+    if order is not None:
+        _chk(order, torch.int32, (Bn,), "order")
+    _call("crx_lmpc_solve_ordered_dev", C.byref(desc), C.c_int(Bn), _ptr(active) if active is not None else None,
+          _ptr(order) if order is not None else None, _ptr(x0), _ptr(u_old),
           _ptr(A), _ptr(B), _ptr(Cm), _ptr(ss), _ptr(qfun), _ptr(n_ss), _ptr(ws.X), _ptr(ws.U), _ptr(ws.lam), _ptr(ws.cost),
           _ptr(ws.status), _ptr(ws.kkt), _ptr(ws.iters), _stream())
     return ws

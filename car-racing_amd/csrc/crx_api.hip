@@ -432,13 +432,20 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
 int crx_cbf_solve_masked_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
                              const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, double* X,
                              double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters, void* stream) {
-    return crx_cbf_solve_dims_dev(d, batch, active, x0, xt, obs_s, obs_ey, lap_off, n_obs, nullptr, X, U, sigma, cost, status, kkt, iters, stream);
+    return crx_cbf_solve_ordered_dev(d, batch, active, nullptr, x0, xt, obs_s, obs_ey, lap_off, n_obs, nullptr, X, U, sigma, cost, status, kkt, iters, stream);
 }
 
 int crx_cbf_solve_dims_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
                            const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs,
                            const double* obs_dims, double* X, double* U, double* sigma, double* cost, int32_t* status, double* kkt,
                            int32_t* iters, void* stream) {
+    return crx_cbf_solve_ordered_dev(d, batch, active, nullptr, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims, X, U, sigma, cost, status, kkt, iters, stream);
+}
+
+int crx_cbf_solve_ordered_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const int32_t* order, const double* x0,
+                              const double* xt, const double* obs_s, const double* obs_ey, const double* lap_off,
+                              const int32_t* n_obs, const double* obs_dims, double* X, double* U, double* sigma, double* cost,
+                              int32_t* status, double* kkt, int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_kparams kp;
     if (int rc = fill_cbf(kp, d, batch)) return rc;
@@ -448,7 +455,7 @@ int crx_cbf_solve_dims_dev(const crx_cbf_desc* d, int batch, const int32_t* acti
         return fail(CRX_ERR_ARG, "NULL obstacle array with n_obs_max > 0");
     kp.x0 = x0; kp.xt = xt; kp.obs_s = obs_s; kp.obs_ey = obs_ey; kp.lap_off = lap_off; kp.n_obs = n_obs;
     kp.X = X; kp.U = U; kp.sigma = sigma; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
-    kp.active = active; kp.obs_dims = d->n_obs_max > 0 ? obs_dims : nullptr;
+    kp.active = active; kp.order = order; kp.obs_dims = d->n_obs_max > 0 ? obs_dims : nullptr;
     return launch_solve(kp, d->n_obs_max, (hipStream_t)stream);
 }
 
@@ -801,6 +808,13 @@ int crx_lmpc_solve_masked_dev(const crx_lmpc_desc* d, int batch, const int32_t* 
                               const double* A, const double* B, const double* C, const double* ss, const double* qfun,
                               const int32_t* n_ss, double* X, double* U, double* lambda, double* cost, int32_t* status,
                               double* kkt, int32_t* iters, void* stream) {
+    return crx_lmpc_solve_ordered_dev(d, batch, active, nullptr, x0, u_old, A, B, C, ss, qfun, n_ss, X, U, lambda, cost, status, kkt, iters, stream);
+}
+
+int crx_lmpc_solve_ordered_dev(const crx_lmpc_desc* d, int batch, const int32_t* active, const int32_t* order, const double* x0,
+                               const double* u_old, const double* A, const double* B, const double* C, const double* ss,
+                               const double* qfun, const int32_t* n_ss, double* X, double* U, double* lambda, double* cost,
+                               int32_t* status, double* kkt, int32_t* iters, void* stream) {
     if (int rc = ensure_init()) return rc;
     crx_lmpc_kparams kp;
     if (int rc = fill_lmpc(kp, d, batch)) return rc;
@@ -809,7 +823,7 @@ int crx_lmpc_solve_masked_dev(const crx_lmpc_desc* d, int batch, const int32_t* 
         return fail(CRX_ERR_ARG, "NULL array argument");
     kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
     kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
-    kp.active = active;
+    kp.active = active; kp.order = order;
     if (g_trace_rows > 0) { kp.trace = (double*)g_trace.p; kp.trace_problem = g_trace_problem; kp.trace_rows = g_trace_rows; }
     kp.poison = g_poison;
     timing_begin((hipStream_t)stream);
@@ -1104,6 +1118,43 @@ int crx_planner_plan(const crx_planner_desc* d, const crx_select_desc* sd, int n
     if (int rc = crx_planner_plan_dev(d, sd, n_scen, dx0, dbs, dbe, dlb, dub, dnv, dos, doe, dof, dX, dU, dc, ds, dk, di,
                                       dfl, dsc, dbX, g_stream)) return rc;
     return sg.down(g_stream);
+}
+
+}  // extern "C"
+
+// ---- dispatch order of a solver launch ------------------------------------------------------------------------------
+extern "C" {
+
+int crx_order_longest_first_dev(int batch, const int32_t* iters, const int32_t* active, int32_t* order, void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (batch < 0) return fail(CRX_ERR_ARG, "bad batch");
+    if (batch == 0) return CRX_OK;
+    if (!iters || !order) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_order_kparams op;
+    memset(&op, 0, sizeof(op));
+    op.batch = batch; op.mode = 0; op.iters = iters; op.active = active; op.order = order;
+    hipError_t e = crx_launch_order(op, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "order launch: %s", hipGetErrorString(e));
+    return CRX_OK;
+}
+
+int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* obs_s,
+                      const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, int32_t* order,
+                      void* stream) {
+    if (int rc = ensure_init()) return rc;
+    if (!d || batch < 0) return fail(CRX_ERR_ARG, "bad descriptor / batch");
+    if (d->N < 1 || d->N > CRX_MAX_N || d->n_obs_max < 0 || d->n_obs_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "bad N / n_obs_max");
+    if (d->degree != 2 && d->degree != 4 && d->degree != 6 && d->degree != 8) return fail(CRX_ERR_ARG, "degree must be 2, 4, 6 or 8");
+    if (batch == 0) return CRX_OK;
+    if (!x0 || !order || !n_obs || (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off))) return fail(CRX_ERR_ARG, "NULL array argument");
+    crx_order_kparams op;
+    memset(&op, 0, sizeof(op));
+    op.batch = batch; op.mode = 1; op.active = active; op.order = order;
+    op.V = d->n_obs_max; op.stride = d->N + 1; op.degree = d->degree; op.margin = d->margin; op.l_sum = d->l_sum; op.w_sum = d->w_sum;
+    op.x0 = x0; op.obs_s = obs_s; op.obs_ey = obs_ey; op.lap_off = lap_off; op.obs_dims = d->n_obs_max > 0 ? obs_dims : nullptr; op.n_obs = n_obs;
+    hipError_t e = crx_launch_order(op, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CRX_ERR_HIP, "order launch: %s", hipGetErrorString(e));
+    return CRX_OK;
 }
 
 }  // extern "C"

@@ -1068,8 +1068,11 @@ crx_solve_kernel(const crx_kparams kp) {
     constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int* si = (int*)(sm + L::END_D);
-    const int b = blockIdx.x, lane = threadIdx.x, N = kp.N;
-    if (b >= kp.batch) return;
+    const int lane = threadIdx.x, N = kp.N;
+    if ((int)blockIdx.x >= kp.batch) return;
+    // dispatch order [r3]: workgroups start in launch order, so a caller that knows which problems are long (the iteration counts of
+    // the previous control step) lists them first and the launch does not end waiting for a straggler that started last
+    const int b = kp.order ? min(max(kp.order[blockIdx.x], 0), kp.batch - 1) : (int)blockIdx.x;
     if (kp.active && kp.active[kp.active_div > 1 ? b / kp.active_div : b] == 0) {   // masked launch: this problem is not part of it
         if (lane == 0) { kp.status[b] = CRX_SKIPPED; kp.iters[b] = 0; }
         return;

@@ -30,6 +30,7 @@ struct crx_kparams {
     int poison;   // diagnostics: fill the LDS slice with NaN before set-up (catches reads of stale LDS)
     const int32_t* active;   // optional [batch / active_div]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
     int active_div;          // problems per mask entry (planner: the regions of a scenario share one entry); 0 or 1: one each
+    const int32_t* order;    // optional [batch]: workgroup i solves problem order[i] (longest-first dispatch); NULL: i
 };
 
 struct crx_lmpc_kparams {
@@ -45,6 +46,7 @@ struct crx_lmpc_kparams {
     int trace_problem, trace_rows;
     int poison;      // diagnostics: fill the LDS slice with NaN before set-up
     const int32_t* active;   // optional [batch]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
+    const int32_t* order;    // optional [batch]: workgroup i solves problem order[i] (longest-first dispatch); NULL: i
 };
 
 struct crx_select_kparams {
@@ -132,6 +134,18 @@ size_t crx_solve_lds_bytes(int N, int nobs_template);
 int crx_solve_resident_per_cu(int N, int nobs_template);
 hipError_t crx_launch_path(const crx_path_kparams& pp, hipStream_t st);
 hipError_t crx_launch_cbfprep(const crx_cbfprep_kparams& cp, hipStream_t st);
+
+// dispatch order of a solver launch (include/crx.h, "Dispatch order"): a stable counting sort of the batch by a 257-valued key
+struct crx_order_kparams {
+    int batch, mode;             // mode 0: iteration counts of the previous solve, descending; 1: smallest start barrier, ascending
+    const int32_t *iters, *active;
+    int32_t* order;
+    int V, stride, degree;       // mode 1: obstacle slots, N + 1, exponent of the ellipse
+    double margin, l_sum, w_sum;
+    const double *x0, *obs_s, *obs_ey, *lap_off, *obs_dims;
+    const int32_t* n_obs;
+};
+hipError_t crx_launch_order(const crx_order_kparams& op, hipStream_t st);
 
 // device-resident racing-game loop: the bookkeeping between the solver launches (crx.montecarlo.GameLaps / LmpcLaps)
 struct crx_game_kparams {

@@ -202,8 +202,8 @@ template <int NMAX, bool DENSE>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
     using L = LL<NMAX, DENSE>;
     extern __shared__ double sm[];
-    const int pb = blockIdx.x;
-    if (pb >= kp.batch) return;
+    if ((int)blockIdx.x >= kp.batch) return;
+    const int pb = kp.order ? min(max(kp.order[blockIdx.x], 0), kp.batch - 1) : (int)blockIdx.x;   // dispatch order, see crx_solve_kernel
     if (kp.active && kp.active[pb] == 0) {   // masked launch: this problem is not part of it
         if (threadIdx.x == 0) { kp.status[pb] = CRX_SKIPPED; kp.iters[pb] = 0; }
         return;

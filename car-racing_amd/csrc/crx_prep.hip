@@ -603,6 +603,127 @@ __global__ void __launch_bounds__(256) crx_game_log_kernel(const crx_game_kparam
     gp.n_log[b] = n + 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dispatch order (include/crx.h, "Dispatch order").  A key of 257 values per problem, key 0 dispatched first:
+//   mode 0  255 - min(iterations of the previous solve, 255)              (longest first)
+//   mode 1  from the smallest barrier value h of the START state over the problem's obstacles: inside a safety ellipse
+//           (h < 0: the NLP that needs the restoration phase; BASELINE configs[3] draw: 38 iterations on average, 16 outside)
+//           128 linear steps of h + 1 + margin, outside 4.25 steps per doubling of 1 + h (3 % in distance at degree 6)
+//   256     masked-out problems (active[b] == 0): they return at once, last.
+// crx_order_key_kernel (mode 1, one thread per problem, the whole chip) leaves the keys in order[]; crx_order_kernel -- ONE
+// workgroup of 16 waves -- sorts the batch by key with a STABLE counting sort (wave w owns a contiguous segment; ranks inside a
+// 64-problem step by lane comparison), so the order, and with it the timing of the solver launch that uses it, is a pure
+// function of the keys.  The keys sit in LDS (2 B each) between the counting and the scatter pass: batch <= CRX_ORDER_LDS_KEYS;
+// larger batches evaluate the key twice instead.  HBM: the key's inputs once (twice beyond the LDS limit), 4 B out per problem.
+// ------------------------------------------------------------------------------------------------
+#define CRX_ORDER_WAVES 16
+#define CRX_ORDER_KEYS 257
+#define CRX_ORDER_LDS_KEYS 65536
+
+__device__ __forceinline__ int crx_order_key(const crx_order_kparams& op, int b) {
+    if (op.active && op.active[b] == 0) return CRX_ORDER_KEYS - 1;
+    if (op.mode == 0) return 255 - min(max(op.iters[b], 0), 255);
+    const int V = op.V, n = min(max(op.n_obs[b], 0), V);
+    const double s = op.x0[(size_t)b * 6 + 4], ey = op.x0[(size_t)b * 6 + 5];
+    double hmin = 1e30;
+    for (int o = 0; o < n; o++) {
+        const size_t r = (size_t)b * V + o;
+        const double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+        const double ds = (op.obs_s[r * op.stride] + op.lap_off[r] - s) / ls, de = (op.obs_ey[r * op.stride] - ey) / ws;
+        double ps = ds * ds, pe = de * de;
+        for (int k = 2; k < op.degree; k += 2) { ps *= ds * ds; pe *= de * de; }
+        hmin = fmin(hmin, ps + pe - 1.0 - op.margin);
+    }
+    if (hmin < 0.0) return min(max((int)((hmin + 1.0 + op.margin) * (128.0 / (1.0 + op.margin))), 0), 127);
+    const double t = 128.0 + 4.25 * log2(1.0 + hmin);      // 255 at h = 1e9: an obstacle ~30 ellipse lengths away
+    return t < 255.0 ? (int)t : 255;
+}
+
+__global__ void __launch_bounds__(256) crx_order_key_kernel(const crx_order_kparams op) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < op.batch) op.order[b] = crx_order_key(op, b);
+}
+
+// keys_in_order: order[] holds the keys (crx_order_key_kernel ran); cache: the keys fit in LDS
+template <bool CACHE>
+__global__ void __launch_bounds__(64 * CRX_ORDER_WAVES) crx_order_kernel(const crx_order_kparams op, const int keys_in_order) {
+    extern __shared__ int order_lds[];
+    int (*hist)[CRX_ORDER_KEYS] = (int (*)[CRX_ORDER_KEYS])order_lds;   // per (wave, key): count, then first output position
+    int* start = order_lds + CRX_ORDER_WAVES * CRX_ORDER_KEYS;
+    unsigned short* keys = (unsigned short*)(start + CRX_ORDER_KEYS + 1);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int steps = (op.batch + 64 * CRX_ORDER_WAVES - 1) / (64 * CRX_ORDER_WAVES);   // 64-problem steps per wave segment
+    const int seg0 = w * steps * 64;
+    for (int i = tid; i < CRX_ORDER_WAVES * CRX_ORDER_KEYS; i += blockDim.x) order_lds[i] = 0;
+    __syncthreads();
+    for (int st = 0; st < steps; st++) {
+        const int b = seg0 + st * 64 + lane;
+        if (b < op.batch) {
+            const int key = keys_in_order ? min(max(op.order[b], 0), CRX_ORDER_KEYS - 1) : crx_order_key(op, b);
+            if (CACHE) keys[b] = (unsigned short)key;
+            atomicAdd(&hist[w][key], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < CRX_ORDER_KEYS) {
+        int t = 0;
+        for (int v = 0; v < CRX_ORDER_WAVES; v++) t += hist[v][tid];
+        start[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < CRX_ORDER_KEYS; k++) { const int t = start[k]; start[k] = run; run += t; }
+    }
+    __syncthreads();
+    if (tid < CRX_ORDER_KEYS) {
+        int run = start[tid];
+        for (int v = 0; v < CRX_ORDER_WAVES; v++) { const int t = hist[v][tid]; hist[v][tid] = run; run += t; }
+    }
+    __syncthreads();
+    for (int st = 0; st < steps; st++) {
+        const int b = seg0 + st * 64 + lane;
+        const int key = b < op.batch ? (CACHE ? (int)keys[b] : crx_order_key(op, b)) : -1;
+        int rank = 0, same = 0;
+        for (int k = 0; k < 64; k++) {
+            const int other = __shfl(key, k);
+            rank += (other == key && k < lane);
+            same += (other == key);
+        }
+        const int base = key >= 0 ? hist[w][key] : 0;
+        __syncthreads();
+        if (key >= 0) {
+            op.order[base + rank] = b;
+            if (rank == same - 1) hist[w][key] = base + same;   // the last lane of every key of this step moves the key's cursor
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t crx_launch_order(const crx_order_kparams& op, hipStream_t st) {
+    if (op.batch == 0) return hipSuccess;
+    const bool cache = op.batch <= CRX_ORDER_LDS_KEYS;
+    const size_t fixed = (size_t)(CRX_ORDER_WAVES * CRX_ORDER_KEYS + CRX_ORDER_KEYS + 1) * sizeof(int);
+    const size_t bytes = fixed + (cache ? (size_t)op.batch * sizeof(unsigned short) : 0);
+    static int attr_set_on = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (attr_set_on != dev) {
+        hipError_t e = hipFuncSetAttribute((const void*)crx_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(fixed + (size_t)CRX_ORDER_LDS_KEYS * sizeof(unsigned short)));
+        if (e != hipSuccess) return e;
+        attr_set_on = dev;
+    }
+    int keyed = 0;
+    if (op.mode == 1 && cache) {          // the barrier key on the whole chip, left in order[]
+        hipLaunchKernelGGL(crx_order_key_kernel, dim3((op.batch + 255) / 256), dim3(256), 0, st, op);
+        keyed = 1;
+    }
+    if (cache) hipLaunchKernelGGL(crx_order_kernel<true>, dim3(1), dim3(64 * CRX_ORDER_WAVES), bytes, st, op, keyed);
+    else hipLaunchKernelGGL(crx_order_kernel<false>, dim3(1), dim3(64 * CRX_ORDER_WAVES), bytes, st, op, keyed);
+    return hipGetLastError();
+}
+
 hipError_t crx_launch_game(int which, const crx_game_kparams& gp, hipStream_t st) {
     if (gp.batch == 0) return hipSuccess;
     const long long n = which == 0 ? (long long)gp.batch * gp.n_cars : (which == 2 ? (long long)gp.batch * (8 * gp.N + 6) : gp.batch);

@@ -45,7 +45,8 @@ extern "C" {
 #endif
 
 #define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
-                          crx_comm_* / crx_allgather_winners_dev (RCCL); additions only, every 0.1.2 entry point unchanged
+                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order); additions
+                          only, every 0.1.2 entry point unchanged
                           (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
                            0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
 #define CRX_NX 6
@@ -541,6 +542,33 @@ int crx_cbf_solve_dims_dev(const crx_cbf_desc* d, int batch, const int32_t* acti
                            const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs,
                            const double* obs_dims, double* X, double* U, double* sigma, double* cost, int32_t* status, double* kkt,
                            int32_t* iters, void* stream);
+/* Dispatch order.  The workgroups of a launch start in launch order and a launch ends with its slowest problem: when the problems
+ * that need many iterations are listed first -- a closed loop knows them: the iteration counts of the previous control step -- the
+ * launch no longer waits for a straggler that started last (BASELINE configs[3], 16384 NLPs of 8..166 iterations on 1024 resident
+ * slots: list scheduling in index order 398 iteration-units, longest first 338).  order [batch] int32 on the device = a permutation of
+ * 0..batch-1: workgroup i solves problem order[i]; results land at the problem's own index; NULL = index order.  Entries are
+ * clamped to [0, batch); a non-permutation solves some problems twice and others not at all (the caller's business).
+ * crx_cbf_solve_ordered_dev is the superset entry point (mask, order, per-obstacle dimensions; each may be NULL). */
+int crx_cbf_solve_ordered_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const int32_t* order, const double* x0,
+                              const double* xt, const double* obs_s, const double* obs_ey, const double* lap_off,
+                              const int32_t* n_obs, const double* obs_dims, double* X, double* U, double* sigma, double* cost,
+                              int32_t* status, double* kkt, int32_t* iters, void* stream);
+/* The order itself, computed on the device (one launch, a stable counting sort; equal keys keep index order):
+ *   crx_order_longest_first_dev  from the iteration counts of the previous solve of these problems (iters [batch], e.g. the iters
+ *                                output of the previous control step), longest first;
+ *   crx_cbf_order_dev            with no previous solve: by the smallest barrier value of the START state over the problem's
+ *                                obstacles, h = (ds/l)^degree + (dey/w)^degree - 1 - margin at stage 0 (control.py:529-537), ascending --
+ *                                the car that starts inside or beside a safety ellipse is the NLP that needs most iterations.
+ * Problems with active[b] == 0 go last (active may be NULL).  Measured on BASELINE configs[3] (16384 NLPs, one launch):
+ * index order 24.9 ms, crx_cbf_order_dev 19.5 ms, crx_order_longest_first_dev 16.6 ms. */
+int crx_order_longest_first_dev(int batch, const int32_t* iters, const int32_t* active, int32_t* order, void* stream);
+int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* obs_s,
+                      const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, int32_t* order,
+                      void* stream);
+int crx_lmpc_solve_ordered_dev(const crx_lmpc_desc* d, int batch, const int32_t* active, const int32_t* order, const double* x0,
+                               const double* u_old, const double* A, const double* B, const double* C, const double* ss,
+                               const double* qfun, const int32_t* n_ss, double* X, double* U, double* lambda, double* cost,
+                               int32_t* status, double* kkt, int32_t* iters, void* stream);
 /* Masked launches (device-resident loops in which every problem of the batch takes ONE of several branches per step, e.g.
  * LMPCRacingGame.calc_input, utils/base.py:456-583: overtake planner + tracking NLP, or learning-MPC): active [batch]
  * int32 on the device, 0 = this problem is not part of the launch -- its wavefront returns at once, status[b] =

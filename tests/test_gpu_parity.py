@@ -989,6 +989,77 @@ def test_masked_launches(gpu, golden_racing_game, AB):
         np.testing.assert_array_equal(getattr(wl, k).cpu().numpy()[on], getattr(fl, k).cpu().numpy()[on])
 
 
+def test_dispatch_order_is_bit_identical(gpu, golden_racing_game, AB):
+    """crx_*_solve_ordered_dev: workgroup i solves problem order[i]; every problem gets exactly the bits the index-order launch
+    gives it, with the mask and without (longest-first dispatch changes WHEN a problem runs, nothing else)."""
+    import torch
+    from crx import abi, synth, torch_api
+    A, B = AB
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)   # noqa: E731
+    p = synth.cfg4_tracking_cbf(3000, N=20, seed=31, safe_start=False)
+    d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    a = [t(p[k]) for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [t(p["n_obs"], torch.int32)]
+    full = torch_api.cbf_solve_dev(d, *a)
+    order = torch_api.longest_first(full.iters)
+    o = order.cpu().numpy()
+    np.testing.assert_array_equal(o, np.argsort(-np.minimum(full.iters.cpu().numpy(), 255), kind="stable"))   # a stable counting sort
+    ws = torch_api.cbf_solve_dev(d, *a, order=order)
+    rnd = torch.from_numpy(np.random.default_rng(3).permutation(3000).astype(np.int32)).to(dev)
+    ws2 = torch_api.cbf_solve_dev(d, *a, order=rnd)
+    for k in ("X", "U", "sigma", "cost", "status", "iters", "kkt"):
+        np.testing.assert_array_equal(getattr(ws, k).cpu().numpy(), getattr(full, k).cpu().numpy())
+        np.testing.assert_array_equal(getattr(ws2, k).cpu().numpy(), getattr(full, k).cpu().numpy())
+    act = torch.from_numpy((np.arange(3000) % 3 != 1).astype(np.int32)).to(dev)
+    wm = torch_api.CbfWorkspace(d, 3000, dev)
+    wm.X.fill_(-7.0)
+    om = torch_api.longest_first(full.iters, act)
+    omc, itc = om.cpu().numpy(), full.iters.cpu().numpy()
+    n_on = int((act != 0).sum().item())
+    assert sorted(omc.tolist()) == list(range(3000)) and (act.cpu().numpy()[omc[:n_on]] != 0).all() and (np.diff(itc[omc[:n_on]]) <= 0).all()
+    torch_api.cbf_solve_dev(d, *a, ws=wm, active=act, order=om)
+    # the order with no previous solve: ascending start barrier, a permutation, stable (checked against numpy on the same key)
+    op = torch_api.cbf_order_dev(d, a[0], a[2], a[3], a[4], a[5]).cpu().numpy()
+    ds = (p["obs_s"][:, :, 0] + p["lap_off"] - p["x0"][:, 4:5]) / d.l_sum
+    de = (p["obs_ey"][:, :, 0] - p["x0"][:, 5:6]) / d.w_sum
+    h = np.where(np.arange(3)[None, :] < p["n_obs"][:, None], ds ** d.degree + de ** d.degree - 1.0 - d.margin, 1e30).min(axis=1)
+    hc = np.minimum(h, 1e12)
+    key = np.where(h < 0, np.clip(((np.minimum(h, 0.0) + 1.0 + d.margin) * (128.0 / (1.0 + d.margin))).astype(np.int64), 0, 127),
+                   np.minimum(128.0 + 4.25 * np.log2(1.0 + np.maximum(hc, 0.0)), 255.0).astype(np.int64))
+    assert sorted(op.tolist()) == list(range(3000))
+    assert (np.diff(key[op]) >= 0).sum() >= 2990            # a key on a bucket edge may round differently on the device: a handful at most
+    assert (h < 0).sum() > 10 and (h[op[:(h < 0).sum()]] < 0).all()   # the cars that start inside a safety ellipse come first
+    wp = torch_api.cbf_solve_dev(d, *a, order=torch.from_numpy(op).to(dev))
+    np.testing.assert_array_equal(wp.X.cpu().numpy(), full.X.cpu().numpy())
+    # beyond the LDS key cache (65536 problems) the sort evaluates the key twice: same order as the cached path on the same keys
+    rep = 24
+    big_it = full.iters.repeat(rep)
+    ob = torch_api.longest_first(big_it).cpu().numpy()
+    np.testing.assert_array_equal(ob, np.argsort(-np.minimum(big_it.cpu().numpy(), 255), kind="stable"))
+    big = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in (a[0], a[2], a[3], a[4], a[5])]
+    opb = torch_api.cbf_order_dev(d, *big).cpu().numpy()
+    assert sorted(opb.tolist()) == list(range(3000 * rep))
+    assert (np.diff(key[opb % 3000]) >= 0).sum() >= 3000 * rep - 10 * rep
+    small = torch_api.cbf_order_dev(d, *[x[:60000].contiguous() for x in big]).cpu().numpy()      # cached path
+    kd = lambda o: key[o % 3000]   # noqa: E731
+    first = np.searchsorted(kd(small), 128)               # device keys: identical code in both paths, so the inside-ellipse block
+    assert (h[small[:first] % 3000] < 0).all() and (h[opb[:first] % 3000] < 0).all()
+    on = act.cpu().numpy() != 0
+    assert (wm.status.cpu().numpy()[~on] == abi.CRX_SKIPPED).all() and (wm.X.cpu().numpy()[~on] == -7.0).all()
+    for k in ("X", "U", "cost", "status", "iters", "kkt"):
+        np.testing.assert_array_equal(getattr(wm, k).cpu().numpy()[on], getattr(full, k).cpu().numpy()[on])
+    # learning-MPC QP
+    dl, al = helpers.lmpc_inputs(golden_racing_game)
+    n = al[0].shape[0]
+    N = dl.N
+    tl = [t(al[0]), t(al[1]), t(al[2]).reshape(n, N, 36), t(al[3]).reshape(n, N, 12), t(al[4]).reshape(n, N, 6), t(al[5]), t(al[6]),
+          torch.full((n,), al[5].shape[2], dtype=torch.int32, device=dev)]
+    fl = torch_api.lmpc_solve_dev(dl, *tl)
+    wl = torch_api.lmpc_solve_dev(dl, *tl, order=torch_api.longest_first(fl.iters))
+    for k in ("X", "U", "lam", "cost", "status", "iters", "kkt"):
+        np.testing.assert_array_equal(getattr(wl, k).cpu().numpy(), getattr(fl, k).cpu().numpy())
+
+
 def test_zero_obstacle_nlps_incl_infeasible(gpu, orc, AB):
     """The 0-obstacle instantiation in controller mode (control.mpc_lti form, control.py:198-248, and mpc_multi_agents
     without vehicles in its window): 256 tracking problems on a narrow track (ey_max = 0.15) from states up to 0.14 off the
