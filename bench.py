@@ -167,8 +167,12 @@ def make_cbf(cx, key, args, batch=None, filtered=False):
     # dispatch order (include/crx.h): computed inside the timed step, one more launch -- from the iteration counts of the previous
     # step (what a receding-horizon loop has) or, with no previous solve, from the start barrier of every problem
     obuf = torch.empty(w.batch, dtype=torch.int32, device=cx.dev)
+    mode = args.dispatch
+    if mode == "auto":    # more problems than resident slots (256 CUs x 4): the launch has a tail worth ordering; else all start at once
+        mode = "start_barrier" if w.batch > 1024 else "index"
+    w.extra["dispatch"] = mode
     order = {"index": lambda: None, "longest_first": lambda: torch_api.longest_first(w.ws.iters, out=obuf),
-             "start_barrier": lambda: torch_api.cbf_order_dev(w.desc, t_in[0], t_in[2], t_in[3], t_in[4], t_in[5], out=obuf)}[args.dispatch]
+             "start_barrier": lambda: torch_api.cbf_order_dev(w.desc, *t_in, out=obuf)}[mode]
     w.step = w.solve = lambda: torch_api.cbf_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
     keys = ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")
     w.cpu = ("cbf", w.desc, {k: p[k] for k in keys})
@@ -298,6 +302,7 @@ def make_lmpc(cx, args, batch=None):
     w.kernel = "crx_lmpc_kernel"
     obuf = torch.empty(w.batch, dtype=torch.int32, device=cx.dev)
     order = (lambda: torch_api.longest_first(w.ws.iters, out=obuf)) if args.dispatch == "longest_first" else (lambda: None)
+    w.extra = {"dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     w.step = w.solve = lambda: torch_api.lmpc_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
     w.name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, w.batch)
     w.cpu = ("lmpc", w.desc, {k: p[k] for k in keys + ("n_ss",)})
@@ -332,7 +337,7 @@ def make_races(cx, args, batch=None):
                                                           order=montecarlo._order(r, r.ws.iters))) for r in parts]
     w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
               "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant); %d sub-batches on %d HIP streams" % (w.batch, len(parts), len(parts)))
-    w.extra = {"race_streams": len(parts)}
+    w.extra = {"race_streams": len(parts), "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     return w
 
 
@@ -371,7 +376,7 @@ def make_game(cx, args, batch=None):
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
     w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full",
-               "race_streams": len(parts)}
+               "race_streams": len(parts), "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     return w
 
 
@@ -416,7 +421,8 @@ def make_overtake(cx, args, batch=None):
               "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
               "selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
-    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch", "race_streams": len(parts)}
+    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch", "race_streams": len(parts),
+               "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     # the scene stage keeps at most CRX_MAX_OBS vehicles of interest per race (the nearest): how often were there more?
     w.post = lambda: {"scene_overflow_races": int(sum((g.overflow_seen > 0).sum().item() for g in parts))}
     return w
@@ -570,7 +576,7 @@ def compact(rec):
            "max_iter_frac": c["status_frac"]["max_iter"], "skipped_masked_frac": c["status_frac"]["skipped_masked"],
            "iters_p50": c["iters_p50"], "iters_p90": c["iters_p90"], "iters_max": c["iters_max"], "roofline_frac": r["frac"],
            "achieved_GBps": r["achieved"], "traffic": r["traffic"], "resident_per_cu": r["resident_problems_per_cu"]}
-    for k in ("p50_step_latency_ms", "p50_host_call_one_control_step_ms"):
+    for k in ("p50_step_latency_ms", "p50_host_call_one_control_step_ms", "dispatch"):
         if c.get(k) is not None:
             out[k] = c[k]
     if "allgather_ms" in rec:
@@ -666,10 +672,11 @@ def main():
                     help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
     ap.add_argument("--race-streams", type=int, default=2,
                     help="closed-loop workloads (races, game, overtake): independent sub-batches of the races on this many HIP streams (1 = one batch)")
-    ap.add_argument("--dispatch", default="index", choices=["index", "longest_first", "start_barrier"],
-                    help="workgroup -> problem mapping of the solver launches (crx_*_solve_ordered_dev): launch order; the problems whose "
-                         "previous solve took most iterations first (crx_order_longest_first_dev); cfg2 / cfg4 only: smallest start barrier "
-                         "first, no previous solve needed (crx_cbf_order_dev).  The order kernel is part of the timed step")
+    ap.add_argument("--dispatch", default="auto", choices=["auto", "index", "longest_first", "start_barrier"],
+                    help="workgroup -> problem mapping of the solver launches (crx_*_solve_ordered_dev): index = launch order; longest_first = "
+                         "the problems whose previous solve took most iterations first (crx_order_longest_first_dev: what a closed loop has); "
+                         "start_barrier (cfg2 / cfg4) = from the problem's own inputs, no previous solve needed (crx_cbf_order_dev); auto = "
+                         "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
@@ -707,8 +714,6 @@ def main():
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
             "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}
     head = make_plumbing_headline(cx) if args.plumbing_check else make[args.workload or "cfg2"]()
-    if head.kind != "planner" and not args.plumbing_check:   # the planner QPs are uniform (7..15 iterations): nothing to reorder
-        head.extra = dict(head.extra or {}, dispatch=args.dispatch)
     rec = measure(cx, head, args.steps, args.warmup, with_latency=not args.plumbing_check)
     out = {"metric": METRIC, "value": rec["value"], "value_converged": rec["value_converged"], "unit": "solves/s", "n_gpus": cx.world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],

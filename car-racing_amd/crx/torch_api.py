@@ -71,10 +71,12 @@ def longest_first(iters, active=None, out=None):
     return order
 
 
-def cbf_order_dev(desc, x0, obs_s, obs_ey, lap_off, n_obs, obs_dims=None, active=None, out=None):
-    """crx_cbf_order_dev: dispatch order of a CBF-NLP launch with no previous solve to go by -- smallest start barrier first."""
+def cbf_order_dev(desc, x0, xt, obs_s, obs_ey, lap_off, n_obs, obs_dims=None, active=None, out=None):
+    """crx_cbf_order_dev: dispatch order of a CBF-NLP launch with no previous solve to go by, from the arguments of cbf_solve_dev --
+    cars that start inside a safety ellipse first, then those whose un-steered path enters one, then the rest."""
     N, V, Bn = desc.N, desc.n_obs_max, x0.shape[0]
     _chk(x0, torch.float64, (Bn, 6), "x0")
+    _chk(xt, torch.float64, (Bn, N + 1, 6) if desc.per_stage_target else (Bn, 6), "xt")
     _chk(obs_s, torch.float64, (Bn, V, N + 1), "obs_s")
     _chk(obs_ey, torch.float64, (Bn, V, N + 1), "obs_ey")
     _chk(lap_off, torch.float64, (Bn, V), "lap_off")
@@ -85,7 +87,7 @@ def cbf_order_dev(desc, x0, obs_s, obs_ey, lap_off, n_obs, obs_dims=None, active
         _chk(active, torch.int32, (Bn,), "active")
     order = out if out is not None else torch.empty(Bn, dtype=torch.int32, device=x0.device)
     _chk(order, torch.int32, (Bn,), "order")
-    _call("crx_cbf_order_dev", C.byref(desc), C.c_int(Bn), _ptr(active), _ptr(x0), _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs),
+    _call("crx_cbf_order_dev", C.byref(desc), C.c_int(Bn), _ptr(active), _ptr(x0), _ptr(xt), _ptr(obs_s), _ptr(obs_ey), _ptr(lap_off), _ptr(n_obs),
           _ptr(obs_dims), _ptr(order), _stream())
     return order
 

@@ -1138,19 +1138,20 @@ int crx_order_longest_first_dev(int batch, const int32_t* iters, const int32_t* 
     return CRX_OK;
 }
 
-int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* obs_s,
-                      const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, int32_t* order,
-                      void* stream) {
+int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                      const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims,
+                      int32_t* order, void* stream) {
     if (int rc = ensure_init()) return rc;
     if (!d || batch < 0) return fail(CRX_ERR_ARG, "bad descriptor / batch");
     if (d->N < 1 || d->N > CRX_MAX_N || d->n_obs_max < 0 || d->n_obs_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "bad N / n_obs_max");
     if (d->degree != 2 && d->degree != 4 && d->degree != 6 && d->degree != 8) return fail(CRX_ERR_ARG, "degree must be 2, 4, 6 or 8");
     if (batch == 0) return CRX_OK;
-    if (!x0 || !order || !n_obs || (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off))) return fail(CRX_ERR_ARG, "NULL array argument");
+    if (!x0 || !xt || !order || !n_obs || (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off))) return fail(CRX_ERR_ARG, "NULL array argument");
     crx_order_kparams op;
     memset(&op, 0, sizeof(op));
     op.batch = batch; op.mode = 1; op.active = active; op.order = order;
     op.V = d->n_obs_max; op.stride = d->N + 1; op.degree = d->degree; op.margin = d->margin; op.l_sum = d->l_sum; op.w_sum = d->w_sum;
+    op.per_stage_target = d->per_stage_target; op.ds_per_vx = d->A[4 * 6 + 0]; op.xt = xt;
     op.x0 = x0; op.obs_s = obs_s; op.obs_ey = obs_ey; op.lap_off = lap_off; op.obs_dims = d->n_obs_max > 0 ? obs_dims : nullptr; op.n_obs = n_obs;
     hipError_t e = crx_launch_order(op, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "order launch: %s", hipGetErrorString(e));

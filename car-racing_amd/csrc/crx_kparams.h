@@ -140,9 +140,9 @@ struct crx_order_kparams {
     int batch, mode;             // mode 0: iteration counts of the previous solve, descending; 1: smallest start barrier, ascending
     const int32_t *iters, *active;
     int32_t* order;
-    int V, stride, degree;       // mode 1: obstacle slots, N + 1, exponent of the ellipse
-    double margin, l_sum, w_sum;
-    const double *x0, *obs_s, *obs_ey, *lap_off, *obs_dims;
+    int V, stride, degree, per_stage_target;   // mode 1: obstacle slots, N + 1, exponent of the ellipse, layout of xt
+    double margin, l_sum, w_sum, ds_per_vx;    // ds_per_vx = A[4][0]: progress per stage and unit speed
+    const double *x0, *xt, *obs_s, *obs_ey, *lap_off, *obs_dims;
     const int32_t* n_obs;
 };
 hipError_t crx_launch_order(const crx_order_kparams& op, hipStream_t st);

@@ -606,9 +606,11 @@ __global__ void __launch_bounds__(256) crx_game_log_kernel(const crx_game_kparam
 // ------------------------------------------------------------------------------------------------
 // Dispatch order (include/crx.h, "Dispatch order").  A key of 257 values per problem, key 0 dispatched first:
 //   mode 0  255 - min(iterations of the previous solve, 255)              (longest first)
-//   mode 1  from the smallest barrier value h of the START state over the problem's obstacles: inside a safety ellipse
-//           (h < 0: the NLP that needs the restoration phase; BASELINE configs[3] draw: 38 iterations on average, 16 outside)
-//           128 linear steps of h + 1 + margin, outside 4.25 steps per doubling of 1 + h (3 % in distance at degree 6)
+//   mode 1  with no previous solve, from the barrier h = (ds/l)^degree + (dey/w)^degree - 1 - margin of two cheap guesses
+//           (BASELINE configs[3] draw, iterations by class: 38 / 21 / 14 / 12 on average):
+//           0..127    the START state is inside a safety ellipse (h0 < 0: the NLP that needs the restoration phase), deepest first;
+//           128..191  the un-steered PATH -- s_j = s_0 + j A[4][0] vx_0 along the target ey_j -- enters one (hP < 0), deepest first;
+//           192..255  neither: 2.1 steps per doubling of 1 + hP, nearest first.
 //   256     masked-out problems (active[b] == 0): they return at once, last.
 // crx_order_key_kernel (mode 1, one thread per problem, the whole chip) leaves the keys in order[]; crx_order_kernel -- ONE
 // workgroup of 16 waves -- sorts the batch by key with a STABLE counting sort (wave w owns a contiguous segment; ranks inside a
@@ -635,7 +637,22 @@ __device__ __forceinline__ int crx_order_key(const crx_order_kparams& op, int b)
         hmin = fmin(hmin, ps + pe - 1.0 - op.margin);
     }
     if (hmin < 0.0) return min(max((int)((hmin + 1.0 + op.margin) * (128.0 / (1.0 + op.margin))), 0), 127);
-    const double t = 128.0 + 4.25 * log2(1.0 + hmin);      // 255 at h = 1e9: an obstacle ~30 ellipse lengths away
+    const double vx = op.x0[(size_t)b * 6];
+    double hp = 1e30;
+    for (int j = 0; j < op.stride; j++) {
+        const double sj = s + (double)j * op.ds_per_vx * vx;
+        const double eyj = op.per_stage_target ? op.xt[((size_t)b * op.stride + j) * 6 + 5] : op.xt[(size_t)b * 6 + 5];
+        for (int o = 0; o < n; o++) {
+            const size_t r = (size_t)b * V + o;
+            const double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+            const double ds = (op.obs_s[r * op.stride + j] + op.lap_off[r] - sj) / ls, de = (op.obs_ey[r * op.stride + j] - eyj) / ws;
+            double ps = ds * ds, pe = de * de;
+            for (int k = 2; k < op.degree; k += 2) { ps *= ds * ds; pe *= de * de; }
+            hp = fmin(hp, ps + pe - 1.0 - op.margin);
+        }
+    }
+    if (hp < 0.0) return 128 + min(max((int)((hp + 1.0 + op.margin) * (64.0 / (1.0 + op.margin))), 0), 63);
+    const double t = 192.0 + 2.1 * log2(1.0 + hp);         // 255 at hP = 1e9: an obstacle ~30 ellipse lengths off the path
     return t < 255.0 ? (int)t : 255;
 }
 

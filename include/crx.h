@@ -556,15 +556,17 @@ int crx_cbf_solve_ordered_dev(const crx_cbf_desc* d, int batch, const int32_t* a
 /* The order itself, computed on the device (one launch, a stable counting sort; equal keys keep index order):
  *   crx_order_longest_first_dev  from the iteration counts of the previous solve of these problems (iters [batch], e.g. the iters
  *                                output of the previous control step), longest first;
- *   crx_cbf_order_dev            with no previous solve: by the smallest barrier value of the START state over the problem's
- *                                obstacles, h = (ds/l)^degree + (dey/w)^degree - 1 - margin at stage 0 (control.py:529-537), ascending --
- *                                the car that starts inside or beside a safety ellipse is the NLP that needs most iterations.
- * Problems with active[b] == 0 go last (active may be NULL).  Measured on BASELINE configs[3] (16384 NLPs, one launch):
- * index order 24.9 ms, crx_cbf_order_dev 19.5 ms, crx_order_longest_first_dev 16.6 ms. */
+ *   crx_cbf_order_dev            with no previous solve, from the problem's own inputs (the arrays of crx_cbf_solve_dev): the
+ *                                barrier h = (ds/l)^degree + (dey/w)^degree - 1 - margin (control.py:529-537) of the START state
+ *                                and of the un-steered PATH (s_0 + j A[4][0] vx_0 along the target ey).  First the cars that start
+ *                                inside a safety ellipse (deepest first: the NLPs that need the restoration phase), then those
+ *                                whose path enters one, then the rest, nearest first.
+ * Problems with active[b] == 0 go last (active may be NULL).  Measured on BASELINE configs[3] (16384 NLPs, one launch): DESIGN.md
+ * section 5.6. */
 int crx_order_longest_first_dev(int batch, const int32_t* iters, const int32_t* active, int32_t* order, void* stream);
-int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* obs_s,
-                      const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, int32_t* order,
-                      void* stream);
+int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, const double* x0, const double* xt,
+                      const double* obs_s, const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims,
+                      int32_t* order, void* stream);
 int crx_lmpc_solve_ordered_dev(const crx_lmpc_desc* d, int batch, const int32_t* active, const int32_t* order, const double* x0,
                                const double* u_old, const double* A, const double* B, const double* C, const double* ss,
                                const double* qfun, const int32_t* n_ss, double* X, double* U, double* lambda, double* cost,

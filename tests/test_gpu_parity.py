@@ -1018,36 +1018,35 @@ def test_dispatch_order_is_bit_identical(gpu, golden_racing_game, AB):
     n_on = int((act != 0).sum().item())
     assert sorted(omc.tolist()) == list(range(3000)) and (act.cpu().numpy()[omc[:n_on]] != 0).all() and (np.diff(itc[omc[:n_on]]) <= 0).all()
     torch_api.cbf_solve_dev(d, *a, ws=wm, active=act, order=om)
-    # the order with no previous solve: ascending start barrier, a permutation, stable (checked against numpy on the same key)
-    op = torch_api.cbf_order_dev(d, a[0], a[2], a[3], a[4], a[5]).cpu().numpy()
-    ds = (p["obs_s"][:, :, 0] + p["lap_off"] - p["x0"][:, 4:5]) / d.l_sum
-    de = (p["obs_ey"][:, :, 0] - p["x0"][:, 5:6]) / d.w_sum
-    h = np.where(np.arange(3)[None, :] < p["n_obs"][:, None], ds ** d.degree + de ** d.degree - 1.0 - d.margin, 1e30).min(axis=1)
-    hc = np.minimum(h, 1e12)
-    key = np.where(h < 0, np.clip(((np.minimum(h, 0.0) + 1.0 + d.margin) * (128.0 / (1.0 + d.margin))).astype(np.int64), 0, 127),
-                   np.minimum(128.0 + 4.25 * np.log2(1.0 + np.maximum(hc, 0.0)), 255.0).astype(np.int64))
-    assert sorted(op.tolist()) == list(range(3000))
-    assert (np.diff(key[op]) >= 0).sum() >= 2990            # a key on a bucket edge may round differently on the device: a handful at most
-    assert (h < 0).sum() > 10 and (h[op[:(h < 0).sum()]] < 0).all()   # the cars that start inside a safety ellipse come first
+    # the order with no previous solve (crx_cbf_order_dev): a permutation; cars that start inside a safety ellipse first (deepest
+    # first), then those whose un-steered path enters one, then the rest -- checked against numpy on the same two barriers
+    op = torch_api.cbf_order_dev(d, *a).cpu().numpy()
+    live = np.arange(3)[None, :] < p["n_obs"][:, None]
+
+    def barrier(j, s, ey):
+        ds = (p["obs_s"][:, :, j] + p["lap_off"] - s[:, None]) / d.l_sum
+        de = (p["obs_ey"][:, :, j] - ey[:, None]) / d.w_sum
+        return np.where(live, ds ** d.degree + de ** d.degree - 1.0 - d.margin, 1e30).min(axis=1)
+    h0 = barrier(0, p["x0"][:, 4], p["x0"][:, 5])
+    hp = np.min([barrier(j, p["x0"][:, 4] + j * A[4, 0] * p["x0"][:, 0], p["xt"][:, j, 5]) for j in range(21)], axis=0)
+    cls = np.where(h0 < 0, 0, np.where(hp < 0, 1, 2))
+    assert sorted(op.tolist()) == list(range(3000)) and min((cls == c).sum() for c in range(3)) > 10
+    assert (np.diff(cls[op]) < 0).sum() <= 3                 # a barrier within rounding of 0 may change class on the device
+    n0 = int((cls == 0).sum())
+    k0 = ((np.minimum(h0, 0.0) + 1.0 + d.margin) * (128.0 / (1.0 + d.margin))).astype(np.int64)
+    assert (np.diff(k0[op[:n0 - 3]]) >= 0).sum() >= n0 - 10  # inside: 128 linear steps of h0, ascending
     wp = torch_api.cbf_solve_dev(d, *a, order=torch.from_numpy(op).to(dev))
     np.testing.assert_array_equal(wp.X.cpu().numpy(), full.X.cpu().numpy())
-    # beyond the LDS key cache (65536 problems) the sort evaluates the key twice: same order as the cached path on the same keys
+    # beyond the LDS key cache (65536 problems) the sort evaluates the key twice: same order as numpy on the same keys
     rep = 24
     big_it = full.iters.repeat(rep)
     ob = torch_api.longest_first(big_it).cpu().numpy()
     np.testing.assert_array_equal(ob, np.argsort(-np.minimum(big_it.cpu().numpy(), 255), kind="stable"))
-    big = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in (a[0], a[2], a[3], a[4], a[5])]
+    big = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in a]
     opb = torch_api.cbf_order_dev(d, *big).cpu().numpy()
     assert sorted(opb.tolist()) == list(range(3000 * rep))
-    assert (np.diff(key[opb % 3000]) >= 0).sum() >= 3000 * rep - 10 * rep
-    small = torch_api.cbf_order_dev(d, *[x[:60000].contiguous() for x in big]).cpu().numpy()      # cached path
-    kd = lambda o: key[o % 3000]   # noqa: E731
-    first = np.searchsorted(kd(small), 128)               # device keys: identical code in both paths, so the inside-ellipse block
-    assert (h[small[:first] % 3000] < 0).all() and (h[opb[:first] % 3000] < 0).all()
-    on = act.cpu().numpy() != 0
-    assert (wm.status.cpu().numpy()[~on] == abi.CRX_SKIPPED).all() and (wm.X.cpu().numpy()[~on] == -7.0).all()
-    for k in ("X", "U", "cost", "status", "iters", "kkt"):
-        np.testing.assert_array_equal(getattr(wm, k).cpu().numpy()[on], getattr(full, k).cpu().numpy()[on])
+    small = torch_api.cbf_order_dev(d, *[x[:60000].contiguous() for x in big]).cpu().numpy()      # cached path, same key code
+    np.testing.assert_array_equal(small, opb[opb < 60000])
     # learning-MPC QP
     dl, al = helpers.lmpc_inputs(golden_racing_game)
     n = al[0].shape[0]

@@ -56,7 +56,7 @@ orders = {"index": None, "longest_first(previous iters)": torch_api.longest_firs
           "random permutation": torch.from_numpy(np.random.default_rng(1).permutation(n).astype(np.int32)).to(dev)}
 for name, o in orders.items():
     print("%-46s %.3f ms per launch of %d" % (name, run(o), n))
-orders = {"crx_order_longest_first_dev": lambda: torch_api.longest_first(it), "crx_cbf_order_dev": lambda: torch_api.cbf_order_dev(d, a[0], a[2], a[3], a[4], a[5]),
+orders = {"crx_order_longest_first_dev": lambda: torch_api.longest_first(it), "crx_cbf_order_dev": lambda: torch_api.cbf_order_dev(d, *a),
           "torch: key + argsort": lambda: torch.argsort(prior_key(), stable=True).to(torch.int32)}
 for name, f in orders.items():
     o = f()
