@@ -55,7 +55,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "car-racing_amd", "csrc")
-    for f in ("crx_kernels.hip", "crx_wave.h", "Makefile"):
+    for f in ("crx_kernels.hip", "crx_kernels_obs.hip", "crx_wave.h", "Makefile"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

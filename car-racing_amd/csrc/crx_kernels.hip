@@ -1057,8 +1057,11 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
 // spills then; make EXTRA=-DCRX_PLANNER_WAVES=1 restores the uncapped build.)
 #define CRX_PLANNER_WAVES 3
 #endif
+#ifndef CRX_OBS1_WAVES
+#define CRX_OBS1_WAVES 2
+#endif
 template <int NOBS, int NMAX> struct MinWaves {
-    static constexpr int v = ((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? 2 : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
+    static constexpr int v = ((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? CRX_OBS1_WAVES : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
 };
 
 template <int NOBS, int NMAX>
@@ -1675,6 +1678,12 @@ crx_solve_kernel(const crx_kparams kp) {
     if (lane == 0) { kp.status[b] = status; kp.kkt[b] = E0; kp.iters[b] = it; }
 }
 
+// This file is compiled TWICE (Makefile): as it stands for the planner instantiations <0, *> and everything else in it, and
+// through crx_kernels_obs.hip (CRX_TU_OBSTACLES) for the obstacle instantiations <1..3, *> alone -- with the machine scheduler's
+// iterative-ilp strategy, which is worth +3.7 % on BASELINE configs[1] (0.991 -> 0.956 ms per 256 NLPs) and +7 % on configs[3] to
+// the obstacle kernels and costs the planner kernels 1 % (tools/gpu_round3_l.sh: max-ilp, max-memory-clause, iterative-minreg
+// and the occupancy / latency bias were measured beside it).  Same arithmetic either way: the schedule does not re-associate.
+#ifndef CRX_TU_OBSTACLES
 // ------------------------------------------------------------------------------------------------
 // (6) region selection (planning/overtake_traj_planner.py:205-246): one wave per scenario, lanes
 // over (side, stage) collision tests.
@@ -1714,6 +1723,8 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
     for (int e = lane; e < (N + 1) * 6; e += WAVE) sp.best_X[(size_t)s * (N + 1) * 6 + e] = Xb[e];
 }
 
+#endif  // !CRX_TU_OBSTACLES
+
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
@@ -1742,15 +1753,24 @@ static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
     return launch_t<NOBS, CRX_MAX_N>(kp, st);
 }
 
-hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st) {
-    if (kp.batch == 0) return hipSuccess;
+// the obstacle instantiations live in the other translation unit
+hipError_t crx_launch_solve_obs(const crx_kparams& kp, int nobs_template, hipStream_t st);
+int crx_solve_resident_per_cu_obs(int N, int nobs_template);
+
+#ifdef CRX_TU_OBSTACLES
+hipError_t crx_launch_solve_obs(const crx_kparams& kp, int nobs_template, hipStream_t st) {
     switch (nobs_template) {
-        case 0: return launch_n<0>(kp, st);
         case 1: return launch_n<1>(kp, st);
         case 2: return launch_n<2>(kp, st);
         case 3: return launch_n<3>(kp, st);
         default: return hipErrorInvalidValue;
     }
+}
+#else
+hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st) {
+    if (kp.batch == 0) return hipSuccess;
+    if (nobs_template == 0) return launch_n<0>(kp, st);
+    return crx_launch_solve_obs(kp, nobs_template, st);
 }
 
 size_t crx_solve_lds_bytes(int N, int nobs_template) {
@@ -1762,6 +1782,8 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
         default: return small ? Lay<3, 12>::BYTES : (N <= 20 ? Lay<3, 20>::BYTES : Lay<3, CRX_MAX_N>::BYTES);
     }
 }
+
+#endif  // CRX_TU_OBSTACLES
 
 // resident single-wave workgroups per CU of the instantiation that would run (N, nobs_template): the runtime's
 // answer, i.e. min over the LDS and the register file
@@ -1779,13 +1801,17 @@ static int occ_n(int N) {
     if (NOBS == 3 && N <= 20) return occ_t<3, 20>();
     return occ_t<NOBS, CRX_MAX_N>();
 }
-int crx_solve_resident_per_cu(int N, int nobs_template) {
+#ifdef CRX_TU_OBSTACLES
+int crx_solve_resident_per_cu_obs(int N, int nobs_template) {
     switch (nobs_template) {
-        case 0: return occ_n<0>(N);
         case 1: return occ_n<1>(N);
         case 2: return occ_n<2>(N);
         default: return occ_n<3>(N);
     }
+}
+#else
+int crx_solve_resident_per_cu(int N, int nobs_template) {
+    return nobs_template == 0 ? occ_n<0>(N) : crx_solve_resident_per_cu_obs(N, nobs_template);
 }
 
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st) {
@@ -1820,3 +1846,4 @@ hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st
     hipLaunchKernelGGL(crx_debug_reduce_kernel, dim3(1), dim3(WAVE), 0, st, in, out);
     return hipGetLastError();
 }
+#endif  // !CRX_TU_OBSTACLES
