@@ -92,7 +92,13 @@ __device__ __forceinline__ bool lp_solve5(double (&Q)[5][5], double (&rhs)[NRHS]
 // wavefront fence) until the status word is collected.  One wave per race left a CU with two or three waves in flight,
 // each running 12 stages of dependent LDS round trips one after the other: 1.15 ms per 1024 races; with four waves
 // per race (three stages each, eight waves per CU) the same arithmetic, bit for bit, takes a third of that.
+// [r3] More waves per race were measured again (tools/gpu_round3_o.sh, 4096 races, the kernel alone): 6 -> 1.15 ms, 8 -> 1.08,
+// 12 (one stage per wave, one 129 KB workgroup per CU) -> 0.75, 16 -> 0.88 against 0.875 ms here; the twelve-wave build moves a
+// closed-loop step by 1 % (3.32 -> 3.27 ms learning-MPC laps, racing game unchanged: the big workgroup overlaps less with the
+// other stream's kernels) and idles waves for N < 12 -- left at four.
+#ifndef LP_WAVES
 #define LP_WAVES 4
+#endif
 #define LP_WAVE_DOUBLES(P_) ((size_t)(P_) + 2 * LP_MAXNB + 48 + LP_MAXNB /* isel: 2*MAXNB ints */)
 
 __global__ void __launch_bounds__(WAVE * LP_WAVES) crx_lmpc_prep_kernel(const crx_lmpcprep_kparams kp) {
