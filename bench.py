@@ -670,7 +670,7 @@ def main():
     ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
-    ap.add_argument("--race-streams", type=int, default=2,
+    ap.add_argument("--race-streams", type=int, default=4,
                     help="closed-loop workloads (races, game, overtake): independent sub-batches of the races on this many HIP streams (1 = one batch)")
     ap.add_argument("--dispatch", default="auto", choices=["auto", "index", "longest_first", "start_barrier"],
                     help="workgroup -> problem mapping of the solver launches (crx_*_solve_ordered_dev): index = launch order; longest_first = "

@@ -52,16 +52,31 @@ class Concurrent:
     MpccbfRaces / LmpcLaps / GameLaps objects over disjoint slices of the races; step() issues one control step of every part and
     returns without waiting; call torch.cuda.synchronize() (or sync()) before reading results.
     Streams only overlap when they sit on different HARDWARE queues: the HIP runtime multiplexes a process's streams onto
-    GPU_MAX_HW_QUEUES of them (default 4) and streams sharing one serialise.  Two sub-batches of GameLaps are six streams: set
-    GPU_MAX_HW_QUEUES=8 in the environment before the runtime initialises (bench.py does).  Measured, 4096 races per step
-    (tools/gpu_round3_i.sh): races 0.784 -> 0.687 ms, learning-MPC laps 3.82 -> 3.31 ms, racing game 3.56 -> 3.25 ms with two
-    sub-batches and 8 queues; with 4 queues the racing game LOSES (3.97 ms: its two branch streams collide)."""
+    GPU_MAX_HW_QUEUES of them (default 4) and streams sharing one serialise -- two sub-batches on one queue are SLOWER than one
+    batch.  Which streams share is not ours to choose and, with torch's stream pool, depended on how many streams the process
+    had handed out before (3.24 .. 5.6 ms per racing-game step: tools/stream_offset_probe.py), so the streams are libcrx's:
+    crx_streams_create measures which of its candidates overlap and returns a set that does (include/crx.h "Streams").  Two
+    sub-batches of GameLaps want six (one each + the two branch streams of each): set GPU_MAX_HW_QUEUES=8 in the environment
+    before the runtime initialises (bench.py does); with fewer queues than that the parts run their branches one after the
+    other on their sub-batch stream.  Measured, 4096 races per step (tools/gpu_round3_i.sh): races 0.784 -> 0.687 ms,
+    learning-MPC laps 3.82 -> 3.31 ms, racing game 3.56 -> 3.25 ms with two sub-batches and 8 queues."""
 
-    def __init__(self, parts, device=None):
+    def __init__(self, parts, device=None, streams=None):
         self.parts = list(parts)
         dev = torch.device(device if device is not None else "cuda")
         self.device = dev
-        self.streams = [torch.cuda.Stream(device=dev) for _ in self.parts]
+        K = len(self.parts)
+        inner = [p for p in self.parts if hasattr(p, "set_branch_streams")]
+        if streams is not None:            # the caller's streams (K, or K + 2 per GameLaps part), taken as they are
+            self.n_concurrent = len(streams)
+        else:
+            streams, self.n_concurrent = torch_api.new_streams(K + 2 * len(inner), dev)   # the first n_concurrent overlap pairwise
+        self.streams = streams[:K]
+        for i, part in enumerate(inner):
+            if K == 1 or self.n_concurrent >= K + 2 * len(inner):
+                part.set_branch_streams(streams[K + 2 * i], streams[K + 2 * i + 1])
+            else:                          # not enough hardware queues for nested streams: branches in sequence on the part's stream
+                part.overlap = False
         cur = torch.cuda.current_stream(dev)
         for st in self.streams:            # whatever set the parts up on the caller's stream comes first
             st.wait_stream(cur)
@@ -377,7 +392,8 @@ class GameLaps:
         self.overflow_seen = torch.zeros((Bn,), **i32)    # scene overflow (more vehicles of interest than slots), accumulated
         # the two branches of a step are independent until the commit: their kernels go to two HIP streams and overlap (the
         # masked launches of a branch leave part of the chip idle: a third of the races plan and track, the rest regress and solve)
-        self.s_ot, self.s_lm = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.s_ot = self.s_lm = None   # set_branch_streams, or two of libcrx's at the first step
+        self.overlap = True            # False: both branches on the caller's stream, one after the other
         self.t = 0.0
 
     def step(self):
@@ -388,7 +404,7 @@ class GameLaps:
         torch_api.planner_scene_dev(self.scene, lm.xc, self.n_all, self.veh, self.pred_s, self.pred_e, ws=self.sws)
         torch_api.game_masks_dev(self.sws.n_veh, self.m_ot, self.m_lm, overflow=self.sws.overflow, overflow_seen=self.overflow_seen)
         self.overtake = self.m_ot                                  # int32 mask; bool(overtake[b]) = race b is in the overtake branch
-        self._branches(self.m_ot, self.m_lm, overlap=True)
+        self._branches(self.m_ot, self.m_lm, overlap=self.overlap)
         torch_api.game_commit_dev(N, self.Np, self.m_ot, self.tws.U, lm.ws.X, lm.ws.U, self.selws.flag, self.u, lm.u_old, lm.u_prev,
                                   self.lin_points, self.lin_input, lm.step_no, lm.addpoint_step, self.old_flag)
         torch_api.lmpc_addpoint_dev(lm.pdesc, lm.ss, lm.us, lm.time_ss, lm.it, lm.addpoint_step, lm.xc, self.u, 2)
@@ -398,9 +414,17 @@ class GameLaps:
         self.t += lm.timestep
         lm.log_and_handover(self.u)
 
+    def set_branch_streams(self, s_ot, s_lm):
+        """The two streams the branches of a step run on (crx.montecarlo.Concurrent hands out streams it measured to overlap)."""
+        self.s_ot, self.s_lm = s_ot, s_lm
+
     def _branches(self, m_ot, m_lm, overlap=False):
         """The solver launches of both branches (masked: every race runs its own branch's kernels only); overlap: each branch
         on its own stream, forked from and joined to the current one."""
+        if overlap and self.s_ot is None:
+            (self.s_ot, self.s_lm), nc = torch_api.new_streams(2, self.lm.xc.device)
+            if nc < 2:
+                overlap = self.overlap = False
         if overlap:
             cur = torch.cuda.current_stream(self.lm.xc.device)
             self.s_ot.wait_stream(cur); self.s_lm.wait_stream(cur)

@@ -41,6 +41,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", _state["device"])).cuda_stream)
 
 
+def new_streams(n, device=None):
+    """crx_streams_create: n HIP streams of which the first `n_concurrent` were MEASURED to sit on pairwise different hardware
+    queues (torch's own stream pool gives no such guarantee: include/crx.h "Streams"), wrapped as torch.cuda.ExternalStream.
+    Returns (streams, n_concurrent).  They live as long as the process."""
+    binding()
+    arr = (C.c_void_p * n)()
+    nc = C.c_int(0)
+    _call("crx_streams_create", C.c_int(n), arr, C.byref(nc))
+    dev = torch.device("cuda", _state["device"]) if device is None else torch.device(device)
+    return [torch.cuda.ExternalStream(int(arr[i]), device=dev) for i in range(n)], int(nc.value)
+
+
 class CbfWorkspace:
     """Pre-allocated outputs for repeated cbf_solve_dev calls of one shape."""
 

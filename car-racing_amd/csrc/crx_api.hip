@@ -11,6 +11,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -1307,6 +1308,76 @@ int crx_comm_init_rank(const void* id, int world, int rank) {
     RCCL_TRY(g_rccl.CommInitRank(&g_comm, world, uid, rank));
     g_world = world; g_rank = rank;
     return CRX_OK;
+}
+
+// one wavefront that keeps a CU busy for `ticks` of the constant 100 MHz clock: two of them on two streams finish in the time of
+// one if, and only if, the streams sit on different hardware queues
+__global__ void __launch_bounds__(64) crx_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+static double spin_ms(hipStream_t a, hipStream_t b, long long ticks) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(crx_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    if (b) hipLaunchKernelGGL(crx_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipStreamSynchronize(a);
+    if (b) (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int crx_streams_create(int n, void** streams, int* n_concurrent) {
+    if (int rc = ensure_init()) return rc;
+    if (n < 0 || n > 64 || (n > 0 && !streams)) return fail(CRX_ERR_ARG, "bad stream count / NULL array");
+    if (n_concurrent) *n_concurrent = 0;
+    if (n == 0) return CRX_OK;
+    HIP_TRY(hipSetDevice(g_device));
+    // candidates: more than asked for, so that a set of n on pairwise different queues can be picked (if the runtime has that many)
+    const int m = n + 8;
+    std::vector<hipStream_t> cand(m, nullptr);
+    for (int i = 0; i < m; i++) {
+        hipError_t e = hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (int j2 = 0; j2 < i; j2++) (void)hipStreamDestroy(cand[j2]);
+            return fail(CRX_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+        }
+    }
+    const long long ticks = 15000;   // 150 us
+    for (int i = 0; i < m; i++) (void)spin_ms(cand[i], nullptr, 100);   // first use: the runtime binds the queue, the kernel is loaded
+    double single = 1e30;
+    for (int i = 0; i < m; i++) single = fmin(single, spin_ms(cand[i], nullptr, ticks));
+    // greedy: a stream joins the set if a pair of spins with every member takes the time of one (twice measured, the faster counts)
+    std::vector<int> pick;
+    for (int i = 0; i < m && (int)pick.size() < n; i++) {
+        bool ok = true;
+        for (int p : pick) {
+            const double t = fmin(spin_ms(cand[p], cand[i], ticks), spin_ms(cand[p], cand[i], ticks));
+            if (t > 1.6 * single) { ok = false; break; }
+        }
+        if (ok) pick.push_back(i);
+    }
+    const int nc = (int)pick.size();
+    std::vector<char> used(m, 0);
+    for (int p : pick) used[p] = 1;
+    for (int i = 0; i < m && (int)pick.size() < n; i++)      // fewer queues than streams asked for: the rest share
+        if (!used[i]) { pick.push_back(i); used[i] = 1; }
+    for (int i = 0; i < n; i++) streams[i] = (void*)cand[pick[i]];
+    for (int i = 0; i < m; i++)
+        if (!used[i]) (void)hipStreamDestroy(cand[i]);
+    if (n_concurrent) *n_concurrent = nc;
+    return CRX_OK;
+}
+
+int crx_streams_destroy(int n, void** streams) {
+    if (n < 0 || (n > 0 && !streams)) return fail(CRX_ERR_ARG, "bad stream count / NULL array");
+    int rc = CRX_OK;
+    for (int i = 0; i < n; i++) {
+        if (!streams[i]) continue;
+        (void)hipStreamSynchronize((hipStream_t)streams[i]);
+        if (hipStreamDestroy((hipStream_t)streams[i]) != hipSuccess) rc = fail(CRX_ERR_HIP, "hipStreamDestroy failed");
+        streams[i] = nullptr;
+    }
+    return rc;
 }
 
 int crx_comm_world(void) { return g_comm ? g_world : 0; }

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
-                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order); additions
+                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*; additions
                           only, every 0.1.2 entry point unchanged
                           (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
                            0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
@@ -634,6 +634,22 @@ int crx_comm_rank(void);    /* -1 without a communicator */
 int crx_comm_destroy(void);
 int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const double* best_X, double* send,
                               double* recv, void* stream);
+
+/* Streams for device-resident loops that overlap independent launches (the two branches of a racing-game step, concurrent
+ * sub-batches of races: crx.montecarlo).  Streams only overlap when they sit on different HARDWARE queues; the HIP runtime hands
+ * its GPU_MAX_HW_QUEUES queues (default 4; set the variable before the process touches the GPU) to streams round-robin IN
+ * CREATION ORDER.  A framework's stream pool is created interleaved with streams the caller never sees (PyTorch: low- and
+ * high-priority pool entries alternate), so consecutive pool streams share queues in a pattern that depends on what the process
+ * did before: measured on the 4096-race racing game with two sub-batches, 3.24 ms per step or 3.5 / 3.8 / 4.6 ms depending only
+ * on how many pool streams had been handed out earlier (tools/stream_offset_probe.py; which streams share a queue is not a
+ * simple function of the creation order either: tools/queue_probe.py).  crx_streams_create therefore MEASURES: it creates n + 8
+ * non-blocking streams on the device of crx_init, runs pairs of 150 us single-wavefront spin kernels on them (two streams on
+ * different queues finish a pair in the time of one kernel, two on the same queue in the time of two) and returns n streams of
+ * which the first *n_concurrent were seen to overlap pairwise (all n when the runtime has that many queues; the rest share);
+ * the other candidates are destroyed.  About 30 ms, once.  Pass them as the `stream` argument of the *_dev entry points
+ * (PyTorch: torch.cuda.ExternalStream).  crx_streams_destroy synchronises and destroys them. */
+int crx_streams_create(int n, void** streams /* [n] out */, int* n_concurrent /* out, may be NULL */);
+int crx_streams_destroy(int n, void** streams);
 
 /* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
  * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this.

@@ -571,3 +571,21 @@ def test_concurrent_sub_batches_are_bit_identical(AB, golden_racing_game):
     assert torch.equal(conc.cat(lambda p: p.lm.xc), whole.lm.xc) and torch.equal(conc.cat(lambda p: p.old_flag), whole.old_flag)
     assert torch.equal(conc.cat(lambda p: p.lm.ss), whole.lm.ss) and torch.equal(conc.cat(lambda p: p.lm.laps), whole.lm.laps)
     assert int((whole.lm.laps >= 1).sum()) >= Bn // 3
+
+
+def test_streams_create():
+    """crx_streams_create: n distinct usable streams, the first n_concurrent of them measured to overlap pairwise (at least two
+    with any GPU_MAX_HW_QUEUES >= 2); work issued on them is ordinary stream work."""
+    import crx
+    import torch
+    from crx import torch_api
+    crx.init()
+    streams, nc = torch_api.new_streams(5)
+    assert len(streams) == 5 and len({s.cuda_stream for s in streams}) == 5 and 2 <= nc <= 5
+    outs = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            outs.append(torch.arange(1000, device="cuda", dtype=torch.float64).cumsum(0))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert float(o[-1]) == 999 * 1000 / 2
