@@ -337,7 +337,7 @@ def make_races(cx, args, batch=None):
                                                           order=montecarlo._order(r, r.ws.iters))) for r in parts]
     w.name = ("closed-loop MPC-CBF races (tests/auto_mpccbf_test.py scenario family): %d races per GPU, one control step of every race per "
               "step (predictions, window filter, NLP N=10 with 2 scripted cars, plant); %d sub-batches on %d HIP streams" % (w.batch, len(parts), len(parts)))
-    w.extra = {"race_streams": len(parts), "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
+    w.extra = {"race_streams": len(parts), "kernel_ms_is": "sum of the sub-batch launches of one step, each timed alone (in the step they overlap)", "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     return w
 
 
@@ -376,7 +376,7 @@ def make_game(cx, args, batch=None):
     w.name = ("learning-MPC laps of the racing game (tests/auto_racing_game_test.py lap 3): %d races per GPU from the reference's recorded safe "
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
     w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full",
-               "race_streams": len(parts), "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
+               "race_streams": len(parts), "kernel_ms_is": "sum of the sub-batch launches of one step, each timed alone (in the step they overlap)", "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     return w
 
 
@@ -421,7 +421,7 @@ def make_overtake(cx, args, batch=None):
               "scripted cars each (the reference's random traffic), one control step of every race per step: scene, Bezier/bounds, 4 region QPs + "
               "selection, tracking NLP (N=10, CBF rows), "
               "12 regressions + LMPC QP, add_point, plant -- masked launches, every race runs its own branch" % Bn)
-    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch", "race_streams": len(parts),
+    w.extra = {"note": "status / iteration fields describe the tracking NLP of the overtake branch", "race_streams": len(parts), "kernel_ms_is": "sum of the sub-batch launches of one step, each timed alone (in the step they overlap)",
                "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     # the scene stage keeps at most CRX_MAX_OBS vehicles of interest per race (the nearest): how often were there more?
     w.post = lambda: {"scene_overflow_races": int(sum((g.overflow_seen > 0).sum().item() for g in parts))}
