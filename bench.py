@@ -677,6 +677,8 @@ def main():
                          "the problems whose previous solve took most iterations first (crx_order_longest_first_dev: what a closed loop has); "
                          "start_barrier (cfg2 / cfg4) = from the problem's own inputs, no previous solve needed (crx_cbf_order_dev); auto = "
                          "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
+    ap.add_argument("--no-reach-screen", action="store_true",
+                    help="planner QPs: switch the reachability screen off (crx_set_reach_screen(0)): every region goes through the interior-point iteration")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
@@ -704,6 +706,8 @@ def main():
             dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
         import crx
         crx.init(cx.local)
+        if args.no_reach_screen:
+            crx.lib().crx_set_reach_screen(0)
     from crx import dist as cdist
     cdist.COLLECTIVE = args.collective
     if args.force_collective:

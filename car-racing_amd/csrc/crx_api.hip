@@ -171,6 +171,8 @@ void timing_end(hipStream_t st) {
     g_ev_valid = g_ev_valid && hipEventRecord(g_ev1, st) == hipSuccess;
 }
 
+int g_reach_screen = 1;   // crx_set_reach_screen
+
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
         !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0))
@@ -191,6 +193,21 @@ int fill_planner(crx_kparams& kp, const crx_planner_desc* d, int batch) {
     kp.delta_max = d->delta_max; kp.a_max = d->a_max; kp.v_min = -INFINITY; kp.v_max = d->vx_max; kp.ey_max = INFINITY;
     kp.alpha = 0.0; kp.margin = 0.0; kp.l_sum = 1.0; kp.w_sum = 1.0;
     kp.dt_ref = d->dt_ref; kp.fallback_gain = d->fallback_gain; kp.opts = d->opts;
+    // reachability screen (crx_kernels.hip, set-up): reach_gain[j] = sum_{m < j} |e_ey' A^m B| (delta_max, a_max)'
+    kp.reach_screen = g_reach_screen;
+    double w[6] = {0, 0, 0, 0, 0, 1}, acc = 0.0;
+    kp.reach_gain[0] = 0.0;
+    memcpy(kp.reach_row[0], w, sizeof(w));
+    for (int j = 1; j < d->N; j++) {
+        double v0 = 0.0, v1 = 0.0, wn[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) { v0 += w[i] * d->B[i * 2]; v1 += w[i] * d->B[i * 2 + 1]; }
+        acc += fabs(v0) * d->delta_max + fabs(v1) * d->a_max;
+        kp.reach_gain[j] = acc;
+        for (int a = 0; a < 6; a++)
+            for (int i = 0; i < 6; i++) wn[a] += w[i] * d->A[i * 6 + a];
+        memcpy(w, wn, sizeof(w));
+        memcpy(kp.reach_row[j], w, sizeof(w));
+    }
     return 0;
 }
 
@@ -341,6 +358,8 @@ double crx_last_kernel_ms(void) {
     if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
     return (double)ms;
 }
+
+void crx_set_reach_screen(int enable) { g_reach_screen = enable ? 1 : 0; }
 
 void crx_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;

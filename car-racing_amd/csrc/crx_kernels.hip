@@ -1038,6 +1038,37 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
     return changed;
 }
 
+// The planner's answer for a region whose QP has no solution: the reference's fall-back trajectory
+// (overtake_traj_planner.py:365-374), zero inputs, cost +inf.
+// The reference builds it from the start-line-WRAPPED ego state xcurv_ego (:366-369) although the QP's x_0 is the raw
+// ego.xcurv (quirk Q5).  Only s differs between the two, and the wrapped s is the first Bezier control point
+// (planner_helper.py:49; the Bernstein weights at t = 0 are exactly 1, 0, 0, 0), so it is read from there.
+template <class L>
+__device__ __forceinline__ void planner_fallback(double* sm, const crx_kparams& kp, int b, int lane, int N) {
+    double* Xb = kp.X + (size_t)b * (N + 1) * 6;
+    double* Ub = kp.U + (size_t)b * N * 2;
+    const double vx0 = kp.x0[(size_t)b * 6];
+    double* bs = sm + L::hg;
+    double* be = sm + L::Hd;
+    for (int j = lane; j <= N; j += WAVE) {
+        bs[j] = kp.bez_s[(size_t)b * (N + 1) + j];
+        be[j] = kp.bez_ey[(size_t)b * (N + 1) + j];
+    }
+    SYNC();
+    const double s0 = bs[0];
+    for (int e = lane; e < (N + 1) * 6; e += WAVE) {
+        const int j = e / 6, i = e - j * 6;
+        const double st = s0 + kp.fallback_gain * j * kp.dt_ref * vx0;
+        double v = 0.0;
+        if (i == 0) v = kp.fallback_gain * vx0;
+        else if (i == 4) v = st;
+        else if (i == 5) v = interp_lin(bs, be, N + 1, fmin(fmax(st, bs[0]), bs[N]));
+        Xb[e] = v;
+    }
+    for (int e = lane; e < N * 2; e += WAVE) Ub[e] = 0.0;
+    if (lane == 0) kp.cost[b] = INFINITY;
+}
+
 // ------------------------------------------------------------------------------------------------
 // (5) the solver kernel
 // ------------------------------------------------------------------------------------------------
@@ -1079,6 +1110,29 @@ crx_solve_kernel(const crx_kparams kp) {
     if (kp.active && kp.active[kp.active_div > 1 ? b / kp.active_div : b] == 0) {   // masked launch: this problem is not part of it
         if (lane == 0) { kp.status[b] = CRX_SKIPPED; kp.iters[b] = 0; }
         return;
+    }
+    // [r3] Reachability screen of the planner QP, before anything is set up.  41 % of the regions of the BASELINE draw ask for a
+    // lateral offset the bicycle cannot reach (~0.25 m of authority over 1 s): ey_j = e_ey' A^j x0 + sum_m e_ey' A^m B
+    // u_{j-1-m}, so with |delta| <= delta_max, |a| <= a_max NO input sequence moves ey_j further than reach_gain[j] from its free
+    // response reach_row[j] . x0 -- whatever the other rows do (dropping them only enlarges the feasible set).  A bound on ey_j
+    // outside that interval by more than 1e-6 (the violation at which a failed solve is called infeasible) is a PROOF of
+    // infeasibility: every infeasible region of the draw ends here, for one dot product per stage (the multiplier certificate of
+    // DESIGN.md 4.3 needed the set-up and 2.7 iterations on them); the oracle applies the same test, so verdicts and iteration
+    // counts (0 for these) stay equal.  Answer = the reference's for a failed solve: fall-back trajectory, CRX_INFEASIBLE.
+    if (NOBS == 0 && kp.mode == 0 && kp.reach_screen) {
+        bool out = false;
+        for (int j = lane; j < N; j += WAVE) {
+            double fr = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) fr += kp.reach_row[j][i] * kp.x0[(size_t)b * 6 + i];
+            const double g = kp.reach_gain[j];
+            out = out || kp.ey_lb[(size_t)b * N + j] > fr + g + 1e-6 || kp.ey_ub[b] < fr - g - 1e-6;
+        }
+        if (__ballot(out) != 0ull) {
+            planner_fallback<L>(sm, kp, b, lane, N);
+            if (lane == 0) { kp.status[b] = CRX_INFEASIBLE; kp.kkt[b] = INFINITY; kp.iters[b] = 0; }
+            return;
+        }
     }
     if (kp.poison) {   // diagnostics (crx_debug_poison_lds): any read of LDS this kernel did not write turns into NaN
         for (int e = lane; e < (int)(L::BYTES / 8); e += WAVE) sm[e] = __longlong_as_double(0x7ff8dead0000beefLL);
@@ -1131,6 +1185,16 @@ crx_solve_kernel(const crx_kparams kp) {
     SYNC();
     if (lane < 6) LD(L::Z + lane) = kp.x0[(size_t)b * 6 + lane];
     SYNC();
+    // starting point: u = 0, sigma = 0, x by roll-out
+    for (int k = 0; k < N; k++) {
+        if (lane < 6) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s += LD(L::M + lane * NZ + j) * LD(L::Z + k * NZ + j);
+            LD(L::Z + (k + 1) * NZ + lane) = s;
+        }
+        SYNC();
+    }
     int infeas0 = 0;
     if (kp.mode == 0) {
         // planner front-end (overtake_traj_planner.py:266-334); bez arrays staged in hg/Hd scratch
@@ -1240,16 +1304,6 @@ crx_solve_kernel(const crx_kparams kp) {
         LD(L::rdt + j) = 0.0; LD(L::rtt + j) = 1.0;
     }
     SYNC();
-    // starting point: u = 0, sigma = 0, x by roll-out
-    for (int k = 0; k < N; k++) {
-        if (lane < 6) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; j++) s += LD(L::M + lane * NZ + j) * LD(L::Z + k * NZ + j);
-            LD(L::Z + (k + 1) * NZ + lane) = s;
-        }
-        SYNC();
-    }
     // CBF row scaling at the start (IPOPT's gradient-based scaling, measured in the reference's variables)
     if (NOBS) {
         for (int e = lane; e < N * NOBS; e += WAVE) {
@@ -1640,30 +1694,7 @@ crx_solve_kernel(const crx_kparams kp) {
     double* Xb = kp.X + (size_t)b * (N + 1) * 6;
     double* Ub = kp.U + (size_t)b * N * 2;
     if (kp.mode == 0 && status != 0) {
-        // reference fall-back trajectory (overtake_traj_planner.py:365-374)
-        // The reference builds it from the start-line-WRAPPED ego state xcurv_ego (:366-369) although the QP's x_0 is the raw
-        // ego.xcurv (quirk Q5).  Only s differs between the two, and the wrapped s is the first Bezier control point
-        // (planner_helper.py:49; the Bernstein weights at t = 0 are exactly 1, 0, 0, 0), so it is read from there.
-        const double vx0 = kp.x0[(size_t)b * 6];
-        double* bs = sm + L::hg;
-        double* be = sm + L::Hd;
-        for (int j = lane; j <= N; j += WAVE) {
-            bs[j] = kp.bez_s[(size_t)b * (N + 1) + j];
-            be[j] = kp.bez_ey[(size_t)b * (N + 1) + j];
-        }
-        SYNC();
-        const double s0 = bs[0];
-        for (int e = lane; e < (N + 1) * 6; e += WAVE) {
-            const int j = e / 6, i = e - j * 6;
-            const double st = s0 + kp.fallback_gain * j * kp.dt_ref * vx0;
-            double v = 0.0;
-            if (i == 0) v = kp.fallback_gain * vx0;
-            else if (i == 4) v = st;
-            else if (i == 5) v = interp_lin(bs, be, N + 1, fmin(fmax(st, bs[0]), bs[N]));
-            Xb[e] = v;
-        }
-        for (int e = lane; e < N * 2; e += WAVE) Ub[e] = 0.0;
-        if (lane == 0) kp.cost[b] = INFINITY;
+        planner_fallback<L>(sm, kp, b, lane, N);
     } else {
         for (int e = lane; e < (N + 1) * 6; e += WAVE) { const int k = e / 6, i = e - k * 6; Xb[e] = LD(L::Z + k * NZ + i); }
         for (int e = lane; e < N * 2; e += WAVE) Ub[e] = LD(L::Z + (e >> 1) * NZ + NX + (e & 1));
@@ -1749,7 +1780,9 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
 template <int NOBS>
 static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
     if (kp.N <= 12) return launch_t<NOBS, 12>(kp, st);
-    if (NOBS == 3 && kp.N <= 20) return launch_t<3, 20>(kp, st);
+    if constexpr (NOBS == 3) {       // (if constexpr: <3,20> must exist in ONE translation unit only, the obstacle one)
+        if (kp.N <= 20) return launch_t<3, 20>(kp, st);
+    }
     return launch_t<NOBS, CRX_MAX_N>(kp, st);
 }
 
@@ -1798,7 +1831,9 @@ static int occ_t() {
 template <int NOBS>
 static int occ_n(int N) {
     if (N <= 12) return occ_t<NOBS, 12>();
-    if (NOBS == 3 && N <= 20) return occ_t<3, 20>();
+    if constexpr (NOBS == 3) {
+        if (N <= 20) return occ_t<3, 20>();
+    }
     return occ_t<NOBS, CRX_MAX_N>();
 }
 #ifdef CRX_TU_OBSTACLES

@@ -31,6 +31,11 @@ struct crx_kparams {
     const int32_t* active;   // optional [batch / active_div]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
     int active_div;          // problems per mask entry (planner: the regions of a scenario share one entry); 0 or 1: one each
     const int32_t* order;    // optional [batch]: workgroup i solves problem order[i] (longest-first dispatch); NULL: i
+    // planner QP: reachability screen (crx_kernels.hip, first thing the kernel does).  reach_row[j] = e_ey' A^j: the free response
+    // of ey_j is reach_row[j] . x0; reach_gain[j] = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)': how far the inputs can move it
+    int reach_screen;
+    double reach_gain[CRX_MAX_N];
+    double reach_row[CRX_MAX_N][6];
 };
 
 struct crx_lmpc_kparams {

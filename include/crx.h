@@ -658,6 +658,14 @@ int crx_streams_destroy(int n, void** streams);
 void crx_set_timing(int enable);
 double crx_last_kernel_ms(void);
 
+/* Reachability screen of the planner's region QPs (on by default; process-global switch for measurements).  The inputs are
+ * boxed, so ey_j cannot leave [free response -+ reach_j], reach_j = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)'; a region whose
+ * ey bound at some stage lies outside that interval by more than 1e-6 has no feasible trajectory -- a proof, independent of
+ * the other rows -- and is answered before the interior-point iteration is set up: status CRX_INFEASIBLE, iters 0, kkt +inf,
+ * X = the reference's fall-back trajectory, cost +inf (what a failed solve returns anyway).  On the BASELINE draws every
+ * infeasible region (41 %) ends there.  0 = every QP goes through the interior-point iteration (round-2 behaviour). */
+void crx_set_reach_screen(int enable);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,8 +392,8 @@ void crx_oracle_set_verbose(int v) { g_verbose = v; }
  * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
  * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1).  Defaults = the shipped algorithm;
  * the kernel has no such knobs. */
-static double g_knob[8] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0};
-void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 8) g_knob[i] = v; }
+static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, /* 8: reachability screen of the planner QPs */ 1, 0, 0, 0, 0, 0, 0, 0};
+void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v; }
 
 /* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
  * its restoration phase).  What jams on crash states (ego inside, or about to enter, an obstacle's unsafe set) is the
@@ -784,8 +784,32 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
         /* rows on the fixed x0 are constants: feasible -> inert, violated -> IPOPT cannot succeed */
         if (xb[5] < p->elo[0] - d->opts.tol || xb[5] > p->ehi[0] + d->opts.tol) infeas0 = 1;
         result_t r;
+        /* reachability screen (libcrx: crx_kernels.hip set-up, include/crx.h crx_set_reach_screen): with boxed inputs ey_j stays
+         * within reach_j of its free response, reach_j = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)'; a bound on ey_j outside
+         * that interval by more than 1e-6 proves the region infeasible before any iteration */
+        int screened = 0;
+        if (g_knob[8] != 0.0) {
+            double xk[6], wv[6] = {0, 0, 0, 0, 0, 1}, acc = 0.0;
+            memcpy(xk, xb, sizeof(xk));
+            for (int j = 0; j < N; j++) {
+                if (j >= 1) {
+                    double v0 = 0.0, v1 = 0.0, wn[6] = {0, 0, 0, 0, 0, 0}, xn[6];
+                    for (int i = 0; i < 6; i++) { v0 += wv[i] * d->B[i * 2]; v1 += wv[i] * d->B[i * 2 + 1]; }
+                    acc += fabs(v0) * d->delta_max + fabs(v1) * d->a_max;
+                    for (int a = 0; a < 6; a++)
+                        for (int i = 0; i < 6; i++) wn[a] += wv[i] * d->A[i * 6 + a];
+                    memcpy(wv, wn, sizeof(wv));
+                    for (int i = 0; i < 6; i++) { double s_ = 0.0; for (int a = 0; a < 6; a++) s_ += d->A[i * 6 + a] * xk[a]; xn[i] = s_; }
+                    memcpy(xk, xn, sizeof(xk));
+                }
+                if (p->elo[j] > xk[5] + acc + 1e-6 || p->ehi[j] < xk[5] - acc - 1e-6) screened = 1;
+            }
+        }
+        if (screened) { r.status = CRX_INFEASIBLE; r.iters = 0; r.kkt = INFINITY; r.cost = INFINITY; }
+        else {
         setup(w, p, &d->opts);
         ipm_solve(w, &r);
+        }
         if (infeas0) r.status = CRX_INFEASIBLE;
         double* Xb = X + (size_t)(N + 1) * 6 * b;
         double* Ub = U + (size_t)N * 2 * b;

@@ -313,6 +313,37 @@ def test_synthetic_planner_batch_and_selection(gpu, orc, AB, N):
         np.testing.assert_array_equal(pl[k], sg[k])
 
 
+def test_reach_screen_changes_no_verdict(gpu, orc, AB):
+    """The reachability screen of the planner QPs (include/crx.h crx_set_reach_screen): with it and without it every region gets
+    the same verdict, the same trajectory (the fall-back one where the QP has none) and the same selection; the screened regions
+    report 0 iterations, all others the iterations they had; it catches nearly all infeasible regions of the BASELINE draw; and
+    the kernel screens exactly the regions the oracle screens."""
+    import crx
+    from crx import abi, synth
+    A, B = AB
+    N = 12
+    p = synth.cfg3_planner(512, N=N, seed=3)
+    d = abi.planner_desc(N, A, B)
+    args = [p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
+    on = gpu.planner_solve(d, *args)
+    crx.lib().crx_set_reach_screen(0)
+    try:
+        off = gpu.planner_solve(d, *args)
+    finally:
+        crx.lib().crx_set_reach_screen(1)
+    np.testing.assert_array_equal(on["status"], off["status"])
+    np.testing.assert_array_equal(on["X"], off["X"])
+    np.testing.assert_array_equal(on["U"], off["U"])
+    screened = (on["status"] == abi.CRX_INFEASIBLE) & (on["iters"] == 0)
+    assert (off["iters"][screened] >= 1).all() and (on["iters"][~screened] == off["iters"][~screened]).all()
+    assert np.isinf(on["kkt"][screened]).all() and np.isinf(on["cost"][screened]).all()
+    n_bad = int((on["status"] != 0).sum())
+    assert 0.3 * len(screened) < n_bad < 0.5 * len(screened) and screened.sum() >= 0.9 * n_bad, (int(screened.sum()), n_bad)
+    ro = orc.planner_solve(d, *args)
+    np.testing.assert_array_equal(ro["status"], on["status"])
+    np.testing.assert_array_equal((ro["status"] == abi.CRX_INFEASIBLE) & (ro["iters"] == 0), screened)
+
+
 def test_golden_lmpc(gpu, orc, golden_racing_game):
     """Learning-MPC QPs recorded from the reference's LMPC lap: kernel (block Cholesky in LDS) vs the
     oracle (full KKT LU) vs the certified goldens."""

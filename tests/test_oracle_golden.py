@@ -335,6 +335,21 @@ def test_planner_verdicts_against_an_lp_solver(orc, AB):
     assert not wrong, wrong
     assert 300 < n_inf < 600                                   # ~41 % of the draw, as BASELINE's cfg3 recipe produces them
     assert it[st != 0].mean() < 5.0 and it[st != 0].max() <= 20   # the proof is found early
+    # [r3] the reachability screen (include/crx.h crx_set_reach_screen; oracle knob 8) answers before the first iteration: it
+    # must flag nothing the interior-point route (multiplier certificate) solves, and it catches the regions
+    # the bicycle cannot reach -- on this draw nearly all of the infeasible ones
+    import ctypes
+    screened = (st == 2) & (it == 0)
+    orc.lib.crx_oracle_set_knob(8, ctypes.c_double(0.0))
+    try:
+        r0 = orc.planner_solve(d, *[p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")])
+    finally:
+        orc.lib.crx_oracle_set_knob(8, ctypes.c_double(1.0))
+    st0, it0 = np.asarray(r0["status"]), np.asarray(r0["iters"])
+    np.testing.assert_array_equal(st0, st)                       # the same verdict either way
+    assert (it0[screened] >= 1).all() and (it0[~screened] == it[~screened]).all()
+    np.testing.assert_array_equal(np.asarray(r0["X"]), np.asarray(r["X"]))   # and the same trajectory (fall-back for the failed ones)
+    assert screened.sum() >= 0.9 * (st != 0).sum(), (int(screened.sum()), int((st != 0).sum()))
 
 
 def test_lmpc_noise_floor_qps_end_early(orc):
