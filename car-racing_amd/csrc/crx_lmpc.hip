@@ -36,11 +36,12 @@
 #include "crx_wave.h"
 
 #define LMAXF 16
+#define CRX_LMPC_SS44 44   // the reference's num_ss_points (utils/base.py:357): capacity of the six-per-CU instantiation
 
-template <int NMAX, bool DENSE = true>
+template <int NMAX, bool DENSE = true, int MSS = CRX_MAX_SS>
 struct LL {
     static constexpr int NU2 = 2 * NMAX + 6 /* inputs + initial-state relaxation */, LDK = NU2 + 1, KR = NU2 + 7;
-    static constexpr int MS = CRX_MAX_SS;
+    static constexpr int MS = MSS;   // capacity of the safe-set arrays: CRX_MAX_SS, or 44 (the reference's num_ss_points) for the 6-per-CU instantiation
     static constexpr int MR = 4 * NMAX + 3 * (NMAX - 1) + MS;
     // offsets in doubles.  A, B, C are read only while the roll-out xf and the sensitivities S are built (before the first
     // iteration) and share the storage of K, which the first K_u assembly overwrites.
@@ -63,15 +64,19 @@ struct LL {
     static constexpr int u = qf + MS, du = u + NU2, g0u = du + NU2, gu = g0u + NU2, ru = gu + NU2;
     static constexpr int lam = ru + NU2, dlam = lam + MS, rl = dlam + MS;
     static constexpr int y = rl + MS, dy = y + 8, e = dy + 8, bx = e + 8, Wt = bx + 8;
-    static constexpr int ik = Wt + 36;                         // inverse pivots of L_u
-    static constexpr int t = ik + NU2, nu = t + MR, c = nu + MR, rp = c + MR, dt = rp + MR, dnu = dt + MR, wv = dnu + MR;
+    // [r3] 31 664 -> 27 248 B at NMAX = 12, MS = 44: SIX instead of five QPs per CU (<= 27 264 B).  The inverse pivots of L_u live in
+    // the padding column of K (ik + j * IKS); rp = c - t and dt = rp + J dz are no longer stored but formed where they are
+    // read, by the same operations on the same operands (c stays intact through the iteration: dnu, dead after the K_u
+    // assembly, takes the multiplier step that used to be parked in c) -- identical bits
+    static constexpr int ik = K + LDK + NU2, IKS = LDK;        // padding column of rows 1..NU2 (row 0's is l_chol's store sink)
+    static constexpr int t = Wt + 36, nu = t + MR, c = nu + MR, dnu = c + MR, wv = dnu + MR;
     static constexpr int w0 = wv + MR, w5 = w0 + NMAX;
     static constexpr int Fth = w5 + NMAX, Fph = Fth + LMAXF;
     static constexpr int dmy = Fph + LMAXF;                    // sink of address-predicated stores
     static constexpr int END = dmy + 2;
     static constexpr int TB = t;                               // set-up / write-back scratch over the row arrays: one stage of the
                                                                // full sensitivity block [6][NU2]; the plan X [NMAX+1][6]
-    static_assert(6 * NU2 <= 7 * MR && 6 * (NMAX + 1) <= 7 * MR, "scratch fits");
+    static_assert(6 * NU2 <= 5 * MR && 6 * (NMAX + 1) <= 5 * MR, "scratch fits");
     // (G = D + T T' is never assembled -- product-form factorisation in registers -- so the footprint no longer depends on
     // the safe-set size; with the compact sensitivity table 38.9 KB at NMAX = 12 = four problems per CU, 77 KB / two before)
     static constexpr size_t bytes(int /*n_ss_max*/) { return (size_t)END * 8; }
@@ -130,9 +135,9 @@ __device__ __forceinline__ double hu_dot(const double* sm, const LCtx& x, const 
     if (const bool rv = r0_ + (lane_) < (m_); true) if (const int r = rv ? r0_ + (lane_) : 0; true)
 
 // rows c_j(v) for the current iterate; rp = c - t
-template <int NMAX, bool DENSE>
+template <int NMAX, bool DENSE, int MSS>
 __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc_kparams& kp) {
-    using L = LL<NMAX, DENSE>;
+    using L = LL<NMAX, DENSE, MSS>;
     // straight-line: every lane evaluates all three row kinds on clamped indices and selects; lanes past the last row
     // recompute row 0.  The state rows sum over ALL inputs -- S[k][.][a] is zero for a >= 2k, the bound was a shortcut.
     for (int r0 = 0; r0 < x.m; r0 += WAVE) {
@@ -154,14 +159,13 @@ __device__ __forceinline__ void l_rows(double* sm, const LCtx& x, const crx_lmpc
         const double clam = LDS(L::lam + ((!isbox && !isst) ? r - x.r_lam : 0));
         const double cv = sel(isbox, cbox, sel(isst, cst, clam));
         LDS(L::c + r) = cv;
-        LDS(L::rp + r) = cv - LDS(L::t + r);
     }
 }
 
 // (ru, rl) = g + E'y - J'w   with w = the row array at offset `wo`
-template <int NMAX, bool DENSE>
+template <int NMAX, bool DENSE, int MSS>
 __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc_kparams& kp, int wo) {
-    using L = LL<NMAX, DENSE>;
+    using L = LL<NMAX, DENSE, MSS>;
     {
         const bool kv = x.lane >= 1 && x.lane < x.N;
         const int k = kv ? x.lane : 1, r = x.r_st + 3 * (k - 1);
@@ -198,9 +202,9 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
     SYNC();
 }
 
-template <int NMAX, bool DENSE>
+template <int NMAX, bool DENSE, int MSS>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
-    using L = LL<NMAX, DENSE>;
+    using L = LL<NMAX, DENSE, MSS>;
     extern __shared__ double sm[];
     if ((int)blockIdx.x >= kp.batch) return;
     const int pb = kp.order ? min(max(kp.order[blockIdx.x], 0), kp.batch - 1) : (int)blockIdx.x;   // dispatch order, see crx_solve_kernel
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         if (lane < 8) LDS(L::y + lane) = 0.0;
         for (int r = lane; r < m; r += WAVE) LDS(L::t + r) = 0.0;
         SYNC();
-        l_rows<NMAX, DENSE>(sm, x, kp);
+        l_rows<NMAX, DENSE, MSS>(sm, x, kp);
         SYNC();
         for (int r = lane; r < m; r += WAVE) {
             LDS(L::t + r) = fmax(fabs(LDS(L::c + r)), o.slack_push);
@@ -378,7 +382,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
 #endif
             TICK();
             // ---- rows, gradient, equality residual ----
-            l_rows<NMAX, DENSE>(sm, x, kp);
+            l_rows<NMAX, DENSE, MSS>(sm, x, kp);
             {   // gu = g0u + Hu u (lane = row); lanes past nv run row 0 and store to the sink.  Two accumulators.
                 const bool av = lane < nv;
                 const int a = av ? lane : 0;
@@ -407,10 +411,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             SYNC();
             TICK();   // 1
             // ---- error measure ----
-            l_lagr<NMAX, DENSE>(sm, x, kp, L::nu);
+            l_lagr<NMAX, DENSE, MSS>(sm, x, kp, L::nu);
             double nus = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
             LROWS(r, rv, lane, m) {
-                const double tt = LDS(L::t + r), nn = LDS(L::nu + r), rr = fabs(LDS(L::rp + r));
+                const double tt = LDS(L::t + r), nn = LDS(L::nu + r), rr = fabs(LDS(L::c + r) - tt);
                 nus += sel(rv, nn, 0.0);
                 e_p = fmax(e_p, rr);
                 theta += sel(rv, rr, 0.0);
@@ -476,12 +480,13 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             // ---- Sigma (in dnu), omega = mu/t - Sigma rp (in wv); rhs = -(g + E'y - J'omega) ----
             LROWS(r, rv, lane, m) {
                 (void)rv;
-                const double ti = frcp(LDS(L::t + r)), sg = LDS(L::nu + r) * ti;
+                const double tt = LDS(L::t + r), ti = frcp(tt), sg = LDS(L::nu + r) * ti;
+                const double rpr = LDS(L::c + r) - tt;
                 LDS(L::dnu + r) = sg;
-                LDS(L::wv + r) = fma(-sg, LDS(L::rp + r), mu * ti);
+                LDS(L::wv + r) = fma(-sg, rpr, mu * ti);
             }
             SYNC();
-            l_lagr<NMAX, DENSE>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
+            l_lagr<NMAX, DENSE, MSS>(sm, x, kp, L::wv);   // ru, rl = -(rhs)
             // stage weights of the state rows for K_u
             {
                 const bool kv = lane >= 1 && lane < N;
@@ -533,7 +538,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             }
             SYNC();
             TICK();   // 5
-            int ok = l_chol(sm, L::K, L::LDK, L::ik, nv, 7, lane);
+            int ok = l_chol(sm, L::K, L::LDK, L::ik, nv, 7, lane, L::IKS);
             TICK();   // 6
             if (!ok) break;
             // ---- W~ and b_x ----
@@ -680,7 +685,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                     for (int r = 0; r < 6; r++) s = fma(-LDS(L::K + (nv + r) * L::LDK + a), dyx[r], s);
                     b1[0] = sel(lane < nv, s, 0.0);
                 }
-                l_backsub<1>(sm, L::K, L::LDK, L::ik, nv, lane, b1);
+                l_backsub<1>(sm, L::K, L::LDK, L::ik, nv, lane, b1, L::IKS);
                 LDS(LSINK(lane < nv, L::du + lane)) = b1[0];
             }
             SYNC();
@@ -703,14 +708,13 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 const double jlam = LDS(L::dlam + ((!isbox && !isst) ? r - x.r_lam : 0));
                 const double jd = sel(isbox, jbox, sel(isst, jst, jlam));
                 const double tt = LDS(L::t + r), nn = LDS(L::nu + r), ti = frcp(tt);
-                const double dtt = LDS(L::rp + r) + jd;
+                const double dtt = (LDS(L::c + r) - tt) + jd;
                 const double dn = (mu - tt * nn - nn * dtt) * ti;
                 LDS(L::wv + r) = jd;
-                LDS(L::dt + r) = dtt;
                 rp_max = fmax(rp_max, -dtt * ti);
                 rd_max = fmax(rd_max, -dn * frcp(nn));
                 Dphi = fma(sel(rv, -mu * dtt, 0.0), ti, Dphi);
-                LDS(L::c + r) = dn;   // dnu parked in c (c is recomputed at the top of the next iteration)
+                LDS(L::dnu + r) = dn;   // the multiplier step, in the array Sigma has left (dead after the K_u assembly)
             }
             double gdv = 0.0, qd = 0.0;
             {
@@ -739,8 +743,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 double thn = 0.0;
                 LogAcc la;
                 LROWS(r, rv, lane, m) {
-                    const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
-                    double tn = fma(al, LDS(L::dt + r), LDS(L::t + r));
+                    const double tt = LDS(L::t + r), jd = LDS(L::wv + r), rpr = LDS(L::c + r) - tt;
+                    const double cj = (rpr + tt) + al * jd;
+                    double tn = fma(al, rpr + jd, tt);
                     tn = fmax(tn, cj);
                     la.mul(sel(rv, tn, 1.0));
                     thn += sel(rv, fabs(cj - tn), 0.0);
@@ -776,9 +781,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             logsum_t = lt;
             double numax = 0.0;
             LROWS(r, rv, lane, m) {
-                const double cj = (LDS(L::rp + r) + LDS(L::t + r)) + al * LDS(L::wv + r);
-                const double tn = fmax(fma(al, LDS(L::dt + r), LDS(L::t + r)), cj);
-                double nn = fma(a_d, LDS(L::c + r), LDS(L::nu + r));
+                const double tt = LDS(L::t + r), jd = LDS(L::wv + r), rpr = LDS(L::c + r) - tt;
+                const double cj = (rpr + tt) + al * jd;
+                const double tn = fmax(fma(al, rpr + jd, tt), cj);
+                double nn = fma(a_d, LDS(L::dnu + r), LDS(L::nu + r));
                 const double mut = mu * frcp(tn);
                 nn = fmin(fmax(nn, mut * 1e-10), mut * 1e10);
                 LDS(LSINK(rv, L::t + r)) = tn;          // read-modify-write
@@ -842,19 +848,19 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     }
 }
 
-template <int NMAX, bool DENSE>
+template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS>
 static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
-    const size_t bytes = LL<NMAX, DENSE>::bytes(kp.n_ss_max);
+    const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(kp.n_ss_max);
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device
     static int attr_set_on = -1;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (attr_set_on != dev) {
-        hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_set_on = dev;
     }
-    hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE, MSS>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
 }
 
@@ -868,19 +874,28 @@ static bool lmpc_dense(const crx_lmpc_kparams& kp) {
 hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     if (kp.batch == 0) return hipSuccess;
     if (lmpc_dense(kp)) return kp.N <= 12 ? launch_l<12, true>(kp, st) : launch_l<CRX_LMPC_MAX_N, true>(kp, st);
+    // the reference's configuration (N = 12, Q = 0, 44 safe-set points: utils/base.py:350-376) has its own instantiation: six per CU
+    if (kp.N <= 12 && kp.n_ss_max <= CRX_LMPC_SS44) return launch_l<12, false, CRX_LMPC_SS44>(kp, st);
     return kp.N <= 12 ? launch_l<12, false>(kp, st) : launch_l<CRX_LMPC_MAX_N, false>(kp, st);
 }
 
-template <int NMAX, bool DENSE>
+template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS>
 static int occ_l(int n_ss_max) {
     int n = 0;
-    const size_t bytes = LL<NMAX, DENSE>::bytes(n_ss_max);
-    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE>, WAVE, bytes) != hipSuccess) return -1;
+    const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(n_ss_max);
+    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE, MSS>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }
 // (diagnostics: the Q == 0 instantiation, which is what the reference's parameters select)
-int crx_lmpc_resident_per_cu(int N, int n_ss_max) { return N <= 12 ? occ_l<12, false>(n_ss_max) : occ_l<CRX_LMPC_MAX_N, false>(n_ss_max); }
+int crx_lmpc_resident_per_cu(int N, int n_ss_max) {
+    if (N <= 12 && n_ss_max <= CRX_LMPC_SS44) return occ_l<12, false, CRX_LMPC_SS44>(n_ss_max);
+    return N <= 12 ? occ_l<12, false>(n_ss_max) : occ_l<CRX_LMPC_MAX_N, false>(n_ss_max);
+}
 
-size_t crx_lmpc_lds_bytes(int N, int n_ss_max) { return N <= 12 ? LL<12, false>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N, false>::bytes(n_ss_max); }
+size_t crx_lmpc_lds_bytes(int N, int n_ss_max) {
+    if (N <= 12 && n_ss_max <= CRX_LMPC_SS44) return LL<12, false, CRX_LMPC_SS44>::bytes(n_ss_max);
+    return N <= 12 ? LL<12, false>::bytes(n_ss_max) : LL<CRX_LMPC_MAX_N, false>::bytes(n_ss_max);
+}
+static_assert(LL<12, false, CRX_LMPC_SS44>::bytes(CRX_LMPC_SS44) <= 27264, "six learning-MPC QPs per CU");
 static_assert(LL<CRX_LMPC_MAX_N, true>::bytes(CRX_MAX_SS) <= 160 * 1024, "LDS budget");

@@ -217,8 +217,9 @@ __device__ __forceinline__ double excl_suffix(double v, int lane) {
 // Lane i owns row i.  Blocked by 4 columns: the panel product against all finished columns is one long
 // loop of independent LDS reads (own row entry + 4 broadcast entries per k), the 4x4 diagonal block is
 // finished in registers with v_readlane broadcasts -- one LDS round trip per 4 columns instead of per
-// column.  Returns 0 if a pivot is not positive.
-__device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int n, int extra, int lane) {
+// column.  Returns 0 if a pivot is not positive.  The inverse pivots go to sm[inv + j * inv_st] (inv_st = LD: a column of
+// the array itself, e.g. its padding column from row 1 on -- row 0's last column is the sink of the masked stores).
+__device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int n, int extra, int lane, int inv_st = 1) {
     const int rows = n + extra;
     const int ri = base + lane * LD;
     int ok = 1;
@@ -260,7 +261,7 @@ __device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int
             l[c] = sel(col, sel(lane == j, d, s[c]) * rinv, 0.0);
             const int sink = base + LD - 1;       // last column of row 0: upper triangle, never read
             sm[seli(col && mine && lane >= j, ri + j, sink)] = l[c];
-            sm[seli(lane == 0 && col, inv + j, sink)] = rinv;
+            sm[seli(lane == 0 && col, inv + j * inv_st, sink)] = rinv;
         }
         if (!ok) return 0;
         SYNC();
@@ -271,13 +272,13 @@ __device__ __forceinline__ int l_chol(double* sm, int base, int LD, int inv, int
 // x <- L^-T x for `NR` right-hand sides held one entry per lane (lane i = entry i), L as above.  The
 // LDS operands of four steps are fetched ahead of the dependent readlane/fma chain.
 template <int NR>
-__device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, int inv, int n, int lane, double* b) {
+__device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, int inv, int n, int lane, double* b, int inv_st = 1) {
     int j = n - 1;
     for (; j >= 3; j -= 4) {
         double rinv[4], lj[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            rinv[q] = sm[inv + j - q];
+            rinv[q] = sm[inv + (j - q) * inv_st];
             lj[q] = sel(lane < j - q, sm[base + (j - q) * LD + seli(lane < j - q, lane, 0)], 0.0);
         }
 #pragma unroll
@@ -289,7 +290,7 @@ __device__ __forceinline__ void l_backsub(const double* sm, int base, int LD, in
             }
     }
     for (; j >= 0; j--) {
-        const double rinv = sm[inv + j];
+        const double rinv = sm[inv + j * inv_st];
         const double lj = sel(lane < j, sm[base + j * LD + seli(lane < j, lane, 0)], 0.0);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
