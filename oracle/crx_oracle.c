@@ -501,7 +501,7 @@ static void ipm_solve(work_t* w, result_t* res) {
         int viol = 0;
         for (int j = 0; j < m; j++)
             if (w->row[j].kind == ROW_CBF && w->row[j].k <= (int)g_knob[6] && w->c[j] < 0.0) viol = 1;
-        if (viol && restore_slacks(w, o->mu_init)) { n_restore = 1; it_limit = 1 + o->restore_iters; first = 1; }
+        if (viol && restore_slacks(w, o->mu_init)) { if (g_knob[9] == 0.0) { n_restore = 1; it_limit = 1 + o->restore_iters; } first = 1; }
     }
     for (it = 0;; it++) {
         /* residuals */
