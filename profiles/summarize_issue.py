@@ -2,13 +2,19 @@
 launches (rocprofv3 --pmc passes of tools/gpu_round3_c.sh, csv under gpurun_out/r3c/).  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
 count quad-cycles (4 clocks) summed over all waves; SQ_INSTS_* count instructions.
 Usage: python profiles/summarize_issue.py > profiles/r03_pmc_issue.txt"""
-import collections, csv, glob, os
+import collections, csv, glob, os, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-D = os.path.join(ROOT, "gpurun_out", "r3c")
+FINAL = len(sys.argv) > 1 and sys.argv[1] == "r3u"     # python profiles/summarize_issue.py r3u > profiles/r03_pmc_issue_final.txt
+D = os.path.join(ROOT, "gpurun_out", "r3u" if FINAL else "r3c")
 RUNS = [("cfg4 <3,20> slim layout, 4 waves per CU (this round)", "pmc_cfg4_default_", 16384, 19.2),
         ("cfg4 <3,20> full layout, 3 waves per CU (round-2 build)", "pmc_cfg4_r2like_", 16384, 19.2),
         ("cfg2 <1,12> at batch 16384, 8 waves per CU", "pmc_cfg2_", 16384, 12.7),
         ("cfg3 <0,12> at 65536 QPs, 12 waves per CU", "pmc_cfg3_", 65536, 6.9)]
+if FINAL:   # the final build of round 3 (tools/gpu_round3_u.sh): obstacle unit scheduled with iterative-ilp, lane maps hoisted in <3,20>
+    RUNS = [("cfg4 <3,20>, 4 waves per CU, index order", "pmc_cfg4_default_", 16384, 19.2),
+            ("cfg2 <1,12> at batch 16384, 8 waves per CU", "pmc_cfg2_", 16384, 12.7),
+            ("cfg3 <0,12> at 65536 QPs, 12 waves per CU, reachability screen ON (41 % of the waves end before set-up)", "pmc_cfg3_", 65536, 6.0),
+            ("cfg3 <0,12> at 65536 QPs, reachability screen OFF", "pmc_cfg3off_", 65536, 7.1)]
 
 
 def load(prefix, grid):
@@ -20,7 +26,11 @@ def load(prefix, grid):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-print(__doc__.split("Usage")[0].strip())
+print(__doc__.split("Usage")[0].strip() if not FINAL else
+      "profiles/r03_pmc_issue_final.txt: the same counters on the FINAL build of round 3 (rocprofv3 --pmc passes of tools/gpu_round3_u.sh,\n"
+      "csv under gpurun_out/r3u/): obstacle instantiations scheduled with iterative-ilp, lane maps hoisted in <3,20>, planner QPs with and\n"
+      "without the reachability screen.  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (4 clocks) summed over all waves;\n"
+      "SQ_INSTS_* count instructions.  (Mean iterations per solve are those of the bench line of the same batch.)")
 print()
 for title, prefix, n, it_mean in RUNS:
     c = load(prefix, n)
@@ -43,7 +53,8 @@ for title, prefix, n, it_mean in RUNS:
     if "SQC_ICACHE_REQ" in c:
         print("  -- instruction cache: %.4g requests, %.4g misses (hit rate %.4f %%)" % (c["SQC_ICACHE_REQ"], c["SQC_ICACHE_MISSES"], 100 * c["SQC_ICACHE_HITS"] / c["SQC_ICACHE_REQ"]))
     print()
-print("""Reading.  A single-wave workgroup owns a SIMD's issue slot once every four clocks, so a wave retires at most one instruction per
+if not FINAL:
+    print("""Reading.  A single-wave workgroup owns a SIMD's issue slot once every four clocks, so a wave retires at most one instruction per
 4 clocks.  The obstacle instantiations keep 257..512 registers per lane = ONE wave per SIMD: their iteration is ~15 k (<3,20>) / ~10 k
 (<1,12>) instructions = 60 k / 40 k clocks of pure issue, which is 70..90 % of the iteration time of a lone wave (89.7 k / 41 k clocks,
 profiles/r02_phase_cycles.txt).  They are bound by the INSTRUCTION COUNT, not by latency, LDS or the instruction cache (hit rate
