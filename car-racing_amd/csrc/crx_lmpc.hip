@@ -36,6 +36,9 @@
 #include "crx_wave.h"
 
 #define LMAXF 16
+#ifndef CRX_LMPC_LATE
+#define CRX_LMPC_LATE 25   // stagnation rule: iterations with mu < 1e-6 before the QP is left on its noise floor (oracle: LATE_ITERS)
+#endif
 #define CRX_LMPC_SS44 44   // the reference's num_ss_points (utils/base.py:357): capacity of the six-per-CU instantiation
 
 template <int NMAX, bool DENSE = true, int MSS = CRX_MAX_SS>
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             E0 = fmax(e_d, fmax(e_p, e_c));
             if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
             if (it >= o.max_iter) break;
-            if (mu < 1e-6 && ++late >= 25) break;
+            if (mu < 1e-6 && ++late >= CRX_LMPC_LATE) break;
             // Still violated: look for the proof that it must be (first attempt only; oracle/crx_oracle_lmpc.c
             // lmpc_certificate()) [r2].  Domain D: inputs in their box, lambd in the unit simplex.  With nu >= 0 on the state
             // rows and ANY y on x_N - SS lambd = 0,  F(v) = sum nu_j c_j(u) - y'e(v)  is linear and >= 0 at every feasible v:
