@@ -4,7 +4,7 @@ crx.montecarlo.GameLaps against crx.synth.multi_tests_traffic.  Prints what such
 learning-MPC laps, overtakes, contacts, races that left the track.
 The plant runs WITH the reference's bounded process noise (utils/base.py:929-939), as the reference's script does unless
 --zero-noise is given (overtake_planner_test.py:41-42): crx_plant_step_noise_dev, draws from a seeded torch generator.
-usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3] [noise_seed=1 | none]"""
+usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3] [noise_seed=1 | none] [sub-batches=1]"""
 import os
 import sys
 import time
@@ -35,37 +35,51 @@ def main():
     qf = np.ascontiguousarray(g["ss/Qfun0"].T); time_ss = g["ss/time_ss"].astype(np.int32)
     x0 = np.tile(g["lmpc/x"][0], (Bn, 1)); xg0 = np.tile(g["lap1/xglob"][-1], (Bn, 1))
     s0, v, ey = synth.multi_tests_traffic(Bn, V, seed=1)
-    tile = lambda a: np.tile(a[None], (Bn,) + (1,) * a.ndim)   # noqa: E731
-    r = montecarlo.GameLaps(track.point_and_tangent, L, track.width, A, B, opt, tile(ss), tile(us), tile(qf), tile(time_ss),
-                            np.full(Bn, 2, dtype=np.int32), x0, xg0, tile(ss[0, 1:N + 2]), tile(us[0, 1:N + 1]), s0, v, ey, noise_seed=seed)
-    dev = r.lm.xc.device
-    cs0, cv, cey = (torch.as_tensor(a, device=dev) for a in (s0, v, ey))
-    lap_steps = [[] for _ in range(Bn)]
-    prev_laps = r.lm.laps.clone()
-    min_gap = torch.full((Bn,), 1e9, dtype=torch.float64, device=dev)       # min over time and cars of (ds/l)^6 + (dey/w)^6 (>= 1: no contact)
-    off = torch.zeros((Bn,), dtype=torch.bool, device=dev)
-    ey_max = torch.zeros((Bn,), dtype=torch.float64, device=dev)
-    ot_steps = torch.zeros((Bn,), dtype=torch.int64, device=dev)
-    ahead0 = None
+    K = int(sys.argv[5]) if len(sys.argv) > 5 else 1      # concurrent sub-batches (crx.montecarlo.Concurrent); the per-step statistics below are ~15 small torch launches per sub-batch, which makes this loop launch-bound beyond K = 1..2 (bench.py --workload overtake, without them, gains from 4)
+    cuts = [(Bn * i) // K for i in range(K + 1)]
+    parts = []
+    for i in range(K):
+        sl = slice(cuts[i], cuts[i + 1]); n = sl.stop - sl.start
+        tl = lambda a: np.tile(a[None], (n,) + (1,) * a.ndim)   # noqa: E731
+        parts.append(montecarlo.GameLaps(track.point_and_tangent, L, track.width, A, B, opt, tl(ss), tl(us), tl(qf), tl(time_ss),
+                                         np.full(n, 2, dtype=np.int32), x0[sl], xg0[sl], tl(ss[0, 1:N + 2]), tl(us[0, 1:N + 1]), s0[sl], v[sl], ey[sl],
+                                         noise_seed=None if seed is None else seed + i))
+    conc = montecarlo.Concurrent(parts)
+    dev = parts[0].lm.xc.device
+    # per-race statistics stay on the device and are updated on the sub-batch's own stream: no host synchronisation inside the loop
+    st = []
+    for i, r in enumerate(parts):
+        sl = slice(cuts[i], cuts[i + 1]); n = sl.stop - sl.start
+        st.append(dict(cs0=torch.as_tensor(s0[sl], device=dev), cv=torch.as_tensor(v[sl], device=dev), cey=torch.as_tensor(ey[sl], device=dev),
+                       prev=r.lm.laps.clone(), ncross=torch.zeros(n, dtype=torch.int32, device=dev),
+                       t1=torch.zeros(n, dtype=torch.int32, device=dev), t2=torch.zeros(n, dtype=torch.int32, device=dev),
+                       gap=torch.full((n,), 1e9, dtype=torch.float64, device=dev), off=torch.zeros(n, dtype=torch.bool, device=dev),
+                       eymax=torch.zeros(n, dtype=torch.float64, device=dev), ot=torch.zeros(n, dtype=torch.int64, device=dev)))
     torch.cuda.synchronize(); t0 = time.time()
     for k in range(steps):
-        r.step()
-        cars = cv * r.t + cs0
-        ds = torch.remainder(r.lm.xc[:, 4:5] - cars + 0.5 * L, L) - 0.5 * L
-        de = r.lm.xc[:, 5:6] - cey
-        min_gap = torch.minimum(min_gap, ((ds / 0.4) ** 6 + (de / 0.2) ** 6).min(dim=1).values)
-        off |= r.lm.xc[:, 5].abs() > track.width
-        ey_max = torch.maximum(ey_max, r.lm.xc[:, 5].abs())
-        ot_steps += r.overtake.long()
-        crossed = (r.lm.laps > prev_laps).cpu().numpy(); prev_laps = r.lm.laps.clone()
-        for b in np.nonzero(crossed)[0]:
-            lap_steps[b].append(k + 1)
+        for r, q, stream in zip(parts, st, conc.streams):
+            with torch.cuda.stream(stream):
+                r.step()
+                cars = q["cv"] * r.t + q["cs0"]
+                ds = torch.remainder(r.lm.xc[:, 4:5] - cars + 0.5 * L, L) - 0.5 * L
+                de = r.lm.xc[:, 5:6] - q["cey"]
+                q["gap"] = torch.minimum(q["gap"], ((ds / 0.4) ** 6 + (de / 0.2) ** 6).min(dim=1).values)   # >= 1: no contact
+                q["off"] |= r.lm.xc[:, 5].abs() > track.width
+                q["eymax"] = torch.maximum(q["eymax"], r.lm.xc[:, 5].abs())
+                q["ot"] += r.overtake.long()
+                crossed = r.lm.laps > q["prev"]
+                q["t1"] = torch.where(crossed & (q["ncross"] == 0), k + 1, q["t1"])
+                q["t2"] = torch.where(crossed & (q["ncross"] == 1), k + 1, q["t2"])
+                q["ncross"] += crossed.int()
+                q["prev"] = r.lm.laps.clone()
     torch.cuda.synchronize(); wall = time.time() - t0
-    laps = np.array([len(x) for x in lap_steps])
-    first = np.array([x[0] for x in lap_steps if len(x) >= 1]); second = np.array([x[1] - x[0] for x in lap_steps if len(x) >= 2])
-    mg = min_gap.cpu().numpy()
-    print("%d races x %d steps against %d random cars each, process noise %s: %.2f s wall = %.3g race-steps/s" % (
-        Bn, steps, V, "ON (seed %d)" % seed if seed is not None else "off", wall, Bn * steps / wall))
+    cat = lambda key: torch.cat([q[key] for q in st]).cpu().numpy()   # noqa: E731
+    laps, t1, t2 = cat("ncross"), cat("t1"), cat("t2")
+    first, second = t1[laps >= 1], (t2 - t1)[laps >= 2]
+    mg, off, ey_max, ot_steps = cat("gap"), torch.cat([q["off"] for q in st]), torch.cat([q["eymax"] for q in st]), torch.cat([q["ot"] for q in st])
+    xc_all = torch.cat([r.lm.xc for r in parts])
+    print("%d races x %d steps against %d random cars each, process noise %s, %d concurrent sub-batches: %.2f s wall = %.3g race-steps/s" % (
+        Bn, steps, V, "ON (seed %d)" % seed if seed is not None else "off", K, wall, Bn * steps / wall))
     print("laps completed per race: %s" % dict(zip(*np.unique(laps, return_counts=True))))
     if len(first):
         print("first learning-MPC lap : steps p5 %d p50 %d p95 %d" % tuple(np.percentile(first, [5, 50, 95])))
@@ -75,7 +89,7 @@ def main():
     print("contact with a car (super-ellipse (ds/0.4)^6 + (dey/0.2)^6 < 1 at some step): %d races (%.1f %%)" % ((mg < 1.0).sum(), 100 * (mg < 1.0).mean()))
     print("left the track (|ey| > %.1f at some step): %d races (%.1f %%)" % (track.width, off.sum().item(), 100 * off.float().mean().item()))
     print("max |ey| over the run: p50 %.3f p90 %.3f p99 %.3f max %.3f" % tuple(np.percentile(ey_max.cpu().numpy(), [50, 90, 99, 100])))
-    print("non-finite states: %d" % int((~torch.isfinite(r.lm.xc)).any(dim=1).sum().item()))
+    print("non-finite states: %d" % int((~torch.isfinite(xc_all)).any(dim=1).sum().item()))
 
 
 if __name__ == "__main__":
