@@ -843,7 +843,7 @@ int crx_lmpc_solve_ordered_dev(const crx_lmpc_desc* d, int batch, const int32_t*
         return fail(CRX_ERR_ARG, "NULL array argument");
     kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
     kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
-    kp.active = active; kp.order = order;
+    kp.active = active; kp.order = order; kp.reach_screen = g_reach_screen;
     if (g_trace_rows > 0) { kp.trace = (double*)g_trace.p; kp.trace_problem = g_trace_problem; kp.trace_rows = g_trace_rows; }
     kp.poison = g_poison;
     timing_begin((hipStream_t)stream);

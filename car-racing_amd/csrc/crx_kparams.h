@@ -52,6 +52,7 @@ struct crx_lmpc_kparams {
     int poison;      // diagnostics: fill the LDS slice with NaN before set-up
     const int32_t* active;   // optional [batch]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
     const int32_t* order;    // optional [batch]: workgroup i solves problem order[i] (longest-first dispatch); NULL: i
+    int reach_screen;        // terminal-set reachability screen of the first attempt (crx_lmpc.hip)
 };
 
 struct crx_select_kparams {

@@ -335,9 +335,42 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     x.r_lam = x.r_st + 3 * (N - 1);
     x.r_el = x.r_lam + M;
 
-    int status = CRX_MAX_ITER, total_it = 0;
+    // [r3] Reachability screen of the first attempt.  The inputs are boxed, so component c of x_N stays within g_c = sum_a |dx_N,c / du_a|
+    // umax_a of its free response (both are on the table after the set-up: xf, the stage-N rows of S), and the terminal equality
+    // x_N = SS lambd with lambd in the unit simplex needs x_N,c inside [min_j SS_cj, max_j SS_cj].  Disjoint intervals (by more than
+    // 1e-6 of their scale) in ANY component prove that the reference's QP has no feasible point, whatever its other rows say: the
+    // first attempt -- 1..10 iterations until the multiplier certificate finds the same -- is skipped and the relaxed second attempt
+    // runs as it would have.  Five packed wave reductions per QP; catches 6 of the 11 infeasible recorded QPs; the oracle applies the
+    // same test (crx_oracle_lmpc.c).
+    int first_attempt = 0;
+    if (kp.reach_screen) {
+        double g[6], hi[6], nlo[6];
+        const int a = lane < nu2 ? lane : 0, j = lane < M ? lane : 0;
+        const double um = (a & 1) ? kp.a_max : kp.delta_max;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; c6++) {
+            g[c6] = sel(lane < nu2, fabs(LDS(L::S + L::srowN(c6) * L::NU2 + a)) * um, 0.0);
+            const double sv = LDS(L::SS + c6 * L::MS + j);
+            hi[c6] = sel(lane < M, sv, -HUGE_VAL);
+            nlo[c6] = sel(lane < M, -sv, -HUGE_VAL);
+        }
+        double z0 = 0.0, z1 = 0.0;
+        wave_sum4(g[0], g[1], g[2], g[3]);
+        wave_sum4(g[4], g[5], z0, z1);
+        wave_max4(hi[0], hi[1], hi[2], hi[3]);
+        wave_max4(hi[4], hi[5], nlo[0], nlo[1]);
+        wave_max4(nlo[2], nlo[3], nlo[4], nlo[5]);
+        bool out = false;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; c6++) {
+            const double fr = LDS(L::xf + 6 * N + c6), lo = -nlo[c6], tol = 1e-6 * fmax(1.0, fmax(fabs(lo), fabs(hi[c6])));
+            out = out || fr - g[c6] > hi[c6] + tol || fr + g[c6] < lo - tol;
+        }
+        first_attempt = out ? 1 : 0;   // uniform: every lane holds the same reduced values
+    }
+    int status = first_attempt ? CRX_INFEASIBLE : CRX_MAX_ITER, total_it = 0;
     double E0 = HUGE_VAL, f = 0.0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = first_attempt; attempt < 2; attempt++) {
         x.el = attempt;
         x.nv = nu2 + (attempt ? 6 : 0);
         x.m = x.r_el;

@@ -663,7 +663,11 @@ double crx_last_kernel_ms(void);
  * ey bound at some stage lies outside that interval by more than 1e-6 has no feasible trajectory -- a proof, independent of
  * the other rows -- and is answered before the interior-point iteration is set up: status CRX_INFEASIBLE, iters 0, kkt +inf,
  * X = the reference's fall-back trajectory, cost +inf (what a failed solve returns anyway).  On the BASELINE draws every
- * infeasible region (41 %) ends there.  0 = every QP goes through the interior-point iteration (round-2 behaviour). */
+ * infeasible region (41 %) ends there.  0 = every QP goes through the interior-point iteration (round-2 behaviour).
+ * The same switch covers the learning-MPC QP's first attempt (the reference's own QP, terminal state pinned to the hull of the safe
+ * set): component c of x_N stays within sum_a |dx_N,c / du_a| umax_a of its free response, and x_N = SS lambd needs it inside
+ * [min_j SS_cj, max_j SS_cj]; disjoint intervals in any component prove the attempt infeasible, it is skipped (its iterations do not
+ * appear in iters) and the relaxed second attempt runs as it would have: same X, U, lambda, status CRX_INFEASIBLE. */
 void crx_set_reach_screen(int enable);
 
 #ifdef __cplusplus

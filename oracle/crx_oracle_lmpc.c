@@ -587,6 +587,9 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
     res->cost = f;
 }
 
+static int lmpc_reach_screen_on = 1;
+void crx_oracle_lmpc_set_reach_screen(int on) { lmpc_reach_screen_on = on; }
+
 int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
                           const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
                           double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
@@ -611,7 +614,23 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
             w->ss = ss + (size_t)6 * Mx * b; w->qf = qfun + (size_t)Mx * b;
             lres_t r;
             int bad0 = lmpc_setup(w, 0), total = 0;
-            lmpc_ipm(w, &r);
+            /* Reachability screen of the first attempt [r3] (libcrx: crx_lmpc.hip, include/crx.h crx_set_reach_screen): the inputs are
+             * boxed, so component c of x_N stays within g_c = sum_a |dx_N,c / du_a| umax_a of its free response, and the terminal
+             * equality x_N = SS lambd (lambd in the unit simplex) needs x_N,c inside [min_j SS_cj, max_j SS_cj].  Disjoint intervals
+             * (by more than 1e-6 of their scale) in ANY component prove that the reference's QP has no feasible point, whatever its
+             * other rows say: the first attempt is skipped (0 iterations) and the relaxed second attempt runs as it would have. */
+            int screened = 0;
+            if (lmpc_reach_screen_on) {
+                for (int c = 0; c < 6; c++) {
+                    double g = 0.0, lo = HUGE_VAL, hi = -HUGE_VAL;
+                    for (int a = 0; a < 2 * N; a++) g += fabs(w->S[N][c][a]) * ((a & 1) ? d->a_max : d->delta_max);
+                    for (int j = 0; j < w->M; j++) { const double v = w->ss[(size_t)c * Mx + j]; if (v < lo) lo = v; if (v > hi) hi = v; }
+                    const double fr = w->xf[N][c], tol = 1e-6 * fmax(1.0, fmax(fabs(lo), fabs(hi)));
+                    if (fr - g > hi + tol || fr + g < lo - tol) screened = 1;
+                }
+            }
+            if (screened) { r.status = CRX_INFEASIBLE; r.iters = 0; r.kkt = HUGE_VAL; r.cost = 0.0; }
+            else lmpc_ipm(w, &r);
             total = r.iters;
             if (r.status != CRX_CONVERGED || bad0) {
                 lmpc_setup(w, 1);

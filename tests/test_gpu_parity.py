@@ -365,6 +365,32 @@ def test_golden_lmpc(gpu, orc, golden_racing_game):
     np.testing.assert_array_equal(r1["X"], rg["X"][3:9])
 
 
+def test_lmpc_reach_screen_skips_only_the_first_attempt(gpu, orc, golden_racing_game):
+    """The terminal-set reachability screen of the learning-MPC QP (include/crx.h crx_set_reach_screen): with it and without it
+    every recorded QP ends with the same status, plan, inputs and hull weights; the screened ones (first attempt skipped) report
+    fewer iterations, nothing else changes; several of the recorded infeasible QPs are caught; kernel and oracle agree on which."""
+    import crx
+    d, args = helpers.lmpc_inputs(golden_racing_game)
+    on = gpu.lmpc_solve(d, *args)
+    crx.lib().crx_set_reach_screen(0)
+    try:
+        off = gpu.lmpc_solve(d, *args)
+    finally:
+        crx.lib().crx_set_reach_screen(1)
+    for k in ("status", "X", "U", "lam", "cost"):
+        np.testing.assert_array_equal(on[k], off[k])
+    fewer = on["iters"] < off["iters"]
+    assert (on["iters"] <= off["iters"]).all() and fewer.sum() >= 4 and (on["status"][fewer] == 2).all()
+    ro = orc.lmpc_solve(d, *args)
+    orc.lib.crx_oracle_lmpc_set_reach_screen(0)
+    try:
+        ro_off = orc.lmpc_solve(d, *args)
+    finally:
+        orc.lib.crx_oracle_lmpc_set_reach_screen(1)
+    np.testing.assert_array_equal(ro["iters"] < ro_off["iters"], fewer)      # the same QPs are screened on both sides
+    np.testing.assert_array_equal(ro["status"], on["status"])
+
+
 def test_lmpc_noise_floor_qps(gpu, orc):
     """Eight learning-MPC QPs captured from the batched closed loop (tools/lmpc_stragglers.py) whose local model is unstable
     (|A| entries of 50, as in the reference's own recorded models): the free response reaches 1e7 and the KKT error of the

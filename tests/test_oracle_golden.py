@@ -352,6 +352,24 @@ def test_planner_verdicts_against_an_lp_solver(orc, AB):
     assert screened.sum() >= 0.9 * (st != 0).sum(), (int(screened.sum()), int((st != 0).sum()))
 
 
+def test_lmpc_reach_screen_oracle(orc, golden_racing_game):
+    """Oracle side of the learning-MPC reachability screen: skipping a first attempt that is provably infeasible changes
+    nothing but the iteration count."""
+    import helpers
+    d, args = helpers.lmpc_inputs(golden_racing_game)
+    on = orc.lmpc_solve(d, *args)
+    orc.lib.crx_oracle_lmpc_set_reach_screen(0)
+    try:
+        off = orc.lmpc_solve(d, *args)
+    finally:
+        orc.lib.crx_oracle_lmpc_set_reach_screen(1)
+    for k in ("status", "X", "U", "lam", "cost"):
+        np.testing.assert_array_equal(on[k], off[k])
+    fewer = on["iters"] < off["iters"]
+    assert (on["iters"] <= off["iters"]).all() and fewer.sum() >= 4 and (on["status"][fewer] == 2).all()
+    assert (on["status"][golden_racing_game["lmpc_success"]] == 0).all()     # no solvable QP is touched
+
+
 def test_lmpc_noise_floor_qps_end_early(orc):
     """tests/golden/lmpc_noise_floor.npz (see tests/test_gpu_parity.py::test_lmpc_noise_floor_qps): the oracle leaves these
     QPs after < 80 iterations with a status != 0, not after max_iter."""
