@@ -342,7 +342,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     // first attempt -- 1..10 iterations until the multiplier certificate finds the same -- is skipped and the relaxed second attempt
     // runs as it would have.  Five packed wave reductions per QP; catches 6 of the 11 infeasible recorded QPs; the oracle applies the
     // same test (crx_oracle_lmpc.c).
-    int first_attempt = 0;
+    // A row violated by the fixed x_0 (bad0: the car is off the track or too fast NOW) makes the reference's QP infeasible before
+    // anything is solved: the first attempt used to run to its end and be thrown away -- skipped likewise.
+    int first_attempt = (kp.reach_screen && bad0) ? 1 : 0;
     if (kp.reach_screen) {
         double g[6], hi[6], nlo[6];
         const int a = lane < nu2 ? lane : 0, j = lane < M ? lane : 0;
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             const double fr = LDS(L::xf + 6 * N + c6), lo = -nlo[c6], tol = 1e-6 * fmax(1.0, fmax(fabs(lo), fabs(hi[c6])));
             out = out || fr - g[c6] > hi[c6] + tol || fr + g[c6] < lo - tol;
         }
-        first_attempt = out ? 1 : 0;   // uniform: every lane holds the same reduced values
+        first_attempt |= out ? 1 : 0;   // uniform: every lane holds the same reduced values
     }
     int status = first_attempt ? CRX_INFEASIBLE : CRX_MAX_ITER, total_it = 0;
     double E0 = HUGE_VAL, f = 0.0;

@@ -619,7 +619,7 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
              * equality x_N = SS lambd (lambd in the unit simplex) needs x_N,c inside [min_j SS_cj, max_j SS_cj].  Disjoint intervals
              * (by more than 1e-6 of their scale) in ANY component prove that the reference's QP has no feasible point, whatever its
              * other rows say: the first attempt is skipped (0 iterations) and the relaxed second attempt runs as it would have. */
-            int screened = 0;
+            int screened = lmpc_reach_screen_on && bad0;   /* a row the fixed x_0 violates: nothing to attempt */
             if (lmpc_reach_screen_on) {
                 for (int c = 0; c < 6; c++) {
                     double g = 0.0, lo = HUGE_VAL, hi = -HUGE_VAL;
