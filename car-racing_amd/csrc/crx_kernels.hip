@@ -39,6 +39,9 @@
 #ifndef CRX_W2_FLOOR
 #define CRX_W2_FLOOR 0 /* 1: pin <2,12> at two waves per SIMD (256 registers, 76 B of scratch) = 6 instead of 4 problems per CU */
 #endif
+#ifndef CRX_DEG6
+#define CRX_DEG6 1   // 0: every CBF launch takes the general-exponent instantiation (A/B builds)
+#endif
 #ifndef CRX_SLIM
 #define CRX_SLIM 1 /* make EXTRA=-DCRX_SLIM=0: the full LDS layout for every instantiation (A/B builds, tools/ab_slim.sh) */
 #endif
@@ -55,6 +58,10 @@ __device__ __forceinline__ double ipow_d(double a, int p) {
     r = sel(h >= 2, r * a2, r);
     r = sel(h >= 3, r * a2, r);
     r = sel(h >= 4, r * a2, r);
+    // [r3] with a compile-time exponent (crx_solve_kernel<.., DEG = 6>) the chain above folds into plain products, and the last of
+    // them would be CONTRACTED into the caller's addition (hipcc fuses across inlined code): different last bits than the select
+    // chain gives, enough to move a chaotic closed loop (test_mpccbf_racing_m_shape).  The empty asm keeps the product a product.
+    asm volatile("" : "+v"(r));
     return r;
 }
 
@@ -1095,7 +1102,11 @@ template <int NOBS, int NMAX> struct MinWaves {
     static constexpr int v = ((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? CRX_OBS1_WAVES : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
 };
 
-template <int NOBS, int NMAX>
+// DEG [r3]: the exponent of the super-ellipse as a compile-time constant (6 = the reference's literal, control.py:528 / :312; 0 = read
+// kp.degree).  Every device function is inlined into the kernel and reads the exponent from the context, so with DEG = 6 the
+// select chains of ipow_d (~18 instructions per call, 4..12 calls per CBF row evaluation) fold into the two or three products they
+// stand for -- same association, same bits, no branch in the row passes (a run-time `if (p == 6)` there was measured 3 % SLOWER).
+template <int NOBS, int NMAX, int DEG = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
 crx_solve_kernel(const crx_kparams kp) {
     using L = Lay<NOBS, NMAX>;
@@ -1142,7 +1153,7 @@ crx_solve_kernel(const crx_kparams kp) {
     c.N = N; c.lane = lane; c.m = N * NR + NOBS; c.nobs = 0;
     const int m = c.m;
     c.alpha = kp.alpha; c.om = 1.0 - kp.alpha; c.cm = 1.0 + kp.margin;
-    c.degree = kp.degree; c.wsig = kp.w_slack; c.lin_sN = 0.0; c.cconst = 0.0;
+    c.degree = DEG ? DEG : kp.degree; c.wsig = kp.w_slack; c.lin_sN = 0.0; c.cconst = 0.0;
     c.b_d = kp.delta_max; c.b_a = kp.a_max; c.b_vlo = kp.v_min; c.b_vhi = kp.v_max; c.b_e = kp.ey_max;
 
     // ---- (3) set-up: one coalesced pass over this problem's inputs -----------------------------------
@@ -1759,7 +1770,7 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
-template <int NOBS, int NMAX>
+template <int NOBS, int NMAX, int DEG = 0>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
@@ -1767,23 +1778,33 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (attr_set_on != dev) {
-        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_set_on = dev;
     }
-    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
+}
+// obstacle instantiations: the degree-6 one for the reference's exponent, the general one for 2 / 4 / 8
+template <int NOBS, int NMAX>
+static hipError_t launch_d(const crx_kparams& kp, hipStream_t st) {
+#if CRX_DEG6
+    if constexpr (NOBS > 0) {
+        if (kp.degree == 6) return launch_t<NOBS, NMAX, 6>(kp, st);
+    }
+#endif
+    return launch_t<NOBS, NMAX, 0>(kp, st);
 }
 
 // horizon classes: 12 and CRX_MAX_N for every obstacle count, plus 20 for the 3-obstacle instantiation
 // (BASELINE config 4: N = 20)
 template <int NOBS>
 static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
-    if (kp.N <= 12) return launch_t<NOBS, 12>(kp, st);
+    if (kp.N <= 12) return launch_d<NOBS, 12>(kp, st);
     if constexpr (NOBS == 3) {       // (if constexpr: <3,20> must exist in ONE translation unit only, the obstacle one)
-        if (kp.N <= 20) return launch_t<3, 20>(kp, st);
+        if (kp.N <= 20) return launch_d<3, 20>(kp, st);
     }
-    return launch_t<NOBS, CRX_MAX_N>(kp, st);
+    return launch_d<NOBS, CRX_MAX_N>(kp, st);
 }
 
 // the obstacle instantiations live in the other translation unit
@@ -1824,8 +1845,9 @@ template <int NOBS, int NMAX>
 static int occ_t() {
     int n = 0;
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
-    if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX>, WAVE, bytes) != hipSuccess) return -1;
+    constexpr int DEG = NOBS > 0 ? 6 : 0;   // the instantiation the reference's parameters select
+    if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }
 template <int NOBS>
