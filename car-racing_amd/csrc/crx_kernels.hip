@@ -39,6 +39,9 @@
 #ifndef CRX_W2_FLOOR
 #define CRX_W2_FLOOR 0 /* 1: pin <2,12> at two waves per SIMD (256 registers, 76 B of scratch) = 6 instead of 4 problems per CU */
 #endif
+#ifndef CRX_NFIX
+#define CRX_NFIX 1   // 0: every launch reads the horizon from its arguments (A/B builds)
+#endif
 #ifndef CRX_DEG6
 #define CRX_DEG6 1   // 0: every CBF launch takes the general-exponent instantiation (A/B builds)
 #endif
@@ -1106,14 +1109,19 @@ template <int NOBS, int NMAX> struct MinWaves {
 // kp.degree).  Every device function is inlined into the kernel and reads the exponent from the context, so with DEG = 6 the
 // select chains of ipow_d (~18 instructions per call, 4..12 calls per CBF row evaluation) fold into the two or three products they
 // stand for -- same association, same bits, no branch in the row passes (a run-time `if (p == 6)` there was measured 3 % SLOWER).
-template <int NOBS, int NMAX, int DEG = 0>
+// NFIX [r3]: the horizon as a compile-time constant (10, 12 or 20: the reference's defaults and the BASELINE configs; 0 = read kp.N).
+// The trip counts of the stage loops, the number of row passes (m = N NR + NOBS rows over 64 lanes) and the stage addresses become
+// immediates: cfg2 0.942 -> 0.868 ms per 256 NLPs (+8.6 %), cfg3 +8 %, the cfg5 shard +6 %, cfg4 +3.7 % (tools/gpu_round3_aa.sh), same
+// operations in the same order.
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
 crx_solve_kernel(const crx_kparams kp) {
+    static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int* si = (int*)(sm + L::END_D);
-    const int lane = threadIdx.x, N = kp.N;
+    const int lane = threadIdx.x, N = NFIX ? NFIX : kp.N;
     if ((int)blockIdx.x >= kp.batch) return;
     // dispatch order [r3]: workgroups start in launch order, so a caller that knows which problems are long (the iteration counts of
     // the previous control step) lists them first and the launch does not end waiting for a straggler that started last
@@ -1770,7 +1778,7 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
-template <int NOBS, int NMAX, int DEG = 0>
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
@@ -1778,22 +1786,37 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (attr_set_on != dev) {
-        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_set_on = dev;
     }
-    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
+}
+// fixed-horizon instantiations: N = 10 (the reference's defaults: utils/base.py:281, :390), 12 (BASELINE configs[1], [2], [4]), 20 (configs[3])
+template <int NOBS, int NMAX, int DEG>
+static hipError_t launch_h(const crx_kparams& kp, hipStream_t st) {
+#if CRX_NFIX
+    if constexpr (NMAX == 12) {
+        if (kp.N == 12) return launch_t<NOBS, 12, DEG, 12>(kp, st);
+        if (kp.N == 10) return launch_t<NOBS, 12, DEG, 10>(kp, st);
+    }
+    if constexpr (NMAX == 20) {
+        if (kp.N == 20) return launch_t<NOBS, 20, DEG, 20>(kp, st);
+    }
+#endif
+    return launch_t<NOBS, NMAX, DEG, 0>(kp, st);
 }
 // obstacle instantiations: the degree-6 one for the reference's exponent, the general one for 2 / 4 / 8
 template <int NOBS, int NMAX>
 static hipError_t launch_d(const crx_kparams& kp, hipStream_t st) {
 #if CRX_DEG6
     if constexpr (NOBS > 0) {
-        if (kp.degree == 6) return launch_t<NOBS, NMAX, 6>(kp, st);
+        if (kp.degree == 6) return launch_h<NOBS, NMAX, 6>(kp, st);
+        return launch_t<NOBS, NMAX, 0, 0>(kp, st);      // other exponents: one general instantiation
     }
 #endif
-    return launch_t<NOBS, NMAX, 0>(kp, st);
+    return launch_h<NOBS, NMAX, 0>(kp, st);
 }
 
 // horizon classes: 12 and CRX_MAX_N for every obstacle count, plus 20 for the 3-obstacle instantiation

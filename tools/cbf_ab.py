@@ -1,5 +1,5 @@
-"""A/B of two builds of the obstacle instantiations of the solver kernel, bit for bit: the cfg2 draw (4096 NLPs), the cfg4 draw (4096),
-the races closed loop (40 steps of 4096 races).  Usage: [CRX_LIB=...] python tools/cbf_ab.py TAG; python tools/cbf_ab.py --compare A B"""
+"""A/B of two builds of the solver kernel, bit for bit: the cfg2 draw (4096 NLPs), the cfg4 draw (4096), planner QPs (N = 12 and 10), 30
+steps of the racing game with traffic (1024 races) and 40 steps of the MPC-CBF races (4096).  Usage: [CRX_LIB=...] python tools/cbf_ab.py TAG; python tools/cbf_ab.py --compare A B"""
 import argparse
 import os
 import sys
@@ -31,7 +31,21 @@ r = gpu.cbf_solve(abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 
                   *[p[k] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")])
 for k, v in r.items():
     out["cfg4/" + k] = np.asarray(v)
+p = synth.cfg3_planner(1024, N=12, seed=3)
+r = gpu.planner_solve(abi.planner_desc(12, A, B), *[p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")])
+for k, v in r.items():
+    out["cfg3/" + k] = np.asarray(v)
+p = synth.cfg3_planner(256, N=10, seed=5)
+r = gpu.planner_solve(abi.planner_desc(10, A, B), *[p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")])
+for k, v in r.items():
+    out["plan10/" + k] = np.asarray(v)
 cx = bench.Ctx()
+wo = bench.make_overtake(cx, argparse.Namespace(race_streams=1, dispatch="index"), 1024)
+po = wo.step.__self__.parts[0]
+for _ in range(30):
+    wo.step()
+torch.cuda.synchronize()
+out["overtake/xc"] = po.lm.xc.cpu().numpy(); out["overtake/tU"] = po.tws.U.cpu().numpy(); out["overtake/titers"] = po.tws.iters.cpu().numpy()
 w = bench.make_races(cx, argparse.Namespace(race_streams=1, dispatch="index"), 4096)
 pr = w.step.__self__.parts[0]
 for _ in range(40):
