@@ -205,8 +205,12 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
     SYNC();
 }
 
-template <int NMAX, bool DENSE, int MSS>
+// NFIX [r3]: the horizon as a compile-time constant (12, the reference's lmpc_param.num_horizon; 0 = read kp.N), as in crx_solve_kernel:
+// +3 % on the stand-alone launch and on the closed-loop step (tools/gpu_round3_ac.sh), identical bits (tools/lmpc_ab.py).  The safe-set
+// count as a constant too was measured beside it and does not pay.
+template <int NMAX, bool DENSE, int MSS, int NFIX = 0>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
+    static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = LL<NMAX, DENSE, MSS>;
     extern __shared__ double sm[];
     if ((int)blockIdx.x >= kp.batch) return;
@@ -217,8 +221,8 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     }
     LCtx x;
     x.lane = threadIdx.x;
-    x.N = kp.N;
-    x.nu2 = 2 * kp.N;
+    x.N = NFIX ? NFIX : kp.N;
+    x.nu2 = 2 * x.N;
     x.M = min(max(kp.n_ss[pb], 1), kp.n_ss_max);   // device-resident counts cannot be validated on the host: clamp (M indexes LDS)
     const int lane = x.lane, N = x.N, nu2 = x.nu2, M = x.M, Mx = kp.n_ss_max;
     const crx_ipm_opts& o = kp.opts;
@@ -886,7 +890,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
     }
 }
 
-template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS>
+template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS, int NFIX = 0>
 static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
     const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(kp.n_ss_max);
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device
@@ -894,11 +898,11 @@ static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (attr_set_on != dev) {
-        hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_set_on = dev;
     }
-    hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE, MSS>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
     return hipGetLastError();
 }
 
@@ -913,6 +917,7 @@ hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     if (kp.batch == 0) return hipSuccess;
     if (lmpc_dense(kp)) return kp.N <= 12 ? launch_l<12, true>(kp, st) : launch_l<CRX_LMPC_MAX_N, true>(kp, st);
     // the reference's configuration (N = 12, Q = 0, 44 safe-set points: utils/base.py:350-376) has its own instantiation: six per CU
+    if (kp.N == 12 && kp.n_ss_max <= CRX_LMPC_SS44) return launch_l<12, false, CRX_LMPC_SS44, 12>(kp, st);
     if (kp.N <= 12 && kp.n_ss_max <= CRX_LMPC_SS44) return launch_l<12, false, CRX_LMPC_SS44>(kp, st);
     return kp.N <= 12 ? launch_l<12, false>(kp, st) : launch_l<CRX_LMPC_MAX_N, false>(kp, st);
 }
