@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
-                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*; additions
+                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*, crx_set_reach_screen; additions
                           only, every 0.1.2 entry point unchanged
                           (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
                            0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
