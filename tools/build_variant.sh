@@ -8,6 +8,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; EXTRA=$2; shift 2 || true
 FILES=${@:-crx_kernels.hip crx_kernels_obs.hip}
+PLAN_SCHED=${PLAN_SCHED--mllvm -amdgpu-sched-strategy=max-ilp}          # PLAN_SCHED= (empty): the planner unit with the default scheduler
 OBS_SCHED=${OBS_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}   # OBS_SCHED= (empty) builds the obstacle unit with the default scheduler
 S=$R/car-racing_amd/csrc
 D=$R/tools/ab/$NAME
@@ -16,7 +17,7 @@ make -C $S -s
 OBJS=""
 for f in crx_kernels crx_kernels_obs crx_lmpc crx_prep crx_lmpcprep crx_api; do
   if echo " $FILES " | grep -q " $f.hip "; then
-    LICM=""; [ $f = crx_kernels ] && LICM="-mllvm -disable-machine-licm"; [ $f = crx_kernels_obs ] && LICM="-mllvm -disable-machine-licm $OBS_SCHED"
+    LICM=""; [ $f = crx_kernels ] && LICM="-mllvm -disable-machine-licm $PLAN_SCHED"; [ $f = crx_kernels_obs ] && LICM="-mllvm -disable-machine-licm $OBS_SCHED"
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $LICM $EXTRA -I$S -c $S/$f.hip -o $D/$f.o
     OBJS="$OBJS $D/$f.o"
   else
