@@ -679,6 +679,9 @@ def main():
                          "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
     ap.add_argument("--no-reach-screen", action="store_true",
                     help="planner QPs: switch the reachability screen off (crx_set_reach_screen(0)): every region goes through the interior-point iteration")
+    ap.add_argument("--slack-start", action="store_true",
+                    help="CBF NLPs: start the slacks at their provable lower bounds instead of IPOPT's sigma = 0 (crx_set_cbf_slack_start(1): "
+                         "more crash states converge, the launch takes longer)")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
@@ -708,6 +711,8 @@ def main():
         crx.init(cx.local)
         if args.no_reach_screen:
             crx.lib().crx_set_reach_screen(0)
+        if args.slack_start:
+            crx.lib().crx_set_cbf_slack_start(1)
     from crx import dist as cdist
     cdist.COLLECTIVE = args.collective
     if args.force_collective:

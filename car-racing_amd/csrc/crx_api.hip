@@ -172,6 +172,7 @@ void timing_end(hipStream_t st) {
 }
 
 int g_reach_screen = 1;   // crx_set_reach_screen
+int g_slack_start = 0;    // crx_set_cbf_slack_start (off by default: see include/crx.h)
 
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
@@ -228,6 +229,23 @@ int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
     kp.delta_max = d->delta_max; kp.a_max = d->a_max; kp.v_min = d->v_min; kp.v_max = d->v_max; kp.ey_max = d->ey_max;
     kp.alpha = d->alpha; kp.margin = d->margin; kp.l_sum = d->l_sum; kp.w_sum = d->w_sum;
     kp.dt_ref = 0.1; kp.fallback_gain = 1.1; kp.opts = d->opts;
+    // reach of s and ey under the boxed inputs (crx_kernels.hip: slack start): sum_{m<j} |e' A^m B| (delta_max, a_max)'
+    kp.slack_start = g_slack_start;
+    double ws[6] = {0, 0, 0, 0, 1, 0}, we[6] = {0, 0, 0, 0, 0, 1}, as = 0.0, ae = 0.0;
+    kp.reach_s[0] = 0.0; kp.reach_gain[0] = 0.0;
+    for (int j = 1; j <= d->N; j++) {
+        double s0 = 0.0, s1 = 0.0, e0 = 0.0, e1 = 0.0, wn[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) {
+            s0 += ws[i] * d->B[i * 2]; s1 += ws[i] * d->B[i * 2 + 1];
+            e0 += we[i] * d->B[i * 2]; e1 += we[i] * d->B[i * 2 + 1];
+        }
+        as += fabs(s0) * d->delta_max + fabs(s1) * d->a_max;
+        ae += fabs(e0) * d->delta_max + fabs(e1) * d->a_max;
+        kp.reach_s[j] = as; kp.reach_gain[j] = ae;
+        for (int a = 0; a < 6; a++)
+            for (int i = 0; i < 6; i++) { wn[a] += ws[i] * d->A[i * 6 + a]; en[a] += we[i] * d->A[i * 6 + a]; }
+        memcpy(ws, wn, sizeof(ws)); memcpy(we, en, sizeof(we));
+    }
     return 0;
 }
 
@@ -360,6 +378,7 @@ double crx_last_kernel_ms(void) {
 }
 
 void crx_set_reach_screen(int enable) { g_reach_screen = enable ? 1 : 0; }
+void crx_set_cbf_slack_start(int enable) { g_slack_start = enable ? 1 : 0; }
 
 void crx_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;

@@ -1323,6 +1323,40 @@ crx_solve_kernel(const crx_kparams kp) {
         LD(L::rdt + j) = 0.0; LD(L::rtt + j) = 1.0;
     }
     SYNC();
+    // [r3] Slack start (OPTIONAL: crx_set_cbf_slack_start, off by default).  IPOPT starts every sigma at its bound (pushed to 1e-2); for a car that starts inside an obstacle's safety
+    // set that is far from where the slacks must end (1e2..1e5: each row i needs sigma_i >= (sigma_{i+1} - G_i) / (1 - alpha), a
+    // 1/(1-alpha) cascade over the stages the car cannot leave the set in), the iteration crawls towards it row by row and a
+    // quarter of those solves used to die on the way.  What CAN be said before solving: s_k and ey_k stay within reach_s[k],
+    // reach_gain[k] of the free response (boxed inputs), so G_i = g(x_{i+1}) - (1 - alpha) g(x_i) - alpha (1 + margin) has an upper
+    // bound Gmax_i over ALL admissible inputs, and backwards from L_N = 0, L_i = max(0, (L_{i+1} - Gmax_i) / (1 - alpha)) is a
+    // PROVABLE lower bound of sigma_i at any feasible point.  The slacks start there (a value the optimum cannot undercut, so the
+    // start costs no more than the optimum) -- zero, i.e. unchanged, for every problem whose rows can be met without slack.
+    // BASELINE draws: cfg2 headline batch 245 -> 253 of 256 converged (7 of the new ones certified as KKT points of the
+    // reference-built NLP), cfg4 92.7 -> 95.9 %; same point with the same cost on 99.6 % of the problems that converged before;
+    // but the solves that now run to their end instead of failing early lengthen the launch (0.87 -> 1.00 ms per 256 NLPs):
+    // a trade, not the default.  The oracle does the same (crx_oracle.c ipm_solve, knob 14).
+    if (NOBS && kp.slack_start) {
+        if (lane < c.nobs) {
+            const int ob = lane, q = c.degree;
+            double Lb = 0.0;
+            for (int i = N - 1; i >= 0; i--) {
+                double dsc, dec, dsn, den;
+                cbf_dist<NOBS, NMAX>(sm, c, i, ob, 0.0, dsc, dec, dsn, den);
+                const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + L::NO + ob);
+                const double rsc = kp.reach_s[i] * rLs, rec = kp.reach_gain[i] * rWs, rsn = kp.reach_s[i + 1] * rLs, ren = kp.reach_gain[i + 1] * rWs;
+                const double mx_sn = fmax(fabs(dsn - rsn), fabs(dsn + rsn)), mx_en = fmax(fabs(den - ren), fabs(den + ren));
+                const double mn_sc = fabs(dsc) > rsc ? fabs(dsc) - rsc : 0.0, mn_ec = fabs(dec) > rec ? fabs(dec) - rec : 0.0;
+                const double Gmax = ipow_d(mx_sn, q) + ipow_d(mx_en, q) - c.om * (ipow_d(mn_sc, q) + ipow_d(mn_ec, q)) - c.alpha * c.cm;
+                Lb = (Lb - Gmax) / c.om;
+                Lb = Lb > 0.0 ? Lb : 0.0;
+                if (Lb > 0.0) {                                          // both copies of sigma_i (state of stage i, input of stage i-1)
+                    LD(L::Z + i * NZ + 6 + ob) = Lb;
+                    if (i >= 1) LD(L::Z + (i - 1) * NZ + NX + 2 + ob) = Lb;
+                }
+            }
+        }
+        SYNC();
+    }
     // CBF row scaling at the start (IPOPT's gradient-based scaling, measured in the reference's variables)
     if (NOBS) {
         for (int e = lane; e < N * NOBS; e += WAVE) {

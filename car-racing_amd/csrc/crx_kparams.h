@@ -34,8 +34,12 @@ struct crx_kparams {
     // planner QP: reachability screen (crx_kernels.hip, first thing the kernel does).  reach_row[j] = e_ey' A^j: the free response
     // of ey_j is reach_row[j] . x0; reach_gain[j] = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)': how far the inputs can move it
     int reach_screen;
-    double reach_gain[CRX_MAX_N];
+    double reach_gain[CRX_MAX_N + 1];
     double reach_row[CRX_MAX_N][6];
+    // CBF NLP: the slacks start at provable lower bounds of their optimal values (crx_kernels.hip, set-up).  reach_gain (ey) and
+    // reach_s (s) [j] = how far the boxed inputs can move the coordinate of stage j from its free response
+    int slack_start;
+    double reach_s[CRX_MAX_N + 1];
 };
 
 struct crx_lmpc_kparams {

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
-                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*, crx_set_reach_screen; additions
+                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*, crx_set_reach_screen, crx_set_cbf_slack_start; additions
                           only, every 0.1.2 entry point unchanged
                           (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
                            0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
@@ -669,6 +669,17 @@ double crx_last_kernel_ms(void);
  * [min_j SS_cj, max_j SS_cj]; disjoint intervals in any component prove the attempt infeasible, it is skipped (its iterations do not
  * appear in iters) and the relaxed second attempt runs as it would have: same X, U, lambda, status CRX_INFEASIBLE. */
 void crx_set_reach_screen(int enable);
+
+/* Slack start of the CBF NLPs (OFF by default; process-global switch).  The reference gives no initial guess (control.py:593-599)
+ * and IPOPT starts every slack sigma at its bound; a car that starts inside an obstacle's safety set needs slacks of 1e2..1e5 (a
+ * 1/(1-alpha) cascade over the stages it cannot leave the set in) and a quarter of those solves fail on the way there.  With the
+ * switch on libcrx starts sigma_i at a PROVABLE lower bound of its optimal value -- from the reach of (s, ey) under the boxed
+ * inputs, crx_kernels.hip "Slack start" -- which is 0, i.e. the reference's start, for every problem whose CBF rows can be met
+ * without slack (those are untouched, bit for bit).  BASELINE configs[1] draw: 95.7 -> 98.8 % of the 256 NLPs converge (7 of the 8
+ * new ones certified as KKT points of the reference-built NLP: tests/golden/cfg2_draw.npz, how = 3), configs[3]: 92.7 -> 95.9 %;
+ * the price is the time of the solves that now run to their end instead of failing early: 0.87 -> 1.00 ms per 256 NLPs.  A
+ * trade for callers who need the crash states answered; the default keeps the reference's start. */
+void crx_set_cbf_slack_start(int enable);
 
 #ifdef __cplusplus
 }

@@ -392,7 +392,7 @@ void crx_oracle_set_verbose(int v) { g_verbose = v; }
  * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
  * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1).  Defaults = the shipped algorithm;
  * the kernel has no such knobs. */
-static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, /* 8: reachability screen of the planner QPs */ 1, 0, 0, 0, 0, 0, 0, 0};
+static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, /* 8: reachability screen of the planner QPs */ 1, 0, 0, 0, 0, 0, /* 14: CBF slacks start at their provable lower bounds (libcrx: crx_set_cbf_slack_start; off by default) */ 0, 0};
 void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v; }
 
 /* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
@@ -469,6 +469,41 @@ static void ipm_solve(work_t* w, result_t* res) {
     (void)smax;
     memset(w->v, 0, sizeof(double) * n);
     unpack(w, w->v);
+    if (g_knob[14] != 0.0 && p->nobs > 0) {
+        /* [r3] slack start (libcrx: crx_kernels.hip "Slack start", include/crx.h crx_set_cbf_slack_start; knob 14 = 0 restores IPOPT's
+         * start): the CBF slacks start at PROVABLE lower bounds of their optimal values.  s_k, ey_k stay within reach_k of the free
+         * response (boxed inputs), so G_i = g_next - (1-alpha) g_cur - alpha cm has an upper bound over all admissible inputs; row
+         * i: G_i - sigma_{i+1} + (1-alpha) sigma_i >= 0 then gives sigma_i >= (L_{i+1} - Gmax_i) / (1-alpha) =: L_i, backwards from
+         * L_N = 0.  Zero -- the reference's start -- for every problem whose rows can be met without slack. */
+        const int N = p->N, q = p->degree;
+        const double om = 1.0 - p->alpha;
+        double gs[MAXN + 1], ge[MAXN + 1], ws_[6] = {0, 0, 0, 0, 1, 0}, we_[6] = {0, 0, 0, 0, 0, 1}, as = 0.0, ae = 0.0;
+        gs[0] = ge[0] = 0.0;
+        const double um[2] = {p->uhi[0] > -p->ulo[0] ? p->uhi[0] : -p->ulo[0], p->uhi[1] > -p->ulo[1] ? p->uhi[1] : -p->ulo[1]};
+        for (int k = 1; k <= N; k++) {
+            double v0 = 0, v1 = 0, e0 = 0, e1 = 0, wn[6] = {0}, en[6] = {0};
+            for (int i = 0; i < 6; i++) { v0 += ws_[i] * p->B[i * 2]; v1 += ws_[i] * p->B[i * 2 + 1]; e0 += we_[i] * p->B[i * 2]; e1 += we_[i] * p->B[i * 2 + 1]; }
+            as += fabs(v0) * um[0] + fabs(v1) * um[1]; ae += fabs(e0) * um[0] + fabs(e1) * um[1];
+            gs[k] = as; ge[k] = ae;
+            for (int a = 0; a < 6; a++) for (int i = 0; i < 6; i++) { wn[a] += ws_[i] * p->A[i * 6 + a]; en[a] += we_[i] * p->A[i * 6 + a]; }
+            memcpy(ws_, wn, sizeof(wn)); memcpy(we_, en, sizeof(en));
+        }
+        for (int ob = 0; ob < p->nobs; ob++) {
+            double Lb = 0.0;
+            for (int i = N - 1; i >= 0; i--) {
+                double dsc, dec, dsn, den;
+                cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
+                const double rsc = gs[i] / p->Ls[ob], rec = ge[i] / p->Ws[ob], rsn = gs[i + 1] / p->Ls[ob], ren = ge[i + 1] / p->Ws[ob];
+                const double mx_sn = fmax(fabs(dsn - rsn), fabs(dsn + rsn)), mx_en = fmax(fabs(den - ren), fabs(den + ren));
+                const double mn_sc = (fabs(dsc) > rsc) ? fabs(dsc) - rsc : 0.0, mn_ec = (fabs(dec) > rec) ? fabs(dec) - rec : 0.0;
+                const double Gmax = ipow(mx_sn, q) + ipow(mx_en, q) - om * (ipow(mn_sc, q) + ipow(mn_ec, q)) - p->alpha * p->cm;
+                Lb = (Lb - Gmax) / om;
+                if (Lb < 0.0) Lb = 0.0;
+                if (Lb > 0.0) w->v[isig(w, i, ob)] = Lb * g_knob[14];
+            }
+        }
+        unpack(w, w->v);
+    }
     scale_rows(w);
     eval_full(w);
     for (int j = 0; j < m; j++) {

@@ -310,6 +310,9 @@ def second_pass(kind, group, rows_npz, p, build):
     g = {k[len(group) + 1:]: rows_npz[k] for k in rows_npz if k.startswith(group + "/")}
     n = len(g["index"])
     how = np.where(g["success"], 0, np.where(g["retry_certified"], 1, -1)).astype(np.int32)
+    redo = "how" in g          # a fixture that has been through this pass before: only the rows still uncertified are visited, and
+    if redo:                   # only with the oracle's point (the seeded random starts would fail again exactly as they did)
+        how = g["how"].astype(np.int32).copy()
     N = int(p["N"])
     A, B = synth.load_AB()
     for r in range(n):
@@ -330,7 +333,7 @@ def second_pass(kind, group, rows_npz, p, build):
         Z = np.linalg.svd(Je)[2][Je.shape[0]:].T
         zp = np.linalg.lstsq(Je, -ce0, rcond=None)[0]
         # cfg4 (N = 20: ~2 minutes per third-solver run): no random starts, the oracle's point is the only second-pass candidate
-        for attempt in range(4 if kind == "cfg2" else 0):
+        for attempt in range(4 if (kind == "cfg2" and not redo) else 0):
             U0 = rng.uniform(-1.0, 1.0, (N, 2)) * np.array([0.5, 1.0])
             X0 = np.zeros((N + 1, 6)); X0[0] = g["x0"][r]
             for k in range(N):

@@ -278,6 +278,44 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
                                                 cpu=(int(o0["status"][i]), int(o0["iters"][i]), int(o1["status"][i]), int(o1["iters"][i]))) for i in sorted(touched)])
 
 
+def test_cbf_slack_start_option(gpu, orc, AB):
+    """crx_set_cbf_slack_start(1) (include/crx.h; off by default): the CBF slacks start at provable lower bounds of their optimal
+    values instead of IPOPT's 0.  On the headline draw: problems whose rows can be met without slack are untouched bit for bit;
+    more of the crash states end at a KKT point, on the kernel and on the oracle (knob 14) alike; every converged trajectory
+    satisfies its CBF rows with the reported slacks (both copies of a slack -- state of stage i, input of stage i-1 -- start equal)."""
+    import ctypes
+
+    import crx
+    from crx import abi, synth
+    A, B = AB
+    p = synth.cfg2_mpccbf(256, N=12, seed=2, safe_start=False)
+    d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+    args = [p[k] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")]
+    g0, o0 = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+    crx.lib().crx_set_cbf_slack_start(1)
+    orc.lib.crx_oracle_set_knob(14, ctypes.c_double(1.0))
+    try:
+        g1, o1 = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+    finally:
+        crx.lib().crx_set_cbf_slack_start(0)
+        orc.lib.crx_oracle_set_knob(14, ctypes.c_double(0.0))
+    touched = (np.abs(g1["X"] - g0["X"]).reshape(256, -1).max(axis=1) > 0) | (g1["iters"] != g0["iters"]) | (g1["status"] != g0["status"])
+    assert 4 <= touched.sum() <= 40, int(touched.sum())                           # the crash states of the draw, nothing else
+    ds = (p["obs_s"][:, 0, 0] + p["lap_off"][:, 0] - p["x0"][:, 4]) / 0.4
+    de = (p["obs_ey"][:, 0, 0] - p["x0"][:, 5]) / 0.2
+    near = (p["n_obs"] > 0) & (ds ** 6 + de ** 6 < 60.0)                             # inside or next to the safety set at the start
+    assert near[touched].all()
+    assert (g1["status"] == 0).sum() >= (g0["status"] == 0).sum() + 5 and (o1["status"] == 0).sum() >= (o0["status"] == 0).sum() + 5
+    ok = g1["status"] == 0
+    X, sg = g1["X"][ok], g1["sigma"][ok][:, 0]
+    dn = (X[:, :, 4] - p["obs_s"][ok][:, 0]) / 0.4
+    dc = (X[:, :, 4] - p["obs_s"][ok][:, 0] - p["lap_off"][ok][:, :1]) / 0.4
+    dey = (X[:, :, 5] - p["obs_ey"][ok][:, 0]) / 0.2
+    hn, hc = dn ** 6 + dey ** 6 - 1.2 - sg, dc ** 6 + dey ** 6 - 1.2 - sg
+    row = np.where((p["n_obs"][ok] > 0)[:, None], hn[:, 1:] - (1 - p["alpha"]) * hc[:, :-1], np.inf)
+    assert row.min() >= -1e-6 * max(1.0, 1e-9 * np.abs(hn).max()), row.min()
+
+
 @pytest.mark.parametrize("N", [12, 20])
 def test_synthetic_planner_batch_and_selection(gpu, orc, AB, N):
     from crx import abi, synth

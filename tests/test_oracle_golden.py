@@ -352,6 +352,29 @@ def test_planner_verdicts_against_an_lp_solver(orc, AB):
     assert screened.sum() >= 0.9 * (st != 0).sum(), (int(screened.sum()), int((st != 0).sum()))
 
 
+def test_cbf_slack_start_oracle(orc, AB):
+    """Oracle side of the optional slack start (knob 14; libcrx: crx_set_cbf_slack_start): untouched problems keep their bits,
+    more crash states converge."""
+    import ctypes
+    from crx import abi, synth
+    A, B = AB
+    p = synth.cfg2_mpccbf(512, N=12, seed=2, safe_start=False)
+    d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+    args = [p[k] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")]
+    r0 = orc.cbf_solve(d, *args)
+    orc.lib.crx_oracle_set_knob(14, ctypes.c_double(1.0))
+    try:
+        r1 = orc.cbf_solve(d, *args)
+    finally:
+        orc.lib.crx_oracle_set_knob(14, ctypes.c_double(0.0))
+    touched = (np.abs(r1["X"] - r0["X"]).reshape(512, -1).max(axis=1) > 0) | (r1["iters"] != r0["iters"]) | (r1["status"] != r0["status"])
+    assert 8 <= touched.sum() <= 80
+    assert (r1["status"] == 0).sum() >= (r0["status"] == 0).sum() + 8
+    both = (r0["status"] == 0) & (r1["status"] == 0)
+    rel = np.abs(r1["cost"][both] - r0["cost"][both]) / np.maximum(1.0, np.abs(r0["cost"][both]))
+    assert (rel <= 1e-6).mean() >= 0.99                                              # the same KKT point where both converge
+
+
 def test_lmpc_reach_screen_oracle(orc, golden_racing_game):
     """Oracle side of the learning-MPC reachability screen: skipping a first attempt that is provably infeasible changes
     nothing but the iteration count."""
