@@ -76,15 +76,17 @@ def algorithmic_bytes(kind, N, n_obs):
 class Ctx:
     """Process-wide state of one bench invocation."""
 
-    def __init__(self, plumbing=False):
+    def __init__(self):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        # --plumbing-check (tests/test_bench_plumbing.py): the multi-rank control flow of this file -- self-spawn, rendezvous,
-        # sharding, barriers, max-over-ranks timing, the collective, the JSON line -- on CPU tensors over gloo with a stand-in
-        # solver back-end, so that a typo in it cannot surface first on the driver's 8-GPU box.  Measures nothing.
-        self.plumbing = plumbing
-        self.dev = torch.device("cpu") if plumbing else torch.device("cuda", self.local)
+        self.dev = self.device()
+
+    def device(self):
+        return torch.device("cuda", self.local)
+
+    def dsync(self):
+        torch.cuda.synchronize()
 
     def to_dev(self, a, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -93,8 +95,7 @@ class Ctx:
     def sync_all(self):
         if self.world > 1:
             dist.barrier()
-        if not self.plumbing:
-            torch.cuda.synchronize()
+        self.dsync()
 
 
 class Workload:
@@ -235,7 +236,7 @@ def make_sweep(cx, args, scaling):
         n_local = args.sweep_per_gpu
         n_total = n_local * cx.world
         raw = synth.cfg3_raw(n_local, N=12, seed=5 + 1000 * cx.rank)
-    sw = pipeline.PlannerSweep(raw, A, B, n_total, cx.dev, backend=plumbing_backend() if cx.plumbing else None)
+    sw = pipeline.PlannerSweep(raw, A, B, n_total, cx.dev, backend=SWEEP_BACKEND() if SWEEP_BACKEND else None)
     w.key, w.kind, w.baseline_config, w.N, w.n_obs, w.scaling = "cfg5_" + scaling, "planner", 4, 12, 0, scaling
     w.desc, w.ws = sw.desc, sw.ws
     w.batch = w.units = sw.n_local * (sw.V + 1)
@@ -247,38 +248,6 @@ def make_sweep(cx, args, scaling):
                   scaling, n_total, sw.n_local, sw.V + 1, cx.world))
     w.extra = {"scenarios_total": int(n_total), "scenarios_this_rank": int(sw.n_local), "winner_record_bytes": int(sw.exchange.rec * 8),
                "allgather_bytes_per_rank_out": int(sw.exchange.recv.numel() * 8)}
-    return w
-
-
-def plumbing_backend():
-    """--plumbing-check: the stand-in solver back-end named by CRX_BENCH_BACKEND = module:Class (tests/test_bench_plumbing.py
-    passes the one of tests/test_distributed_gloo.py); status / iteration outputs are zeroed so that measure() can read them."""
-    import importlib
-    mod, cls = os.environ["CRX_BENCH_BACKEND"].split(":")
-    be = getattr(importlib.import_module(mod), cls)()
-    inner = be.PlannerWorkspace
-
-    def zeroed(desc, batch, device):
-        ws = inner(desc, batch, device)
-        for k in ("status", "iters", "kkt", "cost", "X", "U"):
-            getattr(ws, k).zero_()
-        return ws
-
-    be.PlannerWorkspace = zeroed
-    return be
-
-
-def make_plumbing_headline(cx):
-    """--plumbing-check: a stand-in for the headline workload (no solver on CPU): same measure() path, a trivial step."""
-    w = Workload()
-    w.key, w.kind, w.N, w.n_obs, w.batch, w.units, w.kernel, w.baseline_config = "plumbing", "cbf", 12, 1, 256, 256, "none", 1
-    w.name = "plumbing check: no solver ran"
-    from crx import abi, synth
-    A, B = synth.load_AB()
-    w.desc = abi.cbf_desc(12, 1, A, B)
-    w.ws = type("WS", (), dict(status=torch.zeros(256, dtype=torch.int32), iters=torch.zeros(256, dtype=torch.int32), kkt=torch.zeros(256, dtype=torch.float64)))()
-    acc = torch.zeros(1)
-    w.step = w.solve = lambda: acc.add_(1.0)
     return w
 
 
@@ -428,11 +397,35 @@ def make_overtake(cx, args, batch=None):
     return w
 
 
+def kernel_ms_samples(cx, w, reps):
+    """Per-launch device time of the dominant kernel, HIP events recorded by libcrx on the stream the launch goes to (`crx_timer_*`,
+    include/crx.h).  solve() re-issues the dominant launch of the last step() with the same inputs and the same mask (closed-loop
+    workloads keep the state the launch was built for); concurrent sub-batches: the launches of one step, timed one after the other."""
+    from crx import torch_api
+    tm = torch_api.Timer()
+    kms = []
+    for _ in range(reps):
+        t_ms = 0.0
+        for f in (getattr(w, "solve_parts", None) or [w.solve]):
+            tm.begin()
+            f()
+            tm.end()
+            t_ms += tm.ms()
+        kms.append(t_ms)
+    return kms
+
+
+def occupancy(w):
+    """(LDS bytes of one problem = one single-wave workgroup, problems resident per CU as the runtime computes it: min(LDS, registers))."""
+    import crx
+    L = crx.lib()
+    lk = 1 if w.kind == "lmpc" else 0
+    L.crx_debug_lds_bytes.restype = C.c_long
+    return int(L.crx_debug_lds_bytes(lk, int(w.N), int(w.n_obs))), int(L.crx_debug_resident_per_cu(lk, int(w.N), int(w.n_obs)))
+
+
 def measure(cx, w, steps, warmup, with_latency=True):
     """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
-    import crx
-    L = None if cx.plumbing else crx.lib()
-    dsync = (lambda: None) if cx.plumbing else torch.cuda.synchronize
     for _ in range(warmup):
         w.step()
     cx.sync_all()
@@ -450,7 +443,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
         t = torch.tensor([w.units], dtype=torch.int64, device=cx.dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         units_all = int(t.item())
-    value = units_all * steps / elapsed
+    launched_rate = units_all * steps / elapsed
     allgather_ms = None
     if w.gather is not None:                           # the collective alone, same barrier / synchronize bracket
         reps = min(50, max(5, steps))
@@ -467,7 +460,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
         for _ in range(min(100, max(10, steps))):
             t1 = time.perf_counter()
             w.step()
-            dsync()
+            cx.dsync()
             lat.append((time.perf_counter() - t1) * 1e3)
         # ONE control step as the reference's class surface issues it: host arrays in, host arrays out -- PCIe-inclusive
         if w.host_call is not None:
@@ -478,33 +471,18 @@ def measure(cx, w, steps, warmup, with_latency=True):
                 hlat.append((time.perf_counter() - t1) * 1e3)
     # ---- status / iteration fields: read after one more step(), i.e. they describe a launch the workload really issues
     w.step()
-    dsync()
+    cx.dsync()
     st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
-    # ---- per-launch time of the dominant kernel: HIP events recorded by libcrx on the launch stream.  solve() re-issues
-    # the dominant launch of that last step() with the same inputs and the same mask (closed-loop workloads keep the state
-    # the launch was built for)
-    kms = []
-    if cx.plumbing:
-        kms = [1.0]
-    else:
-        L.crx_set_timing(1)
-        for _ in range(min(50, max(5, steps))):
-            if getattr(w, "solve_parts", None):     # concurrent sub-batches: the launches of one step, timed one after the other
-                t_ms = 0.0
-                for f in w.solve_parts:
-                    f()
-                    t_ms += L.crx_last_kernel_ms()
-                kms.append(t_ms)
-            else:
-                w.solve()
-                kms.append(L.crx_last_kernel_ms())
-        L.crx_set_timing(0)
+    kms = kernel_ms_samples(cx, w, min(50, max(5, steps)))
     k_ms = float(np.mean(kms))
     conv = st == 0
+    if w.kind == "planner":     # a region QP PROVED infeasible (screen / certificate) is an answered problem: the planner consumes the verdict
+        conv = conv | (st == 2)
     ran = st != 4
     N, n_obs = w.N, w.n_obs
     abytes = algorithmic_bytes(w.kind, N, n_obs)
     launched = int(ran.sum())                          # masked launches: the problems whose wavefront did not return at once
+    conv_of_launched = float(conv[ran].mean()) if ran.any() else 0.0
     achieved = abytes * launched / (k_ms * 1e-3) / 1e9
     # analytic FP64 work: Riccati factor + solves per interior-point iteration
     nx, nu = 6 + n_obs, 2 + n_obs
@@ -516,23 +494,16 @@ def measure(cx, w, steps, warmup, with_latency=True):
         flop_iter = nu2 ** 3 / 3 + 2 * 7 * nu2 * nu2 / 2 + (45 * 6 + 6 * 12 + 24 * 4) * M + 4 * (N - 1) * nu2 * nu2 / 2 \
             + 2 * nu2 * nu2 + 12 * (N - 1) * nu2
     gflops = float(it.sum()) * flop_iter / (k_ms * 1e-3) / 1e9
-    lk = 1 if w.kind == "lmpc" else 0
-    lds, resident = 1, 0
-    if not cx.plumbing:
-        L.crx_debug_lds_bytes.restype = C.c_long
-        lds = int(L.crx_debug_lds_bytes(lk, int(N), int(n_obs)))
-        resident = int(L.crx_debug_resident_per_cu(lk, int(N), int(n_obs)))   # runtime: min(LDS, registers)
-    traffic = tnote = None
-    tsrc = "none: no rocprofv3 --pmc summary under profiles/ for this workload and batch"
+    lds, resident = occupancy(w)
+    traffic, tsrc = None, "none"     # none: no rocprofv3 --pmc summary under profiles/ for this workload and batch
     try:  # PMC-measured HBM bytes per launch of this workload at this batch (profiles/, rocprofv3 --pmc, calibrated)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
         e = pm.get(w.key.replace("cfg2_filtered", "cfg2").replace("cfg5_weak", "cfg5"))
         if e and e["batch"] == w.batch:
             if pm.get("kernel_source_sha256") == kernel_source_hash():
-                traffic, tnote = e["traffic_bytes"], pm.get("note")
-                tsrc = "profiles/pmc_hbm_traffic.json (kept rocprofv3 --pmc summary of an earlier run of this command, same kernel sources %s); not measured in this run" % pm.get("kernel_source_sha256")
+                traffic, tsrc = e["traffic_bytes"], "kept"      # kept rocprofv3 --pmc summary of this command on these kernel sources; not measured in this run
             else:
-                tsrc = "stale: profiles/pmc_hbm_traffic.json was measured on kernel sources %s, this build is %s" % (pm.get("kernel_source_sha256"), kernel_source_hash())
+                tsrc = "stale"                                   # the kept summary was measured on other kernel sources
     except Exception:
         traffic = None
     cfg = {"workload": w.name, "baseline_config": w.baseline_config, "batch_per_gpu": int(w.batch), "problems_launched": launched,
@@ -540,8 +511,8 @@ def measure(cx, w, steps, warmup, with_latency=True):
            "tol": w.desc.opts.tol,
            "status_frac": {"converged": float(conv.mean()), "max_iter": float((st == 1).mean()),
                            "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean()),
-                           "skipped_masked": float((st == 4).mean())},
-           "converged_frac": float(conv.mean()), "converged_frac_of_launched": float(conv[ran].mean()) if ran.any() else None,
+                           "skipped_masked": float((st == 4).mean()), "stalled": float((st == 5).mean())},
+           "converged_frac": float(conv.mean()), "converged_frac_of_launched": conv_of_launched if ran.any() else None,
            "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
            "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
            "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
@@ -552,36 +523,66 @@ def measure(cx, w, steps, warmup, with_latency=True):
         cfg.update(w.extra)
     if getattr(w, "post", None):
         cfg.update(w.post())
-    rec = {"key": w.key, "value": value, "value_converged": value * float(conv[ran].mean()) if ran.any() else 0.0, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-           "scaling": w.scaling, "config": cfg,
+    # `value` leads with CONVERGED solves (status 0 at tol; planner QPs: or PROVED infeasible, the verdict being the answer the planner
+    # consumes): a problem the solver gave up on is not a solve; `value_launched` = every problem the launch worked on
+    rec = {"key": w.key, "value": launched_rate * conv_of_launched, "value_launched": launched_rate, "unit": "solves/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": w.scaling, "config": cfg,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "traffic_note": tnote,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "kernel": w.kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
-                        "note": "serial-dependency/FP64-latency bound, not HBM bound (DESIGN.md section 5)",
+                        "note": "serial-dependency/FP64-issue bound, not HBM bound (DESIGN.md section 5)",
                         "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
-                        "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // lds)}}
+                        "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // max(lds, 1))}}
     if allgather_ms is not None:
         rec["allgather_ms"] = allgather_ms
         rec["world_size"] = dist.get_world_size() if dist.is_initialized() else 1
     return rec
 
 
-def compact(rec):
-    """One sub-config in a dozen scalars for the top-level `summary` (the driver's record keeps top-level scalars and
-    dicts but drops the `configs` array): everything DESIGN.md section 6's table quotes."""
+def r4(x):
+    """four significant digits: the stdout line is for the driver's parser, the full precision goes to the full record"""
+    if isinstance(x, float) and x == x and abs(x) != float("inf"):
+        return float("%.4g" % x)
+    return x
+
+
+def summary8(rec):
+    """One sub-config in EIGHT numbers for the stdout line: converged solves/s, launched solves/s, ms per step, ms of
+    the dominant kernel, converged share of the launched problems, median and maximum iteration count, HBM-roofline fraction."""
     c, r = rec["config"], rec["roofline"]
-    out = {"value": rec["value"], "value_converged": rec["value_converged"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
-           "batch_per_gpu": c["batch_per_gpu"], "problems_launched": c["problems_launched"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
-           "converged_frac": c["converged_frac"], "infeasible_frac": c["status_frac"]["infeasible"], "restored_frac": c["status_frac"]["restored"],
-           "max_iter_frac": c["status_frac"]["max_iter"], "skipped_masked_frac": c["status_frac"]["skipped_masked"],
-           "iters_p50": c["iters_p50"], "iters_p90": c["iters_p90"], "iters_max": c["iters_max"], "roofline_frac": r["frac"],
-           "achieved_GBps": r["achieved"], "traffic": r["traffic"], "resident_per_cu": r["resident_problems_per_cu"]}
-    for k in ("p50_step_latency_ms", "p50_host_call_one_control_step_ms", "dispatch"):
-        if c.get(k) is not None:
-            out[k] = c[k]
+    out = {"value": r4(rec["value"]), "value_launched": r4(rec["value_launched"]), "ms_per_step": r4(rec["ms_per_step"]), "kernel_ms": r4(r["kernel_ms"]),
+           "converged": r4(c["converged_frac_of_launched"]), "iters_p50": c["iters_p50"], "iters_max": c["iters_max"], "roofline_frac": r4(r["frac"])}
     if "allgather_ms" in rec:
-        out["allgather_ms"] = rec["allgather_ms"]
+        out["allgather_ms"] = r4(rec["allgather_ms"])
     return out
+
+
+def stdout_line(full):
+    """The ONE line rank 0 prints: headline scalars, `config`, `roofline`, `cpu_baseline`, and `summary` = eight numbers per
+    sub-config.  Short on purpose (< 6 KB: the round-3 line had grown to 24 KB and the driver could not parse it); the full
+    record -- every sub-config with its own config / roofline object -- is written to `full_record` (a file)."""
+    c, r = full["config"], full["roofline"]
+    line = {k: (r4(full[k]) if k in ("value", "value_launched", "ms_per_step") else full[k]) for k in
+            ("metric", "value", "value_launched", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    ck = ("workload", "baseline_config", "batch_per_gpu", "problems_launched", "horizon", "n_obs", "tol", "converged_frac", "kkt_max_converged",
+          "iters_p50", "iters_p90", "iters_max", "p50_step_latency_ms", "p99_step_latency_ms", "p50_host_call_one_control_step_ms", "dispatch")
+    line["config"] = {k: r4(c[k]) for k in ck if c.get(k) is not None}
+    line["config"]["workload"] = str(c["workload"])[:160]
+    line["config"]["status_frac"] = {k: r4(v) for k, v in c["status_frac"].items() if v}
+    line["roofline"] = {k: r4(r[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+                                                "algorithmic_bytes_per_solve", "fp64_gflops", "fp64_frac_of_valu_peak", "lds_bytes_per_problem",
+                                                "resident_problems_per_cu")}
+    for k in ("allgather_ms", "world_size"):
+        if k in full:
+            line[k] = r4(full[k])
+    b = full.get("cpu_baseline")
+    if b:
+        line["cpu_baseline"] = {"value": r4(b["value"]), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "sample": b["sample"][:120],
+                                "one_thread": r4(b["one_thread"]["value"]), "scipy_slsqp_one_thread": r4(b.get("scipy_slsqp", {}).get("value")),
+                                "reference_casadi": "unavailable" if "unavailable" in b.get("reference", "") else "importable, not timed"}
+    line["summary"] = {rec["key"]: summary8(rec) for rec in [full["headline"]] + full.get("configs", [])}
+    line["full_record"] = full.get("full_record")
+    return line
 
 
 def cpu_baseline(w):
@@ -648,11 +649,72 @@ def self_spawn(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # re-launch THIS program (sys.argv[0]: bench.py, or the harness of tests/test_bench_plumbing.py that drives it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+SWEEP_BACKEND = None   # solver back-end of the cfg5 sweep (None = crx.torch_api = libcrx; the CPU harness in tests/ puts its stand-in here)
+
+
+def init_backend(cx, args):
+    """GPU, process group (nccl = RCCL) and libcrx for this rank."""
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(cx.local)
+    if cx.world > 1 or (args.force_collective and args.collective == "torch"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
+    import crx
+    from crx import abi
+    crx.init(cx.local)
+    # solver options that differ from the defaults travel in crx_ipm_opts of every descriptor this run builds (ABI 0.2: no process-global switches)
+    if args.no_reach_screen:
+        abi.OPTS_OVERRIDE["reach_screen"] = 0
+    if args.slack_start is not None:
+        abi.OPTS_OVERRIDE["slack_start"] = int(args.slack_start)
+
+
+def shutdown_backend(cx, args):
+    from crx import dist as cdist
+    cdist.CrxComm.destroy()
+
+
+def headline_workload(cx, args, make):
+    return make[args.workload or "cfg2"]()
+
+
+def sub_configs(cx, args):
+    """every other single-GPU BASELINE config in the same driver-timed run: (key, maker, steps, warmup, with_latency); slow configs get fewer steps (stated)"""
+    if args.workload is not None or args.no_sub_configs:
+        return []
+    return [("cfg2_filtered", lambda: make_cbf(cx, "cfg2_filtered", args, None, filtered=True), args.steps, args.warmup, False),
+            ("cfg3", lambda: make_planner(cx, args), args.steps, args.warmup, True),
+            ("cfg4", lambda: make_cbf(cx, "cfg4", args), min(args.steps, 30), min(args.warmup, 3), True),
+            ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5), True),
+            ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3), False),
+            ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2), False),
+            ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5), False),
+            ("overtake", lambda: make_overtake(cx, args), min(args.steps, 60), min(args.warmup, 5), False),
+            ("races", lambda: make_races(cx, args), min(args.steps, 30), min(args.warmup, 3), False)]
+
+
+def write_full_record(full, path):
+    """The full record (every sub-config with its config / roofline objects) goes to a FILE, not to stdout.  Default: gpurun_out/ (the
+    scratch directory that travels back from the GPU box); copy what is to be kept into profiles/."""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        print("bench.py: full record not written (%s)" % e, file=sys.stderr)
+        return None
 
 
 def main():
@@ -661,58 +723,41 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game", "overtake"],
-                    help="measure only this workload (default: headline cfg2 + every other single-GPU config in `configs`)")
+                    help="measure only this workload (default: headline cfg2 + every other single-GPU config in `summary`)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="cfg5 only")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4/lmpc/races) or scenarios (cfg3); 0 = BASELINE size")
     ap.add_argument("--sweep-per-gpu", type=int, default=16384, help="cfg5 weak: scenarios per GPU")
     ap.add_argument("--sweep-total", type=int, default=131072, help="cfg5 strong: scenarios in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true", help="headline only")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full_last.json"),
+                    help="file that receives the full record (stdout carries the short line only)")
     ap.add_argument("--force-collective", action="store_true",
-                    help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (plumbing check on a 1-GPU box)")
+                    help="initialise the nccl (= RCCL) process group and issue the winners' all-gather even at world size 1 (a 1-GPU box can exercise the collective)")
     ap.add_argument("--race-streams", type=int, default=4,
                     help="closed-loop workloads (races, game, overtake): independent sub-batches of the races on this many HIP streams (1 = one batch)")
     ap.add_argument("--dispatch", default="auto", choices=["auto", "index", "longest_first", "start_barrier"],
                     help="workgroup -> problem mapping of the solver launches (crx_*_solve_ordered_dev): index = launch order; longest_first = "
-                         "the problems whose previous solve took most iterations first (crx_order_longest_first_dev: what a closed loop has); "
+                         "the problems whose previous solve took most iterations first (crx_order_longest_first_dev: what a closed loop has; on the "
+                         "STATIC batches cfg2 / cfg4 / lmpc the previous solve is the same problem, i.e. an oracle order: an upper bound); "
                          "start_barrier (cfg2 / cfg4) = from the problem's own inputs, no previous solve needed (crx_cbf_order_dev); auto = "
                          "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
     ap.add_argument("--no-reach-screen", action="store_true",
-                    help="planner QPs: switch the reachability screen off (crx_set_reach_screen(0)): every region goes through the interior-point iteration")
-    ap.add_argument("--slack-start", action="store_true",
-                    help="CBF NLPs: start the slacks at their provable lower bounds instead of IPOPT's sigma = 0 (crx_set_cbf_slack_start(1): "
-                         "more crash states converge, the launch takes longer)")
-    ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
+                    help="planner QPs: reachability screen off (crx_ipm_opts.reach_screen = 0): every region goes through the interior-point iteration")
+    ap.add_argument("--slack-start", type=int, default=None, choices=[0, 1, 2],
+                    help="CBF NLPs, crx_ipm_opts.slack_start: 0 = IPOPT's sigma = 0 start only, 1 = start the slacks at their provable lower bounds, "
+                         "2 (default) = IPOPT's start, and a solve that stalls on violated CBF rows restarts once from the lower bounds")
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
-    cx = Ctx(plumbing=args.plumbing_check)
+    cx = Ctx()
     if args.gpus != cx.world:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, cx.world), file=sys.stderr)
         sys.exit(2)
-    if args.plumbing_check:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        if cx.world > 1:
-            dist.init_process_group("gloo", rank=cx.rank, world_size=cx.world)
-    else:
-        if not torch.cuda.is_available():
-            print("bench.py: no GPU visible; libcrx has no CPU path", file=sys.stderr)
-            sys.exit(2)
-        torch.cuda.set_device(cx.local)
-        if cx.world > 1 or (args.force_collective and args.collective == "torch"):
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29512")
-            dist.init_process_group("nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
-        import crx
-        crx.init(cx.local)
-        if args.no_reach_screen:
-            crx.lib().crx_set_reach_screen(0)
-        if args.slack_start:
-            crx.lib().crx_set_cbf_slack_start(1)
+    init_backend(cx, args)
     from crx import dist as cdist
     cdist.COLLECTIVE = args.collective
     if args.force_collective:
@@ -722,47 +767,29 @@ def main():
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
             "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}
-    head = make_plumbing_headline(cx) if args.plumbing_check else make[args.workload or "cfg2"]()
-    rec = measure(cx, head, args.steps, args.warmup, with_latency=not args.plumbing_check)
-    out = {"metric": METRIC, "value": rec["value"], "value_converged": rec["value_converged"], "unit": "solves/s", "n_gpus": cx.world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "summary": {head.key: compact(rec)}, "config": rec["config"],
-           "roofline": rec["roofline"]}
+    head = headline_workload(cx, args, make)
+    rec = measure(cx, head, args.steps, args.warmup, with_latency=head.host_call is not None)
+    full = {"metric": METRIC, "value": rec["value"], "value_launched": rec["value_launched"], "unit": "solves/s", "n_gpus": cx.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"], "headline": rec,
+            "kernel_source_sha256": kernel_source_hash()}
     for k in ("allgather_ms", "world_size"):
         if k in rec:
-            out[k] = rec[k]
+            full[k] = rec[k]
     if cx.rank == 0 and not args.no_cpu_baseline and head.cpu is not None:
-        out["cpu_baseline"] = cpu_baseline(head)
-    if args.plumbing_check:
-        out["configs"] = []
-        for key, sc in (("cfg5_weak", "weak"), ("cfg5_strong", "strong")):
-            r = measure(cx, make_sweep(cx, args, sc), 2, 1, with_latency=False)
-            out["configs"].append(r)
-            out["summary"][key] = compact(r)
-    elif args.workload is None and not args.no_sub_configs:
-        # every other single-GPU BASELINE config in the same driver-timed run; slow configs get fewer steps (stated)
-        subs = [("cfg2_filtered", lambda: make_cbf(cx, "cfg2_filtered", args, None, filtered=True), args.steps, args.warmup),
-                ("cfg3", lambda: make_planner(cx, args), args.steps, args.warmup),
-                ("cfg4", lambda: make_cbf(cx, "cfg4", args), min(args.steps, 30), min(args.warmup, 3)),
-                ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5)),
-                ("cfg5_weak", lambda: make_sweep(cx, args, "weak"), min(args.steps, 40), min(args.warmup, 3)),
-                ("cfg5_strong", lambda: make_sweep(cx, args, "strong"), min(args.steps, 10), min(args.warmup, 2)),
-                ("game", lambda: make_game(cx, args), min(args.steps, 60), min(args.warmup, 5)),
-                ("overtake", lambda: make_overtake(cx, args), min(args.steps, 60), min(args.warmup, 5)),
-                ("races", lambda: make_races(cx, args), min(args.steps, 30), min(args.warmup, 3))]
-        out["configs"] = []
-        for key, mk, st, wu in subs:
-            w = mk()
-            r = measure(cx, w, st, wu, with_latency=key in ("cfg3", "cfg4", "lmpc"))
-            out["configs"].append(r)
-            out["summary"][key] = compact(r)
-            del w
+        full["cpu_baseline"] = cpu_baseline(head)
+    full["configs"] = []
+    for key, mk, st, wu, wl in sub_configs(cx, args):
+        w = mk()
+        full["configs"].append(measure(cx, w, st, wu, with_latency=wl))
+        del w
+        if torch.cuda.is_available():
             torch.cuda.empty_cache()
-    if not args.plumbing_check:
-        cdist.CrxComm.destroy()
+    shutdown_backend(cx, args)
     if dist.is_initialized():
         dist.destroy_process_group()
     if cx.rank == 0:
+        full["full_record"] = write_full_record(full, args.full_out)
         # the JSON line must be the LAST line on stdout: RCCL prints its version banner through C stdio, which (on a pipe)
         # is flushed only at exit, i.e. after anything Python printed -- flush C stdio first, then print
         try:
@@ -770,7 +797,7 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out))
+        print(json.dumps(stdout_line(full)))
         sys.stdout.flush()
 
 

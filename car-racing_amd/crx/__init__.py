@@ -38,7 +38,7 @@ def lib():
             pass
         _state["lib"] = ctypes.CDLL(LIB_PATH)
         _state["lib"].crx_last_error.restype = ctypes.c_char_p
-        _state["lib"].crx_last_kernel_ms.restype = ctypes.c_double
+        _state["lib"].crx_timer_ms.restype = ctypes.c_double
     return _state["lib"]
 
 

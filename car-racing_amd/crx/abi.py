@@ -11,7 +11,7 @@ import numpy as np
 CRX_MAX_N = 24
 CRX_MAX_OBS = 3
 
-CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED, CRX_SKIPPED = 0, 1, 2, 3, 4
+CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED, CRX_SKIPPED, CRX_STALLED = 0, 1, 2, 3, 4, 5
 
 
 class IpmOpts(C.Structure):
@@ -26,12 +26,23 @@ class IpmOpts(C.Structure):
         ("tau_min", C.c_double),
         ("slack_push", C.c_double),
         ("grad_scale_max", C.c_double),
+        ("reach_screen", C.c_int32),
+        ("slack_start", C.c_int32),
     ]
 
 
-def default_opts():
-    """IPOPT defaults the reference inherits (control.py:593 passes print options only)."""
-    return IpmOpts(1e-8, 200, 25, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0)
+# Options that differ from the defaults for every descriptor built through default_opts() from now on (bench.py's
+# --no-reach-screen / --slack-start, A/B tools).  Options travel in the descriptor: libcrx has no process-global switches.
+OPTS_OVERRIDE = {}
+
+
+def default_opts(**kw):
+    """IPOPT defaults the reference inherits (control.py:593 passes print options only) + libcrx's own two switches
+    (include/crx.h crx_ipm_opts: reach_screen = 1, slack_start = 2)."""
+    o = IpmOpts(1e-8, 200, 25, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0, 1, 2)
+    for k, v in {**OPTS_OVERRIDE, **kw}.items():
+        setattr(o, k, v)
+    return o
 
 
 class PlannerDesc(C.Structure):

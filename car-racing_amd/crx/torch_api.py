@@ -53,6 +53,31 @@ def new_streams(n, device=None):
     return [torch.cuda.ExternalStream(int(arr[i]), device=dev) for i in range(n)], int(nc.value)
 
 
+class Timer:
+    """crx_timer_* (include/crx.h): device time of what is enqueued between begin() and end() on torch's current stream."""
+
+    def __init__(self):
+        binding()
+        self.h = C.c_void_p(0)
+        _call("crx_timer_create", C.byref(self.h))
+
+    def begin(self):
+        _call("crx_timer_begin", self.h, _stream())
+
+    def end(self):
+        _call("crx_timer_end", self.h, _stream())
+
+    def ms(self):
+        return float(lib().crx_timer_ms(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().crx_timer_destroy(self.h)
+        except Exception:
+            pass
+
+
 class CbfWorkspace:
     """Pre-allocated outputs for repeated cbf_solve_dev calls of one shape."""
 

@@ -26,9 +26,6 @@ std::mutex g_mu;
 int g_device = -1;
 bool g_init = false;
 hipStream_t g_stream = nullptr;
-bool g_timing = false;
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-bool g_ev_valid = false;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -158,26 +155,11 @@ struct Carver {
     }
 };
 
-void timing_begin(hipStream_t st) {
-    if (!g_timing) return;
-    if (!g_ev0) {
-        (void)hipEventCreate(&g_ev0);
-        (void)hipEventCreate(&g_ev1);
-    }
-    g_ev_valid = g_ev0 && g_ev1 && hipEventRecord(g_ev0, st) == hipSuccess;
-}
-void timing_end(hipStream_t st) {
-    if (!g_timing) return;
-    g_ev_valid = g_ev_valid && hipEventRecord(g_ev1, st) == hipSuccess;
-}
-
-int g_reach_screen = 1;   // crx_set_reach_screen
-int g_slack_start = 0;    // crx_set_cbf_slack_start (off by default: see include/crx.h)
-
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
-        !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0))
-        return fail(CRX_ERR_ARG, "invalid crx_ipm_opts");
+        !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0) ||
+        o.slack_start < 0 || o.slack_start > 2)
+        return fail(CRX_ERR_ARG, "invalid crx_ipm_opts (a descriptor built for libcrx 0.1.x? crx_ipm_opts grew in 0.2: include/crx.h)");
     return 0;
 }
 
@@ -195,7 +177,7 @@ int fill_planner(crx_kparams& kp, const crx_planner_desc* d, int batch) {
     kp.alpha = 0.0; kp.margin = 0.0; kp.l_sum = 1.0; kp.w_sum = 1.0;
     kp.dt_ref = d->dt_ref; kp.fallback_gain = d->fallback_gain; kp.opts = d->opts;
     // reachability screen (crx_kernels.hip, set-up): reach_gain[j] = sum_{m < j} |e_ey' A^m B| (delta_max, a_max)'
-    kp.reach_screen = g_reach_screen;
+    kp.reach_screen = d->opts.reach_screen ? 1 : 0;
     double w[6] = {0, 0, 0, 0, 0, 1}, acc = 0.0;
     kp.reach_gain[0] = 0.0;
     memcpy(kp.reach_row[0], w, sizeof(w));
@@ -230,7 +212,7 @@ int fill_cbf(crx_kparams& kp, const crx_cbf_desc* d, int batch) {
     kp.alpha = d->alpha; kp.margin = d->margin; kp.l_sum = d->l_sum; kp.w_sum = d->w_sum;
     kp.dt_ref = 0.1; kp.fallback_gain = 1.1; kp.opts = d->opts;
     // reach of s and ey under the boxed inputs (crx_kernels.hip: slack start): sum_{m<j} |e' A^m B| (delta_max, a_max)'
-    kp.slack_start = g_slack_start;
+    kp.slack_start = d->opts.slack_start;
     double ws[6] = {0, 0, 0, 0, 1, 0}, we[6] = {0, 0, 0, 0, 0, 1}, as = 0.0, ae = 0.0;
     kp.reach_s[0] = 0.0; kp.reach_gain[0] = 0.0;
     for (int j = 1; j <= d->N; j++) {
@@ -255,9 +237,7 @@ int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
     kq.poison = g_poison;
     size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
     if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
-    timing_begin(st);
     hipError_t e = crx_launch_solve(kq, tmpl, st);
-    timing_end(st);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "solver launch: %s", hipGetErrorString(e));
     return 0;
 }
@@ -287,13 +267,11 @@ int crx_init(int device) {
     HIP_TRY(hipSetDevice(device));
     if (g_init && g_device == device) return CRX_OK;
     if (g_init && g_device >= 0) {
-        // everything below belongs to the old device: release it there (events and the trace buffer included --
-        // recording a stale event fails silently and crx_last_kernel_ms would return garbage)
+        // everything below belongs to the old device: release it there (the trace buffer included)
         (void)hipSetDevice(g_device);
         if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         g_in.release(); g_out.release(); g_hin.release(); g_hout.release(); g_trace.release();
-        if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); g_ev0 = g_ev1 = nullptr; }
-        g_ev_valid = false; g_trace_rows = 0;
+        g_trace_rows = 0;
         HIP_TRY(hipSetDevice(device));
     }
     HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
@@ -309,12 +287,9 @@ void crx_shutdown(void) {
     g_in.release(); g_out.release(); g_hin.release(); g_hout.release(); g_trace.release();
     g_trace_rows = 0;
     if (g_stream) (void)hipStreamDestroy(g_stream);
-    if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); }
-    g_stream = nullptr; g_ev0 = g_ev1 = nullptr; g_ev_valid = false;
+    g_stream = nullptr;
     g_init = false; g_device = -1;
 }
-
-void crx_set_timing(int enable) { g_timing = enable != 0; }
 
 // diagnostics (not in crx.h): record e_d, e_p, e_c, mu, alpha, alpha_dual, delta_w, accept-type per
 // iteration of one problem of the following solves
@@ -369,20 +344,56 @@ int crx_debug_resident_per_cu(int kind, int N, int n) {
     return kind == 0 ? crx_solve_resident_per_cu(N, n) : crx_lmpc_resident_per_cu(N, n);
 }
 
-double crx_last_kernel_ms(void) {
-    if (!g_ev_valid) return -1.0;
+// ---- timers: a pair of HIP events per object, no global state (include/crx.h) -----------------------------------------
+struct CrxTimer { hipEvent_t e0, e1; bool armed; };
+
+int crx_timer_create(void** timer) {
+    if (int rc = ensure_init()) return rc;
+    if (!timer) return fail(CRX_ERR_ARG, "timer is NULL");
+    HIP_TRY(hipSetDevice(g_device));
+    CrxTimer* t = new CrxTimer{nullptr, nullptr, false};
+    if (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) {
+        if (t->e0) (void)hipEventDestroy(t->e0);
+        delete t;
+        return fail(CRX_ERR_HIP, "hipEventCreate failed");
+    }
+    *timer = t;
+    return CRX_OK;
+}
+int crx_timer_destroy(void* timer) {
+    CrxTimer* t = (CrxTimer*)timer;
+    if (!t) return CRX_OK;
+    (void)hipEventDestroy(t->e0); (void)hipEventDestroy(t->e1);
+    delete t;
+    return CRX_OK;
+}
+int crx_timer_begin(void* timer, void* stream) {
+    CrxTimer* t = (CrxTimer*)timer;
+    if (!t) return fail(CRX_ERR_ARG, "timer is NULL");
+    t->armed = false;
+    HIP_TRY(hipEventRecord(t->e0, (hipStream_t)stream));
+    return CRX_OK;
+}
+int crx_timer_end(void* timer, void* stream) {
+    CrxTimer* t = (CrxTimer*)timer;
+    if (!t) return fail(CRX_ERR_ARG, "timer is NULL");
+    HIP_TRY(hipEventRecord(t->e1, (hipStream_t)stream));
+    t->armed = true;
+    return CRX_OK;
+}
+double crx_timer_ms(void* timer) {
+    CrxTimer* t = (CrxTimer*)timer;
+    if (!t || !t->armed) return -1.0;
     float ms = 0.f;
-    if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
-    if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(t->e1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, t->e0, t->e1) != hipSuccess) return -1.0;
     return (double)ms;
 }
-
-void crx_set_reach_screen(int enable) { g_reach_screen = enable ? 1 : 0; }
-void crx_set_cbf_slack_start(int enable) { g_slack_start = enable ? 1 : 0; }
 
 void crx_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2; o->grad_scale_max = 100.0;
+    o->reach_screen = 1; o->slack_start = 2;
 }
 
 void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B) {
@@ -862,12 +873,10 @@ int crx_lmpc_solve_ordered_dev(const crx_lmpc_desc* d, int batch, const int32_t*
         return fail(CRX_ERR_ARG, "NULL array argument");
     kp.x0 = x0; kp.u_old = u_old; kp.A = A; kp.B = B; kp.C = C; kp.ss = ss; kp.qfun = qfun; kp.n_ss = n_ss;
     kp.X = X; kp.U = U; kp.lambda = lambda; kp.cost = cost; kp.status = status; kp.kkt = kkt; kp.iters = iters;
-    kp.active = active; kp.order = order; kp.reach_screen = g_reach_screen;
+    kp.active = active; kp.order = order; kp.reach_screen = d->opts.reach_screen ? 1 : 0;
     if (g_trace_rows > 0) { kp.trace = (double*)g_trace.p; kp.trace_problem = g_trace_problem; kp.trace_rows = g_trace_rows; }
     kp.poison = g_poison;
-    timing_begin((hipStream_t)stream);
     hipError_t e = crx_launch_lmpc(kp, (hipStream_t)stream);
-    timing_end((hipStream_t)stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "lmpc launch: %s", hipGetErrorString(e));
     return CRX_OK;
 }

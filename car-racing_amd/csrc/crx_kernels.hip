@@ -36,6 +36,9 @@
 #ifndef CRX_OPAQUE_LANE
 #define CRX_OPAQUE_LANE 1 /* make EXTRA=-DCRX_OPAQUE_LANE=0: round-2 behaviour (lane maps hoisted out of the interior-point loop) */
 #endif
+#ifndef CRX_OPAQUE_OUTER
+#define CRX_OPAQUE_OUTER 0 /* 0: A/B builds without the per-pass lane barrier of the (re)start loop */
+#endif
 #ifndef CRX_W2_FLOOR
 #define CRX_W2_FLOOR 0 /* 1: pin <2,12> at two waves per SIMD (256 registers, 76 B of scratch) = 6 instead of 4 problems per CU */
 #endif
@@ -1048,6 +1051,130 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
     return changed;
 }
 
+// Crash path of the MPC-CBF NLP (crx_ipm_opts.slack_start == 2; same arithmetic as oracle/crx_oracle.c crash_point()).
+// For GIVEN inputs the cheapest slacks of the rows  G_i + (1 - alpha) sigma_i - sigma_{i+1} >= 0, sigma >= 0  are the backward cascade
+// sigma_N = 0, sigma_i = max(0, (sigma_{i+1} - G_i) / (1 - alpha)), and phi(u) = f(u) + w sum sigma(u) is the exact-penalty value of u.
+// A crash state (ego inside, or about to enter, a safety set) is (re)started from a FEASIBLE INTERIOR point instead of u = 0, sigma = 0:
+// the best of a 5 x 5 grid of constant input pairs (0.9 of the box, states inside their boxes) by phi, with its cascade pushed
+// strictly inside.  One candidate per lane, 16 at a time: the lane rolls its trajectory out in registers, parks (s_k, ey_k) in the row
+// arrays rt .. rtt (dead at the start; at a restart they are re-initialised right after) and walks the cascade backwards.
+// crash_search() returns the winning candidate, -1 when none keeps the states inside their boxes; it runs BEFORE the interior-point
+// loop, for the problems that may need it (a provable crash state, or a CBF row violated at the zero start) -- inside the (re)start loop
+// its temporaries sat on top of the ~200 registers the sweeps hoist out of the loops (64 .. 164 B of scratch per lane).  crash_write()
+// is the light half and is what the restart runs.
+template <int NOBS, int NMAX>
+__device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_kparams& kp) {
+    using L = Lay<NOBS, NMAX>;
+    constexpr int NX = L::NX, NZ = L::NZ, CH = 16, G1 = 5;
+    static_assert(NOBS == 0 || CH * 2 * (NMAX + 1) <= 5 * L::MR, "the candidates' (s, ey) samples fit in the row arrays rt .. rtt");
+    if (NOBS == 0) return -1;
+    const int N = c.N, N1 = N + 1, lane = c.lane;
+    double* scr = sm + L::rt;
+    const int q = c.degree;
+    double best = INFINITY;
+    int bestc = -1;
+    for (int r = 0; r * CH < G1 * G1; r++) {
+        const int cand = r * CH + lane;
+        const int a = cand / G1, b = cand - a * G1;
+        const double u0 = 0.9 * (2.0 * a / (G1 - 1) - 1.0) * kp.delta_max, u1 = 0.9 * (2.0 * b / (G1 - 1) - 1.0) * kp.a_max;
+        double val = INFINITY;
+        if (lane < CH && cand < G1 * G1) {
+            double x[6], v = 0.0;
+            bool inside = true;
+#pragma unroll
+            for (int i = 0; i < 6; i++) x[i] = LD(L::Z + i);
+            scr[0 * CH + lane] = x[4]; scr[1 * CH + lane] = x[5];
+            for (int k = 1; k <= N; k++) {
+                double xn[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) t += kp.A[i * 6 + j] * x[j];
+                    t += kp.B[i * 2] * u0 + kp.B[i * 2 + 1] * u1;
+                    xn[i] = t;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] = xn[i];
+                inside = inside && x[0] > kp.v_min + 1e-3 && x[0] < kp.v_max - 1e-3 && x[5] > -kp.ey_max + 1e-3 && x[5] < kp.ey_max - 1e-3;
+#pragma unroll
+                for (int i = 0; i < 6; i++) { const double e = x[i] - LD(L::xr + k * 6 + i); v += LD(L::cst + i) * e * e; }
+                scr[(2 * k) * CH + lane] = x[4]; scr[(2 * k + 1) * CH + lane] = x[5];
+            }
+            for (int k = 0; k < N; k++) v += kp.wr[0] * u0 * u0 + kp.wr[1] * u1 * u1;
+            double casc = 0.0;
+            for (int ob = 0; ob < c.nobs; ob++) {
+                const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + L::NO + ob), lo = LD(L::cst + 12 + ob);
+                double snext = 0.0;
+                for (int i = N - 1; i >= 0; i--) {
+                    const double dsc = (scr[(2 * i) * CH + lane] - LD(L::obs_s + ob * N1 + i) - lo) * rLs;
+                    const double dec = (scr[(2 * i + 1) * CH + lane] - LD(L::obs_e + ob * N1 + i)) * rWs;
+                    const double dsn = (scr[(2 * i + 2) * CH + lane] - LD(L::obs_s + ob * N1 + i + 1)) * rLs;
+                    const double den = (scr[(2 * i + 3) * CH + lane] - LD(L::obs_e + ob * N1 + i + 1)) * rWs;
+                    const double G = ipow_d(dsn, q) + ipow_d(den, q) - c.om * (ipow_d(dsc, q) + ipow_d(dec, q)) - c.alpha * c.cm;
+                    double si = (snext - G) / c.om;
+                    si = si < 0.0 ? 0.0 : si;
+                    casc += si;
+                    snext = si;
+                }
+            }
+            v += c.wsig * casc;
+            val = inside ? v : INFINITY;
+        }
+        const double vm = wave_min(val);
+        if (vm < best) {                                  // first minimum wins (candidates in ascending order)
+            const unsigned long long hit = __ballot(val == vm);
+            bestc = r * CH + (__ffsll((long long)hit) - 1);
+            best = vm;
+        }
+    }
+    return bestc;
+}
+// ... and the point itself for candidate `bestc` of crash_search(): inputs, rolled-out states, the cascade pushed inside
+template <int NOBS, int NMAX, bool cascade>
+__device__ __forceinline__ void crash_write(double* sm, const Ctx& c, const crx_kparams& kp, int bestc) {
+    using L = Lay<NOBS, NMAX>;
+    constexpr int NX = L::NX, NZ = L::NZ, G1 = 5;
+    if (NOBS == 0) return;
+    const int N = c.N, lane = c.lane, q = c.degree;
+    const int a = bestc / G1, b = bestc - a * G1;
+    const double u0 = 0.9 * (2.0 * a / (G1 - 1) - 1.0) * kp.delta_max, u1 = 0.9 * (2.0 * b / (G1 - 1) - 1.0) * kp.a_max;
+    SYNC();
+    for (int e = lane; e < N * 2; e += WAVE) LD(L::Z + (e >> 1) * NZ + NX + (e & 1)) = (e & 1) ? u1 : u0;
+    SYNC();
+    for (int k = 0; k < N; k++) {
+        if (lane < 6) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += LD(L::M + lane * NZ + j) * LD(L::Z + k * NZ + j);
+            t += LD(L::M + lane * NZ + NX) * u0 + LD(L::M + lane * NZ + NX + 1) * u1;
+            LD(L::Z + (k + 1) * NZ + lane) = t;
+        }
+        SYNC();
+    }
+    if (lane < c.nobs) {
+        const int ob = lane;
+        const double push = kp.opts.slack_push;
+        double snext = push;
+        LD(L::Z + N * NZ + 6 + ob) = push;
+        LD(L::Z + (N - 1) * NZ + NX + 2 + ob) = push;
+        for (int i = N - 1; i >= 0; i--) {
+            double si = push;
+            if constexpr (cascade) {    // (the restart leaves the cascade to restore_slacks(), which it shares with the closed-form restoration)
+                double dsc, dec, dsn, den;
+                cbf_dist<NOBS, NMAX>(sm, c, i, ob, 0.0, dsc, dec, dsn, den);
+                const double G = ipow_d(dsn, q) + ipow_d(den, q) - c.om * (ipow_d(dsc, q) + ipow_d(dec, q)) - c.alpha * c.cm;
+                si = (snext - G + push) / c.om;
+                si = si < push ? push : si;
+            }
+            LD(L::Z + i * NZ + 6 + ob) = si;                                   // both copies of sigma_i (state of stage i, input of stage i-1)
+            if (i >= 1) LD(L::Z + (i - 1) * NZ + NX + 2 + ob) = si;
+            snext = si;
+        }
+    }
+    SYNC();
+}
+
 // The planner's answer for a region whose QP has no solution: the reference's fall-back trajectory
 // (overtake_traj_planner.py:365-374), zero inputs, cost +inf.
 // The reference builds it from the start-line-WRAPPED ego state xcurv_ego (:366-369) although the QP's x_0 is the raw
@@ -1323,19 +1450,19 @@ crx_solve_kernel(const crx_kparams kp) {
         LD(L::rdt + j) = 0.0; LD(L::rtt + j) = 1.0;
     }
     SYNC();
-    // [r3] Slack start (OPTIONAL: crx_set_cbf_slack_start, off by default).  IPOPT starts every sigma at its bound (pushed to 1e-2); for a car that starts inside an obstacle's safety
-    // set that is far from where the slacks must end (1e2..1e5: each row i needs sigma_i >= (sigma_{i+1} - G_i) / (1 - alpha), a
-    // 1/(1-alpha) cascade over the stages the car cannot leave the set in), the iteration crawls towards it row by row and a
-    // quarter of those solves used to die on the way.  What CAN be said before solving: s_k and ey_k stay within reach_s[k],
+    const crx_ipm_opts o = kp.opts;
+    // [r3] Provable lower bounds of the slacks.  IPOPT starts every sigma at its bound (pushed to 1e-2); a car that starts inside an
+    // obstacle's safety set needs slacks of 1e2..1e5 (each row i needs sigma_i >= (sigma_{i+1} - G_i) / (1 - alpha): a 1/(1-alpha) growth
+    // over the stages the car cannot leave the set in).  What CAN be said before solving: s_k and ey_k stay within reach_s[k],
     // reach_gain[k] of the free response (boxed inputs), so G_i = g(x_{i+1}) - (1 - alpha) g(x_i) - alpha (1 + margin) has an upper
     // bound Gmax_i over ALL admissible inputs, and backwards from L_N = 0, L_i = max(0, (L_{i+1} - Gmax_i) / (1 - alpha)) is a
-    // PROVABLE lower bound of sigma_i at any feasible point.  The slacks start there (a value the optimum cannot undercut, so the
-    // start costs no more than the optimum) -- zero, i.e. unchanged, for every problem whose rows can be met without slack.
-    // BASELINE draws: cfg2 headline batch 245 -> 253 of 256 converged (7 of the new ones certified as KKT points of the
-    // reference-built NLP), cfg4 92.7 -> 95.9 %; same point with the same cost on 99.6 % of the problems that converged before;
-    // but the solves that now run to their end instead of failing early lengthen the launch (0.87 -> 1.00 ms per 256 NLPs):
-    // a trade, not the default.  The oracle does the same (crx_oracle.c ipm_solve, knob 14).
-    if (NOBS && kp.slack_start) {
+    // PROVABLE lower bound of sigma_i at any feasible point.  slack_start == 1 (libcrx 0.1.3's option) starts the slacks there;
+    // slack_start == 2 (default, [r4]) only asks WHETHER some L_i is positive -- a crash state -- and then takes the crash path
+    // (crash_point() above).  Zero, i.e. nothing changes, for every problem whose rows can be met without slack.  Same arithmetic as
+    // oracle/crx_oracle.c slack_lower_bounds().
+    int crash_state = 0;
+    if (NOBS && kp.slack_start && c.om > 1e-6) {
+        bool any = false;
         if (lane < c.nobs) {
             const int ob = lane, q = c.degree;
             double Lb = 0.0;
@@ -1349,67 +1476,28 @@ crx_solve_kernel(const crx_kparams kp) {
                 const double Gmax = ipow_d(mx_sn, q) + ipow_d(mx_en, q) - c.om * (ipow_d(mn_sc, q) + ipow_d(mn_ec, q)) - c.alpha * c.cm;
                 Lb = (Lb - Gmax) / c.om;
                 Lb = Lb > 0.0 ? Lb : 0.0;
-                if (Lb > 0.0) {                                          // both copies of sigma_i (state of stage i, input of stage i-1)
-                    LD(L::Z + i * NZ + 6 + ob) = Lb;
-                    if (i >= 1) LD(L::Z + (i - 1) * NZ + NX + 2 + ob) = Lb;
+                if (Lb > 0.0) {
+                    any = true;
+                    if (kp.slack_start == 1) {                          // both copies of sigma_i (state of stage i, input of stage i-1)
+                        LD(L::Z + i * NZ + 6 + ob) = Lb;
+                        if (i >= 1) LD(L::Z + (i - 1) * NZ + NX + 2 + ob) = Lb;
+                    }
                 }
             }
         }
+        crash_state = __ballot(any) != 0ull;
         SYNC();
     }
-    // CBF row scaling at the start (IPOPT's gradient-based scaling, measured in the reference's variables)
-    if (NOBS) {
-        for (int e = lane; e < N * NOBS; e += WAVE) {
-            const int k = e / NOBS, o = e - k * NOBS;
-            if (o < c.nobs) {
-                double dsc, dec, dsn, den;
-                cbf_dist<NOBS, NMAX>(sm, c, k, o, 0.0, dsc, dec, dsn, den);
-                const int q = c.degree;
-                double gm = 1.0;
-                const double rLs = LD(L::cst + 16 + o), rWs = LD(L::cst + 16 + NOBS + o);
-                gm = fmax(gm, fabs(q * ipow_d(dsn, q - 1) * rLs));
-                gm = fmax(gm, fabs(q * ipow_d(den, q - 1) * rWs));
-                if (k > 0) {
-                    gm = fmax(gm, fabs(c.om * q * ipow_d(dsc, q - 1) * rLs));
-                    gm = fmax(gm, fabs(c.om * q * ipow_d(dec, q - 1) * rWs));
-                }
-                LD(L::SLIM ? L::csc + k * L::NO + o : L::rsc + k * NR + 8 + NOBS + o) = fmin(1.0, kp.opts.grad_scale_max / gm);
-            }
-        }
-        SYNC();
-    }
-    eval_rows<NOBS, NMAX>(sm, si, c);
-    SYNC();
-    for (int j = lane; j < m; j += WAVE)
-        if (row_scale<L>(sm, si, j, N) != 0.0) LD(L::rt + j) = fmax(fabs(LD(L::rc + j)), kp.opts.slack_push);
-    // multiplier start on simple-bound rows: the reduced cost gradient that pushes against the bound
-    for (int j = lane; j < m; j += WAVE) { LD(L::rtt + j) = LD(L::rnu + j); LD(L::rnu + j) = 0.0; }
-    SYNC();
-    first_order<NOBS, NMAX>(sm, si, c);          // with nu = 0: ga = grad f
-    (void)dual_infeasibility<NOBS, NMAX>(sm, c);  // ga <- reduced cost gradient (inputs, sigma_0)
-    for (int j = lane; j < m; j += WAVE) {
-        double nu = LD(L::rtt + j);
-        const int pk = RIVT(si, j);
-        if (nu != 0.0 && (pk & RIV_SIMPLE)) {
-            const int iv = RIV_IDX(pk);
-            const int kk = iv / NZ, a = iv - kk * NZ;
-            if (a >= NX || (kk == 0 && a >= 6)) {          // input or sigma_0 coordinate
-                const double gg = RIV_SGN(pk) * LD(L::ga + iv);
-                if (gg > 1.0) nu = gg;
-            }
-        }
-        LD(L::rnu + j) = nu;
-        LD(L::rtt + j) = 1.0;
-    }
-    SYNC();
-    first_order<NOBS, NMAX>(sm, si, c);
-
-    const crx_ipm_opts o = kp.opts;
+    // [r4] crash path (include/crx.h crx_ipm_opts.slack_start == 2): a provable crash state starts from the feasible interior point of
+    // crash_point(); a solve that started at zero and stalls on violated CBF rows restarts ONCE from such a point.  `crash` = this
+    // solve is on the crash path (it also selects the convexified inertia retry below).
+    const bool crash_path = NOBS > 0 && kp.slack_start == 2 && o.restore_iters >= 0 && c.om > 1e-6 && c.nobs > 0;
+    int crash = 0;
     double mu = o.mu_init, dw_last = 0.0, E0 = INFINITY, theta_min = 0.0, theta_max = INFINITY;
-    double f = cost_value<NOBS, NMAX>(sm, c, 0.0);
+    double f = 0.0;
     int nf = 0, status = 1, it = 0;
     double mact = 0.0;
-    for (int j = lane; j < m; j += WAVE) mact += (row_scale<L>(sm, si, j, N) != 0.0) ? 1.0 : 0.0;
+    for (int j = lane; j < m; j += WAVE) mact += (LD(L::rnu + j) != 0.0) ? 1.0 : 0.0;   // rnu = presence flag of the row (table loop above)
     mact = wave_sum(mact);
     const double kappa_sigma = 1e10, smax = 100.0, eta = 1e-8;
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1435,24 +1523,109 @@ crx_solve_kernel(const crx_kparams kp) {
         nus = wave_sum(nus); e_p = wave_max(e_p); cmax = wave_max(cmax); cmin = wave_min(cmin);
         logsum_t = lgs.wave_total();
     };
-    row_stats();
-    // The interior-point loop sits inside a retry loop: when the line search finds no acceptable step the (out-of-loop,
-    // rare) restoration below re-initialises the CBF slacks and the loop is entered again, at most twice.  Keeping the
-    // restoration outside the loop body keeps its registers out of the loop's allocation (inside it cost the 1-obstacle
-    // instantiation 14 registers = one resident wave per SIMD).
+    // The interior-point loop sits inside a (re)start loop.  stage 1: take the crash point (a provable crash state at the start; a
+    // stalled solve once); stage 0: slacks and multipliers at the point Z holds; then the iteration.  When the line search finds no
+    // acceptable step the (out-of-loop, rare) crash restart or closed-form restoration below re-initialises and the loop is entered
+    // again.  Keeping all of that outside the loop body keeps its registers out of the loop's allocation (inside, the restoration
+    // cost the 1-obstacle instantiation 14 registers = one resident wave per SIMD).
     // ls_failed: 1 = no acceptable step, 2 = jam (JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the
     // constraints are still violated: the slacks of violated CBF rows are collapsing and every step is cut to nothing --
     // IPOPT's alpha < alpha_min test sends it to restoration from the same situation)
     constexpr int JAM_COUNT = 5, STALL_ITERS = 50;
     const double JAM_ALPHA = 1e-3;
     int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0;
-    theta_min = -1.0;    // < 0: the filter's theta_min / theta_max are taken at the next step (start, and after a restoration)
+    int scaled = 0;
+    // slacks and multipliers at the point Z holds -- the start, and again at the crash restart (every row array is rewritten:
+    // crash_point parks its samples there); then the merit pieces of that point.  Two call sites, both outside the interior-point loop.
+    auto init_point = [&]() {
+        // CBF row scaling at the FIRST starting point (IPOPT's gradient-based scaling, measured in the reference's variables)
+        if (NOBS && !scaled) {
+            for (int e = lane; e < N * NOBS; e += WAVE) {
+                const int k = e / NOBS, ob = e - k * NOBS;
+                if (ob < c.nobs) {
+                    double dsc, dec, dsn, den;
+                    cbf_dist<NOBS, NMAX>(sm, c, k, ob, 0.0, dsc, dec, dsn, den);
+                    const int q = c.degree;
+                    double gm = 1.0;
+                    const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + NOBS + ob);
+                    gm = fmax(gm, fabs(q * ipow_d(dsn, q - 1) * rLs));
+                    gm = fmax(gm, fabs(q * ipow_d(den, q - 1) * rWs));
+                    if (k > 0) {
+                        gm = fmax(gm, fabs(c.om * q * ipow_d(dsc, q - 1) * rLs));
+                        gm = fmax(gm, fabs(c.om * q * ipow_d(dec, q - 1) * rWs));
+                    }
+                    LD(L::SLIM ? L::csc + k * L::NO + ob : L::rsc + k * NR + 8 + NOBS + ob) = fmin(1.0, o.grad_scale_max / gm);
+                }
+            }
+            SYNC();
+        }
+        scaled = 1;
+        // slacks t = max(|c|, push); multipliers 1, simple-bound rows: the reduced cost gradient that pushes against the bound
+        eval_rows<NOBS, NMAX>(sm, si, c);
+        SYNC();
+        for (int j = lane; j < m; j += WAVE) {
+            const bool on = row_scale<L>(sm, si, j, N) != 0.0;
+            LD(L::rt + j) = on ? fmax(fabs(LD(L::rc + j)), o.slack_push) : 1.0;
+            LD(L::rtt + j) = on ? 1.0 : 0.0;        // the multiplier start, parked while first_order runs with nu = 0
+            LD(L::rnu + j) = 0.0;
+            LD(L::rdt + j) = 0.0;
+        }
+        SYNC();
+        first_order<NOBS, NMAX>(sm, si, c);          // with nu = 0: ga = grad f
+        (void)dual_infeasibility<NOBS, NMAX>(sm, c);  // ga <- reduced cost gradient (inputs, sigma_0)
+        for (int j = lane; j < m; j += WAVE) {
+            double nu = LD(L::rtt + j);
+            const int pk = RIVT(si, j);
+            if (nu != 0.0 && (pk & RIV_SIMPLE)) {
+                const int iv = RIV_IDX(pk);
+                const int kk = iv / NZ, a = iv - kk * NZ;
+                if (a >= NX || (kk == 0 && a >= 6)) {          // input or sigma_0 coordinate
+                    const double gg = RIV_SGN(pk) * LD(L::ga + iv);
+                    if (gg > 1.0) nu = gg;
+                }
+            }
+            LD(L::rnu + j) = nu;
+            LD(L::rtt + j) = 1.0;
+        }
+        SYNC();
+        first_order<NOBS, NMAX>(sm, si, c);
+        f = cost_value<NOBS, NMAX>(sm, c, 0.0);
+        row_stats();
+        mu = o.mu_init; nf = 0; dw_last = 0.0; status = 1; jam = 0;
+        theta_min = -1.0; theta_max = INFINITY;   // < 0: the filter's theta_min / theta_max are taken at the next step (start, and after a restart / restoration)
+    };
+    // the candidate search runs here, before the loops, for every problem that may take the crash path: a provable crash state (it starts
+    // from the point), or a CBF row violated at the zero start (it may stall and restart from the point)
+    int crash_cand = -1;
+    if (NOBS && crash_path) {
+        bool viol = false;
+        for (int e = lane; e < N * NOBS; e += WAVE) {
+            const int k = e / L::NO, ob = e - k * L::NO;
+            if (ob < c.nobs) {
+                double dsc, dec, dsn, den;
+                cbf_dist<NOBS, NMAX>(sm, c, k, ob, 0.0, dsc, dec, dsn, den);
+                const int q = c.degree;
+                viol = viol || (ipow_d(dsn, q) + ipow_d(den, q) - c.om * (ipow_d(dsc, q) + ipow_d(dec, q)) - c.alpha * c.cm < 0.0);
+            }
+        }
+        if (crash_state || __ballot(viol) != 0ull) crash_cand = __builtin_amdgcn_readfirstlane(crash_search<NOBS, NMAX>(sm, c, kp));
+        if (crash_state && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; }
+    }
+    init_point();
     for (;;) {
     ls_failed = 0;
     // Nothing is to be carried in registers from one pass to the next: without this barrier the loop-invariant operands
     // of the sweeps (model-matrix rows, lane maps: ~200 registers) are hoisted out of BOTH loops and stay live across
-    // the restoration code, whose own temporaries then push the kernel past 256 registers.
+    // the restart / restoration code, whose own temporaries then push the kernel past 256 registers.
     asm volatile("" ::: "memory");
+#if CRX_OPAQUE_OUTER
+    // [r4] ... and the lane index is made opaque once per PASS of this outer loop (obstacle instantiations): what the sweeps derive
+    // from it is still hoisted out of the interior-point loop (they are issue-bound: the hoisted maps are worth 4..5 %), but only to
+    // the top of the pass, not out of the outer loop -- so it is dead while the crash restart at the bottom of the pass runs.
+    // Without: +21 registers and 64 B of scratch per lane for <1,12>, 164 B for <3,20>.
+    if (NOBS > 0) asm volatile("" : "+v"(c.lane));
+    const int lane = c.lane;   // shadows the kernel's `lane` inside the pass
+#endif
 
     for (;; it++) {
         long long tc0 = CLK();
@@ -1501,10 +1674,20 @@ crx_solve_kernel(const crx_kparams kp) {
         double dw = 0.0;
         long long tsub[4] = {0, 0, 0, 0};
         bool ok;
-        for (int tries = 0;; tries++) {
+        for (int tries = 0, convex = (NOBS > 0 && crash) ? 0 : 1;; ) {
             ok = riccati_backward<NOBS, NMAX>(sm, si, c, dw, tsub);
             if (ok) break;
+            if (NOBS && !convex) {
+                // [r4] crash path (iii): first retry WITHOUT the reverse-convex part of the CBF curvature (-nu hess g_{k+1}, the kS / kE
+                // terms): what remains -- cost, J' Sigma J, the "current" curvature -- is positive definite by construction; IPOPT's
+                // delta_w schedule only if rounding makes even that fail.  (kS / kE are rebuilt by the next assemble_newton.)
+                convex = 1;
+                for (int k = lane; k < N; k += WAVE) { LD(L::kS + k) = 0.0; LD(L::kE + k) = 0.0; }
+                SYNC();
+                continue;
+            }
             dw = tries == 0 ? (dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0)) : dw * (dw_last == 0.0 ? 100.0 : 8.0);
+            tries++;
             if (dw > 1e40) break;
         }
         if (!ok) break;
@@ -1698,25 +1881,38 @@ crx_solve_kernel(const crx_kparams kp) {
         first_order<NOBS, NMAX>(sm, si, c);
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0 && kp.trace_rows > 0)
             kp.trace[(size_t)it * 16 + 8] = (double)(tph[0] + (CLK() - tc8));   // slot 8: KKT rows + accept/first-order
-        if (numax > 1e12 && th > 1e-6) { status = 2; it++; break; }
+        if (numax > 1e12 && th > 1e-6) { status = CRX_STALLED; it++; break; }   // IPOPT's divergence heuristic: not a proof
         // still violated after the step: look for the proof that it must be (linear rows only)
         if (NOBS == 0 && th > 1e-6) {
             if (box_certificate<NOBS, NMAX>(sm, si, c, kp.delta_max, kp.a_max) < -1e-8 * numax) { status = 2; it++; break; }
         }
     }
     if (!ls_failed) break;
-    if (NOBS && o.restore_iters >= 0 && n_restore < 2 && __builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push))) {
-        // slacks of the CBF rows and of the sigma bounds re-initialised like at the start, multipliers centred
+    // [r4] crash path (ii): the solve started at the reference's zero point and stalls on violated CBF rows -- restart ONCE from the
+    // feasible interior point; later failures, or no candidate, fall through to the closed-form restoration
+    int full = 0;
+    if (NOBS && crash_path && n_restore == 0 && !crash && crash_cand >= 0) {
+        crash_write<NOBS, NMAX, false>(sm, c, kp, crash_cand);   // the candidate's inputs and states, sigma = push: restore_slacks() below raises the cascade
+        crash = 1; full = 1;
+    }
+    if (NOBS && o.restore_iters >= 0 && n_restore < 2 && (__builtin_amdgcn_readfirstlane((int)restore_slacks<NOBS, NMAX>(sm, c, o.slack_push)) | full)) {
+        // slacks of the CBF rows and of the sigma bounds re-initialised like at the start, multipliers centred; after a crash restart
+        // (full) the inputs have changed as well: every other row restarts with t = max(|c|, push), nu = 1
         eval_rows<NOBS, NMAX>(sm, si, c);
         SYNC();
         for (int j = lane; j < m; j += WAVE) {
             const bool cbf = ROW_IS_CBF(j, N);
             const int r = j < N * NR ? j % NR : 8;              // rows N*NR.. are the sigma_0 bounds
             const bool sig = NOBS && (j >= N * NR || (r >= 8 && r < 8 + NOBS));
-            if ((cbf || sig) && row_scale<L>(sm, si, j, N) != 0.0) {
+            if (row_scale<L>(sm, si, j, N) != 0.0) {
                 const double t = fmax(fabs(LD(L::rc + j)), o.slack_push);
-                LD(L::rt + j) = t;
-                LD(L::rnu + j) = fmin(fmax(o.mu_init / t, 1e-8), 1e8);
+                if (cbf || sig) {
+                    LD(L::rt + j) = t;
+                    LD(L::rnu + j) = fmin(fmax(o.mu_init / t, 1e-8), 1e8);
+                } else if (full) {
+                    LD(L::rt + j) = t;
+                    LD(L::rnu + j) = 1.0;
+                }
             }
         }
         SYNC();
@@ -1736,11 +1932,12 @@ crx_solve_kernel(const crx_kparams kp) {
         if constexpr (L::SLIM) first_order<NOBS, NMAX>(sm, si, c);
         continue;
     }
-    // no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still violated there
-    if (e_p > 1e-6) status = 2;
+    // no acceptable step and nothing to restore: IPOPT's "converged to a point of local infeasibility" / "restoration failed" if the
+    // constraints are still violated there -- not a proof: CRX_STALLED
+    if (e_p > 1e-6) status = CRX_STALLED;
     break;
     }
-    if (infeas0) status = 2;
+    if (infeas0) status = CRX_INFEASIBLE;        // a bound violated by the fixed x_0: proved
 
     // ---- write back: one coalesced pass ----------------------------------------------------------------
     SYNC();
@@ -1809,6 +2006,10 @@ __global__ void __launch_bounds__(WAVE) crx_select_kernel(const crx_select_kpara
 
 #endif  // !CRX_TU_OBSTACLES
 
+#ifdef CRX_PROBE_ONE
+// tools/kernel_resources.py one NOBS NMAX DEG NFIX: ONE instantiation, compiled alone (seconds instead of minutes)
+template __global__ void crx_solve_kernel<CRX_PROBE_ONE>(const crx_kparams);
+#else
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
@@ -1961,3 +2162,4 @@ hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st
     return hipGetLastError();
 }
 #endif  // !CRX_TU_OBSTACLES
+#endif  // !CRX_PROBE_ONE

@@ -44,11 +44,13 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 130 /* 0.1.3: crx_cbf_solve_dims[_dev] (per-obstacle dimensions), crx_plant_step_noise_dev, crx_game_*_dev,
-                          crx_comm_* / crx_allgather_winners_dev (RCCL), crx_*_solve_ordered_dev, crx_order_longest_first_dev, crx_cbf_order_dev (dispatch order), crx_streams_*, crx_set_reach_screen, crx_set_cbf_slack_start; additions
-                          only, every 0.1.2 entry point unchanged
-                          (0.1.2: infeasibility certificates, *_masked_dev entry points, CRX_SKIPPED, crx_track_prep_dev;
-                           0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters (was reserved0)) */
+#define CRX_VERSION 200 /* 0.2.0: NOT layout-compatible with 0.1.x -- crx_ipm_opts grew by `reach_screen` and `slack_start` (every descriptor
+                          embeds it), the process-global switches crx_set_reach_screen / crx_set_cbf_slack_start / crx_set_timing /
+                          crx_last_kernel_ms are gone (options travel in the descriptor, timing is an object: crx_timer_*), new status
+                          CRX_STALLED (what CRX_INFEASIBLE used to report without a proof).
+                          (0.1.3: per-obstacle dimensions, plant noise, crx_game_*, crx_comm_* (RCCL), dispatch order, crx_streams_*;
+                           0.1.2: infeasibility certificates, *_masked_dev, CRX_SKIPPED, crx_track_prep_dev;
+                           0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters) */
 #define CRX_NX 6
 #define CRX_NU 2
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
@@ -67,15 +69,19 @@ typedef enum crx_err {
 
 typedef enum crx_status {
     CRX_CONVERGED = 0,     /* KKT error <= tol */
-    CRX_MAX_ITER = 1,      /* iteration cap or line-search failure; last iterate returned */
-    CRX_INFEASIBLE = 2,    /* constraints cannot be met (incl. a bound already violated by the fixed x0), or no acceptable
-                              step exists at a point that still violates them (IPOPT: local infeasibility) */
-    CRX_RESTORED = 3,      /* MPC-CBF NLPs only: the solve went through its restoration phase (the step jammed on violated
-                              CBF rows, or the line search failed: a crash state) and used up opts.restore_iters further
-                              iterations without converging.  The returned iterate satisfies every CBF row through its
-                              slacks sigma (least-violation point, zero violation) but is not optimal.  Like every status
-                              != 0 it selects the reference's "use the last iterate" branch (control.py:600-603). */
-    CRX_SKIPPED = 4        /* *_masked_dev launches only: active[b] == 0, the problem was left alone (outputs untouched) */
+    CRX_MAX_ITER = 1,      /* iteration cap, or the line search failed at a point that satisfies the constraints; last iterate returned */
+    CRX_INFEASIBLE = 2,    /* PROVED infeasible: a bound already violated by the fixed x0 (quirk Q9 / the planner's ey_0 rows), the
+                              reachability screen, or the Farkas certificate over the input box (problems whose rows are all linear:
+                              planner QPs, 0-obstacle NLPs, first attempts of the learning-MPC QP).  Never a heuristic. */
+    CRX_RESTORED = 3,      /* MPC-CBF NLPs only: the solve went through its crash path (restart from a feasible interior point, or
+                              the closed-form slack restoration) and used up opts.restore_iters further iterations without
+                              converging.  The returned iterate satisfies every CBF row through its slacks sigma but is not optimal. */
+    CRX_SKIPPED = 4,       /* *_masked_dev launches only: active[b] == 0, the problem was left alone (outputs untouched) */
+    CRX_STALLED = 5        /* gave up WITHOUT a proof at a point that still violates its constraints: no acceptable step (IPOPT:
+                              "restoration failed" / "converged to a point of local infeasibility"), or multipliers past 1e12 (IPOPT's
+                              divergence heuristic).  libcrx <= 0.1.3 reported these as CRX_INFEASIBLE.  Like every status != 0 it
+                              selects the reference's "solver failed" branch (control.py:600-603: keep the last iterate;
+                              overtake_traj_planner.py:365-374: the fall-back trajectory). */
 } crx_status;
 
 /* Interior-point options.  Defaults (crx_ipm_opts_default) restate IPOPT 3.x defaults that the
@@ -92,6 +98,30 @@ typedef struct crx_ipm_opts {
     double tau_min;        /* 0.99  fraction-to-the-boundary */
     double slack_push;     /* 1e-2  initial slack floor (bound_push) */
     double grad_scale_max; /* 100   gradient-based row scaling target (nlp_scaling_max_gradient) */
+    int32_t reach_screen;  /* 1     reachability screens (0 = off: every problem goes through the interior-point iteration).
+                              Planner QPs: the inputs are boxed, so ey_j cannot leave [free response -+ reach_j], reach_j =
+                              sum_{m<j} |e_ey' A^m B| (delta_max, a_max)'; a region whose ey bound at some stage lies outside that
+                              interval by more than 1e-6 has no feasible trajectory -- a proof, independent of the other rows -- and
+                              is answered before the iteration is set up: CRX_INFEASIBLE, iters 0, kkt +inf, X = the reference's
+                              fall-back trajectory, cost +inf.  Learning-MPC QP: the same for the first attempt's terminal set
+                              (x_N = SS lambd needs component c of x_N inside [min_j SS_cj, max_j SS_cj]); the attempt is skipped,
+                              the relaxed second attempt runs as it would have. */
+    int32_t slack_start;   /* 2     start of the MPC-CBF NLPs whose slacks cannot stay at zero (crash states: the ego inside, or about to
+                              enter, an obstacle's safety set; 3..8 % of the BASELINE draws).  The reference passes no initial guess
+                              (control.py:593-599), IPOPT starts at u = 0, sigma = 0 and would enter its restoration phase.
+                              0: that start only; a solve that stalls is restored in closed form (slacks raised at the current
+                                 inputs) -- libcrx 0.1.x behaviour;
+                              1: the slacks start at provable lower bounds of their optimal values (0.1.3's optional switch);
+                              2: CRASH PATH (default).  (i) A problem whose slacks are PROVABLY positive at every admissible input
+                                 (reach of (s, ey) under the boxed inputs) does not start at zero: the best of a 5 x 5 grid of constant
+                                 input pairs by f(u) + w sum sigma(u), sigma(u) = the minimal slack cascade for that u, with that
+                                 cascade pushed strictly inside -- a feasible interior point.  (ii) A solve that started at zero and
+                                 stalls on violated CBF rows (no acceptable step, jam, 50 iterations still infeasible) restarts ONCE
+                                 from such a point instead of being abandoned.  (iii) On the crash path a reduced Hessian of the wrong
+                                 inertia is first retried WITHOUT the reverse-convex part of the CBF curvature (positive definite by
+                                 construction) before IPOPT's delta_w schedule.  Problems that never enter the crash path are untouched,
+                                 bit for bit.  BASELINE configs[1]: 95.7 -> 100 % of the 256 NLPs converge, longest solve 58 -> 38
+                                 iterations; configs[3]: 92.5 -> 98.9 % (oracle). */
 } crx_ipm_opts;
 
 /* ---- planner region QP (overtake_traj_planner.py:263-334) ------------------------------------ */
@@ -651,35 +681,15 @@ int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag
 int crx_streams_create(int n, void** streams /* [n] out */, int* n_concurrent /* out, may be NULL */);
 int crx_streams_destroy(int n, void** streams);
 
-/* Average device time (ms) of the solver kernel in the most recent *_dev/host call, measured with
- * HIP events on the launch stream; < 0 if timing was not enabled.  bench.py's roofline uses this.
- * PROCESS-GLOBAL and unsynchronised (one switch, one pair of events): a measurement aid for one stream at a time -- two
- * threads or streams timing concurrently overwrite each other's events.  Leave it off outside measurements. */
-void crx_set_timing(int enable);
-double crx_last_kernel_ms(void);
-
-/* Reachability screen of the planner's region QPs (on by default; process-global switch for measurements).  The inputs are
- * boxed, so ey_j cannot leave [free response -+ reach_j], reach_j = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)'; a region whose
- * ey bound at some stage lies outside that interval by more than 1e-6 has no feasible trajectory -- a proof, independent of
- * the other rows -- and is answered before the interior-point iteration is set up: status CRX_INFEASIBLE, iters 0, kkt +inf,
- * X = the reference's fall-back trajectory, cost +inf (what a failed solve returns anyway).  On the BASELINE draws every
- * infeasible region (41 %) ends there.  0 = every QP goes through the interior-point iteration (round-2 behaviour).
- * The same switch covers the learning-MPC QP's first attempt (the reference's own QP, terminal state pinned to the hull of the safe
- * set): component c of x_N stays within sum_a |dx_N,c / du_a| umax_a of its free response, and x_N = SS lambd needs it inside
- * [min_j SS_cj, max_j SS_cj]; disjoint intervals in any component prove the attempt infeasible, it is skipped (its iterations do not
- * appear in iters) and the relaxed second attempt runs as it would have: same X, U, lambda, status CRX_INFEASIBLE. */
-void crx_set_reach_screen(int enable);
-
-/* Slack start of the CBF NLPs (OFF by default; process-global switch).  The reference gives no initial guess (control.py:593-599)
- * and IPOPT starts every slack sigma at its bound; a car that starts inside an obstacle's safety set needs slacks of 1e2..1e5 (a
- * 1/(1-alpha) cascade over the stages it cannot leave the set in) and a quarter of those solves fail on the way there.  With the
- * switch on libcrx starts sigma_i at a PROVABLE lower bound of its optimal value -- from the reach of (s, ey) under the boxed
- * inputs, crx_kernels.hip "Slack start" -- which is 0, i.e. the reference's start, for every problem whose CBF rows can be met
- * without slack (those are untouched, bit for bit).  BASELINE configs[1] draw: 95.7 -> 98.8 % of the 256 NLPs converge (7 of the 8
- * new ones certified as KKT points of the reference-built NLP: tests/golden/cfg2_draw.npz, how = 3), configs[3]: 92.7 -> 95.9 %;
- * the price is the time of the solves that now run to their end instead of failing early: 0.87 -> 1.00 ms per 256 NLPs.  A
- * trade for callers who need the crash states answered; the default keeps the reference's start. */
-void crx_set_cbf_slack_start(int enable);
+/* Device time of what a caller enqueues between two marks on ONE stream, measured with a pair of HIP events the timer object owns
+ * (bench.py's roofline: the solver launch alone).  crx_timer_begin / _end record on `stream` (the stream the bracketed *_dev call
+ * is given); crx_timer_ms blocks until the second event has happened and returns the elapsed milliseconds, < 0 on error.  No global
+ * state: any number of timers may be live on any number of streams and threads. */
+int crx_timer_create(void** timer /* out */);
+int crx_timer_destroy(void* timer);
+int crx_timer_begin(void* timer, void* stream);
+int crx_timer_end(void* timer, void* stream);
+double crx_timer_ms(void* timer);
 
 #ifdef __cplusplus
 }

@@ -251,7 +251,11 @@ static void eval_fc(work_t* w, const double* v, double* f, double* c) {
     for (int j = 0; j < w->m; j++) c[j] = w->d[j] * row_value(w, j);
 }
 
+static long g_nchol = 0, g_niter = 0;
+long crx_oracle_stat(int i) { long v = i ? g_niter : g_nchol; if (i < 0) { g_nchol = g_niter = 0; } return v; }
 static int chol(int n, double H[][MAXRED]) {
+#pragma omp atomic
+    g_nchol++;
     for (int j = 0; j < n; j++) {
         double s = H[j][j];
         for (int k = 0; k < j; k++) s -= H[j][k] * H[j][k];
@@ -390,9 +394,10 @@ static int g_verbose = 0;
 void crx_oracle_set_verbose(int v) { g_verbose = v; }
 /* experiment knobs (tools/tail_knobs.py): 0 JAM_ALPHA, 1 JAM_COUNT, 2 STALL_ITERS, 3 CRAWL_ALPHA, 4 CRAWL_COUNT (0 = off),
  * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
- * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1).  Defaults = the shipped algorithm;
- * the kernel has no such knobs. */
-static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, /* 8: reachability screen of the planner QPs */ 1, 0, 0, 0, 0, 0, /* 14: CBF slacks start at their provable lower bounds (libcrx: crx_set_cbf_slack_start; off by default) */ 0, 0};
+ * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1), 9 do not charge the knob-6
+ * restoration to the budget.  Defaults = the shipped algorithm; the kernel has no such knobs.  (What used to be knobs 8 and 14 are
+ * crx_ipm_opts.reach_screen / .slack_start since ABI 0.2.) */
+static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v; }
 
 /* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
@@ -405,7 +410,7 @@ void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v;
  * strictly inside, their slacks are re-initialised like at the start (t = c) and their multipliers centred (nu = mu/t);
  * the interior-point iteration resumes from there with a fresh filter.  Returns 0 if nothing changed (no CBF rows,
  * alpha = 1, or every row already feasible): the failure then stands. */
-static int restore_slacks(work_t* w, double mu) {
+static int restore_slacks(work_t* w, double mu, int full) {
     const ocp_t* p = w->p;
     const crx_ipm_opts* o = w->o;
     const double om = 1.0 - p->alpha;
@@ -422,11 +427,15 @@ static int restore_slacks(work_t* w, double mu) {
         const double need = (w->sig[ob][i + 1] - G + push) / om;
         if (need > w->sig[ob][i]) { w->sig[ob][i] = need; w->v[isig(w, i, ob)] = need; changed = 1; }
     }
-    if (!changed) return 0;
+    if (!changed && !full) return 0;
     eval_full(w);
     for (int j = 0; j < w->m; j++) {
         const int kind = w->row[j].kind;
-        if (kind != ROW_CBF && kind != ROW_SIG) continue;
+        if (kind != ROW_CBF && kind != ROW_SIG) {
+            /* after a crash restart (full) the inputs have changed as well: every other row restarts with t = max(|c|, push), nu = 1 */
+            if (full) { w->t[j] = fmax(fabs(w->c[j]), o->slack_push); w->nu[j] = 1.0; }
+            continue;
+        }
         w->t[j] = fmax(fabs(w->c[j]), o->slack_push);
         w->nu[j] = fmin(fmax(mu / w->t[j], 1e-8), 1e8);
     }
@@ -461,6 +470,145 @@ static double box_certificate(const work_t* w, double* wv) {
     return S;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Crash path of the MPC-CBF NLP (crx_ipm_opts.slack_start == 2; libcrx: crx_kernels.hip "crash path").
+ *
+ * Every CBF row reads  G_i(x_i, x_{i+1}) + (1 - alpha) sigma_i - sigma_{i+1} >= 0,  sigma >= 0  (control.py:544-562), so for
+ * GIVEN inputs the cheapest slacks are the backward cascade  sigma_N = 0, sigma_i = max(0, (sigma_{i+1} - G_i) / (1 - alpha)),
+ * and  phi(u) = f(u) + w sum sigma(u)  is the exact-penalty value of u.  A crash state (ego inside, or about to enter, an
+ * obstacle's safety set) needs sigma of 1e2..1e5 (a 1/(1-alpha) growth per stage the car cannot leave the set in); from the
+ * reference's start u = 0, sigma = 0 the interior-point iteration crawls there row by row -- each step cut to 1e-2..1e-3 by the
+ * fraction-to-the-boundary rule on ONE collapsed slack -- or dies on the way (where IPOPT would enter its restoration phase).
+ * Instead such a problem is (re)started from a FEASIBLE INTERIOR point: the best of a G x G grid of constant input pairs
+ * (0.9 of the box, states inside their boxes) by phi(u), with its cascade pushed strictly inside.
+ * ---------------------------------------------------------------------------------------------- */
+#define CRASH_GRID 5
+/* G_i of obstacle ob at the rolled-out states w->x */
+static double cbf_G(const work_t* w, int ob, int i) {
+    const ocp_t* p = w->p;
+    const int q = p->degree;
+    double dsc, dec, dsn, den;
+    cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
+    return ipow(dsn, q) + ipow(den, q) - (1.0 - p->alpha) * (ipow(dsc, q) + ipow(dec, q)) - p->alpha * p->cm;
+}
+/* sum over obstacles and stages of the cascade at w->x; push > 0 keeps every row and every sigma >= push inside; store != 0
+ * writes it to w->v */
+static double cascade(work_t* w, double push, int store) {
+    const ocp_t* p = w->p;
+    const double om = 1.0 - p->alpha;
+    const int N = p->N;
+    double tot = 0.0;
+    for (int ob = 0; ob < p->nobs; ob++) {
+        double snext = push;
+        if (store) w->v[isig(w, N, ob)] = snext;
+        tot += snext;
+        for (int i = N - 1; i >= 0; i--) {
+            double si = (snext - cbf_G(w, ob, i) + push) / om;
+            if (si < push) si = push;
+            if (store) w->v[isig(w, i, ob)] = si;
+            tot += si;
+            snext = si;
+        }
+    }
+    return tot;
+}
+/* reach of s and ey under the boxed inputs: gs[k], ge[k] = sum_{m<k} |e' A^m B| (delta_max, a_max)' */
+static void reach_tables(const ocp_t* p, double* gs, double* ge) {
+    double ws_[6] = {0, 0, 0, 0, 1, 0}, we_[6] = {0, 0, 0, 0, 0, 1}, as = 0.0, ae = 0.0;
+    const double um[2] = {p->uhi[0] > -p->ulo[0] ? p->uhi[0] : -p->ulo[0], p->uhi[1] > -p->ulo[1] ? p->uhi[1] : -p->ulo[1]};
+    gs[0] = ge[0] = 0.0;
+    for (int k = 1; k <= p->N; k++) {
+        double v0 = 0, v1 = 0, e0 = 0, e1 = 0, wn[6] = {0}, en[6] = {0};
+        for (int i = 0; i < 6; i++) { v0 += ws_[i] * p->B[i * 2]; v1 += ws_[i] * p->B[i * 2 + 1]; e0 += we_[i] * p->B[i * 2]; e1 += we_[i] * p->B[i * 2 + 1]; }
+        as += fabs(v0) * um[0] + fabs(v1) * um[1]; ae += fabs(e0) * um[0] + fabs(e1) * um[1];
+        gs[k] = as; ge[k] = ae;
+        for (int a = 0; a < 6; a++) for (int i = 0; i < 6; i++) { wn[a] += ws_[i] * p->A[i * 6 + a]; en[a] += we_[i] * p->A[i * 6 + a]; }
+        memcpy(ws_, wn, sizeof(wn)); memcpy(we_, en, sizeof(en));
+    }
+}
+/* PROVABLE lower bounds of the slacks at the zero-input roll-out w->x: s_k, ey_k stay within gs[k], ge[k] of the free response, so
+ * G_i has an upper bound Gmax_i over ALL admissible inputs and, backwards from L_N = 0, L_i = max(0, (L_{i+1} - Gmax_i) / (1-alpha))
+ * bounds sigma_i from below at any feasible point.  Returns whether some L_i > 0; scale != 0 stores scale * L_i as the start
+ * (slack_start == 1, libcrx 0.1.3's option). */
+static int slack_lower_bounds(work_t* w, double scale) {
+    const ocp_t* p = w->p;
+    const int N = p->N, q = p->degree;
+    const double om = 1.0 - p->alpha;
+    double gs[MAXN + 1], ge[MAXN + 1];
+    reach_tables(p, gs, ge);
+    int any = 0;
+    for (int ob = 0; ob < p->nobs; ob++) {
+        double Lb = 0.0;
+        for (int i = N - 1; i >= 0; i--) {
+            double dsc, dec, dsn, den;
+            cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
+            const double rsc = gs[i] / p->Ls[ob], rec = ge[i] / p->Ws[ob], rsn = gs[i + 1] / p->Ls[ob], ren = ge[i + 1] / p->Ws[ob];
+            const double mx_sn = fmax(fabs(dsn - rsn), fabs(dsn + rsn)), mx_en = fmax(fabs(den - ren), fabs(den + ren));
+            const double mn_sc = (fabs(dsc) > rsc) ? fabs(dsc) - rsc : 0.0, mn_ec = (fabs(dec) > rec) ? fabs(dec) - rec : 0.0;
+            const double Gmax = ipow(mx_sn, q) + ipow(mx_en, q) - om * (ipow(mn_sc, q) + ipow(mn_ec, q)) - p->alpha * p->cm;
+            Lb = (Lb - Gmax) / om;
+            if (Lb < 0.0) Lb = 0.0;
+            if (Lb > 0.0) { any = 1; if (scale != 0.0) w->v[isig(w, i, ob)] = Lb * scale; }
+        }
+    }
+    return any;
+}
+/* The feasible interior point of the crash path in w->v (inputs + slacks); returns 0 (w->v untouched) when no candidate keeps
+ * the states inside their boxes.  Candidate c = a * G + b: delta = 0.9 (2a/(G-1) - 1) delta_max, accel = 0.9 (2b/(G-1) - 1) a_max;
+ * value = sum_{k=1..N} sum_i wq_i (x_ki - xr_ki)^2 + sum_{k<N} (wr_0 delta^2 + wr_1 accel^2) + w * cascade (the stage-0 tracking
+ * term is the same for all); first minimum wins. */
+static int crash_point(work_t* w, int with_cascade) {
+    const ocp_t* p = w->p;
+    const int N = p->N, n = w->nred, G1 = CRASH_GRID;
+    static _Thread_local double vkeep[MAXRED];
+    memcpy(vkeep, w->v, sizeof(double) * n);
+    double best = HUGE_VAL, bu[2] = {0, 0};
+    for (int a = 0; a < G1; a++)
+        for (int b = 0; b < G1; b++) {
+            const double u0 = 0.9 * (2.0 * a / (G1 - 1) - 1.0) * p->uhi[0], u1 = 0.9 * (2.0 * b / (G1 - 1) - 1.0) * p->uhi[1];
+            memset(w->v, 0, sizeof(double) * n);
+            for (int k = 0; k < N; k++) { w->v[iu(w, k)] = u0; w->v[iu(w, k) + 1] = u1; }
+            unpack(w, w->v);
+            int inside = 1;
+            double val = 0.0;
+            for (int k = 1; k <= N; k++) {
+                if (!(w->x[k][0] > p->vlo[k] + 1e-3 && w->x[k][0] < p->vhi[k] - 1e-3 && w->x[k][5] > p->elo[k] + 1e-3 && w->x[k][5] < p->ehi[k] - 1e-3)) inside = 0;
+                for (int i = 0; i < 6; i++) { const double e = w->x[k][i] - p->xr[k][i]; val += p->wq[i] * e * e; }
+            }
+            for (int k = 0; k < N; k++) val += p->wr[0] * u0 * u0 + p->wr[1] * u1 * u1;
+            val += p->wsig * cascade(w, 0.0, 0);
+            if (inside && val < best) { best = val; bu[0] = u0; bu[1] = u1; }
+        }
+    if (!(best < HUGE_VAL)) { memcpy(w->v, vkeep, sizeof(double) * n); unpack(w, w->v); return 0; }
+    memset(w->v, 0, sizeof(double) * n);
+    for (int k = 0; k < N; k++) { w->v[iu(w, k)] = bu[0]; w->v[iu(w, k) + 1] = bu[1]; }
+    unpack(w, w->v);
+    if (with_cascade) cascade(w, w->o->slack_push, 1);
+    else   /* the restart: sigma = push everywhere, restore_slacks() raises the cascade (with its row-scaled push) */
+        for (int ob = 0; ob < p->nobs; ob++)
+            for (int k = 0; k <= N; k++) w->v[isig(w, k, ob)] = w->o->slack_push;
+    unpack(w, w->v);
+    return 1;
+}
+/* slacks and multipliers at the point w->v (start, and the restart of the crash path): t = max(|c|, push) -- inside the bound by at
+ * least slack_push and, for a violated row, as large as the violation so that the first fraction-to-the-boundary step is O(1/2),
+ * not O(push) --, nu = 1 except on simple-bound rows, which start at the cost gradient that pushes against the bound (dual-feasible
+ * start for the 1e4-weighted CBF slacks; IPOPT starts all at 1) */
+static void init_rows(work_t* w) {
+    const crx_ipm_opts* o = w->o;
+    eval_full(w);
+    for (int j = 0; j < w->m; j++) {
+        w->t[j] = g_knob[7] != 0.0 ? fmax(w->c[j], o->slack_push * g_knob[7]) : fmax(fabs(w->c[j]), o->slack_push);
+        w->nu[j] = 1.0;
+        const rowdef_t* r = &w->row[j];
+        double gg = 0.0;
+        if (r->kind == ROW_SIG) gg = w->g[isig(w, r->k, r->o)];
+        else if (r->kind == ROW_ULO) gg = w->g[iu(w, r->k) + r->i];
+        else if (r->kind == ROW_UHI) gg = -w->g[iu(w, r->k) + r->i];
+        if (gg > 1.0) w->nu[j] = gg;
+    }
+}
+
 static void ipm_solve(work_t* w, result_t* res) {
     const ocp_t* p = w->p;
     const crx_ipm_opts* o = w->o;
@@ -469,59 +617,21 @@ static void ipm_solve(work_t* w, result_t* res) {
     (void)smax;
     memset(w->v, 0, sizeof(double) * n);
     unpack(w, w->v);
-    if (g_knob[14] != 0.0 && p->nobs > 0) {
-        /* [r3] slack start (libcrx: crx_kernels.hip "Slack start", include/crx.h crx_set_cbf_slack_start; knob 14 = 0 restores IPOPT's
-         * start): the CBF slacks start at PROVABLE lower bounds of their optimal values.  s_k, ey_k stay within reach_k of the free
-         * response (boxed inputs), so G_i = g_next - (1-alpha) g_cur - alpha cm has an upper bound over all admissible inputs; row
-         * i: G_i - sigma_{i+1} + (1-alpha) sigma_i >= 0 then gives sigma_i >= (L_{i+1} - Gmax_i) / (1-alpha) =: L_i, backwards from
-         * L_N = 0.  Zero -- the reference's start -- for every problem whose rows can be met without slack. */
-        const int N = p->N, q = p->degree;
-        const double om = 1.0 - p->alpha;
-        double gs[MAXN + 1], ge[MAXN + 1], ws_[6] = {0, 0, 0, 0, 1, 0}, we_[6] = {0, 0, 0, 0, 0, 1}, as = 0.0, ae = 0.0;
-        gs[0] = ge[0] = 0.0;
-        const double um[2] = {p->uhi[0] > -p->ulo[0] ? p->uhi[0] : -p->ulo[0], p->uhi[1] > -p->ulo[1] ? p->uhi[1] : -p->ulo[1]};
-        for (int k = 1; k <= N; k++) {
-            double v0 = 0, v1 = 0, e0 = 0, e1 = 0, wn[6] = {0}, en[6] = {0};
-            for (int i = 0; i < 6; i++) { v0 += ws_[i] * p->B[i * 2]; v1 += ws_[i] * p->B[i * 2 + 1]; e0 += we_[i] * p->B[i * 2]; e1 += we_[i] * p->B[i * 2 + 1]; }
-            as += fabs(v0) * um[0] + fabs(v1) * um[1]; ae += fabs(e0) * um[0] + fabs(e1) * um[1];
-            gs[k] = as; ge[k] = ae;
-            for (int a = 0; a < 6; a++) for (int i = 0; i < 6; i++) { wn[a] += ws_[i] * p->A[i * 6 + a]; en[a] += we_[i] * p->A[i * 6 + a]; }
-            memcpy(ws_, wn, sizeof(wn)); memcpy(we_, en, sizeof(en));
-        }
-        for (int ob = 0; ob < p->nobs; ob++) {
-            double Lb = 0.0;
-            for (int i = N - 1; i >= 0; i--) {
-                double dsc, dec, dsn, den;
-                cbf_terms(p, w->x, ob, i, &dsc, &dec, &dsn, &den);
-                const double rsc = gs[i] / p->Ls[ob], rec = ge[i] / p->Ws[ob], rsn = gs[i + 1] / p->Ls[ob], ren = ge[i + 1] / p->Ws[ob];
-                const double mx_sn = fmax(fabs(dsn - rsn), fabs(dsn + rsn)), mx_en = fmax(fabs(den - ren), fabs(den + ren));
-                const double mn_sc = (fabs(dsc) > rsc) ? fabs(dsc) - rsc : 0.0, mn_ec = (fabs(dec) > rec) ? fabs(dec) - rec : 0.0;
-                const double Gmax = ipow(mx_sn, q) + ipow(mx_en, q) - om * (ipow(mn_sc, q) + ipow(mn_ec, q)) - p->alpha * p->cm;
-                Lb = (Lb - Gmax) / om;
-                if (Lb < 0.0) Lb = 0.0;
-                if (Lb > 0.0) w->v[isig(w, i, ob)] = Lb * g_knob[14];
-            }
-        }
-        unpack(w, w->v);
+    /* crash path: see crash_point() */
+    const int crash_path = p->nobs > 0 && o->slack_start == 2 && o->restore_iters >= 0 && (1.0 - p->alpha) > 1e-6;
+    int crash = 0;
+    if (p->nobs > 0 && o->slack_start == 1) { slack_lower_bounds(w, 1.0); unpack(w, w->v); }
+    /* the kernel searches its candidates BEFORE the loop, for the problems that may take the crash path: a provable crash state (it
+     * starts from the point) or a CBF row violated at the zero start (it may stall and restart from the point) */
+    int may_restart = 0;
+    if (crash_path) {
+        const int crash_state = slack_lower_bounds(w, 0.0);
+        for (int ob = 0; ob < p->nobs; ob++)
+            for (int i = 0; i < p->N; i++) if (cbf_G(w, ob, i) < 0.0) may_restart = 1;
+        if (crash_state) { may_restart = 1; crash = crash_point(w, 1); }
     }
     scale_rows(w);
-    eval_full(w);
-    for (int j = 0; j < m; j++) {
-        /* slack start: inside the bound by at least slack_push, and for a violated row as large
-         * as the violation so that the first fraction-to-the-boundary step is O(1/2), not O(push) */
-        w->t[j] = g_knob[7] != 0.0 ? fmax(w->c[j], o->slack_push * g_knob[7]) : fmax(fabs(w->c[j]), o->slack_push);
-        w->nu[j] = 1.0;
-        /* simple-bound rows: start the multiplier at the cost gradient that pushes against the
-         * bound (dual-feasible start for the 1e4-weighted CBF slacks; IPOPT starts all at 1) */
-        {
-            const rowdef_t* r = &w->row[j];
-            double gg = 0.0;
-            if (r->kind == ROW_SIG) gg = w->g[isig(w, r->k, r->o)];
-            else if (r->kind == ROW_ULO) gg = w->g[iu(w, r->k) + r->i];
-            else if (r->kind == ROW_UHI) gg = -w->g[iu(w, r->k) + r->i];
-            if (gg > 1.0) w->nu[j] = gg;
-        }
-    }
+    init_rows(w);
     double mu = o->mu_init, dw_last = 0.0, E0 = HUGE_VAL, theta_min = 0.0, theta_max = HUGE_VAL;
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
@@ -536,7 +646,7 @@ static void ipm_solve(work_t* w, result_t* res) {
         int viol = 0;
         for (int j = 0; j < m; j++)
             if (w->row[j].kind == ROW_CBF && w->row[j].k <= (int)g_knob[6] && w->c[j] < 0.0) viol = 1;
-        if (viol && restore_slacks(w, o->mu_init)) { if (g_knob[9] == 0.0) { n_restore = 1; it_limit = 1 + o->restore_iters; } first = 1; }
+        if (viol && restore_slacks(w, o->mu_init, 0)) { if (g_knob[9] == 0.0) { n_restore = 1; it_limit = 1 + o->restore_iters; } first = 1; }
     }
     for (it = 0;; it++) {
         /* residuals */
@@ -580,10 +690,13 @@ static void ipm_solve(work_t* w, result_t* res) {
             } else
                 break;
         }
+#pragma omp atomic
+        g_niter++;
         double tau = fmax(o->tau_min, 1.0 - mu);
         /* H = Hf + curvature + J' Sigma J  (lower triangle) */
+        static _Thread_local double Hneg[MAXRED][MAXRED];   /* the negative-semidefinite part of the CBF curvature */
         for (int a = 0; a < n; a++)
-            for (int b = 0; b <= a; b++) w->H[a][b] = w->Hf[a][b];
+            for (int b = 0; b <= a; b++) { w->H[a][b] = w->Hf[a][b]; Hneg[a][b] = 0.0; }
         for (int j = 0; j < m; j++) {
             if (w->row[j].kind != ROW_CBF) continue;
             int i = w->row[j].k, ob = w->row[j].o, q = p->degree;
@@ -597,11 +710,11 @@ static void ipm_solve(work_t* w, result_t* res) {
             double om = 1.0 - p->alpha;
             /* W -= nu * hess c */
             for (int a = 0; a < n; a++)
-                for (int b = 0; b <= a; b++)
-                    w->H[a][b] += wn * (-hsn * w->Sx[i + 1][4][a] * w->Sx[i + 1][4][b] -
-                                        hen * w->Sx[i + 1][5][a] * w->Sx[i + 1][5][b] +
-                                        om * (hsc * w->Sx[i][4][a] * w->Sx[i][4][b] +
-                                              hec * w->Sx[i][5][a] * w->Sx[i][5][b]));
+                for (int b = 0; b <= a; b++) {
+                    const double ng = wn * (-hsn * w->Sx[i + 1][4][a] * w->Sx[i + 1][4][b] - hen * w->Sx[i + 1][5][a] * w->Sx[i + 1][5][b]);
+                    w->H[a][b] += ng + wn * om * (hsc * w->Sx[i][4][a] * w->Sx[i][4][b] + hec * w->Sx[i][5][a] * w->Sx[i][5][b]);
+                    Hneg[a][b] += ng;
+                }
         }
         for (int j = 0; j < m; j++) {
             double sg = w->nu[j] / w->t[j];
@@ -623,6 +736,18 @@ static void ipm_solve(work_t* w, result_t* res) {
         for (int a = 0; a < n; a++) memcpy(Hs[a], w->H[a], sizeof(double) * (a + 1));
         double dw = 0.0;
         int ok = chol(n, w->H);
+        if (!ok && crash) {   /* crash path: first retry WITHOUT the reverse-convex part of the CBF curvature (-nu hess g_{i+1}): what
+                                 remains is positive definite by construction; IPOPT's delta_w schedule only if that fails */
+            for (int a = 0; a < n; a++) {
+                memcpy(w->H[a], Hs[a], sizeof(double) * (a + 1));
+                for (int b = 0; b <= a; b++) w->H[a][b] -= Hneg[a][b];
+            }
+            ok = chol(n, w->H);
+            dw = -1.0;
+            if (!ok)   /* rounding only: IPOPT's schedule goes on from the convexified matrix */
+                for (int a = 0; a < n; a++)
+                    for (int b = 0; b <= a; b++) Hs[a][b] -= Hneg[a][b];
+        }
         if (!ok) {
             dw = dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0);
             for (;;) {
@@ -638,6 +763,7 @@ static void ipm_solve(work_t* w, result_t* res) {
             if (!ok) break;
             dw_last = dw;
         }
+        if (dw < 0.0) dw = 0.0;
         memcpy(w->dv, w->rhs, sizeof(double) * n);
         chol_solve(n, w->H, w->dv);
         double a_p = 1.0, a_d = 1.0, theta = 0.0, Dphi = 0.0, curv = 0.0;
@@ -714,7 +840,18 @@ static void ipm_solve(work_t* w, result_t* res) {
          * JAM_ALPHA; healthy problems are done (p99 16 iterations, max 30 on the BASELINE draws) or at least feasible by then */
         if (acc && jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
         if (!acc || jam >= JAM_COUNT) {
-            if (o->restore_iters >= 0 && n_restore < (int)g_knob[5] && restore_slacks(w, o->mu_init)) {
+            if (crash_path && may_restart && n_restore < 1 && !crash && crash_point(w, 0)) {
+                /* crash path (ii): the solve started at the reference's zero point and stalls on violated CBF rows -- restart ONCE from
+                 * the feasible interior point: the candidate's inputs, then the closed-form cascade and the re-initialisation the
+                 * restoration uses (all rows) */
+                restore_slacks(w, o->mu_init, 1);
+                if (g_verbose) fprintf(stderr, "      RESTART from the crash point (acc %d jam %d)\n", acc, jam);
+                crash = 1;
+                n_restore++; it_limit = it + 1 + o->restore_iters;
+                mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0; jam = 0;
+                continue;
+            }
+            if (o->restore_iters >= 0 && n_restore < (int)g_knob[5] && restore_slacks(w, o->mu_init, 0)) {
                 if (g_verbose) fprintf(stderr, "      RESTORE (acc %d jam %d)\n", acc, jam);
                 if (n_restore++ == 0) it_limit = it + 1 + o->restore_iters;
                 mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0; jam = 0;
@@ -725,7 +862,7 @@ static void ipm_solve(work_t* w, result_t* res) {
         if (!acc) {
             /* no acceptable step and nothing to restore: a point of local infeasibility if the constraints are still
              * violated there (IPOPT: "converged to a point of local infeasibility" / "restoration failed") */
-            if (e_p > 1e-6) status = CRX_INFEASIBLE;
+            if (e_p > 1e-6) status = CRX_STALLED;   /* IPOPT: "converged to a point of local infeasibility" / "restoration failed": not a proof */
             break;
         }
         memcpy(w->v, vtrial, sizeof(double) * n);
@@ -739,7 +876,7 @@ static void ipm_solve(work_t* w, result_t* res) {
             if (nn > numax) numax = nn;
             th = fmax(th, fabs(w->c[j] - w->t[j]));
         }
-        if (numax > 1e12 && th > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+        if (numax > 1e12 && th > 1e-6) { status = CRX_STALLED; it++; break; }   /* IPOPT's divergence heuristic: not a proof */
         /* still violated after the step: look for the proof that it must be (linear rows only; a feasible problem is
          * here 0.14 times per solve on average: the slack reset makes th ~ 0 as soon as a point inside the rows is met) */
         if (p->linear_rows && th > 1e-6 && box_certificate(w, tmp) < -1e-8 * numax) { status = CRX_INFEASIBLE; it++; break; }
@@ -769,7 +906,7 @@ static double clip(double x, double lo, double hi) { return x < lo ? lo : (x > h
 void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2;
-    o->grad_scale_max = 100.0;
+    o->grad_scale_max = 100.0; o->reach_screen = 1; o->slack_start = 2;
 }
 
 /* The region QP of generate_traj_per_region as the canonical stage-structured problem (line numbers into
@@ -823,7 +960,7 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
          * within reach_j of its free response, reach_j = sum_{m<j} |e_ey' A^m B| (delta_max, a_max)'; a bound on ey_j outside
          * that interval by more than 1e-6 proves the region infeasible before any iteration */
         int screened = 0;
-        if (g_knob[8] != 0.0) {
+        if (d->opts.reach_screen) {
             double xk[6], wv[6] = {0, 0, 0, 0, 0, 1}, acc = 0.0;
             memcpy(xk, xb, sizeof(xk));
             for (int j = 0; j < N; j++) {

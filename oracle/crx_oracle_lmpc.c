@@ -587,9 +587,6 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
     res->cost = f;
 }
 
-static int lmpc_reach_screen_on = 1;
-void crx_oracle_lmpc_set_reach_screen(int on) { lmpc_reach_screen_on = on; }
-
 int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
                           const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
                           double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
@@ -619,8 +616,8 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
              * equality x_N = SS lambd (lambd in the unit simplex) needs x_N,c inside [min_j SS_cj, max_j SS_cj].  Disjoint intervals
              * (by more than 1e-6 of their scale) in ANY component prove that the reference's QP has no feasible point, whatever its
              * other rows say: the first attempt is skipped (0 iterations) and the relaxed second attempt runs as it would have. */
-            int screened = lmpc_reach_screen_on && bad0;   /* a row the fixed x_0 violates: nothing to attempt */
-            if (lmpc_reach_screen_on) {
+            int screened = d->opts.reach_screen && bad0;   /* a row the fixed x_0 violates: nothing to attempt */
+            if (d->opts.reach_screen) {
                 for (int c = 0; c < 6; c++) {
                     double g = 0.0, lo = HUGE_VAL, hi = -HUGE_VAL;
                     for (int a = 0; a < 2 * N; a++) g += fabs(w->S[N][c][a]) * ((a & 1) ? d->a_max : d->delta_max);

@@ -388,6 +388,67 @@ def upgrade(kind):
     np.savez_compressed(path, **z)
 
 
+def alt_pass(kind):
+    """[r4] The crash path (crx_ipm_opts.slack_start = 2) starts and restarts crash states from another point than the reference's
+    zero start, and a non-convex NLP has more than one KKT point: where the oracle at its DEFAULT options (tol 1e-11) now ends at a
+    point other than the fixture's primary one -- or the fixture has none -- that end point goes through the same solver-agnostic
+    KKT certificate on the reference's recorded graph and is stored beside the primary one: alt_ok / alt_X / alt_U / alt_sigma /
+    alt_cert.  The tests accept either certified point."""
+    sys.path.insert(0, os.path.join(REPO, "car-racing_amd"))
+    sys.path.insert(0, REPO)
+    import oracle
+    from crx import abi
+    orc = oracle.load()
+    path = os.path.join(mg.OUT, "%s_draw.npz" % kind)
+    z = dict(np.load(path))
+    A, B = synth.load_AB()
+    if kind == "cfg2":
+        mk = lambda lf: synth.cfg2_mpccbf(256, N=12, seed=2, safe_start=False, lapped_frac=lf)              # noqa: E731
+        bld = lambda p: (lambda b: mg.mpccbf_case(p["x0"][b], [tuple(c) for c in p["cars"][b]], N=12, alpha=0.8, vt=0.8))   # noqa: E731
+    else:
+        mk = lambda lf: synth.cfg4_tracking_cbf(256, N=20, seed=4, safe_start=False, lapped_frac=lf)        # noqa: E731
+        bld = lambda p: (lambda b: mma_case(p["x0"][b], [tuple(c) for c in p["cars"][b]], p["traj"][b], 20))   # noqa: E731
+    for group, lf in (("draw", 0.0), ("lapped", 0.25)):
+        p = mk(lf)
+        build = bld(p)
+        g = {k[len(group) + 1:]: z[k] for k in z if k.startswith(group + "/")}
+        n, N = len(g["index"]), int(p["N"])
+        idx = g["index"].astype(int)
+        if kind == "cfg2":
+            d = abi.cbf_desc(N, 1, A, B, alpha=float(p["alpha"]), margin=float(p["margin"]))
+        else:
+            d = abi.cbf_desc(N, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+        d.opts.tol = 1e-11
+        ro = orc.cbf_solve(d, *[p[k][idx] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")])
+        alt = dict(ok=np.zeros(n, dtype=bool), X=np.full_like(g["X"], np.nan), U=np.full_like(g["U"], np.nan),
+                   sigma=np.full_like(g["sigma"], np.nan), cert=np.full_like(g["cert"], np.nan))
+        for r, b in enumerate(idx):
+            n_obs = int(g["n_obs_ref"][r])
+            if int(ro["status"][r]) != 0 or int(p["n_obs"][b]) != n_obs:
+                continue
+            if bool(g["certified"][r]) and abs(ro["cost"][r] - g["cert"][r][0]) <= 1e-9 * max(1.0, abs(g["cert"][r][0])):
+                continue                                     # the primary point
+            saved = mg.casadi.Opti.solver_fn
+            mg.casadi.Opti.solver_fn = staticmethod(_record_only)
+            try:
+                build(int(b))
+            finally:
+                mg.casadi.Opti.solver_fn = saved
+            opti = mg.RECORDS[-1][0]
+            zz = _z_of(ro["X"][r], ro["U"][r], ro["sigma"][r][:n_obs])
+            ok, cert = _certify(opti, zz)
+            print("%s/%s #%d alt point: cost %.9g (primary %s) certified %s stat %.2e" % (kind, group, b, ro["cost"][r],
+                  ("%.9g" % g["cert"][r][0]) if g["certified"][r] else "none", ok, cert["stationarity"]), flush=True)
+            if ok:
+                alt["ok"][r] = True
+                alt["X"][r], alt["U"][r] = ro["X"][r], ro["U"][r]
+                alt["sigma"][r][:n_obs] = ro["sigma"][r][:n_obs]
+                alt["cert"][r] = np.array([cert[k] for k in ("f", "stationarity", "eq_violation", "ineq_violation", "min_multiplier", "complementarity")])
+        for k, v in alt.items():
+            z["%s/alt_%s" % (group, k)] = v
+    np.savez_compressed(path, **z)
+
+
 def gen_dims(n=16):
     """control.mpccbf with obstacle vehicles of UNEQUAL size (control.py:529-535 takes l_obs, w_obs from every obstacle's own
     CarParam): the first n problems of the cfg2 draw with a second car added beside the first, both with random dimensions.
@@ -484,6 +545,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if which[0] == "plant_noise":
         gen_plant_noise()
+        sys.exit(0)
+    if which[0] == "alt":
+        for kind in which[1:]:
+            alt_pass(kind)
         sys.exit(0)
     if which[0] == "upgrade":
         for kind in which[1:]:

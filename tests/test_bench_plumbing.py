@@ -1,9 +1,10 @@
-"""bench.py's multi-rank control flow on CPU: `bench.py --gpus 2 --plumbing-check` re-launches itself under
-torch.distributed.run exactly as it does on a GPU node (self-spawn, 127.0.0.1 rendezvous, one process per rank), shards the
-cfg5 sweep weak and strong, runs the product's PlannerSweep.step() with the stand-in back-end of test_distributed_gloo.py over
-gloo, goes through measure()'s barriers / max-over-ranks reductions / collective timing, and rank 0 prints ONE JSON line with
-the fields the driver parses.  Nothing is measured; the point is that a typo in that path cannot surface first on the
-driver's 8-GPU box."""
+"""bench.py's multi-rank control flow on CPU: tests/bench_cpu_harness.py swaps bench.py's GPU hooks for stand-ins and runs bench.main():
+`--gpus 2` re-launches itself under torch.distributed.run exactly as on a GPU node (self-spawn, 127.0.0.1 rendezvous, one process per
+rank), shards the cfg5 sweep weak and strong, runs the product's PlannerSweep.step() with the stand-in back-end of
+test_distributed_gloo.py over gloo, goes through measure()'s barriers / max-over-ranks reductions / collective timing, and rank 0 prints
+ONE short JSON line with the fields the driver parses and writes the full record to a file.  Also: the line stays SHORT at full size
+(the 24 KB line of round 3 could not be parsed)."""
+import glob
 import json
 import os
 import subprocess
@@ -12,34 +13,55 @@ import sys
 import conftest
 
 
-def _run(gpus, extra=()):
+def _run(gpus, tmp_path, extra=()):
     env = dict(os.environ)
-    env["CRX_BENCH_BACKEND"] = "test_distributed_gloo:StubBackend"
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(conftest.ROOT, "tests"), conftest.ROOT, conftest.PKG, env.get("PYTHONPATH", "")])
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--plumbing-check",
-           "--sweep-per-gpu", "6", "--sweep-total", "13", "--no-cpu-baseline"] + list(extra)
+    full = str(tmp_path / "full.json")
+    cmd = [sys.executable, os.path.join(conftest.ROOT, "tests", "bench_cpu_harness.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+           "--sweep-per-gpu", "6", "--sweep-total", "13", "--no-cpu-baseline", "--full-out", full] + list(extra)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    return json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[-1]), lines[-1], json.load(open(full))
 
 
-def test_bench_two_ranks_self_spawn():
-    out = _run(2)
+def test_bench_two_ranks_self_spawn(tmp_path):
+    out, line, full = _run(2, tmp_path)
+    assert len(line) < 6000
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["higher_is_better"] is True
-    for k in ("metric", "value", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "summary"):
+    for k in ("metric", "value", "value_launched", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "summary"):
         assert k in out, k
-    weak, strong = out["configs"]
+    assert "configs" not in out                                  # the stdout line is the SHORT one
+    weak, strong = full["configs"]
     assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
     assert weak["world_size"] == 2 and "allgather_ms" in weak and "allgather_ms" in strong
     assert weak["config"]["scenarios_total"] == 12 and strong["config"]["scenarios_total"] == 13      # ragged strong shards: 7 + 6
     # whole-job units: both ranks' region QPs per step
-    assert abs(weak["value"] * weak["ms_per_step"] * 1e-3 - 12 * 4) < 1e-6
-    assert abs(strong["value"] * strong["ms_per_step"] * 1e-3 - 13 * 4) < 1e-6
-    assert set(out["summary"]) == {"plumbing", "cfg5_weak", "cfg5_strong"}
+    assert abs(weak["value_launched"] * weak["ms_per_step"] * 1e-3 - 12 * 4) < 1e-6
+    assert abs(strong["value_launched"] * strong["ms_per_step"] * 1e-3 - 13 * 4) < 1e-6
+    assert set(out["summary"]) == {"stand_in", "cfg5_weak", "cfg5_strong"}
+    assert all(len(v) <= 9 for v in out["summary"].values())     # eight numbers per sub-config (+ allgather_ms for the sweeps)
 
 
-def test_bench_one_rank_no_process_group():
-    out = _run(1)
-    assert out["n_gpus"] == 1 and out["configs"][1]["config"]["scenarios_this_rank"] == 13
+def test_bench_one_rank_no_process_group(tmp_path):
+    out, line, full = _run(1, tmp_path)
+    assert out["n_gpus"] == 1 and full["configs"][1]["config"]["scenarios_this_rank"] == 13
+
+
+def test_stdout_line_stays_short_at_full_size():
+    """stdout_line() on the FULL records of real default runs kept from the GPU box (profiles/bench_full_*.json: headline + nine
+    sub-configs + cpu_baseline): under 6 KB, with the objects the driver needs."""
+    sys.path.insert(0, conftest.ROOT)
+    import bench
+
+    kept = sorted(glob.glob(os.path.join(conftest.ROOT, "profiles", "bench_full_*.json")))
+    assert kept, "no kept full bench record under profiles/"
+    for path in kept:
+        full = json.load(open(path))
+        line = json.dumps(bench.stdout_line(full))
+        assert len(line) < 6000, (path, len(line))
+        out = json.loads(line)
+        assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0 and len(out["summary"]) >= 10
+        assert out["value"] <= out["value_launched"]

@@ -4,7 +4,10 @@ crx.montecarlo.GameLaps against crx.synth.multi_tests_traffic.  Prints what such
 learning-MPC laps, overtakes, contacts, races that left the track.
 The plant runs WITH the reference's bounded process noise (utils/base.py:929-939), as the reference's script does unless
 --zero-noise is given (overtake_planner_test.py:41-42): crx_plant_step_noise_dev, draws from a seeded torch generator.
-usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3] [noise_seed=1 | none] [sub-batches=1]"""
+usage (GPU box): python tools/multi_tests.py [B=4096] [steps=400] [num_veh=3] [noise_seed=1 | none] [sub-batches=1]
+CRX_OPTS="max_iter=3000,restore_iters=3000,reach_screen=0" in the environment overrides crx_ipm_opts fields of EVERY descriptor the run
+builds (crx.abi.OPTS_OVERRIDE) -- tools/budget_experiment.sh uses it to ask whose collisions these are: the controller's or the
+solver budgets' (VERDICT r3 item 5)."""
 import os
 import sys
 import time
@@ -20,8 +23,13 @@ for p in (ROOT, os.path.join(ROOT, "car-racing_amd")):
 
 def main():
     import torch
-    from crx import montecarlo, synth
+    from crx import abi, montecarlo, synth
     from utils import racing_env
+    for kv in filter(None, os.environ.get("CRX_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        abi.OPTS_OVERRIDE[k] = float(v) if k in ("tol", "mu_init", "kappa_eps", "kappa_mu", "theta_mu", "tau_min", "slack_push", "grad_scale_max") else int(v)
+    if abi.OPTS_OVERRIDE:
+        print("crx_ipm_opts overrides:", abi.OPTS_OVERRIDE)
     Bn = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     V = int(sys.argv[3]) if len(sys.argv) > 3 else 3

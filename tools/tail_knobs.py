@@ -16,10 +16,13 @@ d4 = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50
 DEF = {0: 1e-3, 1: 5, 2: 50, 3: 0.0, 4: 0, 5: 2, 6: -1}
 
 
-def run(knobs, base=None):
+def run(knobs, base=None, slack_start=2):
+    """knobs: oracle experiment knobs (crx_oracle.c g_knob); slack_start: crx_ipm_opts.slack_start of both descriptors"""
     for i, v in {**DEF, **knobs}.items():
         orc.lib.crx_oracle_set_knob(int(i), __import__("ctypes").c_double(float(v)))
     out = []
+    for d in (d2, d4):
+        d.opts.slack_start = int(slack_start)
     for name, p, d in (("cfg2", p2, d2), ("cfg4", p4, d4)):
         r = orc.cbf_solve(d, *[p[k] for k in KEYS])
         st, it = r["status"], r["iters"]
@@ -37,8 +40,11 @@ def run(knobs, base=None):
 
 
 if __name__ == "__main__":
-    base, lines = run({})
-    print("baseline"); [print("  ", l) for l in lines]
+    base, lines = run({}, slack_start=0)
+    print("slack_start = 0 (libcrx 0.1.x: zero start, closed-form slack restoration)"); [print("  ", l) for l in lines]
+    for ss in (1, 2):
+        _, lines = run({}, base, slack_start=ss)
+        print("slack_start = %d" % ss); [print("  ", l) for l in lines]
     trials = [{2: 20}, {3: 0.05, 4: 4}, {3: 0.05, 4: 6}, {3: 0.1, 4: 4}, {3: 0.1, 4: 6}, {3: 0.02, 4: 4}, {3: 0.1, 4: 8}, {3: 0.05, 4: 4, 5: 3}, {3: 0.2, 4: 5}]
     for t in trials:
         _, lines = run(t, base)
