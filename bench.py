@@ -171,7 +171,9 @@ def make_cbf(cx, key, args, batch=None, filtered=False):
     mode = args.dispatch
     if mode == "auto":    # more problems than resident slots (256 CUs x 4): the launch has a tail worth ordering; else all start at once
         mode = "start_barrier" if w.batch > 1024 else "index"
-    w.extra["dispatch"] = mode
+    # (longest_first on a STATIC batch re-solves the same problems: the previous iteration counts are those of the very launch being
+    # ordered -- an oracle order, an upper bound of what a receding-horizon loop gets; labelled so)
+    w.extra["dispatch"] = "longest_first(oracle order on a static batch: upper bound)" if mode == "longest_first" else mode
     order = {"index": lambda: None, "longest_first": lambda: torch_api.longest_first(w.ws.iters, out=obuf),
              "start_barrier": lambda: torch_api.cbf_order_dev(w.desc, *t_in, out=obuf)}[mode]
     w.step = w.solve = lambda: torch_api.cbf_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
@@ -271,7 +273,7 @@ def make_lmpc(cx, args, batch=None):
     w.kernel = "crx_lmpc_kernel"
     obuf = torch.empty(w.batch, dtype=torch.int32, device=cx.dev)
     order = (lambda: torch_api.longest_first(w.ws.iters, out=obuf)) if args.dispatch == "longest_first" else (lambda: None)
-    w.extra = {"dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
+    w.extra = {"dispatch": "longest_first(oracle order on a static batch: upper bound)" if args.dispatch == "longest_first" else "index"}
     w.step = w.solve = lambda: torch_api.lmpc_solve_dev(w.desc, *t_in, ws=w.ws, order=order())
     w.name = "learning-MPC QP (control.py:610-730), N=%d, %d safe-set points, LTV models and safe sets recorded from the reference's LMPC lap, batch %d/GPU" % (N, M, w.batch)
     w.cpu = ("lmpc", w.desc, {k: p[k] for k in keys + ("n_ss",)})

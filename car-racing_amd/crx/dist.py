@@ -84,6 +84,9 @@ class WinnerExchange:
             raise ValueError("rank %d holds %d winners, its shard of %d over %d ranks is %d" % (self.rank, flag.shape[0], self.n_total, self.world, n))
         if COLLECTIVE == "crx" and (self.world > 1 or FORCE_COLLECTIVE):
             # pack + ncclAllGather inside libcrx, on torch's current stream (the winners never pass through torch ops)
+            if self.group is not None:
+                # libcrx holds ONE communicator and it spans the world group: a sub-group exchange would deadlock or gather the wrong ranks
+                raise ValueError("COLLECTIVE == 'crx' gathers over the world group only; pass group=None or use COLLECTIVE = 'torch' for a sub-group")
             import ctypes as C
 
             from . import lib

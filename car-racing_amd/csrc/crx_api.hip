@@ -15,7 +15,19 @@
 #include <mutex>
 #include <vector>
 
-#include <rccl/rccl.h>   // types only: the entry points are resolved at run time (rccl_bind), libcrx does not link librccl
+// RCCL: types only -- the entry points are resolved at run time (rccl_bind), libcrx does not link librccl.  A ROCm install without
+// the RCCL development headers still builds the single-GPU library: the handful of types the five entry points need are declared
+// here then (the stable NCCL 2 ABI: opaque communicator, 128-byte id, int-valued enums)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+}
+#endif
 
 #include "crx_kparams.h"
 
@@ -1194,7 +1206,7 @@ int crx_cbf_order_dev(const crx_cbf_desc* d, int batch, const int32_t* active, c
     if (d->N < 1 || d->N > CRX_MAX_N || d->n_obs_max < 0 || d->n_obs_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "bad N / n_obs_max");
     if (d->degree != 2 && d->degree != 4 && d->degree != 6 && d->degree != 8) return fail(CRX_ERR_ARG, "degree must be 2, 4, 6 or 8");
     if (batch == 0) return CRX_OK;
-    if (!x0 || !xt || !order || !n_obs || (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off))) return fail(CRX_ERR_ARG, "NULL array argument");
+    if (!x0 || !xt || !order || (d->n_obs_max > 0 && (!obs_s || !obs_ey || !lap_off || !n_obs))) return fail(CRX_ERR_ARG, "NULL array argument");
     crx_order_kparams op;
     memset(&op, 0, sizeof(op));
     op.batch = batch; op.mode = 1; op.active = active; op.order = order;

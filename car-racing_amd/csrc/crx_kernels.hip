@@ -1381,8 +1381,12 @@ crx_solve_kernel(const crx_kparams kp) {
                 LD(L::cst + 12 + lane) = lane < c.nobs ? kp.lap_off[(size_t)b * kp.n_obs_max + lane] : 0.0;
                 // obstacle dimensions: per problem and obstacle slot if the caller gave them, else the descriptor's pair
                 const bool own = kp.obs_dims != nullptr && lane < c.nobs;
-                const double ls = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2] : kp.l_sum;
-                const double ws = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2 + 1] : kp.w_sum;
+                double ls = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2] : kp.l_sum;
+                double ws = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2 + 1] : kp.w_sum;
+                // device-resident dimensions cannot be validated on the host (the host-pointer entry point rejects them): a
+                // non-positive or non-finite entry falls back to the descriptor's pair instead of turning the rows into inf / NaN
+                if (!(ls > 0.0) || !isfinite(ls)) ls = kp.l_sum;
+                if (!(ws > 0.0) || !isfinite(ws)) ws = kp.w_sum;
                 LD(L::cst + 16 + lane) = 1.0 / ls;
                 LD(L::cst + 16 + NOBS + lane) = 1.0 / ws;
             }
@@ -1609,7 +1613,9 @@ crx_solve_kernel(const crx_kparams kp) {
             }
         }
         if (crash_state || __ballot(viol) != 0ull) crash_cand = __builtin_amdgcn_readfirstlane(crash_search<NOBS, NMAX>(sm, c, kp));
-        if (crash_state && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; }
+        // (a solve that STARTS on the crash path has a budget too -- three times the restoration budget + 1 -- after which it ends CRX_RESTORED like
+        // a restarted one: feasible through its slacks, not optimal, instead of crawling to max_iter)
+        if (crash_state && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; n_restore = 1; it_limit = 1 + 3 * o.restore_iters; }
     }
     init_point();
     for (;;) {
@@ -1639,7 +1645,7 @@ crx_solve_kernel(const crx_kparams kp) {
         // recomputation is ~19 % more VALU instructions there and costs 4..5 % (cfg2, cfg4, races) although it frees 40..140
         // registers -- they keep the hoisted maps.  (With the barrier, the full-layout 3-obstacle instantiations also produced
         // a kernel that faults on MI355X / ROCm 7.0.2 -- not understood; found by the GPU suite, tools/gpu_round3_b.sh.)
-        if (NOBS == 0) asm volatile("" : "+v"(c.lane));
+        if (NOBS == 0 || CRX_OPAQUE_LANE >= 2) asm volatile("" : "+v"(c.lane));   // (2: every instantiation -- the A/B build of the fault hunt, tools/variants.sh)
         const int lane = c.lane;   // shadows the kernel's `lane` inside the loop body
 #endif
         // ---- KKT error -----------------------------------------------------------------------------
@@ -2097,24 +2103,38 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
 
 #endif  // CRX_TU_OBSTACLES
 
-// resident single-wave workgroups per CU of the instantiation that would run (N, nobs_template): the runtime's
-// answer, i.e. min over the LDS and the register file
-template <int NOBS, int NMAX>
+// resident single-wave workgroups per CU of the instantiation that WOULD RUN (N, nobs_template) with the reference's exponent: the
+// runtime's answer, i.e. min over the LDS and the register file, for the same (DEG, NFIX) selection as launch_d / launch_h -- the
+// fixed-horizon instantiations are other kernels than the general ones, with their own register counts
+template <int NOBS, int NMAX, int NFIX>
 static int occ_t() {
     int n = 0;
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
-    constexpr int DEG = NOBS > 0 ? 6 : 0;   // the instantiation the reference's parameters select
-    if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG>, WAVE, bytes) != hipSuccess) return -1;
+    constexpr int DEG = (NOBS > 0 && CRX_DEG6) ? 6 : 0;
+    if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
+}
+template <int NOBS, int NMAX>
+static int occ_h(int N) {
+#if CRX_NFIX
+    if constexpr (NMAX == 12) {
+        if (N == 12) return occ_t<NOBS, 12, 12>();
+        if (N == 10) return occ_t<NOBS, 12, 10>();
+    }
+    if constexpr (NMAX == 20) {
+        if (N == 20) return occ_t<NOBS, 20, 20>();
+    }
+#endif
+    return occ_t<NOBS, NMAX, 0>();
 }
 template <int NOBS>
 static int occ_n(int N) {
-    if (N <= 12) return occ_t<NOBS, 12>();
+    if (N <= 12) return occ_h<NOBS, 12>(N);
     if constexpr (NOBS == 3) {
-        if (N <= 20) return occ_t<3, 20>();
+        if (N <= 20) return occ_h<3, 20>(N);
     }
-    return occ_t<NOBS, CRX_MAX_N>();
+    return occ_h<NOBS, CRX_MAX_N>(N);
 }
 #ifdef CRX_TU_OBSTACLES
 int crx_solve_resident_per_cu_obs(int N, int nobs_template) {

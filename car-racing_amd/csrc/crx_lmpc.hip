@@ -922,16 +922,18 @@ hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
     return kp.N <= 12 ? launch_l<12, false>(kp, st) : launch_l<CRX_LMPC_MAX_N, false>(kp, st);
 }
 
-template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS>
+template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS, int NFIX = 0>
 static int occ_l(int n_ss_max) {
     int n = 0;
     const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(n_ss_max);
-    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE, MSS>, WAVE, bytes) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }
-// (diagnostics: the Q == 0 instantiation, which is what the reference's parameters select)
+// (diagnostics: the Q == 0 instantiation the launcher would pick for (N, n_ss_max) -- the reference's parameters select it; the
+// same selection as crx_launch_lmpc, fixed-horizon instantiation included: the occupancy of the kernel that is timed)
 int crx_lmpc_resident_per_cu(int N, int n_ss_max) {
+    if (N == 12 && n_ss_max <= CRX_LMPC_SS44) return occ_l<12, false, CRX_LMPC_SS44, 12>(n_ss_max);
     if (N <= 12 && n_ss_max <= CRX_LMPC_SS44) return occ_l<12, false, CRX_LMPC_SS44>(n_ss_max);
     return N <= 12 ? occ_l<12, false>(n_ss_max) : occ_l<CRX_LMPC_MAX_N, false>(n_ss_max);
 }

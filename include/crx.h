@@ -564,7 +564,9 @@ int crx_cbf_solve_dev(const crx_cbf_desc* d, int batch, const double* x0, const 
 /* Per-obstacle dimensions.  The reference takes (l_obs, w_obs) from every obstacle vehicle's own CarParam (control.py:529-535);
  * crx_cbf_desc carries ONE pair (l_sum, w_sum) for the common case of identical cars.  obs_dims [batch][n_obs_max][2] =
  * (l_agent + l_obs, w_agent + w_obs) of every obstacle slot of every problem overrides it (slots >= n_obs[b] are not read);
- * NULL = the descriptor's pair for all.  `active` as in the masked launch below (NULL: all). */
+ * NULL = the descriptor's pair for all.  `active` as in the masked launch below (NULL: all).  Precondition: positive, finite
+ * entries -- the host-pointer entry point checks and fails the call; the *_dev variants cannot (device memory) and let a
+ * non-positive or non-finite entry fall back to the descriptor's pair. */
 int crx_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const double* xt, const double* obs_s,
                        const double* obs_ey, const double* lap_off, const int32_t* n_obs, const double* obs_dims, double* X,
                        double* U, double* sigma, double* cost, int32_t* status, double* kkt, int32_t* iters);

@@ -623,12 +623,12 @@ static void ipm_solve(work_t* w, result_t* res) {
     if (p->nobs > 0 && o->slack_start == 1) { slack_lower_bounds(w, 1.0); unpack(w, w->v); }
     /* the kernel searches its candidates BEFORE the loop, for the problems that may take the crash path: a provable crash state (it
      * starts from the point) or a CBF row violated at the zero start (it may stall and restart from the point) */
-    int may_restart = 0;
+    int may_restart = 0, crash_at_start = 0;
     if (crash_path) {
         const int crash_state = slack_lower_bounds(w, 0.0);
         for (int ob = 0; ob < p->nobs; ob++)
             for (int i = 0; i < p->N; i++) if (cbf_G(w, ob, i) < 0.0) may_restart = 1;
-        if (crash_state) { may_restart = 1; crash = crash_point(w, 1); }
+        if (crash_state) { may_restart = 1; crash = crash_point(w, 1); crash_at_start = crash; }
     }
     scale_rows(w);
     init_rows(w);
@@ -639,6 +639,10 @@ static void ipm_solve(work_t* w, result_t* res) {
     const int JAM_COUNT = (int)g_knob[1], STALL_ITERS = (int)g_knob[2];
     const double JAM_ALPHA = g_knob[0];
     int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
+    /* a solve that STARTS on the crash path has a budget too (three times the restoration budget + 1: it has the whole way to go; 2x
+     * loses 1 % of the three-car draw), after which it ends CRX_RESTORED like a restarted one -- feasible through its slacks, not
+     * optimal -- instead of crawling to max_iter */
+    if (crash_at_start) { n_restore = 1; it_limit = 1 + 3 * o->restore_iters; }
     int crawl = 0;
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     if (g_knob[6] >= 0.0 && o->restore_iters >= 0) {   /* experiment: slacks first -- restore before the first iteration when a
