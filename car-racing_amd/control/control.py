@@ -85,8 +85,10 @@ def mpccbf(xcurv, xtarget, mpc_cbf_param, vehicles, agent_name, lap_length, time
     N = mpc_cbf_param.num_horizon
     others = [n for n in list(vehicles) if n != agent_name]
     preds = _predictions(vehicles, others, time, timestep, N + 1, realtime_flag)
-    if len(others) > _N_OBS_MAX:
-        # keep the kernel's obstacle slots for the vehicles that pass the window test
+    if len(others) > 3:
+        # more vehicles than the tuned instantiations carry (3): only those that pass the window test enter the NLP anyway
+        # (:499-523), so filter first -- up to CRX_MAX_OBS = 6 of them are solved exactly (generic instantiation beyond 3),
+        # more than that and pack_obstacles keeps the nearest and warns
         x1 = np.asarray(xcurv, dtype=float).reshape(1, X_DIM)
         keep, _ = hostprep.cbf_window(x1, np.array([[p[4, 0] for p in preds]]), lap_length)
         preds = [p for p, k in zip(preds, keep[0]) if k]

@@ -362,7 +362,7 @@ class GameLaps:
         Bn = lm.batch
         self.s0, self.v, self.ey = (torch.as_tensor(np.ascontiguousarray(a), **f64) for a in (car_s0, car_v, car_ey))
         VA = self.s0.shape[1]
-        V = min(VA, abi.CRX_MAX_OBS)
+        V = min(VA, abi.CRX_MAX_VEH)
         self.Np, self.V, self.VA, self.L = N_plan, V, VA, lap_length
         self.scene = abi.scene_desc(N_plan, VA, V, lap_length)
         self.prep = abi.prep_desc(N_plan, V, opt_xcurv.shape[0], track_width, lap_length)

@@ -566,7 +566,7 @@ int crx_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0, const
 // ---- selection -------------------------------------------------------------------------------------
 static int check_select(const crx_select_desc* d, int n_scen) {
     if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
-    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS || n_scen < 0)
+    if (d->N < 1 || d->N > CRX_MAX_N || d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_VEH || n_scen < 0)
         return fail(CRX_ERR_ARG, "bad selection dimensions");
     // the kernel wraps predicted s by lap_length (overtake_traj_planner.py:216-217): a zeroed descriptor must be a call
     // failure, not a device loop
@@ -769,7 +769,7 @@ void crx_prep_desc_default(crx_prep_desc* d, int N, int n_veh_max, int n_opt, do
 static int fill_prep(crx_prep_kparams& pp, const crx_prep_desc* d, int n_scen) {
     if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
     if (d->N < 3 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [3,%d]", d->N, CRX_MAX_N);
-    if (d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [0,%d]", d->n_veh_max, CRX_MAX_OBS);
+    if (d->n_veh_max < 0 || d->n_veh_max > CRX_MAX_VEH) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [0,%d]", d->n_veh_max, CRX_MAX_VEH);
     if (d->n_opt < 2) return fail(CRX_ERR_ARG, "n_opt < 2");
     if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
     if (!(d->lap_length > 0.0) || !(d->track_width > 0.0)) return fail(CRX_ERR_ARG, "lap_length and track_width must be positive");
@@ -932,7 +932,7 @@ static int check_scene(const crx_scene_desc* d, int n_scen) {
     if (!d) return fail(CRX_ERR_ARG, "desc is NULL");
     if (d->N < 1 || d->N > CRX_MAX_N) return fail(CRX_ERR_ARG, "N=%d outside [1,%d]", d->N, CRX_MAX_N);
     if (d->n_all_max < 1 || d->n_all_max > 64) return fail(CRX_ERR_ARG, "n_all_max=%d outside [1,64]", d->n_all_max);
-    if (d->n_veh_max < 1 || d->n_veh_max > CRX_MAX_OBS) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [1,%d]", d->n_veh_max, CRX_MAX_OBS);
+    if (d->n_veh_max < 1 || d->n_veh_max > CRX_MAX_VEH) return fail(CRX_ERR_ARG, "n_veh_max=%d outside [1,%d]", d->n_veh_max, CRX_MAX_VEH);
     if (!(d->lap_length > 0.0) || !isfinite(d->lap_length)) return fail(CRX_ERR_ARG, "lap_length must be positive and finite");
     if (n_scen < 0) return fail(CRX_ERR_ARG, "n_scen < 0");
     return 0;

@@ -185,7 +185,7 @@ struct Lay {
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
     static constexpr int Fph = Fth + MAXF;
-    static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 12.. lap_off, 16.. 1/l_sum per obstacle, 16+NOBS.. 1/w_sum per obstacle
+    static constexpr int cst = Fph + MAXF;           // 0..5 wq, 6..7 wr, 8.. lap_off (NOBS <= 8), 16.. 1/l_sum per obstacle, 16+NOBS.. 1/w_sum per obstacle
     static constexpr int dmy = cst + 16 + 2 * NOBS;  // sink of the address-predicated stores (lanes without an entry write here)
     static constexpr int END_D = dmy + 2;
     // int tables (stored after the doubles)
@@ -194,8 +194,11 @@ struct Lay {
     static constexpr int SH_OFF = (END_I + 1) & ~1;  // in ints, from si
     // 16-bit tables (after the ints; SH16())
     static constexpr int riv = 0;                    // [MR]  simple rows: index into Z / dZ | RIV_SIMPLE | RIV_NEG (sign of the Jacobian entry)
-    static constexpr int updP = riv + MR;            // [64] packed (i << 8 | j) lane map of the Riccati update
-    static constexpr int END_S16 = (updP + 64 + 1) & ~1;
+    static constexpr int updP = riv + MR;            // [64 * UCNT] packed (i << 8 | j) lane map of the Riccati update
+    // passes of the update phase: NX (NX + 1) / 2 + NX entries of (P_new | p_new) + NX + 1 feedback columns, one lane each -- one pass for
+    // NX <= 9 (up to three obstacles), two for the generic six-obstacle instantiation [r4]
+    static constexpr int UCNT = (NX * (NX + 1) / 2 + NX + NX + 1 + WAVE - 1) / WAVE;
+    static constexpr int END_S16 = (updP + 64 * UCNT + 1) & ~1;
     // row index of the lower- / upper-bound row of a coordinate (-1 none), after the 16-bit tables (VROW()): one byte
     // each while the row count allows -- with the 16-bit row table this takes the planner instantiation from 14 080 to
     // 13 552 B = 12 instead of 11 problems per CU (the runtime grants 12 up to 13 632 B: tools/ubench/lds_occupancy.hip)
@@ -314,7 +317,7 @@ __device__ __forceinline__ void cbf_dist(const double* sm, const Ctx& c, int k, 
     const double en = LD(L::Z + (k + 1) * L::NZ + 5) + al * LD(L::dZ + (k + 1) * L::NZ + 5);
     // 1 / (l_agent + l_obs), 1 / (w_agent + w_obs) of THIS obstacle (control.py:529-535 takes them per obstacle)
     const double rLs = LD(L::cst + 16 + o), rWs = LD(L::cst + 16 + L::NO + o);
-    dsc = (sc - LD(L::obs_s + o * N1 + k) - LD(L::cst + 12 + o)) * rLs;  // lap-corrected (control.py:539-540)
+    dsc = (sc - LD(L::obs_s + o * N1 + k) - LD(L::cst + 8 + o)) * rLs;  // lap-corrected (control.py:539-540)
     dec = (ec - LD(L::obs_e + o * N1 + k)) * rWs;
     dsn = (sn - LD(L::obs_s + o * N1 + k + 1)) * rLs;                    // NOT corrected (control.py:542, quirk Q1)
     den = (en - LD(L::obs_e + o * N1 + k + 1)) * rWs;
@@ -725,32 +728,43 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
         for (int i = 0; i < NX; i++) mH[q][i] = LD(L::M + i * NZ + hr[q]);
     // sigma columns of T (NOBS > 0): sigma_k -> 0, sigma_{k+1} -> P[:, 6+o]
-    static_assert(NX * 2 * NOBS <= WAVE, "one pass");
-    int t2ld = L::P, t2st = L::dmy;
-    bool t2nxt = false;
-    if (NOBS) {
-        const bool v2 = lane < NX * 2 * NOBS;
-        const int e2 = v2 ? lane : 0;
-        const int i2 = e2 / (2 * L::NO), cc = e2 - i2 * (2 * L::NO);
-        t2nxt = cc >= NOBS;
-        const int o = t2nxt ? cc - NOBS : cc;
-        t2ld = L::P + i2 * NX + 6 + o;
-        t2st = SINK(v2, L::T + i2 * NZ + seli(t2nxt, NX + 2 + o, 6 + o));
+    constexpr int T2CNT = NOBS ? (NX * 2 * NOBS + WAVE - 1) / WAVE : 1;   // one pass up to three obstacles, three for six [r4]
+    int t2ld[T2CNT], t2st[T2CNT];
+    bool t2nxt[T2CNT];
+#pragma unroll
+    for (int q = 0; q < T2CNT; q++) {
+        t2ld[q] = L::P; t2st[q] = L::dmy; t2nxt[q] = false;
+        if (NOBS) {
+            const int l2 = lane + q * WAVE;
+            const bool v2 = l2 < NX * 2 * NOBS;
+            const int e2 = v2 ? l2 : 0;
+            const int i2 = e2 / (2 * L::NO), cc = e2 - i2 * (2 * L::NO);
+            t2nxt[q] = cc >= NOBS;
+            const int o = t2nxt[q] ? cc - NOBS : cc;
+            t2ld[q] = L::P + i2 * NX + 6 + o;
+            t2st[q] = SINK(v2, L::T + i2 * NZ + seli(t2nxt[q], NX + 2 + o, 6 + o));
+        }
     }
     // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
-    // [NP, NP+NX+1) one feedback column each (<= 64 lanes for NX <= 9)
-    constexpr int NP = NX * (NX + 1) / 2 + NX;
-    const int upk = UPDP(si, lane);
-    const int ui = upk >> 8, uj = upk & 255;     // feedback lanes: column uj, ui = 0 (unused)
-    const bool isP = lane < NP, isK = !isP && lane < NP + NX + 1;
-    const bool gcol = uj >= NX;                   // gradient column = column NZ of H
-    const int ujj = gcol ? NZ : uj;
-    const int yiA = L::H + NX * HS + ui, yjA = L::H + NX * HS + ujj, s0A = L::H + ui * HS + ujj;
-    const int pst1 = SINK(isP, seli(gcol, L::pv + ui, L::P + ui * NX + uj));
-    const int pst2 = SINK(isP, seli(gcol, L::pv + ui, L::P + uj * NX + ui));
-    const int kstr = seli(isK, seli(gcol, 1, NX), 0), kstep = seli(isK, seli(gcol, NU, NU * NX), 0);
-    int kst = SINK(isK, seli(gcol, L::kf, L::Kk + uj) + (N - 1) * kstep);
-    const bool exSl = isP && !gcol && ui == uj && ui == 4, exEl = isP && !gcol && ui == uj && ui == 5;
+    // [NP, NP+NX+1) one feedback column each (<= 64 lanes for NX <= 9: one pass; the six-obstacle instantiation takes two [r4])
+    constexpr int NP = NX * (NX + 1) / 2 + NX, UCNT = L::UCNT;
+    int yiA[UCNT], yjA[UCNT], s0A[UCNT], pst1[UCNT], pst2[UCNT], kstr[UCNT], kstep[UCNT], kst[UCNT];
+    bool exSl[UCNT], exEl[UCNT];
+#pragma unroll
+    for (int q = 0; q < UCNT; q++) {
+        const int l = lane + q * WAVE;
+        const int upk = UPDP(si, l);
+        const int ui = upk >> 8, uj = upk & 255;     // feedback lanes: column uj, ui = 0 (unused)
+        const bool isP = l < NP, isK = !isP && l < NP + NX + 1;
+        const bool gcol = uj >= NX;                   // gradient column = column NZ of H
+        const int ujj = gcol ? NZ : uj;
+        yiA[q] = L::H + NX * HS + ui; yjA[q] = L::H + NX * HS + ujj; s0A[q] = L::H + ui * HS + ujj;
+        pst1[q] = SINK(isP, seli(gcol, L::pv + ui, L::P + ui * NX + uj));
+        pst2[q] = SINK(isP, seli(gcol, L::pv + ui, L::P + uj * NX + ui));
+        kstr[q] = seli(isK, seli(gcol, 1, NX), 0); kstep[q] = seli(isK, seli(gcol, NU, NU * NX), 0);
+        kst[q] = SINK(isK, seli(gcol, L::kf, L::Kk + uj) + (N - 1) * kstep[q]);
+        exSl[q] = isP && !gcol && ui == uj && ui == 4; exEl[q] = isP && !gcol && ui == uj && ui == 5;
+    }
     if (tsub) tsub[2] += CLK() - qs;   // set-up of the sweep (terminal P, lane maps, stage-invariant operands)
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
@@ -766,7 +780,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             for (int q = 0; q < TCNT; q++)
 #pragma unroll
                 for (int j = 0; j < 6; j++) pl[q][j] = LD(tld[q] + j);
-            const double p2 = NOBS ? LD(t2ld) : 0.0;
+            double p2[T2CNT];
+#pragma unroll
+            for (int q = 0; q < T2CNT; q++) p2[q] = NOBS ? LD(t2ld[q]) : 0.0;
             LOADS_DONE();
 #pragma unroll
             for (int q = 0; q < TCNT; q++) {
@@ -775,7 +791,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 for (int j = 0; j < 6; j++) t += pl[q][j] * mT[q][j];
                 LD(tst[q]) = t;
             }
-            if (NOBS) LD(t2st) = sel(t2nxt, p2, 0.0);
+            if (NOBS) {
+#pragma unroll
+                for (int q = 0; q < T2CNT; q++) LD(t2st[q]) = sel(t2nxt[q], p2[q], 0.0);
+            }
         }
         SYNC();
         long long q1 = CLK();
@@ -853,14 +872,17 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // (p_new, kff).  P_new is formed from the SAME factor for (i,j) and (j,i): symmetric positive semi-definite
         // by construction.  P/pv are not read in this phase (T and hv are done), so they are overwritten in place.
         {
-            double Lf[NU][NU], Dp[NU], rD[NU], yi[NU], yj[NU];
+            double Lf[NU][NU], Dp[NU], rD[NU], yi[UCNT][NU], yj[UCNT][NU], t[UCNT];
 #pragma unroll
             for (int a = 0; a < NU; a++)
 #pragma unroll
                 for (int b2 = 0; b2 <= a; b2++) Lf[a][b2] = LD(L::H + (NX + a) * HS + NX + b2);
 #pragma unroll
-            for (int a = 0; a < NU; a++) { yi[a] = LD(yiA + a * HS); yj[a] = LD(yjA + a * HS); }
-            double t = LD(s0A);
+            for (int q = 0; q < UCNT; q++) {
+#pragma unroll
+                for (int a = 0; a < NU; a++) { yi[q][a] = LD(yiA[q] + a * HS); yj[q][a] = LD(yjA[q] + a * HS); }
+                t[q] = LD(s0A[q]);
+            }
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
             const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
             LOADS_DONE();
@@ -886,23 +908,26 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 }
             }
 #pragma unroll
-            for (int a = 1; a < NU; a++) {
+            for (int q = 0; q < UCNT; q++) {
 #pragma unroll
-                for (int q = 0; q < a; q++) { yi[a] -= Lf[a][q] * yi[q]; yj[a] -= Lf[a][q] * yj[q]; }
+                for (int a = 1; a < NU; a++) {
+#pragma unroll
+                    for (int qq = 0; qq < a; qq++) { yi[q][a] -= Lf[a][qq] * yi[q][qq]; yj[q][a] -= Lf[a][qq] * yj[q][qq]; }
+                }
+#pragma unroll
+                for (int a = 0; a < NU; a++) { yj[q][a] *= rD[a]; t[q] -= yi[q][a] * yj[q][a]; }
+                t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
+                LD(pst1[q]) = t[q];
+                LD(pst2[q]) = t[q];
+#pragma unroll
+                for (int a = NU - 2; a >= 0; a--) {
+#pragma unroll
+                    for (int qq = a + 1; qq < NU; qq++) yj[q][a] -= Lf[qq][a] * yj[q][qq];
+                }
+#pragma unroll
+                for (int a = 0; a < NU; a++) LD(kst[q] + a * kstr[q]) = -yj[q][a];
+                kst[q] -= kstep[q];
             }
-#pragma unroll
-            for (int a = 0; a < NU; a++) { yj[a] *= rD[a]; t -= yi[a] * yj[a]; }
-            t += sel(exSl, exS, sel(exEl, exE, 0.0));
-            LD(pst1) = t;
-            LD(pst2) = t;
-#pragma unroll
-            for (int a = NU - 2; a >= 0; a--) {
-#pragma unroll
-                for (int q = a + 1; q < NU; q++) yj[a] -= Lf[q][a] * yj[q];
-            }
-#pragma unroll
-            for (int a = 0; a < NU; a++) LD(kst + a * kstr) = -yj[a];
-            kst -= kstep;
         }
         if (!ok) break;  // uniform: every lane computed the same pivots (the entries just stored are discarded with the sweep)
         SYNC();
@@ -1104,7 +1129,7 @@ __device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_
             for (int k = 0; k < N; k++) v += kp.wr[0] * u0 * u0 + kp.wr[1] * u1 * u1;
             double casc = 0.0;
             for (int ob = 0; ob < c.nobs; ob++) {
-                const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + L::NO + ob), lo = LD(L::cst + 12 + ob);
+                const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + L::NO + ob), lo = LD(L::cst + 8 + ob);
                 double snext = 0.0;
                 for (int i = N - 1; i >= 0; i--) {
                     const double dsc = (scr[(2 * i) * CH + lane] - LD(L::obs_s + ob * N1 + i) - lo) * rLs;
@@ -1319,14 +1344,16 @@ crx_solve_kernel(const crx_kparams kp) {
             si[L::triH + e] = (r << 8) | (e - r * (r + 1) / 2);
         }
         constexpr int NP = NX * (NX + 1) / 2 + NX;
-        int i = 0, j = lane - NP;
-        if (lane < NP) {               // pairs i <= j, j in [0, NX]
-            int rem = lane;
-            while (rem >= NX + 1 - i) { rem -= NX + 1 - i; i++; }
-            j = i + rem;
+        for (int l = lane; l < WAVE * L::UCNT; l += WAVE) {
+            int i = 0, j = l - NP;
+            if (l < NP) {               // pairs i <= j, j in [0, NX]
+                int rem = l;
+                while (rem >= NX + 1 - i) { rem -= NX + 1 - i; i++; }
+                j = i + rem;
+            }
+            if (j < 0 || j > NX) j = 0;
+            SH16(si)[L::updP + l] = (unsigned short)((i << 8) | j);
         }
-        if (j < 0 || j > NX) j = 0;
-        SH16(si)[L::updP + lane] = (unsigned short)((i << 8) | j);
     }
     SYNC();
     if (lane < 6) LD(L::Z + lane) = kp.x0[(size_t)b * 6 + lane];
@@ -1378,7 +1405,7 @@ crx_solve_kernel(const crx_kparams kp) {
                 LD(L::obs_e + e) = on ? kp.obs_ey[((size_t)b * kp.n_obs_max) * (N + 1) + e] : 0.0;
             }
             if (lane < NOBS) {
-                LD(L::cst + 12 + lane) = lane < c.nobs ? kp.lap_off[(size_t)b * kp.n_obs_max + lane] : 0.0;
+                LD(L::cst + 8 + lane) = lane < c.nobs ? kp.lap_off[(size_t)b * kp.n_obs_max + lane] : 0.0;
                 // obstacle dimensions: per problem and obstacle slot if the caller gave them, else the descriptor's pair
                 const bool own = kp.obs_dims != nullptr && lane < c.nobs;
                 double ls = own ? kp.obs_dims[((size_t)b * kp.n_obs_max + lane) * 2] : kp.l_sum;
@@ -2081,6 +2108,10 @@ hipError_t crx_launch_solve_obs(const crx_kparams& kp, int nobs_template, hipStr
         case 1: return launch_n<1>(kp, st);
         case 2: return launch_n<2>(kp, st);
         case 3: return launch_n<3>(kp, st);
+        // [r4] four to six obstacles (CRX_MAX_OBS = 6: the reference admits any number, control.py:524-562): ONE generic instantiation
+        // per horizon class -- exponent and horizon read at run time, the Riccati update in two passes, the sigma columns of T in
+        // three; far beyond the register file (the slow path: correct first)
+        case 4: case 5: case 6: return kp.N <= 12 ? launch_t<6, 12, 0, 0>(kp, st) : launch_t<6, CRX_MAX_N, 0, 0>(kp, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -2097,7 +2128,8 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
         case 0: return small ? Lay<0, 12>::BYTES : Lay<0, CRX_MAX_N>::BYTES;
         case 1: return small ? Lay<1, 12>::BYTES : Lay<1, CRX_MAX_N>::BYTES;
         case 2: return small ? Lay<2, 12>::BYTES : Lay<2, CRX_MAX_N>::BYTES;
-        default: return small ? Lay<3, 12>::BYTES : (N <= 20 ? Lay<3, 20>::BYTES : Lay<3, CRX_MAX_N>::BYTES);
+        case 3: return small ? Lay<3, 12>::BYTES : (N <= 20 ? Lay<3, 20>::BYTES : Lay<3, CRX_MAX_N>::BYTES);
+        default: return small ? Lay<6, 12>::BYTES : Lay<6, CRX_MAX_N>::BYTES;
     }
 }
 
@@ -2110,7 +2142,7 @@ template <int NOBS, int NMAX, int NFIX>
 static int occ_t() {
     int n = 0;
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
-    constexpr int DEG = (NOBS > 0 && CRX_DEG6) ? 6 : 0;
+    constexpr int DEG = (NOBS > 0 && NOBS <= 3 && CRX_DEG6) ? 6 : 0;   // (the generic six-obstacle instantiation reads the exponent at run time)
     if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
@@ -2141,7 +2173,8 @@ int crx_solve_resident_per_cu_obs(int N, int nobs_template) {
     switch (nobs_template) {
         case 1: return occ_n<1>(N);
         case 2: return occ_n<2>(N);
-        default: return occ_n<3>(N);
+        case 3: return occ_n<3>(N);
+        default: return N <= 12 ? occ_t<6, 12, 0>() : occ_t<6, CRX_MAX_N, 0>();
     }
 }
 #else

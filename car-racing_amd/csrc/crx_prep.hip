@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(WAVE) crx_scene_kernel(const crx_scene_kparams
     const int na = min(max(sp.n_all[s], 0), VA);
     const double L = d.lap_length, s_e = wrap_above(ego[4], L);
     // vehicles of interest, in dict order (get_overtake_flag :29-42 -> check_ego_agent_distance planner_helper.py:218-266)
-    int idx[CRX_MAX_OBS], nv = 0, over = 0;
+    int idx[CRX_MAX_VEH], nv = 0, over = 0;
     unsigned long long hits = 0ull;
     int nh = 0;
     for (int v = 0; v < na; v++) {
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(WAVE) crx_scene_kernel(const crx_scene_kparams
     for (int v = 0; v < na; v++)
         if ((hits >> v) & 1ull) idx[nv++] = v;
     // partial "sort" (:66-76, quirk Q3): a new vehicle goes to the FRONT if its ey >= the current first one's, else to the back
-    int ord[CRX_MAX_OBS];
+    int ord[CRX_MAX_VEH];
     for (int k = 0; k < nv; k++) {
         const double e = vx_[6 * idx[k] + 5];
         if (k == 0) ord[0] = idx[0];

@@ -47,15 +47,19 @@ extern "C" {
 #define CRX_VERSION 200 /* 0.2.0: NOT layout-compatible with 0.1.x -- crx_ipm_opts grew by `reach_screen` and `slack_start` (every descriptor
                           embeds it), the process-global switches crx_set_reach_screen / crx_set_cbf_slack_start / crx_set_timing /
                           crx_last_kernel_ms are gone (options travel in the descriptor, timing is an object: crx_timer_*), new status
-                          CRX_STALLED (what CRX_INFEASIBLE used to report without a proof).
+                          CRX_STALLED (what CRX_INFEASIBLE used to report without a proof), CRX_MAX_OBS 3 -> 6 (CRX_MAX_VEH = 3 for the planner side).
                           (0.1.3: per-obstacle dimensions, plant noise, crx_game_*, crx_comm_* (RCCL), dispatch order, crx_streams_*;
                            0.1.2: infeasibility certificates, *_masked_dev, CRX_SKIPPED, crx_track_prep_dev;
                            0.1.1: restoration phase, CRX_RESTORED, crx_ipm_opts.restore_iters) */
 #define CRX_NX 6
 #define CRX_NU 2
 #define CRX_MAX_N 24       /* horizon limit (reference runs N=10/12; BASELINE configs go to 20) */
-#define CRX_MAX_OBS 3      /* obstacles per NLP / vehicles of interest per scenario */
-#define CRX_MAX_REGIONS (CRX_MAX_OBS + 1)
+#define CRX_MAX_OBS 6      /* obstacles per MPC-CBF NLP (n_obs_max of crx_cbf_desc).  The reference admits any number (control.py:524-562
+                              loops over every vehicle in the window); its scenarios race 3 cars (overtake_planner_test.py).  Up to 3 run on
+                              the tuned instantiations, 4..6 on ONE generic instantiation per horizon class (correct, slow: twice the
+                              register file).  A caller with more keeps the nearest (crx.hostprep.pack_obstacles warns). */
+#define CRX_MAX_VEH 3      /* vehicles of interest per planner scenario (n_veh_max of the scene / prep / select descriptors); regions = + 1 */
+#define CRX_MAX_REGIONS (CRX_MAX_VEH + 1)
 #define CRX_LMPC_MAX_N 16 /* horizon limit of crx_lmpc_solve (its dense factors share one LDS slice) */
 #define CRX_MAX_SS 60      /* safe-set points per learning-MPC QP (reference: 44) */
 
@@ -350,7 +354,7 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
  *   n_all     [S]            vehicles in the scenario besides the ego, 0..n_all_max, in the reference's dict order
  *   veh_xcurv [S][VA][6]     their current states;  pred_s, pred_ey [S][VA][N+1]  their predictions (get_trajectory_nsteps rows 4, 5)
  *   n_veh [S]                out: vehicles of interest (the planner runs iff > 0);  overflow [S]: of-interest vehicles beyond
- *                            n_veh_max that were dropped (the reference has no limit; libcrx plans around at most CRX_MAX_OBS).
+ *                            n_veh_max that were dropped (the reference has no limit; libcrx plans around at most CRX_MAX_VEH).
  *                            On overflow the n_veh_max vehicles NEAREST to the ego along the closed lap are kept (ties to the
  *                            earlier one), in dict order -- the closest car is never the one dropped.
  *   order [S][V]             out: vehicle index (0..n_all-1) of sorted vehicle k, -1 beyond n_veh
@@ -359,7 +363,7 @@ int crx_planner_prep_dev(const crx_prep_desc* d, int n_scen, const double* x_wra
 typedef struct crx_scene_desc {
     int32_t N;
     int32_t n_all_max;       /* VA: leading dimension of the vehicle arrays */
-    int32_t n_veh_max;       /* V <= CRX_MAX_OBS */
+    int32_t n_veh_max;       /* V <= CRX_MAX_VEH */
     int32_t reserved0;
     double safety_factor;    /* 4.5  RacingGameParam.safety_factor */
     double prediction_factor;/* 0.5  planning_prediction_factor */

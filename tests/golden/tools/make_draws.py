@@ -475,6 +475,45 @@ def gen_dims(n=16):
     np.savez_compressed(os.path.join(mg.OUT, "cfg2_dims.npz"), **out)
 
 
+def gen_many(n=12):
+    """[r4] control.mpccbf with FOUR TO SIX vehicles inside the window (the reference loops over every vehicle, control.py:524-562; libcrx
+    carried three until ABI 0.2): healthy starts of the cfg2 draw with more cars placed around the ego at a distance -- ahead and behind,
+    random lanes and speeds -- so that every one passes the +-2 vx window test.  -> tests/golden/cfg2_many.npz (fields as cfg2_draw.npz)."""
+    p = synth.cfg2_mpccbf(256, N=12, seed=2, safe_start=True)
+    rng = np.random.default_rng(31)
+    rows = []
+    b = 0
+    while len(rows) < n:
+        x0 = p["x0"][b]; b += 1
+        k = int(rng.integers(4, 7))                                   # 4, 5 or 6 cars
+        gaps = np.sort(rng.uniform(-1.6, 1.6, k)) * x0[0]
+        gaps = gaps[np.abs(gaps) > 0.55]                              # none on top of the ego
+        if len(gaps) < 4:
+            continue
+        lanes = 0.7 - 0.1 * rng.integers(0, 15, len(gaps))
+        lanes = np.where(np.abs(lanes - x0[5]) < 0.25, lanes + 0.5 * np.sign(lanes - x0[5] + 1e-9), lanes)   # off the ego's line
+        cars = [(float(x0[4] + gp), float(rng.uniform(0.1, 0.9)), float(np.clip(le, -0.8, 0.8))) for gp, le in zip(gaps, lanes)]
+        r = mg.mpccbf_case(x0, cars, N=12, alpha=0.8, vt=0.8)
+        opti, z, info = mg.RECORDS[-1]
+        n_obs = int(r["n_obs_in_problem"])
+        if n_obs < 4:
+            continue
+        cars6 = np.full((6, 3), np.nan); cars6[: len(cars)] = np.array(cars)
+        sig6 = np.full((6, 13), np.nan); sig6[:n_obs] = np.asarray(r["sigma"]).reshape(n_obs, 13)
+        row = dict(index=b - 1, x0=x0, cars=cars6, n_cars=len(cars), n_obs_ref=n_obs, u_returned=r["u_returned"], X=r["X"], U=r["U"], sigma=sig6, cert=r["cert"])
+        pr = probe(opti, 12, n_obs, x0, 7700 + b)
+        for kk in ("probe_sigma", "probe_cbf"):
+            a6 = np.full((6,) + np.asarray(pr[kk]).shape[1:], np.nan); a6[:n_obs] = np.asarray(pr[kk])[:n_obs]; pr[kk] = a6
+        row.update({kk: v for kk, v in pr.items() if kk in ("probe_U", "probe_sigma", "probe_cbf", "probe_f", "probe_eq")})
+        _classified(row, opti, info, z, 12, n_obs)
+        if np.asarray(row["sigma"]).shape[0] != 6:                    # a point certified by the retry replaced the row: pad again
+            sg = np.full((6, 13), np.nan); sg[:n_obs] = np.asarray(row["sigma"]); row["sigma"] = sg
+        rows.append(row)
+        print("many %2d/%d cars %d n_obs %d success %s iters %d retry %s" % (len(rows), n, len(cars), n_obs, row["success"], row["ipm_iters"], row["retry_certified"]), flush=True)
+    out = {"draw/" + k: v for k, v in _stack(rows).items()}
+    np.savez_compressed(os.path.join(mg.OUT, "cfg2_many.npz"), **out)
+
+
 def gen_plant_noise(n=24):
     """DynamicBicycleModel.forward_dynamics (utils/base.py:897-942) WITH its process noise on random states: the reference's
     own step under np.random.seed(k), the three standard-normal draws it consumed, and the state it returned."""
@@ -542,6 +581,9 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
     if which[0] == "dims":
         gen_dims()
+        sys.exit(0)
+    if which[0] == "many":
+        gen_many()
         sys.exit(0)
     if which[0] == "plant_noise":
         gen_plant_noise()

@@ -362,3 +362,68 @@ def test_unequal_cars_rows_and_solutions(orc, AB):
     assert seen2 >= 8
     for T in (DEFAULT, TIGHT):
         _dims_compare(orc, orc, AB, T)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# [r4] four to six vehicles in the window (control.py:524-562 loops over every vehicle): CRX_MAX_OBS = 6
+# ---------------------------------------------------------------------------------------------------------------------
+def many_batch():
+    """The scenarios of tests/golden/cfg2_many.npz (make_draws.py gen_many: 4..5 cars inside the +-2 vx window, problems built by the
+    reference's unmodified control.mpccbf) through the PRODUCT's host prep: window test and packing into six obstacle slots."""
+    from crx import hostprep
+    g = _group(_load("cfg2_many.npz"), "draw")
+    n, N = len(g["index"]), 12
+    j = np.arange(N + 1)
+    cars = np.where(np.isnan(g["cars"]), 0.0, g["cars"])
+    there = ~np.isnan(g["cars"][:, :, 0])
+    obs_s = cars[:, :, 0, None] + 0.1 * j[None, None, :] * cars[:, :, 1, None]
+    obs_ey = np.repeat(cars[:, :, 2, None], N + 1, axis=2)
+    keep, lap_off = hostprep.cbf_window(g["x0"], obs_s[:, :, 0], LAP)
+    ps, pe, po, nn = hostprep.pack_obstacles(keep & there, obs_s, obs_ey, lap_off, 6)
+    xt = np.tile(np.array([0.8, 0, 0, 0, 0, 0.0]), (n, 1))
+    return g, dict(x0=g["x0"], xt=xt, obs_s=ps, obs_ey=pe, lap_off=po, n_obs=nn)
+
+
+def _many_compare(binding, AB, T):
+    from crx import abi
+    A, B = AB
+    g, p = many_batch()
+    d = abi.cbf_desc(12, 6, A, B, alpha=0.8, margin=0.2)
+    d.opts.tol = T["tol"]
+    res = binding.cbf_solve(d, *[p[k] for k in KEYS])
+    if T["tol"] >= 1e-9:
+        T = dict(T, f=1e-6)     # four or five active degree-6 rows: the barrier perturbation of the cost is ~1e-7 at tol 1e-8 (as on the three-car draw, TOL4)
+    n_cmp = 0
+    for r in range(len(g["index"])):
+        n = int(g["n_obs_ref"][r])
+        assert int(p["n_obs"][r]) == n and n >= 4, (r, p["n_obs"][r], n)                # nothing dropped: every car of the window is in the NLP
+        assert res["status"][r] == 0 and bool(g["certified"][r]), (r, res["status"][r])
+        fg = g["cert"][r][0]
+        df = abs(res["cost"][r] - fg) / max(1.0, abs(fg))
+        if df > T["f"] and res["cost"][r] < fg:
+            continue                                                                     # a better KKT point of the non-convex NLP
+        n_cmp += 1
+        Tl = T.get("loose", T)
+        assert df <= T["f"], (r, res["cost"][r], fg)
+        assert np.abs(res["X"][r] - g["X"][r]).max() <= Tl["x"] and np.abs(res["U"][r] - g["U"][r]).max() <= Tl["u"], (r, np.abs(res["X"][r] - g["X"][r]).max())
+        ds = np.abs(res["sigma"][r][:n] - g["sigma"][r][:n])
+        assert (ds <= 1e-6 * np.maximum(1.0, np.abs(g["sigma"][r][:n]))).all(), (r, ds.max())
+    assert n_cmp >= 10, n_cmp
+    return res
+
+
+def test_many_cars_rows_and_solutions(orc, AB):
+    """Rows: cost and every CBF row of the reference's recorded problem (4..5 obstacle cars) == the oracle's at the probe point;
+    solutions: oracle == the certified KKT points, at both tolerance sets."""
+    from crx import abi
+    A, B = AB
+    g, p = many_batch()
+    d = abi.cbf_desc(12, 6, A, B, alpha=0.8, margin=0.2)
+    for r in range(len(g["index"])):
+        n = int(g["n_obs_ref"][r])
+        pr = helpers.oracle_cbf_probe(orc, d, p["x0"][r], p["xt"][r], p["obs_s"][r], p["obs_ey"][r], p["lap_off"][r], n, g["probe_U"][r], g["probe_sigma"][r][:n])
+        assert _rel(pr["cost"], g["probe_f"][r]) <= 1e-12, r
+        assert (_rel(pr["cbf"][:n], g["probe_cbf"][r][:n]) <= 1e-9).all(), (r, pr["cbf"], g["probe_cbf"][r][:n])
+    assert (g["n_obs_ref"] >= 5).sum() >= 3
+    for T in (DEFAULT, TIGHT):
+        _many_compare(orc, AB, T)

@@ -1437,3 +1437,33 @@ def test_unequal_obstacle_sizes(gpu, orc, AB, T):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(ws.X.cpu().numpy(), rg["X"])
     np.testing.assert_array_equal(ws.status.cpu().numpy(), rg["status"])
+
+
+@pytest.mark.parametrize("T", ["default", "tight"])
+def test_many_obstacles(gpu, orc, AB, T):
+    """[r4] CRX_MAX_OBS = 6 (control.py:524-562 admits any number of vehicles in the window): four and five obstacle cars on the generic
+    six-obstacle instantiation of the solver kernel -- against the certified KKT points of the problems the reference itself built
+    (tests/golden/cfg2_many.npz) and against the oracle, verdict by verdict; and a three-car problem padded to six slots gives the
+    answer of the tuned three-obstacle instantiation (same KKT point through another instantiation)."""
+    import test_draw_fixtures as tdf
+    from crx import abi, synth
+
+    Tt = tdf.DEFAULT if T == "default" else tdf.TIGHT
+    rg = tdf._many_compare(gpu, AB, Tt)
+    A, B = AB
+    g, p = tdf.many_batch()
+    d = abi.cbf_desc(12, 6, A, B, alpha=0.8, margin=0.2)
+    d.opts.tol = Tt["tol"]
+    ro = orc.cbf_solve(d, *[p[k] for k in tdf.KEYS])
+    _assert_same_verdicts("many cars", rg, ro, tol=Tt["tol"], max_tight_stall=2, max_other=1)
+    _cmp("many cars", rg, ro, need_same_status=False, T=Tt if T == "default" else dict(Tt, x=Tt["loose"]["x"], u=Tt["loose"]["u"], xw=Tt["loose"]["xw"]))
+    # three obstacles through six slots == three obstacles through three slots
+    q = synth.cfg4_tracking_cbf(32, N=12, seed=9)
+    kw = dict(alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    d3, d6 = abi.cbf_desc(12, 3, A, B, **kw), abi.cbf_desc(12, 6, A, B, **kw)
+    pad = lambda a: np.concatenate([a, np.zeros((a.shape[0], 3) + a.shape[2:])], axis=1)   # noqa: E731
+    r3 = gpu.cbf_solve(d3, q["x0"], q["xt"], q["obs_s"], q["obs_ey"], q["lap_off"], q["n_obs"])
+    r6 = gpu.cbf_solve(d6, q["x0"], q["xt"], pad(q["obs_s"]), pad(q["obs_ey"]), pad(q["lap_off"]), q["n_obs"])
+    both = (r3["status"] == 0) & (r6["status"] == 0)
+    assert both.sum() >= 28 and (r3["status"] == 0).sum() == (r6["status"] == 0).sum()
+    assert np.abs(r3["X"][both] - r6["X"][both]).max() <= 1e-4 and np.abs(r3["cost"][both] - r6["cost"][both]).max() <= 1e-6 * np.abs(r3["cost"][both]).max()
