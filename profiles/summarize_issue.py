@@ -1,20 +1,17 @@
-"""profiles/r03_pmc_issue.txt: what binds a resident solver wave -- issue / wait / instruction-cache counters of the full-batch
-launches (rocprofv3 --pmc passes of tools/gpu_round3_c.sh, csv under gpurun_out/r3c/).  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
-count quad-cycles (4 clocks) summed over all waves; SQ_INSTS_* count instructions.
-Usage: python profiles/summarize_issue.py > profiles/r03_pmc_issue.txt"""
+"""What binds a resident solver wave -- issue / wait / instruction counters of the full-batch launches (rocprofv3 --pmc passes of
+`tools/gpu_pass.sh TAG issue`, csv under gpurun_out/TAG/).  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (4 clocks) summed
+over all waves; SQ_INSTS_* count instructions.  (Mean iterations per solve: pass them as cfg4,cfg2,cfg3 -- the bench line of the same batch.)
+Usage: python profiles/summarize_issue.py TAG [it_cfg4,it_cfg2,it_cfg3] > profiles/rNN_pmc_issue.txt
+(the summaries of rounds 2-3 -- profiles/r03_pmc_issue*.txt -- were made by the round-3 version of this script, see git history)"""
 import collections, csv, glob, os, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-FINAL = len(sys.argv) > 1 and sys.argv[1] == "r3u"     # python profiles/summarize_issue.py r3u > profiles/r03_pmc_issue_final.txt
-D = os.path.join(ROOT, "gpurun_out", "r3u" if FINAL else "r3c")
-RUNS = [("cfg4 <3,20> slim layout, 4 waves per CU (this round)", "pmc_cfg4_default_", 16384, 19.2),
-        ("cfg4 <3,20> full layout, 3 waves per CU (round-2 build)", "pmc_cfg4_r2like_", 16384, 19.2),
-        ("cfg2 <1,12> at batch 16384, 8 waves per CU", "pmc_cfg2_", 16384, 12.7),
-        ("cfg3 <0,12> at 65536 QPs, 12 waves per CU", "pmc_cfg3_", 65536, 6.9)]
-if FINAL:   # the final build of round 3 (tools/gpu_round3_u.sh): obstacle unit scheduled with iterative-ilp, lane maps hoisted in <3,20>
-    RUNS = [("cfg4 <3,20>, 4 waves per CU, index order", "pmc_cfg4_default_", 16384, 19.2),
-            ("cfg2 <1,12> at batch 16384, 8 waves per CU", "pmc_cfg2_", 16384, 12.7),
-            ("cfg3 <0,12> at 65536 QPs, 12 waves per CU, reachability screen ON (41 % of the waves end before set-up)", "pmc_cfg3_", 65536, 6.0),
-            ("cfg3 <0,12> at 65536 QPs, reachability screen OFF", "pmc_cfg3off_", 65536, 7.1)]
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r4g"
+D = os.path.join(ROOT, "gpurun_out", TAG)
+ITS = [float(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("18.0", "11.6", "6.0"))]
+FINAL = True
+RUNS = [("cfg4 <3,20>, 4 waves per CU, index order", "pmc_cfg4_default_", 16384, ITS[0]),
+        ("cfg2 <1,12> at batch 16384, 8 waves per CU", "pmc_cfg2_", 16384, ITS[1]),
+        ("cfg3 <0,12> at 65536 QPs, 12 waves per CU, reachability screen ON (41 % of the waves end before set-up)", "pmc_cfg3_", 65536, ITS[2])]
 
 
 def load(prefix, grid):
@@ -26,11 +23,7 @@ def load(prefix, grid):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-print(__doc__.split("Usage")[0].strip() if not FINAL else
-      "profiles/r03_pmc_issue_final.txt: the same counters on the FINAL build of round 3 (rocprofv3 --pmc passes of tools/gpu_round3_u.sh,\n"
-      "csv under gpurun_out/r3u/): obstacle instantiations scheduled with iterative-ilp, lane maps hoisted in <3,20>, planner QPs with and\n"
-      "without the reachability screen.  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (4 clocks) summed over all waves;\n"
-      "SQ_INSTS_* count instructions.  (Mean iterations per solve are those of the bench line of the same batch.)")
+print(__doc__.split("Usage")[0].strip() + "\n[" + TAG + "]")
 print()
 for title, prefix, n, it_mean in RUNS:
     c = load(prefix, n)

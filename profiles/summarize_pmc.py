@@ -1,7 +1,7 @@
 """profiles/<round>_pmc_hbm_traffic.txt + profiles/pmc_hbm_traffic.json from the rocprofv3 --pmc passes of tools/gpu_pmc_r2.sh
 (csv output under gpurun_out/pmc3/ -- round 3: tools/gpu_round3_d.sh), corrected with the calibration of tools/gpu_calib.sh (profiles/pmc_calibration.json):
 FETCH_SIZE under-counts an 8 B/lane coalesced stream by the measured factor, WRITE_SIZE counts whole 64 B lines.
-Usage: python profiles/summarize_pmc.py [round-prefix, default r03] [csv directory under gpurun_out/]"""
+Usage: python profiles/summarize_pmc.py [round-prefix, default r04] [csv directory under gpurun_out/, default r4g/pmc]   (tools/gpu_pass.sh TAG pmc writes gpurun_out/TAG/pmc)"""
 import collections
 import csv
 import glob
@@ -10,8 +10,8 @@ import os
 import sys
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-PRE = sys.argv[1] if len(sys.argv) > 1 else "r03"
-SRC = sys.argv[2] if len(sys.argv) > 2 else ("pmc2" if PRE == "r02" else "pmc3")   # directory under gpurun_out/ holding the csv output
+PRE = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SRC = sys.argv[2] if len(sys.argv) > 2 else "r4g/pmc"   # directory under gpurun_out/ holding the csv output
 # workload -> (kernel name fragment, problems per full launch, algorithmic bytes per problem in / out)
 WL = {"cfg2": ("crx_solve_kernel", 256, 39 * 8, 118 * 8), "cfg3": ("crx_solve_kernel", 4096, 57 * 8, 93 * 8),
       "cfg4": ("crx_solve_kernel", 16384, 162 * 8, 232 * 8), "cfg5": ("crx_solve_kernel", 65536, 57 * 8, 93 * 8)}

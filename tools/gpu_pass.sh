@@ -68,7 +68,8 @@ pmc)
       rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $M/${wl}_$ctr -o p -- python $R/bench.py --steps $st --warmup 2 --workload $wl --no-cpu-baseline > /dev/null 2> $M/err_${wl}_$ctr.log
     done
   done )
-  python3 profiles/summarize_pmc.py $TAG $TAG/pmc --out $O | tail -12 ;;
+  find $M -type f ! -name "*counter_collection.csv" ! -name "*.txt" ! -name "*.log" -delete
+  ls $M ;;   # summarise locally: python3 profiles/summarize_pmc.py rNN $TAG/pmc
 issue)
   ( cd /tmp && export TMPDIR=/tmp
   pmc() {  # tag workload batch steps extra-bench-args counters...
@@ -85,7 +86,7 @@ issue)
   pmc cfg2_3 cfg2 16384 3 "--dispatch index" $B
   pmc cfg3_1 cfg3 16384 3 "" $A
   pmc cfg3_3 cfg3 16384 3 "" $B )
-  python3 profiles/summarize_issue.py $TAG > $O/pmc_issue.txt 2>&1; tail -30 $O/pmc_issue.txt ;;
+  ls $O | grep pmc_ ;;   # summarise locally: python3 profiles/summarize_issue.py $TAG it4,it2,it3 > profiles/rNN_pmc_issue.txt
 trace)
   make -C car-racing_amd/csrc -s clean all TRACE=1 2>&1 | grep -i error
   ( for w in cfg2 cfg3 cfg4; do python tools/gpu_solve_trace.py $w; done; python tools/gpu_lmpc_trace.py ) 2>&1 | grep -v amdgpu.ids > $O/phase_cycles.txt
