@@ -1109,6 +1109,9 @@ __device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_
 #pragma unroll
             for (int i = 0; i < 6; i++) x[i] = LD(L::Z + i);
             scr[0 * CH + lane] = x[4]; scr[1 * CH + lane] = x[5];
+            // (no unrolling of the stage loops of this function: with a compile-time horizon they unroll fully, the candidates' live
+            // values pile up and the register allocator spills 512 B per lane in <1,12,6,10> -- outside the iteration, but a scratch frame)
+#pragma unroll 1
             for (int k = 1; k <= N; k++) {
                 double xn[6];
 #pragma unroll
@@ -1126,11 +1129,14 @@ __device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_
                 for (int i = 0; i < 6; i++) { const double e = x[i] - LD(L::xr + k * 6 + i); v += LD(L::cst + i) * e * e; }
                 scr[(2 * k) * CH + lane] = x[4]; scr[(2 * k + 1) * CH + lane] = x[5];
             }
+#pragma unroll 1
             for (int k = 0; k < N; k++) v += kp.wr[0] * u0 * u0 + kp.wr[1] * u1 * u1;
             double casc = 0.0;
+#pragma unroll 1
             for (int ob = 0; ob < c.nobs; ob++) {
                 const double rLs = LD(L::cst + 16 + ob), rWs = LD(L::cst + 16 + L::NO + ob), lo = LD(L::cst + 8 + ob);
                 double snext = 0.0;
+#pragma unroll 1
                 for (int i = N - 1; i >= 0; i--) {
                     const double dsc = (scr[(2 * i) * CH + lane] - LD(L::obs_s + ob * N1 + i) - lo) * rLs;
                     const double dec = (scr[(2 * i + 1) * CH + lane] - LD(L::obs_e + ob * N1 + i)) * rWs;
