@@ -42,6 +42,15 @@
 #ifndef CRX_W2_FLOOR
 #define CRX_W2_FLOOR 0 /* 1: pin <2,12> at two waves per SIMD (256 registers, 76 B of scratch) = 6 instead of 4 problems per CU */
 #endif
+#ifndef CRX_STATIC_LDS
+#define CRX_STATIC_LDS 1   // 0: the solver's LDS as a dynamic (extern) array, as up to libcrx 0.2.0 (A/B builds)
+#endif
+#ifndef CRX_SWEEP_UNROLL
+#define CRX_SWEEP_UNROLL 1   // 1: the forward and adjoint sweeps of the fixed-horizon instantiations are unrolled completely; 0: two stages per trip
+#endif
+#ifndef CRX_RIC_UNROLL
+#define CRX_RIC_UNROLL 0   // stages of the Riccati backward sweep per trip of its loop in the fixed-horizon instantiations; 0 = all of them
+#endif
 #ifndef CRX_NFIX
 #define CRX_NFIX 1   // 0: every launch reads the horizon from its arguments (A/B builds)
 #endif
@@ -293,6 +302,11 @@ __device__ __forceinline__ void tri_decode(int e, int& r, int& a) {
 }
 
 #define LD(off) sm[(off)]
+#ifndef CRX_ROWDPP
+#define CRX_ROWDPP 1   // 0: the sweeps broadcast with v_readlane (A/B builds)
+#endif
+// the adjoint / forward sweeps keep a stage's NZ numbers in lanes 0 .. NZ-1: inside one 16-lane row up to four obstacles
+template <class L> constexpr bool ROWDPP = CRX_ROWDPP && L::NZ <= 16;
 
 // phase clocks of the crx_trace_enable diagnostics.  s_memtime shares lgkmcnt with the LDS and returns out of order, so
 // every clock read in a sweep turns the partial waits around it into full drains: compiled in only by `make TRACE=1`
@@ -502,7 +516,7 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
 // folded into the stage gradients (adding lam'(M dz_k - dx_{k+1}) = 0 to the Newton QP), so the
 // state part vanishes identically and the input part is the (small) reduced gradient.  The Riccati
 // vector recursion then carries residual-sized numbers instead of O(nu) terms that cancel.
-template <int NOBS, int NMAX>
+template <int NOBS, int NMAX, int UNR = 1>
 __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     const int N = c.N, lane = c.lane;
@@ -517,16 +531,26 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     double tot = LD(L::ga + N * L::NZ + la);        // lam_N = the terminal gradient (lanes < NX)
     double gk = LD(L::ga + (N - 1) * L::NZ + la);
     LD(SINK(lane < L::NZ, L::ga + N * L::NZ + lane)) = 0.0;
-    for (int k = N - 1; k >= 0; k--) {
+    auto stage = [&](int k) {
         const double gn = LD(L::ga + (k >= 1 ? k - 1 : 0) * L::NZ + la);   // next stage's gradient, in flight during this one
         double t = gk;
+        if constexpr (ROWDPP<L>) {
+            t = row_dot<L::NX, 0>(tot, mcol, t);
+        } else {
 #pragma unroll
-        for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+            for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+        }
         tot = t;
         emax = fmax(emax, sel(lane >= L::NX && lane < L::NZ, fabs(tot), 0.0));
         const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
         LD(SINK(lane < L::NZ, L::ga + k * L::NZ + lane)) = sel(keep, tot, 0.0);
         gk = gn;
+    };
+    if constexpr (UNR > 1) {   // fixed horizon: straight-line code, stage addresses are immediates [r4]
+#pragma unroll UNR
+        for (int k = N - 1; k >= 0; k--) stage(k);
+    } else {
+        for (int k = N - 1; k >= 0; k--) stage(k);
     }
     SYNC();
     if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(tot));
@@ -573,8 +597,12 @@ __device__ __forceinline__ double box_certificate(double* sm, const int* si, con
         const int kn = k >= 1 ? k - 1 : 0;
         const double gn = LD(L::dZ + kn * L::NZ + la), un = LD(L::Z + kn * L::NZ + la);
         double t = gk;
+        if constexpr (ROWDPP<L>) {
+            t = row_dot<L::NX, 0>(tot, mcol, t);
+        } else {
 #pragma unroll
-        for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+            for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
+        }
         tot = t;
         const double w = -tot;                            // input lanes: (J_s' y) of input a at stage k
         S += sel(isu, w * (sel(w > 0.0, hi, -hi) - uk), 0.0);
@@ -666,7 +694,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 // Riccati backward sweep with regularisation dw on the input / sigma_0 diagonal.  Returns false if
 // a pivot is not positive (wrong inertia).  On success Kk/kf hold the feedback and dZ[0] the step
 // of the free initial components (sigma_0).
-template <int NOBS, int NMAX>
+template <int NOBS, int NMAX, int UNR = 1>
 __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, const Ctx& c, double dw, long long* tsub = nullptr) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
@@ -766,6 +794,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         exSl[q] = isP && !gcol && ui == uj && ui == 4; exEl[q] = isP && !gcol && ui == uj && ui == 5;
     }
     if (tsub) tsub[2] += CLK() - qs;   // set-up of the sweep (terminal P, lane maps, stage-invariant operands)
+#pragma unroll UNR
     for (int k = N - 1; k >= 0; k--) {
         long long q0 = CLK();
         // (Forming H = M'PM in ONE phase straight from P -- NX^2 FMAs per entry, no T -- was tried twice, before and after
@@ -990,7 +1019,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 // stage).  Same operations in the same order as the LDS version: identical bits.  (A one-broadcast-per-stage variant --
 // lane i holding row i of the closed-loop map [M_x + M_u K_k | M_u kff_k], formed from K_{k+1} while stage k runs -- has
 // the shorter chain but costs NU (NX+1) more loads and FMAs per lane and stage: measured 6-13 % SLOWER.)
-template <int NOBS, int NMAX>
+template <int NOBS, int NMAX, int UNR = 1>
 __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
@@ -1005,26 +1034,39 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
 #pragma unroll
     for (int j = 0; j < NX; j++) kr[j] = LD(L::Kk + ua * NX + j);
     kfa = LD(L::kf + ua);
-    for (int k = 0; k < N; k++) {
+    auto stage = [&](int k) {
         double krn[NX], kfn;                           // next stage's feedback row: off the dependent chain
         const int kn = k + 1 < N ? k + 1 : k;
 #pragma unroll
         for (int j = 0; j < NX; j++) krn[j] = LD(L::Kk + (kn * NU + ua) * NX + j);
         kfn = LD(L::kf + kn * NU + ua);
-        double xs[NX], du = kfa, xn = 0.0;
+        double du = kfa, xn = 0.0;
+        if constexpr (ROWDPP<L>) {   // broadcast and FMA in one instruction (crx_wave.h row_dot): same terms in the same order
+            du = row_dot<NX, 0>(zx, kr, du);
+            xn = row_dot<NX, 0>(zx, mrow, xn);
+            xn = row_dot<NU, NX>(du, mrow + NX, xn);
+        } else {
+            double xs[NX];
 #pragma unroll
-        for (int j = 0; j < NX; j++) xs[j] = lane_f64(zx, j);
+            for (int j = 0; j < NX; j++) xs[j] = lane_f64(zx, j);
 #pragma unroll
-        for (int j = 0; j < NX; j++) du += kr[j] * xs[j];
+            for (int j = 0; j < NX; j++) du += kr[j] * xs[j];
 #pragma unroll
-        for (int j = 0; j < NX; j++) xn += mrow[j] * xs[j];
+            for (int j = 0; j < NX; j++) xn += mrow[j] * xs[j];
 #pragma unroll
-        for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
+            for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
+        }
         LD(SINK(lane < NZ, L::dZ + k * NZ + lane)) = sel(isu, du, zx);
         zx = xn;
 #pragma unroll
         for (int j = 0; j < NX; j++) kr[j] = krn[j];
         kfa = kfn;
+    };
+    if constexpr (UNR > 1) {   // fixed horizon [r4]: straight-line code -- the hand-over kr <- krn is a renaming instead of NX + 1 register copies
+#pragma unroll UNR             // per stage, the stage addresses are immediates
+        for (int k = 0; k < N; k++) stage(k);
+    } else {
+        for (int k = 0; k < N; k++) stage(k);
     }
     LD(SINK(lane < NZ, L::dZ + N * NZ + lane)) = sel(lane < NX, zx, 0.0);
     SYNC();
@@ -1271,13 +1313,22 @@ template <int NOBS, int NMAX> struct MinWaves {
 // The trip counts of the stage loops, the number of row passes (m = N NR + NOBS rows over 64 lanes) and the stage addresses become
 // immediates: cfg2 0.942 -> 0.868 ms per 256 NLPs (+8.6 %), cfg3 +8 %, the cfg5 shard +6 %, cfg4 +3.7 % (tools/gpu_round3_aa.sh), same
 // operations in the same order.
+template <int NFIX> struct SweepUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_SWEEP_UNROLL ? NFIX : 2); };   // forward / adjoint sweeps
+template <int NOBS, int NFIX> struct RicUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_RIC_UNROLL == 0 ? NFIX : CRX_RIC_UNROLL); };
 template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
 crx_solve_kernel(const crx_kparams kp) {
     static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
+#if CRX_STATIC_LDS
+    // [r4] The layout is a compile-time constant, so the array is STATIC: the compiler then knows its address (0) and folds it into the
+    // offset fields.  As `extern __shared__` the base stays a symbol until emission and every address computed at run time carries an
+    // `add ..., 0` (204 of them in <1,12,6,12>, 11 in each Riccati stage: bound by instruction issue, they cost like any other).
+    __shared__ __attribute__((aligned(16))) double sm[(L::BYTES + 7) / 8];
+#else
     extern __shared__ __attribute__((aligned(16))) double sm[];
+#endif
     int* si = (int*)(sm + L::END_D);
     const int lane = threadIdx.x, N = NFIX ? NFIX : kp.N;
     if ((int)blockIdx.x >= kp.batch) return;
@@ -1685,7 +1736,7 @@ crx_solve_kernel(const crx_kparams kp) {
         double e_c = cmax;
         const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
         long long tc1 = CLK();
-        const double e_d = dual_infeasibility<NOBS, NMAX>(sm, c) / sd;
+        const double e_d = dual_infeasibility<NOBS, NMAX, (SweepUnroll<NFIX>::v > 2 ? SweepUnroll<NFIX>::v : 1)>(sm, c) / sd;
         long long tc2 = CLK();
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
@@ -1714,7 +1765,7 @@ crx_solve_kernel(const crx_kparams kp) {
         long long tsub[4] = {0, 0, 0, 0};
         bool ok;
         for (int tries = 0, convex = (NOBS > 0 && crash) ? 0 : 1;; ) {
-            ok = riccati_backward<NOBS, NMAX>(sm, si, c, dw, tsub);
+            ok = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v>(sm, si, c, dw, tsub);
             if (ok) break;
             if (NOBS && !convex) {
                 // [r4] crash path (iii): first retry WITHOUT the reverse-convex part of the CBF curvature (-nu hess g_{k+1}, the kS / kE
@@ -1732,7 +1783,7 @@ crx_solve_kernel(const crx_kparams kp) {
         if (!ok) break;
         if (dw != 0.0) dw_last = dw;
         long long tc5 = CLK();
-        riccati_forward<NOBS, NMAX>(sm, c);
+        riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
         long long tc6 = CLK();
         // ---- row steps, step lengths, merit pieces ---------------------------------------------------
         // fraction-to-the-boundary without per-row divisions: a = min(1, tau / max_j(-d_j / v_j))
@@ -2054,6 +2105,9 @@ template __global__ void crx_solve_kernel<CRX_PROBE_ONE>(const crx_kparams);
 // ------------------------------------------------------------------------------------------------
 template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
+#if CRX_STATIC_LDS
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX>), dim3(kp.batch), dim3(WAVE), 0, st, kp);   // the layout is a static array of the kernel
+#else
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
     static int attr_set_on = -1;
@@ -2065,6 +2119,7 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
         attr_set_on = dev;
     }
     hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+#endif
     return hipGetLastError();
 }
 // fixed-horizon instantiations: N = 10 (the reference's defaults: utils/base.py:281, :390), 12 (BASELINE configs[1], [2], [4]), 20 (configs[3])
@@ -2147,9 +2202,13 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
 template <int NOBS, int NMAX, int NFIX>
 static int occ_t() {
     int n = 0;
-    const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     constexpr int DEG = (NOBS > 0 && NOBS <= 3 && CRX_DEG6) ? 6 : 0;   // (the generic six-obstacle instantiation reads the exponent at run time)
+#if CRX_STATIC_LDS
+    const size_t bytes = 0;   // the layout is static LDS of the kernel: the runtime counts it by itself
+#else
+    const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     if (hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+#endif
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }

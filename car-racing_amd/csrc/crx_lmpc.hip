@@ -39,6 +39,9 @@
 #ifndef CRX_LMPC_LATE
 #define CRX_LMPC_LATE 25   // stagnation rule: iterations with mu < 1e-6 before the QP is left on its noise floor (oracle: LATE_ITERS)
 #endif
+#ifndef CRX_STATIC_LDS
+#define CRX_STATIC_LDS 1   // 0: dynamic (extern) LDS as up to libcrx 0.2.0 (A/B builds)
+#endif
 #define CRX_LMPC_SS44 44   // the reference's num_ss_points (utils/base.py:357): capacity of the six-per-CU instantiation
 
 template <int NMAX, bool DENSE = true, int MSS = CRX_MAX_SS>
@@ -208,11 +211,24 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
 // NFIX [r3]: the horizon as a compile-time constant (12, the reference's lmpc_param.num_horizon; 0 = read kp.N), as in crx_solve_kernel:
 // +3 % on the stand-alone launch and on the closed-loop step (tools/gpu_round3_ac.sh), identical bits (tools/lmpc_ab.py).  The safe-set
 // count as a constant too was measured beside it and does not pay.
+// [r4] The fixed-horizon instantiation keeps its (compile-time) layout in a STATIC array: the compiler then knows the address (0) and folds
+// it into the offset fields of the DS instructions instead of adding a symbol that resolves to 0 at every run-time address (crx_solve_kernel
+// has the note): lmpc launch 1.526 -> 1.489 ms, game step 2.76 -> 2.69 ms.  The general instantiations stay on dynamic LDS: static, the
+// compiler also sees how many waves the LDS admits per CU, rounds five or six per CU down to ONE per SIMD and takes > 256 registers (four per
+// CU); and an amdgpu_waves_per_eu(2) floor against that costs the tuned instantiation 8 % (1.654 ms) -- both measured, tools/gpu_pass.sh game:NAME.
+template <int NFIX> struct LmpcStaticLds { static constexpr bool v = CRX_STATIC_LDS && NFIX != 0; };
 template <int NMAX, bool DENSE, int MSS, int NFIX = 0>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {
     static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = LL<NMAX, DENSE, MSS>;
-    extern __shared__ double sm[];
+    double* sm;
+    if constexpr (LmpcStaticLds<NFIX>::v) {
+        __shared__ __attribute__((aligned(16))) double sm_static[L::END];
+        sm = sm_static;
+    } else {
+        extern __shared__ double sm_dynamic[];
+        sm = sm_dynamic;
+    }
     if ((int)blockIdx.x >= kp.batch) return;
     const int pb = kp.order ? min(max(kp.order[blockIdx.x], 0), kp.batch - 1) : (int)blockIdx.x;   // dispatch order, see crx_solve_kernel
     if (kp.active && kp.active[pb] == 0) {   // masked launch: this problem is not part of it
@@ -892,6 +908,10 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
 
 template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS, int NFIX = 0>
 static hipError_t launch_l(const crx_lmpc_kparams& kp, hipStream_t st) {
+    if constexpr (LmpcStaticLds<NFIX>::v) {
+        hipLaunchKernelGGL((crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>), dim3(kp.batch), dim3(WAVE), 0, st, kp);   // the layout is a static array of the kernel
+        return hipGetLastError();
+    }
     const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(kp.n_ss_max);
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device
     static int attr_set_on = -1;
@@ -925,8 +945,9 @@ hipError_t crx_launch_lmpc(const crx_lmpc_kparams& kp, hipStream_t st) {
 template <int NMAX, bool DENSE, int MSS = CRX_MAX_SS, int NFIX = 0>
 static int occ_l(int n_ss_max) {
     int n = 0;
-    const size_t bytes = LL<NMAX, DENSE, MSS>::bytes(n_ss_max);
-    if (hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    const size_t bytes = LmpcStaticLds<NFIX>::v ? 0 : LL<NMAX, DENSE, MSS>::bytes(n_ss_max);   // static LDS: the runtime counts it by itself
+    if (!LmpcStaticLds<NFIX>::v &&
+        hipFuncSetAttribute((const void*)crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_lmpc_kernel<NMAX, DENSE, MSS, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }

@@ -1467,3 +1467,12 @@ def test_many_obstacles(gpu, orc, AB, T):
     both = (r3["status"] == 0) & (r6["status"] == 0)
     assert both.sum() >= 28 and (r3["status"] == 0).sum() == (r6["status"] == 0).sum()
     assert np.abs(r3["X"][both] - r6["X"][both]).max() <= 1e-4 and np.abs(r3["cost"][both] - r6["cost"][both]).max() <= 1e-6 * np.abs(r3["cost"][both]).max()
+    # the largest instantiation, <6, 24> (109 KB of LDS, one problem per CU): horizon 24, three cars in six slots, against the oracle
+    q = synth.cfg4_tracking_cbf(16, N=24, seed=11)
+    d6 = abi.cbf_desc(24, 6, A, B, **kw)
+    d6.opts.tol = Tt["tol"]
+    a6 = (q["x0"], q["xt"], pad(q["obs_s"]), pad(q["obs_ey"]), pad(q["lap_off"]), q["n_obs"])
+    rg, ro = gpu.cbf_solve(d6, *a6), orc.cbf_solve(d6, *a6)
+    _assert_same_verdicts("six slots, N = 24", rg, ro, tol=Tt["tol"], max_tight_stall=1, max_other=1)
+    both = (rg["status"] == 0) & (ro["status"] == 0)
+    assert both.sum() >= 12 and np.abs(rg["cost"][both] - ro["cost"][both]).max() <= 1e-6 * np.abs(ro["cost"][both]).max()

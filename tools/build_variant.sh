@@ -17,7 +17,8 @@ make -C $S -s
 OBJS=""
 for f in crx_kernels crx_kernels_obs crx_lmpc crx_prep crx_lmpcprep crx_api; do
   if echo " $FILES " | grep -q " $f.hip "; then
-    LICM=""; [ $f = crx_kernels ] && LICM="-mllvm -disable-machine-licm $PLAN_SCHED"; [ $f = crx_kernels_obs ] && LICM="-mllvm -disable-machine-licm $OBS_SCHED"
+    NOLICM=${NOLICM--mllvm -disable-machine-licm}                         # NOLICM= (empty): MachineLICM left on
+    LICM=""; [ $f = crx_kernels ] && LICM="$NOLICM $PLAN_SCHED"; [ $f = crx_kernels_obs ] && LICM="$NOLICM $OBS_SCHED"
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $LICM $EXTRA -I$S -c $S/$f.hip -o $D/$f.o
     OBJS="$OBJS $D/$f.o"
   else

@@ -12,6 +12,7 @@
 #   lines     one line per workload (bench.py --workload ...), for A/B-ing; CRX_LIB selects another build
 #   ab:NAME   the `lines` step with CRX_LIB=tools/ab/libcrx_NAME.so (tools/build_variant.sh NAME "FLAGS" beforehand, in the build container)
 #   suite:NAME the GPU parity suite on tools/ab/libcrx_NAME.so
+#   quick, quick:NAME  the four solver workloads of `lines` only (in-tree library / tools/ab/libcrx_NAME.so)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 O=$R/gpurun_out/$TAG
@@ -30,8 +31,22 @@ lines() {  # one line per workload
   timeout 300 python bench.py --workload game --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "game"
   timeout 300 python bench.py --workload overtake --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "overtake"
 }
+quick() {  # the four solver workloads only (A/B-ing kernel builds)
+  timeout 300 python bench.py --workload cfg2 --no-cpu-baseline --steps 200 --warmup 10 2> /dev/null | line "cfg2"
+  timeout 300 python bench.py --workload cfg2 --batch 4096 --no-cpu-baseline --steps 30 --warmup 5 2> /dev/null | line "cfg2x4096"
+  timeout 300 python bench.py --workload cfg3 --no-cpu-baseline --steps 100 --warmup 5 2> /dev/null | line "cfg3"
+  timeout 300 python bench.py --workload cfg4 --no-cpu-baseline --steps 10 --warmup 2 2> /dev/null | line "cfg4"
+}
 for step in "$@"; do
 case $step in
+game:*)   # the learning-MPC workloads on tools/ab/libcrx_NAME.so ("game:" alone = the in-tree library)
+  n=${step#game:}; [ -n "$n" ] && export CRX_LIB=$R/tools/ab/libcrx_$n.so; echo "== lmpc workloads ${n:-in-tree}"
+  ( timeout 300 python bench.py --workload lmpc --no-cpu-baseline --steps 30 --warmup 3 2> /dev/null | line "lmpc"
+    timeout 300 python bench.py --workload game --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "game"
+    timeout 300 python bench.py --workload overtake --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "overtake" ) | tee $O/game_${n:-intree}.txt; unset CRX_LIB ;;
+quick) quick | tee $O/quick.txt ;;
+quick:*)
+  n=${step#quick:}; export CRX_LIB=$R/tools/ab/libcrx_$n.so; echo "== $n"; quick | tee $O/quick_$n.txt; unset CRX_LIB ;;
 suite)
   ( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^  File\|^Extension\|^$" | tail -40 ) > $O/pytest_gpu.log
   grep -h "passed\|failed" $O/pytest_gpu.log | tail -2 ;;
