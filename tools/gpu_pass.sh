@@ -7,11 +7,12 @@
 #   stats     rocprofv3 --kernel-trace --stats of every workload      -> <wl>_kernel_stats.txt (profiles/summarize.py)
 #   pmc       FETCH_SIZE / WRITE_SIZE passes (separate runs, no trace domains beside --kernel-trace) -> pmc_hbm_traffic.{txt,json}
 #   issue     SQ issue / wait / instruction counters of the solver kernels -> pmc_issue.txt (profiles/summarize_issue.py)
-#   trace     per-phase shader cycles of one solve (rebuilds the library with TRACE=1, then back) -> phase_cycles.txt
+#   trace     per-phase shader cycles of one solve, on tools/ab/libcrx_trace.so (built beforehand with -DCRX_PHASE_CLOCKS) -> phase_cycles.txt
 #   budget    tools/budget_experiment.sh (solver budgets vs closed-loop quality) -> budget_experiment.txt
 #   lines     one line per workload (bench.py --workload ...), for A/B-ing; CRX_LIB selects another build
 #   ab:NAME   the `lines` step with CRX_LIB=tools/ab/libcrx_NAME.so (tools/build_variant.sh NAME "FLAGS" beforehand, in the build container)
 #   suite:NAME the GPU parity suite on tools/ab/libcrx_NAME.so
+#   bits:NAME  bit-for-bit comparison of the in-tree library with tools/ab/libcrx_NAME.so on the solver draws and closed loops (tools/cbf_ab.py)
 #   quick, quick:NAME  the four solver workloads of `lines` only (in-tree library / tools/ab/libcrx_NAME.so)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
@@ -44,6 +45,11 @@ game:*)   # the learning-MPC workloads on tools/ab/libcrx_NAME.so ("game:" alone
   ( timeout 300 python bench.py --workload lmpc --no-cpu-baseline --steps 30 --warmup 3 2> /dev/null | line "lmpc"
     timeout 300 python bench.py --workload game --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "game"
     timeout 300 python bench.py --workload overtake --no-cpu-baseline --steps 60 --warmup 5 2> /dev/null | line "overtake" ) | tee $O/game_${n:-intree}.txt; unset CRX_LIB ;;
+bits:*)  # bit-for-bit A/B of the in-tree library against tools/ab/libcrx_NAME.so (tools/cbf_ab.py: solver draws + closed loops)
+  n=${step#bits:}
+  python tools/cbf_ab.py intree > /dev/null 2>&1; CRX_LIB=$R/tools/ab/libcrx_$n.so python tools/cbf_ab.py $n > /dev/null 2>&1
+  python tools/lmpc_ab.py intree > /dev/null 2>&1; CRX_LIB=$R/tools/ab/libcrx_$n.so python tools/lmpc_ab.py $n > /dev/null 2>&1
+  ( python tools/cbf_ab.py --compare intree $n; python tools/lmpc_ab.py --compare intree $n ) | tee $O/bits_$n.txt ;;
 quick) quick | tee $O/quick.txt ;;
 quick:*)
   n=${step#quick:}; export CRX_LIB=$R/tools/ab/libcrx_$n.so; echo "== $n"; quick | tee $O/quick_$n.txt; unset CRX_LIB ;;
@@ -102,10 +108,8 @@ issue)
   pmc cfg3_1 cfg3 16384 3 "" $A
   pmc cfg3_3 cfg3 16384 3 "" $B )
   ls $O | grep pmc_ ;;   # summarise locally: python3 profiles/summarize_issue.py $TAG it4,it2,it3 > profiles/rNN_pmc_issue.txt
-trace)
-  make -C car-racing_amd/csrc -s clean all TRACE=1 2>&1 | grep -i error
-  ( for w in cfg2 cfg3 cfg4; do python tools/gpu_solve_trace.py $w; done; python tools/gpu_lmpc_trace.py ) 2>&1 | grep -v amdgpu.ids > $O/phase_cycles.txt
-  make -C car-racing_amd/csrc -s clean all 2>&1 | grep -i error
+trace)   # needs tools/ab/libcrx_trace.so: tools/build_variant.sh trace "-DCRX_PHASE_CLOCKS" crx_kernels.hip crx_kernels_obs.hip crx_lmpc.hip (build container)
+  ( export CRX_LIB=$R/tools/ab/libcrx_trace.so; for w in cfg2 cfg3 cfg4; do python tools/gpu_solve_trace.py $w; done; python tools/gpu_lmpc_trace.py ) 2>&1 | grep -v "amdgpu.ids\|Warning\|print(\|ret = " > $O/phase_cycles.txt
   cat $O/phase_cycles.txt ;;
 budget)
   bash tools/budget_experiment.sh ${BUDGET_B:-4096} ${BUDGET_STEPS:-400} > /dev/null; cp gpurun_out/budget_experiment.txt $O/; grep "^==\|contact\|left the track\|laps completed\|lap :" $O/budget_experiment.txt ;;

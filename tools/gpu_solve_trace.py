@@ -1,4 +1,5 @@
-"""(phase clocks need a library built with `make -C car-racing_amd/csrc clean all TRACE=1`; the default build compiles them out)
+"""(phase clocks need a library built with -DCRX_PHASE_CLOCKS -- `make TRACE=1`, or tools/build_variant.sh trace "-DCRX_PHASE_CLOCKS" crx_kernels.hip
+crx_kernels_obs.hip crx_lmpc.hip + CRX_LIB=tools/ab/libcrx_trace.so, which is what `tools/gpu_pass.sh TAG trace` uses; the default build compiles them out)
 Diagnostics: per-phase shader cycles of one crx_solve_kernel problem (hidden crx_trace_* entry points).
 usage: gpu_solve_trace.py [cfg2|cfg3|cfg4]"""
 import os, sys, ctypes as C
@@ -12,7 +13,9 @@ gpu = crx.init(); L = crx.lib()
 A, B = synth.load_AB()
 if wl == "cfg3":
     p = synth.cfg3_planner(8, N=12); d = abi.planner_desc(12, A, B)
-    call = lambda: gpu.planner_solve(d, p["x0"][:1], p["bez_s"][:1], p["bez_ey"][:1], p["ey_lb"][:1], p["ey_ub"][:1])
+    rr = gpu.planner_solve(d, p["x0"], p["bez_s"], p["bez_ey"], p["ey_lb"], p["ey_ub"])
+    i0 = int(np.argmax(np.asarray(rr["status"]).reshape(len(p["x0"]), -1)[:, 0] == 0))   # a QP that is solved (41 % are screened out before the iteration)
+    call = lambda: gpu.planner_solve(d, p["x0"][i0:i0 + 1], p["bez_s"][i0:i0 + 1], p["bez_ey"][i0:i0 + 1], p["ey_lb"][i0:i0 + 1], p["ey_ub"][i0:i0 + 1])
 elif wl == "cfg4":
     p = synth.cfg4_tracking_cbf(8, N=20); d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
     call = lambda: gpu.cbf_solve(d, *[p[k][:1] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")])
