@@ -48,6 +48,12 @@
 #ifndef CRX_SWEEP_UNROLL
 #define CRX_SWEEP_UNROLL 1   // 1: the forward and adjoint sweeps of the fixed-horizon instantiations are unrolled completely; 0: two stages per trip
 #endif
+#ifndef CRX_SWEEP_MASK
+#define CRX_SWEEP_MASK 1   // 1: the adjoint / forward sweeps run as one predicated region over lanes < NZ; 0: every lane runs them, sink stores (A/B builds)
+#endif
+#ifndef CRX_STAGE_FENCE
+#define CRX_STAGE_FENCE 1
+#endif
 #ifndef CRX_RIC_UNROLL
 #define CRX_RIC_UNROLL 0   // stages of the Riccati backward sweep per trip of its loop in the fixed-horizon instantiations; 0 = all of them
 #endif
@@ -121,6 +127,13 @@ __device__ __forceinline__ double interp_lin(const double* xs, const double* ys,
 #define ROW_IS_CBF(j, n_) (NOBS > 0 && (j) < (n_) * NR && (j) % NR >= 8 + NOBS)
 // nothing moves across: placed after the loads of a phase so that they are issued back to back
 #define LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
+// end of a stage of an UNROLLED sweep [r4]: without it the scheduler lifts the loads of all later stages to the top of the sweep and the
+// registers they occupy are paid for in scratch (a wave writes its spills once: 100 B per lane were x8 the algorithmic bytes written of a cfg2 launch)
+#if CRX_STAGE_FENCE
+#define STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAGE_FENCE() ((void)0)
+#endif
 
 // row table entries (unsigned 16-bit): index into Z / dZ in bits 0..12 (<= 25 * 14 coordinates), flags above
 #define RIV_SIMPLE (1 << 13) /* table-driven row that is present: c = +-(z[iv] - bound) */
@@ -524,13 +537,21 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     // The costate recursion lives in registers: lane i < NX carries lam[i], the NX values a stage needs are broadcast
     // with v_readlane (scalar operands of the FMAs) -- no LDS round trip on the dependent chain (it was one per
     // stage, ~350 cycles of 12); ga[k] does not depend on the chain, so its loads run ahead.
+    // [r4] The sweep needs lanes 0 .. NZ-1 only: it runs as ONE predicated region (EXEC = those lanes; the DPP broadcasts and
+    // v_readlane read lanes < NX, all inside), so that loads and stores address `base + lane` with the stage offset as an immediate --
+    // sink-address selects, one per stage, were hoisted out of the interior-point loop and paid for in registers (scratch) once the
+    // sweep was unrolled.
+    double tot = 0.0;
+    if (!CRX_SWEEP_MASK || lane < L::NZ) {
+    constexpr bool MK = CRX_SWEEP_MASK;
+    const bool in = MK || lane < L::NZ;
+    const int la = in ? lane : 0;
     double mcol[L::NX];   // column `lane` of the (stage-invariant) model matrix, kept in registers across the sweep
 #pragma unroll
-    for (int i = 0; i < L::NX; i++) mcol[i] = LD(L::M + i * L::NZ + (lane < L::NZ ? lane : 0));
-    const int la = lane < L::NZ ? lane : 0;
-    double tot = LD(L::ga + N * L::NZ + la);        // lam_N = the terminal gradient (lanes < NX)
+    for (int i = 0; i < L::NX; i++) mcol[i] = LD(L::M + i * L::NZ + la);
+    tot = LD(L::ga + N * L::NZ + la);               // lam_N = the terminal gradient (lanes < NX)
     double gk = LD(L::ga + (N - 1) * L::NZ + la);
-    LD(SINK(lane < L::NZ, L::ga + N * L::NZ + lane)) = 0.0;
+    LD(SINK(in, L::ga + N * L::NZ + lane)) = 0.0;
     auto stage = [&](int k) {
         const double gn = LD(L::ga + (k >= 1 ? k - 1 : 0) * L::NZ + la);   // next stage's gradient, in flight during this one
         double t = gk;
@@ -541,16 +562,18 @@ __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
             for (int i = 0; i < L::NX; i++) t += mcol[i] * lane_f64(tot, i);
         }
         tot = t;
-        emax = fmax(emax, sel(lane >= L::NX && lane < L::NZ, fabs(tot), 0.0));
+        emax = fmax(emax, sel(lane >= L::NX && in, fabs(tot), 0.0));
         const bool keep = lane >= L::NX || (k == 0 && lane >= 6);
-        LD(SINK(lane < L::NZ, L::ga + k * L::NZ + lane)) = sel(keep, tot, 0.0);
+        LD(SINK(in, L::ga + k * L::NZ + lane)) = sel(keep, tot, 0.0);
         gk = gn;
+        STAGE_FENCE();
     };
     if constexpr (UNR > 1) {   // fixed horizon: straight-line code, stage addresses are immediates [r4]
 #pragma unroll UNR
         for (int k = N - 1; k >= 0; k--) stage(k);
     } else {
         for (int k = N - 1; k >= 0; k--) stage(k);
+    }
     }
     SYNC();
     if (NOBS && lane >= 6 && lane < 6 + c.nobs) emax = fmax(emax, fabs(tot));
@@ -1024,10 +1047,13 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
     const int N = c.N, lane = c.lane;
+    if (!CRX_SWEEP_MASK || lane < NZ) {   // one predicated region, lanes 0 .. NZ-1: see dual_infeasibility [r4]
+    constexpr bool MK = CRX_SWEEP_MASK;
+    const bool in = MK || lane < NZ;
     double mrow[NZ];      // row `lane` of the model matrix, in registers across the sweep
 #pragma unroll
     for (int j = 0; j < NZ; j++) mrow[j] = LD(L::M + (lane < NX ? lane : 0) * NZ + j);
-    const bool isu = lane >= NX && lane < NZ;
+    const bool isu = lane >= NX && in;
     const int ua = isu ? lane - NX : 0;
     double zx = LD(L::dZ + (lane < NX ? lane : 0));   // dx_0: zero but for the free sigma_0 (riccati_backward)
     double kr[NX], kfa;
@@ -1056,11 +1082,12 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
 #pragma unroll
             for (int a = 0; a < NU; a++) xn += mrow[NX + a] * lane_f64(du, NX + a);
         }
-        LD(SINK(lane < NZ, L::dZ + k * NZ + lane)) = sel(isu, du, zx);
+        LD(SINK(in, L::dZ + k * NZ + lane)) = sel(isu, du, zx);
         zx = xn;
 #pragma unroll
         for (int j = 0; j < NX; j++) kr[j] = krn[j];
         kfa = kfn;
+        STAGE_FENCE();
     };
     if constexpr (UNR > 1) {   // fixed horizon [r4]: straight-line code -- the hand-over kr <- krn is a renaming instead of NX + 1 register copies
 #pragma unroll UNR             // per stage, the stage addresses are immediates
@@ -1068,7 +1095,8 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     } else {
         for (int k = 0; k < N; k++) stage(k);
     }
-    LD(SINK(lane < NZ, L::dZ + N * NZ + lane)) = sel(lane < NX, zx, 0.0);
+    LD(SINK(in, L::dZ + N * NZ + lane)) = sel(lane < NX, zx, 0.0);
+    }
     SYNC();
 }
 
