@@ -778,6 +778,12 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     for (int q = 0; q < HCNT; q++)
 #pragma unroll
         for (int i = 0; i < NX; i++) mH[q][i] = LD(L::M + i * NZ + hr[q]);
+    double m5a[HCNT], m5r[HCNT];   // planner: row 5 of the model matrix at the entry's column / row (coupling cost), stage-invariant too [r4]
+#pragma unroll
+    for (int q = 0; q < HCNT; q++) { m5a[q] = NOBS ? 0.0 : LD(L::M + 5 * NZ + ha[q]); m5r[q] = NOBS ? 0.0 : LD(L::M + 5 * NZ + hr[q]); }
+    double mz[NX];   // column lz of the model matrix (the gradient column hv = M'p + hg): stage-invariant like mT / mH [r4]
+#pragma unroll
+    for (int i = 0; i < NX; i++) mz[i] = LD(L::M + i * NZ + lz);
     // sigma columns of T (NOBS > 0): sigma_k -> 0, sigma_{k+1} -> P[:, 6+o]
     constexpr int T2CNT = NOBS ? (NX * 2 * NOBS + WAVE - 1) / WAVE : 1;   // one pass up to three obstacles, three for six [r4]
     int t2ld[T2CNT], t2st[T2CNT];
@@ -857,7 +863,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             // every operand of the phase is loaded first (LOADS_DONE pins that order: left alone, the scheduler trickles
             // the loads out between the FMAs and the two chains pay the LDS latency one after the other)
             const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
-            double tc[HCNT][NX], hd[HCNT], jr[HCNT][L::NO], ja[HCNT][L::NO], rs[L::NO], m5a[HCNT], m5r[HCNT];
+            double tc[HCNT][NX], hd[HCNT], jr[HCNT][L::NO], ja[HCNT][L::NO], rs[L::NO];
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
 #pragma unroll
@@ -869,9 +875,6 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                         jr[q][o] = LD(L::Jc + (k * L::NO + o) * NZ + hr[q]);
                         ja[q][o] = LD(L::Jc + (k * L::NO + o) * NZ + ha[q]);
                     }
-                } else {
-                    m5a[q] = LD(L::M + 5 * NZ + ha[q]);
-                    m5r[q] = LD(L::M + 5 * NZ + hr[q]);
                 }
             }
             if (NOBS) {
@@ -885,9 +888,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                     }
                 }
             }
-            double hvs = LD(L::hg + k * NZ + lz), mz[NX], pvv[NX];
+            double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
 #pragma unroll
-            for (int i = 0; i < NX; i++) { mz[i] = LD(L::M + i * NZ + lz); pvv[i] = LD(L::pv + i); }
+            for (int i = 0; i < NX; i++) pvv[i] = LD(L::pv + i);
             LOADS_DONE();
             double hs[HCNT];
 #pragma unroll
@@ -967,7 +970,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                     for (int qq = 0; qq < a; qq++) { yi[q][a] -= Lf[a][qq] * yi[q][qq]; yj[q][a] -= Lf[a][qq] * yj[q][qq]; }
                 }
 #pragma unroll
-                for (int a = 0; a < NU; a++) { yj[q][a] *= rD[a]; t[q] -= yi[q][a] * yj[q][a]; }
+                // (yj carries MINUS D^{-1} y from here on: the feedback -L^{-T} D^{-1} y is then stored as it comes out of the back substitution --
+                // negation commutes with every rounding below, the bits are those of the negate-at-the-store form [r4])
+                for (int a = 0; a < NU; a++) { yj[q][a] *= -rD[a]; t[q] = fma(yi[q][a], yj[q][a], t[q]); }
                 t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
                 LD(pst1[q]) = t[q];
                 LD(pst2[q]) = t[q];
@@ -977,7 +982,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                     for (int qq = a + 1; qq < NU; qq++) yj[q][a] -= Lf[qq][a] * yj[q][qq];
                 }
 #pragma unroll
-                for (int a = 0; a < NU; a++) LD(kst[q] + a * kstr[q]) = -yj[q][a];
+                for (int a = 0; a < NU; a++) LD(kst[q] + a * kstr[q]) = yj[q][a];
                 kst[q] -= kstep[q];
             }
         }
