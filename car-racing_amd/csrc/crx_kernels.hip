@@ -185,8 +185,10 @@ struct Lay {
     static constexpr int ga = hg;                    // Lagrangian gradient / reduced form: SAME storage -- assemble_newton turns ga[e]
                                                      // into hg[e] in place, and nothing reads ga again before first_order rebuilds it
     static constexpr int Jc = hg + NV;               // [NMAX][NO][NZ] CBF Jacobians (scaled)
-    static constexpr int kS = Jc + NMAX * NOBS * NZ; // [NMAX] "next" CBF curvature on s_{k+1}
-    static constexpr int kE = kS + (NOBS ? NMAX : 0);   //        ... on ey_{k+1}
+    // [NMAX][2] "next" CBF curvature on (s_{k+1}, ey_{k+1}), interleaved and 16-byte aligned: the backward sweep reads the pair of a stage
+    // with ONE ds_read_b128 [r4] (LDS instructions cost a lone wave more than their issue slot: the data path moves 128 B per clock)
+    static constexpr int kS = (Jc + NMAX * NOBS * NZ + 1) & ~1;
+    static constexpr int kE = kS + 1;
     // Riccati work.  The backward sweep runs while two arrays are dead: the row steps rdt (rewritten by the row-step pass
     // that follows the forward sweep) and the Newton step dZ beyond its first stage (rewritten by the forward sweep; the
     // first stage receives sigma_0 at the end of the backward sweep, after the last H is consumed).  P, pv, T live in the
@@ -195,7 +197,7 @@ struct Lay {
     // waves per SIMD would park 92 of them).
     static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
     static constexpr bool PT_ALIAS = NX * NX + NX + NX * NZ <= MR, H_ALIAS = NZ * HS <= NV;
-    static constexpr int WORK = kE + (NOBS ? NMAX : 0);
+    static constexpr int WORK = kS + (NOBS ? 2 * NMAX : 0);
     static constexpr int P = PT_ALIAS ? rdt : WORK;
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
@@ -708,8 +710,8 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
             ks -= nd * LD(L::G + (k * L::NO + o) * 4 + 0);
             ke -= nd * LD(L::G + (k * L::NO + o) * 4 + 1);
         }
-        LD(L::kS + k) = ks;
-        LD(L::kE + k) = ke;
+        LD(L::kS + 2 * k) = ks;
+        LD(L::kE + 2 * k) = ke;
     }
     SYNC();
 }
@@ -723,9 +725,14 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
     const int N = c.N, lane = c.lane;
     const long long qs = CLK();
+    // [r4] The gradient p of the value function lives in REGISTERS, entry i in lane i: the update phase computes p_new there (its lane
+    // map puts the gradient column first), and the H phase forms hv = M'p + hg with broadcast-FMAs (crx_wave.h row_dot) instead of NX
+    // LDS reads per stage.  (pv in LDS is still written: the sigma_0 solve after the sweep reads it.)
+    constexpr bool PREG = ROWDPP<L> && L::UCNT == 1;
+    double preg = 0.0;
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
     {
-        const double kSn = NOBS ? LD(L::kS + N - 1) : 0.0, kEn = (NOBS ? LD(L::kE + N - 1) : 0.0) + 2.0 * LD(L::wc + N - 1);
+        const double kSn = NOBS ? LD(L::kS + 2 * (N - 1)) : 0.0, kEn = (NOBS ? LD(L::kE + 2 * (N - 1)) : 0.0) + 2.0 * LD(L::wc + N - 1);
 #pragma unroll
         for (int q_ = 0; q_ < (NX * NX + WAVE - 1) / WAVE; q_++) {
             const int e0 = lane + q_ * WAVE;
@@ -736,6 +743,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         }
         const double hgN = LD(L::hg + N * NZ + (lane < NX ? lane : 0));
         LD(SINK(lane < NX, L::pv + lane)) = hgN;
+        preg = hgN;
     }
     SYNC();
     bool ok = true;
@@ -889,8 +897,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 }
             }
             double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
+            if constexpr (!PREG) {
 #pragma unroll
-            for (int i = 0; i < NX; i++) pvv[i] = LD(L::pv + i);
+                for (int i = 0; i < NX; i++) pvv[i] = LD(L::pv + i);
+            }
             LOADS_DONE();
             double hs[HCNT];
 #pragma unroll
@@ -910,8 +920,12 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 }
                 hs[q] = t;
             }
+            if constexpr (PREG) {
+                hvs = row_dot<NX, 0>(preg, mz, hvs);
+            } else {
 #pragma unroll
-            for (int i = 0; i < NX; i++) hvs += mz[i] * pvv[i];
+                for (int i = 0; i < NX; i++) hvs += mz[i] * pvv[i];
+            }
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
                 LD(hst[q]) = hs[q];
@@ -939,9 +953,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 t[q] = LD(s0A[q]);
             }
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
-            const double kSv = NOBS ? LD(L::kS + km) : 0.0, kEv = NOBS ? LD(L::kE + km) : 0.0, wcv = LD(L::wc + km);
+            // (the coupling weight wc is a planner quantity: identically zero with obstacles, and not loaded there)
+            const double kSv = NOBS ? LD(L::kS + 2 * km) : 0.0, kEv = NOBS ? LD(L::kE + 2 * km) : 0.0, wcv = NOBS ? 0.0 : LD(L::wc + km);
             LOADS_DONE();
-            const double exS = sel(k >= 1, kSv, 0.0), exE = sel(k >= 1, kEv + 2.0 * wcv, 0.0);
+            const double exS = sel(k >= 1, kSv, 0.0), exE = sel(k >= 1, NOBS ? kEv : kEv + 2.0 * wcv, 0.0);
             // with C = L D kept beside L (C[i][q] = L[i][q] D[q]) every update on the pivot chain is ONE fma:
             // d_j = H_jj - sum_q L[j][q] C[j][q],  C[i][j] = H_ij - sum_q L[i][q] C[j][q],  L[i][j] = C[i][j] / d_j
             double Cf[NU][NU];
@@ -976,6 +991,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
                 LD(pst1[q]) = t[q];
                 LD(pst2[q]) = t[q];
+                if constexpr (PREG) preg = t[0];   // lanes 0 .. NX-1: p_new (gradient column of the lane map)
 #pragma unroll
                 for (int a = NU - 2; a >= 0; a--) {
 #pragma unroll
@@ -1436,7 +1452,14 @@ crx_solve_kernel(const crx_kparams kp) {
         constexpr int NP = NX * (NX + 1) / 2 + NX;
         for (int l = lane; l < WAVE * L::UCNT; l += WAVE) {
             int i = 0, j = l - NP;
-            if (l < NP) {               // pairs i <= j, j in [0, NX]
+            if (ROWDPP<L> && L::UCNT == 1) {   // gradient column (i, NX) in lanes i < NX (riccati_backward keeps p there), then the pairs i <= j < NX
+                if (l < NX) { i = l; j = NX; }
+                else if (l < NP) {
+                    int rem = l - NX;
+                    while (rem >= NX - i) { rem -= NX - i; i++; }
+                    j = i + rem;
+                }
+            } else if (l < NP) {               // pairs i <= j, j in [0, NX]
                 int rem = l;
                 while (rem >= NX + 1 - i) { rem -= NX + 1 - i; i++; }
                 j = i + rem;
@@ -1805,7 +1828,7 @@ crx_solve_kernel(const crx_kparams kp) {
                 // terms): what remains -- cost, J' Sigma J, the "current" curvature -- is positive definite by construction; IPOPT's
                 // delta_w schedule only if rounding makes even that fail.  (kS / kE are rebuilt by the next assemble_newton.)
                 convex = 1;
-                for (int k = lane; k < N; k += WAVE) { LD(L::kS + k) = 0.0; LD(L::kE + k) = 0.0; }
+                for (int k = lane; k < N; k += WAVE) { LD(L::kS + 2 * k) = 0.0; LD(L::kE + 2 * k) = 0.0; }
                 SYNC();
                 continue;
             }
