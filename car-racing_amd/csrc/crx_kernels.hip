@@ -51,6 +51,9 @@
 #ifndef CRX_SWEEP_MASK
 #define CRX_SWEEP_MASK 1   // 1: the adjoint / forward sweeps run as one predicated region over lanes < NZ; 0: every lane runs them, sink stores (A/B builds)
 #endif
+#ifndef CRX_FWD_ONE_DOT
+#define CRX_FWD_ONE_DOT 1   // forward sweep: one lane-specific dot product per lane and stage (0: state and input chains in every lane; A/B builds)
+#endif
 #ifndef CRX_STAGE_FENCE
 #define CRX_STAGE_FENCE 1
 #endif
@@ -1068,6 +1071,57 @@ __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
     const int N = c.N, lane = c.lane;
+    if constexpr (ROWDPP<L> && CRX_SWEEP_MASK && CRX_FWD_ONE_DOT && NOBS > 0) {   // (planner instantiations: measured 1.5 % slower with it, cfg3)
+        // [r4] ONE dot product per lane and stage.  A state lane i < NX needs x_{k+1}[i] = M[i][0..NX) x_k + M[i][NX..) du_k, an input lane
+        // NX + a needs du_k[a] = kff_k[a] + K_k[a] x_k: both are `c0 + coef . x_k` with lane-specific (c0, coef) -- the coefficients come
+        // from a lane-specific ADDRESS (row i of M, every stage; row a of K_k), not from a select, so the sweep no longer runs both
+        // chains in every lane (17 FMAs -> 10).  The input term M[i][NX..) du_k follows with zero coefficients in the input lanes, whose
+        // value is thereby left as it is.  Same terms in the same order as the two-chain form: identical bits (signs of zero aside).
+        if (lane < NZ) {
+            const bool isx = lane < NX;
+            const int ua = isx ? 0 : lane - NX;
+            int cad = isx ? L::M + lane * NZ : L::Kk + ua * NX;            // + k NU NX in the input lanes
+            const int cstep = isx ? 0 : NU * NX;
+            const int kfad = L::kf + ua;                                     // state lanes read kff_k[0] and multiply it with zero
+            const int sad = L::dZ + lane + (isx ? NZ : 0);                   // state lanes store x_{k+1}, input lanes du_k
+            const double one = isx ? 0.0 : 1.0;
+            double mu_[NU];
+#pragma unroll
+            for (int a = 0; a < NU; a++) mu_[a] = sel(isx, LD(L::M + (isx ? lane : 0) * NZ + NX + a), 0.0);
+            double y = LD(L::dZ + (isx ? lane : 0));   // dx_0: zero but for the free sigma_0 (riccati_backward)
+            double coef[NX], kfv;                      // this stage's coefficients: loaded while the previous stage computes
+#pragma unroll
+            for (int j = 0; j < NX; j++) coef[j] = LD(cad + j);
+            kfv = LD(kfad);
+            auto stage = [&](int k) {
+                double cnx[NX], kfn;
+                const int kn = k + 1 < N ? k + 1 : k;
+                cad += (k + 1 < N) ? cstep : 0;
+#pragma unroll
+                for (int j = 0; j < NX; j++) cnx[j] = LD(cad + j);
+                kfn = LD(kfad + kn * NU);
+                double acc = fma(kfv, one, 0.0);
+                acc = row_dot<NX, 0>(y, coef, acc);
+                const double du = acc;                                       // lanes NX ..: du_k
+                acc = row_dot<NU, NX>(du, mu_, acc);
+                y = acc;
+                LD(sad + k * NZ) = y;
+#pragma unroll
+                for (int j = 0; j < NX; j++) coef[j] = cnx[j];
+                kfv = kfn;
+                STAGE_FENCE();
+            };
+            if constexpr (UNR > 1) {
+#pragma unroll UNR
+                for (int k = 0; k < N; k++) stage(k);
+            } else {
+                for (int k = 0; k < N; k++) stage(k);
+            }
+            LD(SINK(!isx, L::dZ + N * NZ + lane)) = 0.0;                     // no inputs at stage N
+        }
+        SYNC();
+        return;
+    }
     if (!CRX_SWEEP_MASK || lane < NZ) {   // one predicated region, lanes 0 .. NZ-1: see dual_infeasibility [r4]
     constexpr bool MK = CRX_SWEEP_MASK;
     const bool in = MK || lane < NZ;

@@ -57,20 +57,22 @@ __device__ __forceinline__ double lane_f64(double v, int l) {
 // < 16 (the sweeps live in lanes < NZ <= 16; the other rows compute on their own lanes and are discarded).  Same product, same
 // accumulation order, one rounding: identical bits.  The hazard recogniser does not look into inline assembly, and a DPP read of a VGPR
 // needs two wait states after a VALU instruction that wrote it: the whole dot product is ONE asm statement that opens with s_nop 1, so
-// that neither the producer of x nor a copy the register allocator may insert can sit closer than that.  EXEC is all ones where this is used.
+// that neither the producer of x nor a copy the register allocator may insert can sit closer than that; and acc is an EARLY-CLOBBER operand
+// (+&v): were it given the register of x (same value at entry, as in `acc = row_dot(acc_old, m, acc_old)`), the second term would read through
+// DPP what the first has just written -- the same hazard inside the statement (seen: 87 % of a 4096-problem batch lost).  EXEC covers the lanes read.
 #define CRX_DPPT(i) "v_fmac_f64_dpp %0, %1, %" #i " row_newbcast:%"
 #define CRX_DPPE " row_mask:0xf bank_mask:0xf\n\t"
 template <int CNT, int FIRST>
 __device__ __forceinline__ double row_dot(double x, const double* m, double acc) {
     static_assert(CNT >= 2 && CNT <= 9 && FIRST >= 0 && FIRST + CNT <= 16, "row_newbcast reaches the 16 lanes of a row");
-    if constexpr (CNT == 2) asm("s_nop 1\n\t" CRX_DPPT(2) "4" CRX_DPPE CRX_DPPT(3) "5" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "n"(FIRST + 0), "n"(FIRST + 1));
-    else if constexpr (CNT == 3) asm("s_nop 1\n\t" CRX_DPPT(2) "5" CRX_DPPE CRX_DPPT(3) "6" CRX_DPPE CRX_DPPT(4) "7" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2));
-    else if constexpr (CNT == 4) asm("s_nop 1\n\t" CRX_DPPT(2) "6" CRX_DPPE CRX_DPPT(3) "7" CRX_DPPE CRX_DPPT(4) "8" CRX_DPPE CRX_DPPT(5) "9" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3));
-    else if constexpr (CNT == 5) asm("s_nop 1\n\t" CRX_DPPT(2) "7" CRX_DPPE CRX_DPPT(3) "8" CRX_DPPE CRX_DPPT(4) "9" CRX_DPPE CRX_DPPT(5) "10" CRX_DPPE CRX_DPPT(6) "11" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4));
-    else if constexpr (CNT == 6) asm("s_nop 1\n\t" CRX_DPPT(2) "8" CRX_DPPE CRX_DPPT(3) "9" CRX_DPPE CRX_DPPT(4) "10" CRX_DPPE CRX_DPPT(5) "11" CRX_DPPE CRX_DPPT(6) "12" CRX_DPPE CRX_DPPT(7) "13" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5));
-    else if constexpr (CNT == 7) asm("s_nop 1\n\t" CRX_DPPT(2) "9" CRX_DPPE CRX_DPPT(3) "10" CRX_DPPE CRX_DPPT(4) "11" CRX_DPPE CRX_DPPT(5) "12" CRX_DPPE CRX_DPPT(6) "13" CRX_DPPE CRX_DPPT(7) "14" CRX_DPPE CRX_DPPT(8) "15" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6));
-    else if constexpr (CNT == 8) asm("s_nop 1\n\t" CRX_DPPT(2) "10" CRX_DPPE CRX_DPPT(3) "11" CRX_DPPE CRX_DPPT(4) "12" CRX_DPPE CRX_DPPT(5) "13" CRX_DPPE CRX_DPPT(6) "14" CRX_DPPE CRX_DPPT(7) "15" CRX_DPPE CRX_DPPT(8) "16" CRX_DPPE CRX_DPPT(9) "17" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6), "n"(FIRST + 7));
-    else if constexpr (CNT == 9) asm("s_nop 1\n\t" CRX_DPPT(2) "11" CRX_DPPE CRX_DPPT(3) "12" CRX_DPPE CRX_DPPT(4) "13" CRX_DPPE CRX_DPPT(5) "14" CRX_DPPE CRX_DPPT(6) "15" CRX_DPPE CRX_DPPT(7) "16" CRX_DPPE CRX_DPPT(8) "17" CRX_DPPE CRX_DPPT(9) "18" CRX_DPPE CRX_DPPT(10) "19" CRX_DPPE : "+v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6), "n"(FIRST + 7), "n"(FIRST + 8));
+    if constexpr (CNT == 2) asm("s_nop 1\n\t" CRX_DPPT(2) "4" CRX_DPPE CRX_DPPT(3) "5" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "n"(FIRST + 0), "n"(FIRST + 1));
+    else if constexpr (CNT == 3) asm("s_nop 1\n\t" CRX_DPPT(2) "5" CRX_DPPE CRX_DPPT(3) "6" CRX_DPPE CRX_DPPT(4) "7" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2));
+    else if constexpr (CNT == 4) asm("s_nop 1\n\t" CRX_DPPT(2) "6" CRX_DPPE CRX_DPPT(3) "7" CRX_DPPE CRX_DPPT(4) "8" CRX_DPPE CRX_DPPT(5) "9" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3));
+    else if constexpr (CNT == 5) asm("s_nop 1\n\t" CRX_DPPT(2) "7" CRX_DPPE CRX_DPPT(3) "8" CRX_DPPE CRX_DPPT(4) "9" CRX_DPPE CRX_DPPT(5) "10" CRX_DPPE CRX_DPPT(6) "11" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4));
+    else if constexpr (CNT == 6) asm("s_nop 1\n\t" CRX_DPPT(2) "8" CRX_DPPE CRX_DPPT(3) "9" CRX_DPPE CRX_DPPT(4) "10" CRX_DPPE CRX_DPPT(5) "11" CRX_DPPE CRX_DPPT(6) "12" CRX_DPPE CRX_DPPT(7) "13" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5));
+    else if constexpr (CNT == 7) asm("s_nop 1\n\t" CRX_DPPT(2) "9" CRX_DPPE CRX_DPPT(3) "10" CRX_DPPE CRX_DPPT(4) "11" CRX_DPPE CRX_DPPT(5) "12" CRX_DPPE CRX_DPPT(6) "13" CRX_DPPE CRX_DPPT(7) "14" CRX_DPPE CRX_DPPT(8) "15" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6));
+    else if constexpr (CNT == 8) asm("s_nop 1\n\t" CRX_DPPT(2) "10" CRX_DPPE CRX_DPPT(3) "11" CRX_DPPE CRX_DPPT(4) "12" CRX_DPPE CRX_DPPT(5) "13" CRX_DPPE CRX_DPPT(6) "14" CRX_DPPE CRX_DPPT(7) "15" CRX_DPPE CRX_DPPT(8) "16" CRX_DPPE CRX_DPPT(9) "17" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6), "n"(FIRST + 7));
+    else if constexpr (CNT == 9) asm("s_nop 1\n\t" CRX_DPPT(2) "11" CRX_DPPE CRX_DPPT(3) "12" CRX_DPPE CRX_DPPT(4) "13" CRX_DPPE CRX_DPPT(5) "14" CRX_DPPE CRX_DPPT(6) "15" CRX_DPPE CRX_DPPT(7) "16" CRX_DPPE CRX_DPPT(8) "17" CRX_DPPE CRX_DPPT(9) "18" CRX_DPPE CRX_DPPT(10) "19" CRX_DPPE : "+&v"(acc) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "n"(FIRST + 0), "n"(FIRST + 1), "n"(FIRST + 2), "n"(FIRST + 3), "n"(FIRST + 4), "n"(FIRST + 5), "n"(FIRST + 6), "n"(FIRST + 7), "n"(FIRST + 8));
     return acc;
 }
 
