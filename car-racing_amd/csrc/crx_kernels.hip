@@ -54,6 +54,9 @@
 #ifndef CRX_FWD_ONE_DOT
 #define CRX_FWD_ONE_DOT 1   // forward sweep: one lane-specific dot product per lane and stage (0: state and input chains in every lane; A/B builds)
 #endif
+#ifndef CRX_SWEEP_LOCAL_LANE
+#define CRX_SWEEP_LOCAL_LANE 1
+#endif
 #ifndef CRX_STAGE_FENCE
 #define CRX_STAGE_FENCE 1
 #endif
@@ -537,7 +540,11 @@ __device__ __forceinline__ void first_order(double* sm, const int* si, const Ctx
 template <int NOBS, int NMAX, int UNR = 1>
 __device__ __forceinline__ double dual_infeasibility(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
-    const int N = c.N, lane = c.lane;
+    const int N = c.N;
+    int lane = c.lane;
+#if CRX_SWEEP_LOCAL_LANE
+    if (NOBS > 0) asm volatile("" : "+v"(lane));   // see riccati_forward
+#endif
     double emax = 0.0;
     // The costate recursion lives in registers: lane i < NX carries lam[i], the NX values a stage needs are broadcast
     // with v_readlane (scalar operands of the FMAs) -- no LDS round trip on the dependent chain (it was one per
@@ -1070,7 +1077,13 @@ template <int NOBS, int NMAX, int UNR = 1>
 __device__ __forceinline__ void riccati_forward(double* sm, const Ctx& c) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
-    const int N = c.N, lane = c.lane;
+    const int N = c.N;
+    int lane = c.lane;
+#if CRX_SWEEP_LOCAL_LANE
+    // the handful of lane-derived addresses and masks of this sweep are formed HERE, every call: left to the optimiser they are hoisted out of
+    // the interior-point loop and, at the register limit of two waves per SIMD, parked in scratch (one reload each per iteration) [r4]
+    if (NOBS > 0) asm volatile("" : "+v"(lane));
+#endif
     if constexpr (ROWDPP<L> && CRX_SWEEP_MASK && CRX_FWD_ONE_DOT && NOBS > 0) {   // (planner instantiations: measured 1.5 % slower with it, cfg3)
         // [r4] ONE dot product per lane and stage.  A state lane i < NX needs x_{k+1}[i] = M[i][0..NX) x_k + M[i][NX..) du_k, an input lane
         // NX + a needs du_k[a] = kff_k[a] + K_k[a] x_k: both are `c0 + coef . x_k` with lane-specific (c0, coef) -- the coefficients come
