@@ -1744,7 +1744,8 @@ crx_solve_kernel(const crx_kparams kp) {
     // IPOPT's alpha < alpha_min test sends it to restoration from the same situation)
     constexpr int JAM_COUNT = 5, STALL_ITERS = 50;
     const double JAM_ALPHA = 1e-3;
-    int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0;
+    int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0, cvx_run = 0;
+    constexpr int CVX_PROBE = 4;
     int scaled = 0;
     // slacks and multipliers at the point Z holds -- the start, and again at the crash restart (every row array is rewritten:
     // crash_point parks its samples there); then the merit pieces of that point.  Two call sites, both outside the interior-point loop.
@@ -1887,10 +1888,21 @@ crx_solve_kernel(const crx_kparams kp) {
         double dw = 0.0;
         long long tsub[4] = {0, 0, 0, 0};
         bool ok;
-        for (int tries = 0, convex = (NOBS > 0 && crash) ? 0 : 1;; ) {
+        // ... and the convexification is sticky [r4]: after an iteration that needed it the next ones START convexified, every CVX_PROBE-th of
+        // such a run tries the exact matrix first again.  (The exact reduced Hessian of a crash state has the wrong inertia for a dozen
+        // iterations in a row, and the sweep notices at its far end: the longest solve of the headline batch spent 17 % of its clocks on
+        // attempts that were bound to fail.  Same rule in oracle/crx_oracle.c; problems off the crash path never get here.)
+        int used_convex = 0;
+        if (NOBS && crash && cvx_run > 0 && (cvx_run % CVX_PROBE) != 0) {
+            for (int k = lane; k < N; k += WAVE) { LD(L::kS + 2 * k) = 0.0; LD(L::kE + 2 * k) = 0.0; }
+            SYNC();
+            used_convex = 1;
+        }
+        for (int tries = 0, convex = (NOBS > 0 && crash && !used_convex) ? 0 : 1;; ) {
             ok = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v>(sm, si, c, dw, tsub);
             if (ok) break;
             if (NOBS && !convex) {
+                used_convex = 1;
                 // [r4] crash path (iii): first retry WITHOUT the reverse-convex part of the CBF curvature (-nu hess g_{k+1}, the kS / kE
                 // terms): what remains -- cost, J' Sigma J, the "current" curvature -- is positive definite by construction; IPOPT's
                 // delta_w schedule only if rounding makes even that fail.  (kS / kE are rebuilt by the next assemble_newton.)
@@ -1905,6 +1917,7 @@ crx_solve_kernel(const crx_kparams kp) {
         }
         if (!ok) break;
         if (dw != 0.0) dw_last = dw;
+        cvx_run = used_convex ? cvx_run + 1 : 0;
         long long tc5 = CLK();
         riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
         long long tc6 = CLK();

@@ -643,7 +643,8 @@ static void ipm_solve(work_t* w, result_t* res) {
      * loses 1 % of the three-car draw), after which it ends CRX_RESTORED like a restarted one -- feasible through its slacks, not
      * optimal -- instead of crawling to max_iter */
     if (crash_at_start) { n_restore = 1; it_limit = 1 + 3 * o->restore_iters; }
-    int crawl = 0;
+    int crawl = 0, cvx_run = 0;
+    enum { CVX_PROBE = 4 };
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     if (g_knob[6] >= 0.0 && o->restore_iters >= 0) {   /* experiment: slacks first -- restore before the first iteration when a
                                                           CBF row of a stage <= knob is violated at the start point */
@@ -739,9 +740,16 @@ static void ipm_solve(work_t* w, result_t* res) {
         static _Thread_local double Hs[MAXRED][MAXRED];
         for (int a = 0; a < n; a++) memcpy(Hs[a], w->H[a], sizeof(double) * (a + 1));
         double dw = 0.0;
-        int ok = chol(n, w->H);
+        /* ... and the convexification is STICKY: after an iteration that needed it the next ones start with the convexified matrix, every
+         * CVX_PROBE-th of such a run tries the exact one first again (the exact matrix of a crash state fails for a dozen iterations in a
+         * row, each time at the far end of the backward sweep: the headline's longest solve spent 17 % of its time on doomed attempts) */
+        const int cvxp = g_knob[11] < 0.0 ? 1 : (g_knob[11] > 0.0 ? (int)g_knob[11] : CVX_PROBE);   /* experiments: knob 11 */
+        const int start_convex = crash && cvx_run > 0 && (cvx_run % cvxp) != 0;
+        int ok = start_convex ? 0 : chol(n, w->H);
+        if (ok || !crash) cvx_run = 0;
         if (!ok && crash) {   /* crash path: first retry WITHOUT the reverse-convex part of the CBF curvature (-nu hess g_{i+1}): what
                                  remains is positive definite by construction; IPOPT's delta_w schedule only if that fails */
+            cvx_run++;
             for (int a = 0; a < n; a++) {
                 memcpy(w->H[a], Hs[a], sizeof(double) * (a + 1));
                 for (int b = 0; b <= a; b++) w->H[a][b] -= Hneg[a][b];
