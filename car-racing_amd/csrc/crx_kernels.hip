@@ -1826,6 +1826,15 @@ crx_solve_kernel(const crx_kparams kp) {
         if (crash_state && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; n_restore = 1; it_limit = 1 + 3 * o.restore_iters; }
     }
     init_point();
+    if (NOBS && crash) {
+        // [r4] the crash start's barrier parameter comes from its own complementarity (oracle/crx_oracle.c has the note): slacks of 1e2 .. 1e5 with
+        // multipliers of 1 are nowhere near the central path of mu = 0.1, and the iteration crawled for 25 steps before mu moved at all.
+        // mu_0 = 0.1 x mean_j(t_j nu_j) over the present rows, not below mu_init.  (Absent rows hold nu = 0.)
+        double sc = 0.0;
+        for (int j = lane; j < m; j += WAVE) sc += LD(L::rt + j) * LD(L::rnu + j);
+        sc = wave_sum(sc);
+        mu = fmin(fmax(0.1 * sc / fmax(mact, 1.0), o.mu_init), 1e6);
+    }
     for (;;) {
     ls_failed = 0;
     // Nothing is to be carried in registers from one pass to the next: without this barrier the loop-invariant operands

@@ -119,7 +119,8 @@ typedef struct crx_ipm_opts {
                               2: CRASH PATH (default).  (i) A problem whose slacks are PROVABLY positive at every admissible input
                                  (reach of (s, ey) under the boxed inputs) does not start at zero: the best of a 5 x 5 grid of constant
                                  input pairs by f(u) + w sum sigma(u), sigma(u) = the minimal slack cascade for that u, with that
-                                 cascade pushed strictly inside -- a feasible interior point.  (ii) A solve that started at zero and
+                                 cascade pushed strictly inside -- a feasible interior point; its barrier parameter starts at a tenth of
+                                 the point's mean complementarity (not below mu_init), not at mu_init.  (ii) A solve that started at zero and
                                  stalls on violated CBF rows (no acceptable step, jam, 50 iterations still infeasible) restarts ONCE
                                  from such a point instead of being abandoned.  (iii) On the crash path a reduced Hessian of the wrong
                                  inertia is first retried WITHOUT the reverse-convex part of the CBF curvature (positive definite by
