@@ -26,10 +26,13 @@ for trial in range(14):
     if trial == T:
         break
 one = [a[I:I + 1] for a in args]
+if os.environ.get("CRX_MAXIT"): d.opts.max_iter = int(os.environ["CRX_MAXIT"])
+if os.environ.get("CRX_POISON"): L.crx_debug_poison_lds(1)
 L.crx_trace_enable(0, 64)
 r = gpu.cbf_solve(d, *one)
 buf = np.zeros((64, 16)); L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), 64)
 L.crx_trace_enable(0, 0)
 print("trial %d problem %d N %d V %d n_obs %d: iters %d status %d kkt %.3e" % (T, I, N, V, int(one[5][0]), int(r["iters"][0]), int(r["status"][0]), float(r["kkt"][0])))
+print("  X", np.array2string(np.asarray(r["X"])[0].ravel()[:24], precision=17), "\n  U", np.array2string(np.asarray(r["U"])[0].ravel()[:8], precision=17), "\n  sumX %.17e sumU %.17e" % (np.asarray(r["X"]).sum(), np.asarray(r["U"]).sum()))
 for i in range(min(int(r["iters"][0]) + 1, 64)):
     print("  %2d e_d %.17e e_p %.17e e_c %.6e mu %.3e al %.17e a_d %.6e dw %.1e acc %d" % ((i,) + tuple(buf[i, :7]) + (int(buf[i, 7]),)))
