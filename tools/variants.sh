@@ -1,14 +1,25 @@
 #!/bin/bash
 # The A/B builds of the solver kernels whose code generation differs most (a semantically neutral barrier once produced a
-# faulting kernel; every variant must pass the parity suite): run in the build container, then on the GPU box
-#     gpurun -- 'bash tools/gpu_pass.sh TAG suite:slim0 suite:nfix0 suite:deg0 suite:opaque0 suite:opaqueall suite:opaqueall_slim0'
+# faulting kernel; DESIGN.md section 8: a build of an intermediate source state computed one wrong number): every variant must pass the
+# parity suite.  Run in the build container, then on the GPU box
+#     gpurun -- 'bash tools/gpu_pass.sh TAG suite:slim0 suite:nfix0 suite:deg0 suite:opaque0 suite:opaqueall suite:opaqueall_slim0 \
+#                suite:olddiet suite:nodpp suite:nomask suite:local3 suite:local0'
+# [r4b] olddiet = every step of the instruction diet off (dynamic LDS, looped sweeps, v_readlane broadcasts, unmasked sweeps): the pre-diet
+# kernel from today's source; nodpp / nomask / local3 / local0 = one step off, or the lane barrier in both / in neither sweep.
 cd "$(dirname "$0")/.."
+rm -rf tools/ab/*/ tools/ab/*.so
 bash tools/build_variant.sh slim0 "-DCRX_SLIM=0" crx_kernels_obs.hip &
 bash tools/build_variant.sh nfix0 "-DCRX_NFIX=0" &
 bash tools/build_variant.sh deg0 "-DCRX_DEG6=0" crx_kernels_obs.hip &
+bash tools/build_variant.sh olddiet "-DCRX_STATIC_LDS=0 -DCRX_RIC_UNROLL=1 -DCRX_SWEEP_UNROLL=0 -DCRX_ROWDPP=0 -DCRX_SWEEP_MASK=0" crx_kernels.hip crx_kernels_obs.hip crx_lmpc.hip &
 wait
 bash tools/build_variant.sh opaque0 "-DCRX_OPAQUE_LANE=0" crx_kernels.hip &
 bash tools/build_variant.sh opaqueall "-DCRX_OPAQUE_LANE=2" crx_kernels_obs.hip &
 bash tools/build_variant.sh opaqueall_slim0 "-DCRX_OPAQUE_LANE=2 -DCRX_SLIM=0" crx_kernels_obs.hip &
+bash tools/build_variant.sh nodpp "-DCRX_ROWDPP=0" &
+wait
+bash tools/build_variant.sh nomask "-DCRX_SWEEP_MASK=0" &
+bash tools/build_variant.sh local3 "-DCRX_SWEEP_LOCAL_LANE=3" crx_kernels_obs.hip &
+bash tools/build_variant.sh local0 "-DCRX_SWEEP_LOCAL_LANE=0" crx_kernels_obs.hip &
 wait
 ls -la tools/ab/*.so
