@@ -44,7 +44,10 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 200 /* 0.2.0: NOT layout-compatible with 0.1.x -- crx_ipm_opts grew by `reach_screen` and `slack_start` (every descriptor
+#define CRX_VERSION 201 /* 0.2.1: same ABI as 0.2.0; the crash path of the MPC-CBF NLPs (crx_ipm_opts.slack_start = 2) takes the crash start's barrier
+                          parameter from its complementarity and keeps the convexified inertia retry between probes -- other iterates, same end
+                          points or other KKT points on crash states; every problem off the crash path is bit-identical to 0.2.0.
+                          0.2.0: NOT layout-compatible with 0.1.x -- crx_ipm_opts grew by `reach_screen` and `slack_start` (every descriptor
                           embeds it), the process-global switches crx_set_reach_screen / crx_set_cbf_slack_start / crx_set_timing /
                           crx_last_kernel_ms are gone (options travel in the descriptor, timing is an object: crx_timer_*), new status
                           CRX_STALLED (what CRX_INFEASIBLE used to report without a proof), CRX_MAX_OBS 3 -> 6 (CRX_MAX_VEH = 3 for the planner side).
