@@ -1251,8 +1251,15 @@ __device__ __forceinline__ bool restore_slacks(double* sm, const Ctx& c, double 
 template <int NOBS, int NMAX>
 __device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_kparams& kp) {
     using L = Lay<NOBS, NMAX>;
-    constexpr int NX = L::NX, NZ = L::NZ, CH = 16, G1 = 5;
-    static_assert(NOBS == 0 || CH * 2 * (NMAX + 1) <= 5 * L::MR, "the candidates' (s, ey) samples fit in the row arrays rt .. rtt");
+    // CH candidates per round, one lane each: all 25 in ONE round where their (s, ey) samples fit into the row arrays that are rewritten
+    // before they are read again -- rt .. rtt (init_point), and in the full layout rsig, rw behind them (assemble_newton); two rounds of
+    // 16 otherwise [r4b: the search costs a straggler of the headline batch ~2 iterations' worth, and every problem whose zero start
+    // violates a row carries it]
+    constexpr int NX = L::NX, NZ = L::NZ, G1 = 5;
+    constexpr int SPAN = (L::SLIM ? 5 : 7) * L::MR;
+    constexpr int CH = 32 * 2 * (NMAX + 1) <= SPAN ? 32 : 16;
+    static_assert(L::rnu == L::rt + L::MR && L::rtt == L::rt + 4 * L::MR && (L::SLIM || L::rw == L::rt + 6 * L::MR), "rt, rnu, rc, rdt, rtt, rsig, rw are contiguous");
+    static_assert(NOBS == 0 || CH * 2 * (NMAX + 1) <= SPAN, "the candidates' (s, ey) samples fit in the row arrays");
     if (NOBS == 0) return -1;
     const int N = c.N, N1 = N + 1, lane = c.lane;
     double* scr = sm + L::rt;
