@@ -327,7 +327,7 @@ int crx_trace_read(double* host, int rows) {
 // of LDS the kernel did not write shows up as a changed result (tests/test_gpu_parity.py::test_no_stale_lds_reads)
 void crx_debug_poison_lds(int enable) { g_poison = enable != 0; }
 
-// diagnostics (not in crx.h): the packed wave reductions of crx_wave.h on host data, in [4][64] -> out [16]
+// diagnostics (not in crx.h): the packed wave reductions and the DPP dot products of crx_wave.h on host data, in [4][64] -> out [16 + 3 * 64]
 // (tests/test_gpu_parity.py::test_packed_wave_reductions)
 int crx_debug_wave_reduce(const double* in, double* out) {
     if (int rc = ensure_init()) return rc;
@@ -335,9 +335,9 @@ int crx_debug_wave_reduce(const double* in, double* out) {
     std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g_device));
     Stage sg;
-    if (int rc = sg.reserve(256 * 8, 16 * 8)) return rc;
+    if (int rc = sg.reserve(256 * 8, 208 * 8)) return rc;
     double* din = sg.in(in, 256);
-    double* dout = sg.out(out, 16);
+    double* dout = sg.out(out, 208);
     if (int rc = sg.up(g_stream)) return rc;
     hipError_t e = crx_launch_debug_reduce(din, dout, g_stream);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "debug reduce launch: %s", hipGetErrorString(e));

@@ -2409,7 +2409,7 @@ hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st) {
 }
 
 // diagnostics (crx_debug_wave_reduce, not in crx.h): the packed wave reductions of crx_wave.h on four 64-lane inputs.
-// out[0..3] wave_sum4, [4..7] wave_max4, [8..9] wave_sum2 of inputs 0 and 1, [10..11] wave_max2 of inputs 2 and 3,
+// out [16 + 3 * 64]: out[0..3] wave_sum4, [4..7] wave_max4, [8..9] wave_sum2 of inputs 0 and 1, [10..11] wave_max2 of inputs 2 and 3,
 // [12..15] the single-value reductions (sum of 0, max of 1, min of 2, product of the mantissas of 3).
 __global__ void __launch_bounds__(WAVE) crx_debug_reduce_kernel(const double* in, double* out) {
     const int lane = threadIdx.x;
@@ -2428,6 +2428,21 @@ __global__ void __launch_bounds__(WAVE) crx_debug_reduce_kernel(const double* in
         out[0] = s0; out[1] = s1; out[2] = s2; out[3] = s3; out[4] = m0; out[5] = m1; out[6] = m2; out[7] = m3;
         out[8] = p0; out[9] = p1; out[10] = q0; out[11] = q1; out[12] = r0; out[13] = r1; out[14] = r2; out[15] = r3;
     }
+    // [r4] row_dot (v_fmac_f64_dpp row_newbcast): out[16 + lane] = c + sum_{i<7} m_i * (lane i of a's 16-lane row), m_i = (i + 1) b + d, under
+    // full EXEC; out[80 + lane] = the same with terms 3 .. 9 inside an `if (lane < 10)` region (the sweeps' predication; NaN elsewhere);
+    // out[144 + lane] = a three-term dot product of lanes 7 .. 9 whose x is the value just accumulated (the forward sweep's input term)
+    double m[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) m[i] = (double)(i + 1) * b + d;
+    out[16 + lane] = row_dot<7, 0>(a, m, c);
+    double masked = __longlong_as_double(0x7ff8000000000000LL), chained = masked;
+    if (lane < 10) {
+        masked = row_dot<7, 3>(a, m, c);
+        const double first = row_dot<7, 0>(a, m, c);
+        chained = row_dot<3, 7>(first, m, first);
+    }
+    out[80 + lane] = masked;
+    out[144 + lane] = chained;
 }
 
 hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st) {

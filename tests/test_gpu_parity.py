@@ -1203,7 +1203,7 @@ def test_zero_obstacle_nlps_incl_infeasible(gpu, orc, AB):
 
 
 def test_packed_wave_reductions(gpu):
-    """crx_wave.h wave_sum4 / wave_max4 / wave_sum2 / wave_max2 (v_permlane32_swap / v_permlane16_swap + one row reduction)
+    """(and the DPP dot products of the sweeps, row_dot)  crx_wave.h wave_sum4 / wave_max4 / wave_sum2 / wave_max2 (v_permlane32_swap / v_permlane16_swap + one row reduction)
     on random 64-lane inputs through the hidden crx_debug_wave_reduce: the maxima exact, the sums to rounding of a
     different association, each value in ITS output slot (a transposed row map would swap slots 1 and 2)."""
     import ctypes as C
@@ -1216,8 +1216,21 @@ def test_packed_wave_reductions(gpu):
         if trial == 5:
             x = np.tile(np.arange(64.0), (4, 1)) * np.array([[1.0], [2.0], [3.0], [4.0]])     # exact sums 2016 k
         xin = np.ascontiguousarray(x, dtype=np.float64)
-        out = np.zeros(16)
+        out = np.zeros(16 + 3 * 64)
         assert L.crx_debug_wave_reduce(xin.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        # [r4] row_dot: broadcast-and-FMA in one v_fmac_f64_dpp row_newbcast -- lane i of the reader's OWN 16-lane row, under full EXEC, inside
+        # a predicated region (lanes < 10, the sweeps' form), and chained on a value the previous dot product has just written
+        a, b, c, d = x
+        m = [(i + 1.0) * b + d for i in range(7)]
+        row0 = (np.arange(64) // 16) * 16
+        full = c + sum(m[i] * a[row0 + i] for i in range(7))
+        scale = np.abs(c) + sum(np.abs(m[i] * a[row0 + i]) for i in range(7))
+        assert (np.abs(out[16:80] - full) <= 16 * 2.3e-16 * scale).all(), np.abs(out[16:80] - full).max()
+        msk = c[:10] + sum(m[i][:10] * a[3 + i] for i in range(7))
+        assert (np.abs(out[80:90] - msk) <= 16 * 2.3e-16 * (np.abs(c[:10]) + sum(np.abs(m[i][:10] * a[3 + i]) for i in range(7)))).all() and np.isnan(out[90:144]).all()
+        first = full[:10]
+        chn = first + sum(m[i][:10] * first[7 + i] for i in range(3))
+        assert (np.abs(out[144:154] - chn) <= 64 * 2.3e-16 * (np.abs(first) + sum(np.abs(m[i][:10] * first[7 + i]) for i in range(3)) + scale[:10])).all() and np.isnan(out[154:208]).all()
         ref_s, ref_m = x.sum(axis=1), x.max(axis=1)
         tol = 64 * 2.3e-16 * np.abs(x).sum(axis=1)
         assert (np.abs(out[0:4] - ref_s) <= tol).all(), (out[0:4], ref_s)
