@@ -214,6 +214,10 @@ struct Lay {
     static constexpr int H = H_ALIAS ? dZ : WORK2;           // [NZ][HS]  (over dZ from its start: stage 0 of dZ is written only after the sweep)
     static constexpr int Kk = H_ALIAS ? WORK2 : H + NZ * HS; // [NMAX][NU][NX]
     static constexpr int G = SLIM ? Kk : Gpos;
+    // slim [r4b]: Sigma = nu / t of the CBF rows, [NMAX][NO], written by assemble_newton and read by the backward sweep's H phase -- behind H
+    // in dZ, which is dead from the adjoint to the forward sweep (the full layout has rsig for this; recomputing it per stage and pass
+    // was three LDS reads and three VALU instructions per obstacle: 360 of the 12.3 k instructions of a <3,20> iteration)
+    static constexpr int sigS = (SLIM && H_ALIAS && NZ * HS + NMAX * NO <= NV) ? dZ + NZ * HS : -1;
     static_assert(NMAX * NOBS * 4 <= NMAX * NU * NX, "G fits inside Kk");
     static constexpr int kf = Kk + NMAX * NU * NX;   // [NMAX][NU]
     static constexpr int Fth = kf + NMAX * NU;
@@ -722,6 +726,7 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
             const double nd = LD(L::rnu + j) * cbf_scale<L>(sm, k, o);
             ks -= nd * LD(L::G + (k * L::NO + o) * 4 + 0);
             ke -= nd * LD(L::G + (k * L::NO + o) * 4 + 1);
+            if constexpr (L::sigS >= 0) LD(L::sigS + k * L::NO + o) = sel(LD(L::csc + k * L::NO + o) != 0.0, LD(L::rnu + j) * LD(L::rtt + j), 0.0);
         }
         LD(L::kS + 2 * k) = ks;
         LD(L::kE + 2 * k) = ke;
@@ -901,7 +906,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             if (NOBS) {
 #pragma unroll
                 for (int o = 0; o < NOBS; o++) {
-                    if constexpr (L::SLIM) {   // Sigma of the CBF row (k, o): nu / t, 0 for an absent row
+                    if constexpr (L::sigS >= 0) {
+                        rs[o] = LD(L::sigS + k * L::NO + o);
+                    } else if constexpr (L::SLIM) {   // Sigma of the CBF row (k, o): nu / t, 0 for an absent row
                         const int j = k * L::NR + 8 + NOBS + o;
                         rs[o] = sel(LD(L::csc + k * L::NO + o) != 0.0, LD(L::rnu + j) * LD(L::rtt + j), 0.0);
                     } else {
