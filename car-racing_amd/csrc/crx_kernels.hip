@@ -674,6 +674,13 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
             LD(L::rsig + j) = sel(on, sig, 0.0);
             const double cj = LD(L::rc + j);
             LD(L::rw + j) = sel(on, nu - mu * rti + sig * (cj - t), 0.0);
+        } else {
+            // slim [r4b]: w of the row for the coordinate pass below, parked in rdt (dead from the accept pass until the row steps that
+            // follow the forward sweep; the backward sweep's P / T move in only after this function) -- the coordinate pass recomputed it per
+            // coordinate and obstacle from four LDS reads.  Same expression as row_sig_w.
+            const bool on = row_scale<L>(sm, si, j, N) != 0.0;
+            const double sg = nu * rti, cj = LD(L::rc + j);
+            LD(L::rdt + j) = sel(on, nu - mu * rti + sg * (cj - t), 0.0);
         }
     }
     SYNC();
@@ -691,8 +698,8 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
         const int il = rl >= 0 ? rl : 0, ih = rh >= 0 ? rh : 0;
         double sgl, sgh, wl, wh;
         if constexpr (L::SLIM) {   // a row found by coord_rows is present
-            row_sig_w<L>(sm, il, true, mu, LD(L::rt + il), LD(L::rnu + il), LD(L::rtt + il), LD(L::rc + il), sgl, wl);
-            row_sig_w<L>(sm, ih, true, mu, LD(L::rt + ih), LD(L::rnu + ih), LD(L::rtt + ih), LD(L::rc + ih), sgh, wh);
+            sgl = LD(L::rnu + il) * LD(L::rtt + il); wl = LD(L::rdt + il);
+            sgh = LD(L::rnu + ih) * LD(L::rtt + ih); wh = LD(L::rdt + ih);
         } else {
             sgl = LD(L::rsig + il); sgh = LD(L::rsig + ih); wl = LD(L::rw + il); wh = LD(L::rw + ih);
         }
@@ -706,8 +713,12 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
                 const double csj = cbf_scale<L>(sm, kk, ob);
                 const double jca = LD(L::Jc + (kk * L::NO + ob) * L::NZ + a);
                 double rsj_, rwj;
-                row_sig_w<L>(sm, j, csj != 0.0, mu, LD(L::rt + j), LD(L::rnu + j), LD(L::rtt + j), LD(L::rc + j), rsj_, rwj);
-                (void)rsj_;
+                if constexpr (L::SLIM) {
+                    rwj = LD(L::rdt + j);
+                } else {
+                    row_sig_w<L>(sm, j, csj != 0.0, mu, LD(L::rt + j), LD(L::rnu + j), LD(L::rtt + j), LD(L::rc + j), rsj_, rwj);
+                    (void)rsj_;
+                }
                 g += sel(k < N, jca * rwj, 0.0);
                 const double cur = LD(L::rnu + j) * csj * c.om * LD(L::G + (kk * L::NO + ob) * 4 + (a == 4 ? 2 : 3));
                 h += sel(k < N && (a == 4 || a == 5), cur, 0.0);
