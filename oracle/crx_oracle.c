@@ -395,7 +395,8 @@ void crx_oracle_set_verbose(int v) { g_verbose = v; }
 /* experiment knobs (tools/tail_knobs.py): 0 JAM_ALPHA, 1 JAM_COUNT, 2 STALL_ITERS, 3 CRAWL_ALPHA, 4 CRAWL_COUNT (0 = off),
  * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
  * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1), 9 do not charge the knob-6
- * restoration to the budget.  Defaults = the shipped algorithm; the kernel has no such knobs.  (What used to be knobs 8 and 14 are
+ * restoration to the budget, 11 probe period of the sticky convexification (0 = CVX_PROBE, < 0 = every iteration probes: not sticky).
+ * Defaults = the shipped algorithm; the kernel has no such knobs.  (What used to be knobs 8 and 14 are
  * crx_ipm_opts.reach_screen / .slack_start since ABI 0.2.) */
 static double g_knob[16] = {1e-3, 5, 50, 0.0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v; }
