@@ -746,9 +746,10 @@ def main():
                          "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
     ap.add_argument("--no-reach-screen", action="store_true",
                     help="planner QPs: reachability screen off (crx_ipm_opts.reach_screen = 0): every region goes through the interior-point iteration")
-    ap.add_argument("--slack-start", type=int, default=None, choices=[0, 1, 2],
+    ap.add_argument("--slack-start", type=int, default=None, choices=[0, 1, 2, 3],
                     help="CBF NLPs, crx_ipm_opts.slack_start: 0 = IPOPT's sigma = 0 start only, 1 = start the slacks at their provable lower bounds, "
-                         "2 (default) = IPOPT's start, and a solve that stalls on violated CBF rows restarts once from the lower bounds")
+                         "2 (default) = the crash path (provable crash states start from a feasible interior point, a stalled solve restarts from it), "
+                         "3 = the eager crash path (every violated zero start takes that point: faster, further from the reference's local minimum)")
     ap.add_argument("--collective", default="torch", choices=["torch", "crx"],
                     help="cfg5's all-gather: torch.distributed (nccl = RCCL) or libcrx's own crx_allgather_winners_dev (RCCL through the C ABI)")
     args = ap.parse_args()

@@ -170,7 +170,7 @@ struct Carver {
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
         !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0) ||
-        o.slack_start < 0 || o.slack_start > 2)
+        o.slack_start < 0 || o.slack_start > 3)
         return fail(CRX_ERR_ARG, "invalid crx_ipm_opts (a descriptor built for libcrx 0.1.x? crx_ipm_opts grew in 0.2: include/crx.h)");
     return 0;
 }

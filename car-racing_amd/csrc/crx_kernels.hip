@@ -1730,7 +1730,7 @@ crx_solve_kernel(const crx_kparams kp) {
     // [r4] crash path (include/crx.h crx_ipm_opts.slack_start == 2): a provable crash state starts from the feasible interior point of
     // crash_point(); a solve that started at zero and stalls on violated CBF rows restarts ONCE from such a point.  `crash` = this
     // solve is on the crash path (it also selects the convexified inertia retry below).
-    const bool crash_path = NOBS > 0 && kp.slack_start == 2 && o.restore_iters >= 0 && c.om > 1e-6 && c.nobs > 0;
+    const bool crash_path = NOBS > 0 && kp.slack_start >= 2 && o.restore_iters >= 0 && c.om > 1e-6 && c.nobs > 0;
     int crash = 0;
     double mu = o.mu_init, dw_last = 0.0, E0 = INFINITY, theta_min = 0.0, theta_max = INFINITY;
     double f = 0.0;
@@ -1851,7 +1851,8 @@ crx_solve_kernel(const crx_kparams kp) {
         if (crash_state || __ballot(viol) != 0ull) crash_cand = __builtin_amdgcn_readfirstlane(crash_search<NOBS, NMAX>(sm, c, kp));
         // (a solve that STARTS on the crash path has a budget too -- three times the restoration budget + 1 -- after which it ends CRX_RESTORED like
         // a restarted one: feasible through its slacks, not optimal, instead of crawling to max_iter)
-        if (crash_state && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; n_restore = 1; it_limit = 1 + 3 * o.restore_iters; }
+        // (slack_start == 3, eager: a violated zero start is enough -- include/crx.h; the restart then never fires)
+        if ((crash_state || kp.slack_start == 3) && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; n_restore = 1; it_limit = 1 + 3 * o.restore_iters; }
     }
     init_point();
     if (NOBS && crash) {

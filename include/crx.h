@@ -130,7 +130,13 @@ typedef struct crx_ipm_opts {
                                  construction) before IPOPT's delta_w schedule; after an iteration that needed that, the next ones start
                                  without it and every 4th of such a run tries the exact Hessian first again.  Problems that never enter the crash path are untouched,
                                  bit for bit.  BASELINE configs[1]: 95.7 -> 100 % of the 256 NLPs converge, longest solve 58 -> 38
-                                 iterations; configs[3]: 92.5 -> 98.9 % (oracle). */
+                                 iterations; configs[3]: 92.5 -> 98.9 % (oracle). 
+                              3: EAGER crash path (0.2.1).  As 2, but EVERY problem whose zero start violates a CBF row starts from the point, not
+                                 only the provable crash states (the restart of 2 then never fires).  Faster -- BASELINE configs[1]: longest
+                                 solve 36 -> 30 iterations, 0.47 -> 0.39 ms per 256 NLPs; configs[3]: 99.2 -> 99.5 % converged -- and further from the
+                                 reference: a near-miss that the zero start solves ends at the local minimum IPOPT reaches from zero, and at
+                                 another one from the candidate point; the reference's recorded closed loop is reproduced step by step with 2,
+                                 not with 3. */
 } crx_ipm_opts;
 
 /* ---- planner region QP (overtake_traj_planner.py:263-334) ------------------------------------ */
