@@ -3,9 +3,12 @@
 # faulting kernel; DESIGN.md section 8: a build of an intermediate source state computed one wrong number): every variant must pass the
 # parity suite.  Run in the build container, then on the GPU box
 #     gpurun -- 'bash tools/gpu_pass.sh TAG suite:slim0 suite:nfix0 suite:deg0 suite:opaque0 suite:opaqueall suite:opaqueall_slim0 \
-#                suite:olddiet suite:nodpp suite:nomask suite:local3 suite:local0'
+#                suite:nodpp suite:nomask suite:local3 suite:local0 bits:olddiet'
 # [r4b] olddiet = every step of the instruction diet off (dynamic LDS, looped sweeps, v_readlane broadcasts, unmasked sweeps): the pre-diet
-# kernel from today's source; nodpp / nomask / local3 / local0 = one step off, or the lane barrier in both / in neither sweep.
+# kernel from today's source, the reference of the bit-for-bit comparison; nodpp / nomask / local3 / local0 = one step off, or the lane
+# barrier in both / in neither sweep.  (olddiet itself is NOT a suite target any more: built from the final source its general
+# instantiation <1,24,6,0> writes a scrambled X while status, iterations, cost and U equal the shipped build's bit for bit -- the second
+# of the two observations in DESIGN.md section 8; -DCRX_STATIC_LDS=0, -DCRX_ROWDPP=0 -DCRX_SWEEP_MASK=0 and any two of the three pass.)
 cd "$(dirname "$0")/.."
 rm -rf tools/ab/*/ tools/ab/*.so
 bash tools/build_variant.sh slim0 "-DCRX_SLIM=0" crx_kernels_obs.hip &
