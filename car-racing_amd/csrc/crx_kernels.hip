@@ -2205,6 +2205,12 @@ crx_solve_kernel(const crx_kparams kp) {
 
     // ---- write back: one coalesced pass ----------------------------------------------------------------
     SYNC();
+    // [r4b] the lane index is taken afresh here: the addresses of this pass are formed now instead of being carried (in AGPR slots, in the
+    // general instantiations) from the top of the kernel across the whole solve -- DESIGN.md section 8, second observation
+    int lane_wb = threadIdx.x;
+    asm volatile("" : "+v"(lane_wb));
+    {
+    const int lane = lane_wb;   // shadows the kernel's `lane` inside this block
     double* Xb = kp.X + (size_t)b * (N + 1) * 6;
     double* Ub = kp.U + (size_t)b * N * 2;
     if (kp.mode == 0 && status != 0) {
@@ -2221,6 +2227,7 @@ crx_solve_kernel(const crx_kparams kp) {
         }
     }
     if (lane == 0) { kp.status[b] = status; kp.kkt[b] = E0; kp.iters[b] = it; }
+    }
 }
 
 // This file is compiled TWICE (Makefile): as it stands for the planner instantiations <0, *> and everything else in it, and
