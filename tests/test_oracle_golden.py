@@ -376,6 +376,12 @@ def test_cbf_slack_start_oracle(orc, AB):
     assert conv2.mean() >= 0.995 and conv2.sum() > (r[1]["status"] == 0).sum(), (conv2.sum(), n0)   # the crash path: (nearly) every NLP of the draw
     assert np.percentile(r[2]["iters"], 99) <= 35 < np.percentile(r0["iters"], 99)   # ... and the tail is shorter
     assert r[2]["kkt"][conv2].max() <= 1e-8
+    # [r4b] 3 = the eager crash path: every violated zero start takes the candidate point (no restart) -- the whole draw, a shorter tail still;
+    # problems whose zero start violates nothing keep their bits
+    r3 = orc.cbf_solve(abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"], opts=abi.default_opts(slack_start=3)), *args)
+    assert (r3["status"] == 0).mean() >= 0.995 and r3["iters"].max() <= r[2]["iters"].max() and np.percentile(r3["iters"], 99) <= np.percentile(r[2]["iters"], 99)
+    same = (np.abs(r3["X"] - r[2]["X"]).reshape(512, -1).max(axis=1) == 0) & (r3["iters"] == r[2]["iters"])
+    assert 0.85 <= same.mean() < 1.0, same.mean()
 
 
 def test_lmpc_reach_screen_oracle(orc, golden_racing_game):
