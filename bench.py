@@ -55,7 +55,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "car-racing_amd", "csrc")
-    for f in ("crx_kernels.hip", "crx_kernels_obs.hip", "crx_wave.h", "Makefile"):
+    for f in ("crx_kernels.hip", "crx_kernels_obs.hip", "crx_kernels_gen.hip", "crx_wave.h", "Makefile"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -109,6 +109,7 @@ class Workload:
     desc = ws = cpu = None
     host_call = None
     gather = None          # the collective alone (cfg5)
+    rewind = None          # closed-loop workloads: put the races back to the stated lap phase (outside every timed region)
     extra = None
     scaling = "weak"
 
@@ -283,6 +284,26 @@ def make_lmpc(cx, args, batch=None):
     return w
 
 
+def to_lap_phase(cx, w, conc, phase, what):
+    """Closed-loop workloads: `phase` untimed control steps after construction, a snapshot there, and a rewind hook that measure()
+    calls after its warm-up -- the timed steps always cover control steps [phase, phase + steps) of the lap, so the record does not
+    depend on --warmup and two runs with the same --steps report the same lap phase (the share of converged /
+    relaxed learning-MPC QPs changes through the lap)."""
+    from crx import montecarlo
+    for _ in range(phase):
+        conc.step()
+    cx.dsync()
+    snap = montecarlo.Snapshot(conc)
+
+    def rewind():
+        cx.dsync()
+        snap.restore()
+        cx.dsync()
+
+    w.rewind = rewind
+    w.extra["lap_phase"] = "timed steps = control steps [%d, %d + steps) of %s; the status / iteration fields describe step %d + steps" % (phase, phase, what, phase)
+
+
 def make_races(cx, args, batch=None):
     from crx import montecarlo, synth
     from utils import racing_env
@@ -348,6 +369,7 @@ def make_game(cx, args, batch=None):
               "set, one control step of every race per step (12 local regressions + safe-set selection, LMPC QP N=12 / 44 points, add_point, plant)" % Bn)
     w.extra = {"note": "races run lap after lap (crx_lmpc_addtraj_dev hands every completed lap over to the safe set) until the four laps of storage are full",
                "race_streams": len(parts), "kernel_ms_is": "sum of the sub-batch launches of one step, each timed alone (in the step they overlap)", "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
+    to_lap_phase(cx, w, conc, args.lap_phase, "the first learning-MPC lap after the two recorded ones")
     return w
 
 
@@ -396,25 +418,38 @@ def make_overtake(cx, args, batch=None):
                "dispatch": "longest_first" if args.dispatch == "longest_first" else "index"}
     # the scene stage keeps at most CRX_MAX_OBS vehicles of interest per race (the nearest): how often were there more?
     w.post = lambda: {"scene_overflow_races": int(sum((g.overflow_seen > 0).sum().item() for g in parts))}
+    to_lap_phase(cx, w, conc, args.lap_phase, "the racing-game lap with traffic")
     return w
 
 
 def kernel_ms_samples(cx, w, reps):
-    """Per-launch device time of the dominant kernel, HIP events recorded by libcrx on the stream the launch goes to (`crx_timer_*`,
+    """Device time of the dominant kernel, HIP events recorded by libcrx on the stream the launch goes to (`crx_timer_*`,
     include/crx.h).  solve() re-issues the dominant launch of the last step() with the same inputs and the same mask (closed-loop
-    workloads keep the state the launch was built for); concurrent sub-batches: the launches of one step, timed one after the other."""
+    workloads keep the state the launch was built for); concurrent sub-batches: the launches of one step, one after the other.
+    Returns (train, single): `train` = ONE event pair around `reps` back-to-back passes, divided by reps -- the launch as it runs in
+    the timed loop (an event pair costs ~5 us of its own: bracketing every launch made the per-launch figure exceed ms_per_step on
+    the 0.4 ms headline); `single` = the mean of per-pass event pairs (the lone launch, event overhead included)."""
     from crx import torch_api
     tm = torch_api.Timer()
+    fs = getattr(w, "solve_parts", None) or [w.solve]
     kms = []
     for _ in range(reps):
         t_ms = 0.0
-        for f in (getattr(w, "solve_parts", None) or [w.solve]):
+        for f in fs:
             tm.begin()
             f()
             tm.end()
             t_ms += tm.ms()
         kms.append(t_ms)
-    return kms
+    if len(fs) == 1:
+        tm.begin()
+        for _ in range(reps):
+            fs[0]()
+        tm.end()
+        train = tm.ms() / reps
+    else:   # sub-batches on several streams: no single stream carries the train; the per-pass sum stands
+        train = float(np.mean(kms))
+    return train, float(np.mean(kms))
 
 
 def occupancy(w):
@@ -430,6 +465,8 @@ def measure(cx, w, steps, warmup, with_latency=True):
     """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize, MAX over ranks."""
     for _ in range(warmup):
         w.step()
+    if w.rewind is not None:     # closed loops: the timed steps start at the stated lap phase whatever --warmup was
+        w.rewind()
     cx.sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -475,9 +512,9 @@ def measure(cx, w, steps, warmup, with_latency=True):
     w.step()
     cx.dsync()
     st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
-    kms = kernel_ms_samples(cx, w, min(50, max(5, steps)))
-    k_ms = float(np.mean(kms))
+    k_ms, k_ms_single = kernel_ms_samples(cx, w, min(50, max(5, steps)))
     conv = st == 0
+    opt = st == 0               # converged at tol (a proved-infeasible planner QP is ANSWERED, not converged: its kkt is +inf by definition)
     if w.kind == "planner":     # a region QP PROVED infeasible (screen / certificate) is an answered problem: the planner consumes the verdict
         conv = conv | (st == 2)
     ran = st != 4
@@ -515,7 +552,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
                            "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean()),
                            "skipped_masked": float((st == 4).mean()), "stalled": float((st == 5).mean())},
            "converged_frac": float(conv.mean()), "converged_frac_of_launched": conv_of_launched if ran.any() else None,
-           "kkt_max_converged": float(kkt[conv].max()) if conv.any() else None,
+           "kkt_max_converged": float(kkt[opt].max()) if opt.any() else None,
            "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
            "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
     if with_latency:
@@ -531,7 +568,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": w.scaling, "config": cfg,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": w.kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_solve": abytes,
+                        "kernel": w.kernel, "kernel_ms": k_ms, "kernel_ms_single_launch": k_ms_single, "algorithmic_bytes_per_solve": abytes,
                         "note": "serial-dependency/FP64-issue bound, not HBM bound (DESIGN.md section 5)",
                         "fp64_gflops": gflops, "fp64_frac_of_valu_peak": gflops / FP64_VALU_PEAK_GFLOPS,
                         "lds_bytes_per_problem": lds, "resident_problems_per_cu": resident, "lds_limit_per_cu": int((160 * 1024) // max(lds, 1))}}
@@ -571,10 +608,10 @@ def stdout_line(full):
     line["config"] = {k: r4(c[k]) for k in ck if c.get(k) is not None}
     line["config"]["workload"] = str(c["workload"])[:160]
     line["config"]["status_frac"] = {k: r4(v) for k, v in c["status_frac"].items() if v}
-    line["roofline"] = {k: r4(r[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+    line["roofline"] = {k: r4(r[k]) for k in r if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "kernel_ms_single_launch",
                                                 "algorithmic_bytes_per_solve", "fp64_gflops", "fp64_frac_of_valu_peak", "lds_bytes_per_problem",
                                                 "resident_problems_per_cu")}
-    for k in ("allgather_ms", "world_size"):
+    for k in ("allgather_ms", "world_size", "collective"):
         if k in full:
             line[k] = r4(full[k])
     b = full.get("cpu_baseline")
@@ -627,7 +664,8 @@ def cpu_baseline(w):
     vall, rall, eall = timed(n, 10.0)
     out = {"value": vall, "unit": "solves/s", "cores": cores, "cpu_quota_cores": quota, "affinity_cores": affinity, "host_threads": host_threads,
            "speedup_vs_one_thread": vall / v1, "kind": "port",
-           "sample": "%d repetitions of the first %d problems of the same batch, OpenMP over problems, %.1f s wall" % (rall, n, eall),
+           "sample": "%d repetitions of %d problems of the same generator and seed%s, OpenMP over problems, %.1f s wall" % (
+               rall, n, " (the first %d are the batch)" % w.batch if n > w.batch else "", eall),
            "one_thread": {"value": v1, "cores": 1, "sample": "%d repetitions of the first %d problems, %.1f s wall" % (r1, min(n, 256), e1)}}
     if kind == "cbf" and not desc.per_stage_target:
         from oracle import slsqp_baseline
@@ -744,6 +782,8 @@ def main():
                          "STATIC batches cfg2 / cfg4 / lmpc the previous solve is the same problem, i.e. an oracle order: an upper bound); "
                          "start_barrier (cfg2 / cfg4) = from the problem's own inputs, no previous solve needed (crx_cbf_order_dev); auto = "
                          "start_barrier for a CBF batch larger than the resident slots, else index.  The order kernel is part of the timed step")
+    ap.add_argument("--lap-phase", type=int, default=40,
+                    help="closed-loop workloads game / overtake: untimed control steps before the measurement; the timed steps start there whatever --warmup is")
     ap.add_argument("--no-reach-screen", action="store_true",
                     help="planner QPs: reachability screen off (crx_ipm_opts.reach_screen = 0): every region goes through the interior-point iteration")
     ap.add_argument("--slack-start", type=int, default=None, choices=[0, 1, 2, 3],
@@ -788,6 +828,16 @@ def main():
         del w
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
+    if cx.world > 1:
+        # the headline (cfg2, weak) shards by problem and has NO collective; the path's one exchange step is the winners' all-gather of the
+        # planner sweep -- its time over all ranks goes to the top level of the line so that a scaling record shows RCCL saw N ranks
+        for r_ in full["configs"]:
+            if r_["key"] == "cfg5_weak" and "allgather_ms" in r_:
+                full["allgather_ms"], full["world_size"] = r_["allgather_ms"], r_["world_size"]
+                full["collective"] = ("ONE all-gather of %d-byte winner records {int32 flag; int32 status; double X[13][6]} of the cfg5 weak sweep (%d "
+                                      "scenarios per rank), %s over %d ranks; the headline itself has no collective" % (
+                                          r_["config"]["winner_record_bytes"], r_["config"]["scenarios_this_rank"],
+                                          "torch.distributed nccl (= RCCL)" if args.collective == "torch" else "crx_allgather_winners_dev (RCCL)", r_["world_size"]))
     shutdown_backend(cx, args)
     if dist.is_initialized():
         dist.destroy_process_group()

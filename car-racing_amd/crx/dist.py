@@ -63,9 +63,11 @@ def shard_sizes(n_total, world):
 class WinnerExchange:
     """The all-gather of the winners, with its buffers allocated once.
 
-    A winner record is [flag, X (N+1)*6] as float64 (flags are small integers: exact).  Every rank knows the shard
-    sizes from (n_total, world) alone -- shard_bounds is a pure function -- so no size exchange is needed: ragged
-    shards are padded to the largest one and trimmed after the ONE collective."""
+    A winner record is SURVEY.md section 8e's {int32 flag; int32 status; double X[N+1][6]} -- 632 B at N = 12 -- carried as
+    1 + 6 (N + 1) 8-byte words (word 0 = the two int32, bit for bit; the collective only moves bytes).  `status` is the crx_status of
+    the WINNING region's QP: a consumer on another rank can tell a fall-back winner (overtake_traj_planner.py:365-374) from a solved
+    one.  Every rank knows the shard sizes from (n_total, world) alone -- shard_bounds is a pure function -- so no size exchange is
+    needed: ragged shards are padded to the largest one and trimmed after the ONE collective.  Returns (flag, X, status)."""
 
     def __init__(self, n_total, N, device, group=None):
         self.group = group
@@ -78,7 +80,11 @@ class WinnerExchange:
         self.send = torch.zeros((self.n_max, self.rec), dtype=torch.float64, device=device)
         self.recv = torch.empty((self.world * self.n_max, self.rec), dtype=torch.float64, device=device)
 
-    def __call__(self, flag, best_X):
+    def _unpack(self, allrec):
+        head = allrec[:, :1].contiguous().view(torch.int32)          # [n, 2]: flag, status
+        return head[:, 0], allrec[:, 1:].reshape(-1, *self.shape_X), head[:, 1]
+
+    def __call__(self, flag, best_X, status=None):
         n = self.sizes[self.rank]
         if flag.shape[0] != n or best_X.shape[0] != n:
             raise ValueError("rank %d holds %d winners, its shard of %d over %d ranks is %d" % (self.rank, flag.shape[0], self.n_total, self.world, n))
@@ -94,16 +100,19 @@ class WinnerExchange:
             CrxComm.ensure()
             fl = flag.to(torch.int32).contiguous()
             bx = best_X.contiguous()
-            if lib().crx_allgather_winners_dev(C.c_int(n), C.c_int(self.n_max), C.c_int(self.shape_X[0] - 1), _ptr(fl), _ptr(bx), _ptr(self.send),
-                                               _ptr(self.recv), _stream()) != 0:
+            stt = status.to(torch.int32).contiguous() if status is not None else None
+            if lib().crx_allgather_winners_dev(C.c_int(n), C.c_int(self.n_max), C.c_int(self.shape_X[0] - 1), _ptr(fl), _ptr(stt) if stt is not None else None,
+                                               _ptr(bx), _ptr(self.send), _ptr(self.recv), _stream()) != 0:
                 raise RuntimeError("crx_allgather_winners_dev: " + (lib().crx_last_error() or b"").decode())
             if self.even:
                 allrec = self.recv
             else:
                 out = self.recv.view(self.world, self.n_max, self.rec)
                 allrec = torch.cat([out[r, : self.sizes[r]] for r in range(self.world)], dim=0)
-            return allrec[:, 0].to(torch.int32), allrec[:, 1:].reshape(-1, *self.shape_X)
-        self.send[:n, 0] = flag
+            return self._unpack(allrec)
+        head = self.send.view(torch.int32)                            # [n_max, 2 * rec]: word 0 of a record = int32 columns 0 and 1
+        head[:n, 0] = flag
+        head[:n, 1] = status if status is not None else 0
         self.send[:n, 1:] = best_X.reshape(n, self.rec - 1)
         if self.world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVE):
             allrec = self.send[:n]
@@ -114,15 +123,16 @@ class WinnerExchange:
             else:
                 out = self.recv.view(self.world, self.n_max, self.rec)
                 allrec = torch.cat([out[r, : self.sizes[r]] for r in range(self.world)], dim=0)
-        return allrec[:, 0].to(torch.int32), allrec[:, 1:].reshape(-1, *self.shape_X)
+        return self._unpack(allrec)
 
 
-def allgather_winners(flag, best_X, n_total=None):
-    """Gather per-scenario winners from every rank in rank order: flag [n_local] int32, best_X [n_local, N+1, 6] float64
-    -> (flag_all [n_total], best_X_all [n_total, N+1, 6]).  One collective.  `n_total` = scenarios over all ranks
-    (sharded by shard_bounds); None means every rank holds the same number."""
+def allgather_winners(flag, best_X, n_total=None, status=None):
+    """Gather per-scenario winners from every rank in rank order: flag [n_local] int32, best_X [n_local, N+1, 6] float64, status
+    [n_local] int32 (crx_status of the winning region's QP; None: zeros) -> (flag_all [n_total], best_X_all [n_total, N+1, 6],
+    status_all [n_total]).  One collective.  `n_total` = scenarios over all ranks (sharded by shard_bounds); None means every rank
+    holds the same number."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return flag, best_X
+        return flag, best_X, (status if status is not None else torch.zeros_like(flag))
     if n_total is None:
         n_total = flag.shape[0] * dist.get_world_size()
-    return WinnerExchange(n_total, best_X.shape[1] - 1, flag.device)(flag, best_X)
+    return WinnerExchange(n_total, best_X.shape[1] - 1, flag.device)(flag, best_X, status)

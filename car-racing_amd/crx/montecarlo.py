@@ -44,6 +44,43 @@ def _order(obj, iters, active=None):
     return torch_api.longest_first(iters, active)
 
 
+class Snapshot:
+    """The state of a closed-loop object (MpccbfRaces / LmpcLaps / GameLaps, or a Concurrent of them) at this moment: every tensor
+    and every plain number reachable through its attributes (workspaces and nested loops included) is copied; restore() puts the
+    values AND the attribute bindings back (step() swaps xc / xc_next).  bench.py uses it to start the timed steps of the closed-loop
+    workloads at a stated lap phase whatever --steps / --warmup are.  The caller synchronises the device around both calls."""
+
+    def __init__(self, obj):
+        import ctypes
+        self.tensors, self.scalars = [], []
+        seen = set()
+
+        def walk(o):
+            if id(o) in seen:
+                return
+            seen.add(id(o))
+            for k, v in list(vars(o).items()):
+                if torch.is_tensor(v):
+                    self.tensors.append((o, k, v, v.clone()))
+                elif isinstance(v, (bool, int, float)):
+                    self.scalars.append((o, k, v))
+                elif isinstance(v, (list, tuple)):
+                    for e in v:
+                        if hasattr(e, "__dict__") and not isinstance(e, (ctypes.Structure, torch.cuda.Stream, torch.Generator)):
+                            walk(e)
+                elif hasattr(v, "__dict__") and not isinstance(v, (ctypes.Structure, torch.cuda.Stream, torch.Generator, type)):
+                    walk(v)
+
+        walk(obj)
+
+    def restore(self):
+        for o, k, t, c in self.tensors:
+            t.copy_(c)
+            setattr(o, k, t)
+        for o, k, v in self.scalars:
+            setattr(o, k, v)
+
+
 class Concurrent:
     """K independent sub-batches of races stepping on K HIP streams.  Races do not interact, so a batch can be cut anywhere; what
     the cut buys is OVERLAP: the streams free-run (no join per step), a sub-batch's plant (100 serial Euler sub-steps per vehicle:

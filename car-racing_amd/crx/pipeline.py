@@ -43,7 +43,7 @@ class PlannerSweep:
         self.ws = backend.PlannerWorkspace(self.desc, S * R, device)
         self.sws = backend.SelectWorkspace(self.sdesc, S, device)
         self.exchange = cdist.WinnerExchange(n_total, N, device)
-        self.flag_all = self.best_all = None
+        self.flag_all = self.best_all = self.status_all = None
 
     def solve_local(self):
         """prep -> region QPs -> selection for this rank's scenarios (no communication)."""
@@ -54,9 +54,12 @@ class PlannerSweep:
         be.select_dev(self.sdesc, self.n_veh, self.ws.X.view(S, R, N + 1, 6), self.obs_s, self.obs_ey, self.old_flag, ws=self.sws)
 
     def gather(self):
-        self.flag_all, self.best_all = self.exchange(self.sws.flag, self.sws.best_X)
+        # status of the WINNING region's QP (SURVEY 8e's record carries it: a fall-back winner must be recognisable on every rank)
+        S, R = self.n_local, self.V + 1
+        st = self.ws.status.view(S, R).gather(1, self.sws.flag.long().clamp_(0, R - 1).unsqueeze(1)).squeeze(1)
+        self.flag_all, self.best_all, self.status_all = self.exchange(self.sws.flag, self.sws.best_X, st)
 
     def step(self):
         self.solve_local()
         self.gather()
-        return self.flag_all, self.best_all
+        return self.flag_all, self.best_all, self.status_all

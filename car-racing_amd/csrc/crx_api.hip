@@ -1331,15 +1331,23 @@ int rccl_bind() {
         if (r_ != ncclSuccess) return fail(CRX_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));      \
     } while (0)
 
-// winner record = [flag as double, X (N+1)*6]: 79 doubles = 632 B at N = 12; rows past n_local are zero
-__global__ void __launch_bounds__(256) crx_pack_winners_kernel(int n_local, int n_max, int rec, const int32_t* flag, const double* best_X,
-                                                               double* send) {
+// winner record = {int32 flag; int32 status; double X[N+1][6]}: 8 + 624 = 632 B at N = 12, carried as 1 + 6 (N + 1)
+// 8-byte words (word 0 = the two int32, bit for bit; the collective only moves bytes); rows past n_local are zero
+__global__ void __launch_bounds__(256) crx_pack_winners_kernel(int n_local, int n_max, int rec, const int32_t* flag, const int32_t* status,
+                                                               const double* best_X, double* send) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_max * rec) return;
     const size_t s = i / rec;
     const int c = (int)(i - s * rec);
     double v = 0.0;
-    if (s < (size_t)n_local) v = c == 0 ? (double)flag[s] : best_X[s * (rec - 1) + (c - 1)];
+    if (s < (size_t)n_local) {
+        if (c == 0) {
+            const unsigned long long w = (unsigned long long)(uint32_t)flag[s] | ((unsigned long long)(uint32_t)(status ? status[s] : 0) << 32);
+            v = __longlong_as_double((long long)w);
+        } else {
+            v = best_X[s * (rec - 1) + (c - 1)];
+        }
+    }
     send[i] = v;
 }
 }  // namespace
@@ -1450,8 +1458,8 @@ int crx_comm_destroy(void) {
     return CRX_OK;
 }
 
-int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const double* best_X, double* send, double* recv,
-                              void* stream) {
+int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const int32_t* status, const double* best_X, double* send,
+                              double* recv, void* stream) {
     if (int rc = ensure_init()) return rc;
     if (!g_comm) return fail(CRX_ERR_ARG, "no communicator (crx_comm_init_rank)");
     if (n_local < 0 || n_max < n_local || N < 1 || N > CRX_MAX_N) return fail(CRX_ERR_ARG, "bad sizes (n_local %d, n_max %d, N %d)", n_local, n_max, N);
@@ -1460,7 +1468,7 @@ int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag
     const int rec = 1 + (N + 1) * 6;
     const size_t cnt = (size_t)n_max * rec;
     hipLaunchKernelGGL(crx_pack_winners_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_local, n_max, rec, flag,
-                       best_X, send);
+                       status, best_X, send);
     HIP_TRY(hipGetLastError());
     RCCL_TRY(g_rccl.AllGather(send, recv, cnt, ncclFloat64, g_comm, (hipStream_t)stream));
     return CRX_OK;

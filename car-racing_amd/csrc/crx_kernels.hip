@@ -33,6 +33,9 @@
 #include "crx_kparams.h"
 #include "crx_wave.h"
 
+#ifndef CRX_TU_GENERAL
+#define CRX_TU_GENERAL 0   /* 1: crx_kernels_gen.hip -- the general instantiations, built conservatively (section (7)) */
+#endif
 #ifndef CRX_OPAQUE_LANE
 #define CRX_OPAQUE_LANE 1 /* make EXTRA=-DCRX_OPAQUE_LANE=0: round-2 behaviour (lane maps hoisted out of the interior-point loop) */
 #endif
@@ -1445,8 +1448,14 @@ __device__ __forceinline__ void planner_fallback(double* sm, const crx_kparams& 
 #ifndef CRX_OBS1_WAVES
 #define CRX_OBS1_WAVES 2
 #endif
+#ifndef CRX_KERNEL_EXTRA_ATTR
+#define CRX_KERNEL_EXTRA_ATTR
+#endif
+#ifndef CRX_GEN_WAVES
+#define CRX_GEN_WAVES 0   // > 0: every instantiation of this translation unit is held to that many waves per SIMD (crx_kernels_gen.hip: 2 = 256 registers, no AGPRs)
+#endif
 template <int NOBS, int NMAX> struct MinWaves {
-    static constexpr int v = ((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? CRX_OBS1_WAVES : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1);
+    static constexpr int v = CRX_GEN_WAVES ? CRX_GEN_WAVES : (((NOBS == 1 || (CRX_W2_FLOOR && NOBS == 2)) && NMAX == 12) ? CRX_OBS1_WAVES : ((NOBS == 0 && NMAX == 12) ? CRX_PLANNER_WAVES : 1));
 };
 
 // DEG [r3]: the exponent of the super-ellipse as a compile-time constant (6 = the reference's literal, control.py:528 / :312; 0 = read
@@ -1460,7 +1469,7 @@ template <int NOBS, int NMAX> struct MinWaves {
 template <int NFIX> struct SweepUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_SWEEP_UNROLL ? NFIX : 2); };   // forward / adjoint sweeps
 template <int NOBS, int NFIX> struct RicUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_RIC_UNROLL == 0 ? NFIX : CRX_RIC_UNROLL); };
 template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v)))
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v))) CRX_KERNEL_EXTRA_ATTR
 crx_solve_kernel(const crx_kparams kp) {
     static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = Lay<NOBS, NMAX>;
@@ -2303,6 +2312,12 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
 #endif
     return hipGetLastError();
 }
+// [r5] The GENERAL instantiations (run-time horizon NFIX = 0, run-time exponent DEG = 0, the generic 4..6-obstacle ones) live in a third
+// translation unit, crx_kernels_gen.hip, built conservatively: 256 registers and no AGPRs, no inline-assembly DPP,
+// nothing lane-derived hoisted out of the interior-point loop.  This unit and the obstacle unit only hold the tuned fixed-horizon ones.
+hipError_t crx_launch_solve_general(const crx_kparams& kp, int nobs_template, hipStream_t st);
+int crx_solve_resident_per_cu_general(int N, int nobs_template);
+#if !CRX_TU_GENERAL
 // fixed-horizon instantiations: N = 10 (the reference's defaults: utils/base.py:281, :390), 12 (BASELINE configs[1], [2], [4]), 20 (configs[3])
 template <int NOBS, int NMAX, int DEG>
 static hipError_t launch_h(const crx_kparams& kp, hipStream_t st) {
@@ -2315,18 +2330,17 @@ static hipError_t launch_h(const crx_kparams& kp, hipStream_t st) {
         if (kp.N == 20) return launch_t<NOBS, 20, DEG, 20>(kp, st);
     }
 #endif
-    return launch_t<NOBS, NMAX, DEG, 0>(kp, st);
+    return crx_launch_solve_general(kp, NOBS, st);
 }
-// obstacle instantiations: the degree-6 one for the reference's exponent, the general one for 2 / 4 / 8
+// obstacle instantiations: the degree-6 one for the reference's exponent; other exponents (2 / 4 / 8) take the general unit
 template <int NOBS, int NMAX>
 static hipError_t launch_d(const crx_kparams& kp, hipStream_t st) {
-#if CRX_DEG6
-    if constexpr (NOBS > 0) {
+    if constexpr (NOBS > 0 && CRX_DEG6) {
         if (kp.degree == 6) return launch_h<NOBS, NMAX, 6>(kp, st);
-        return launch_t<NOBS, NMAX, 0, 0>(kp, st);      // other exponents: one general instantiation
+        return crx_launch_solve_general(kp, NOBS, st);
+    } else {
+        return launch_h<NOBS, NMAX, 0>(kp, st);
     }
-#endif
-    return launch_h<NOBS, NMAX, 0>(kp, st);
 }
 
 // horizon classes: 12 and CRX_MAX_N for every obstacle count, plus 20 for the 3-obstacle instantiation
@@ -2337,23 +2351,51 @@ static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
     if constexpr (NOBS == 3) {       // (if constexpr: <3,20> must exist in ONE translation unit only, the obstacle one)
         if (kp.N <= 20) return launch_d<3, 20>(kp, st);
     }
-    return launch_d<NOBS, CRX_MAX_N>(kp, st);
+    return crx_launch_solve_general(kp, NOBS, st);
 }
+#endif  // !CRX_TU_GENERAL
 
 // the obstacle instantiations live in the other translation unit
 hipError_t crx_launch_solve_obs(const crx_kparams& kp, int nobs_template, hipStream_t st);
 int crx_solve_resident_per_cu_obs(int N, int nobs_template);
 
-#ifdef CRX_TU_OBSTACLES
+#if CRX_TU_GENERAL
+// horizon class of a general launch: the smallest layout that holds kp.N
+template <int NOBS, int DEG>
+static hipError_t launch_g(const crx_kparams& kp, hipStream_t st) {
+    if (kp.N <= 12) return launch_t<NOBS, 12, DEG, 0>(kp, st);
+    if constexpr (NOBS == 3) {
+        if (kp.N <= 20) return launch_t<3, 20, DEG, 0>(kp, st);
+    }
+    return launch_t<NOBS, CRX_MAX_N, DEG, 0>(kp, st);
+}
+template <int NOBS>
+static hipError_t launch_gd(const crx_kparams& kp, hipStream_t st) {
+    if constexpr (NOBS > 0 && CRX_DEG6) {
+        if (kp.degree == 6) return launch_g<NOBS, 6>(kp, st);
+    }
+    return launch_g<NOBS, 0>(kp, st);
+}
+hipError_t crx_launch_solve_general(const crx_kparams& kp, int nobs_template, hipStream_t st) {
+    switch (nobs_template) {
+        case 0: return launch_gd<0>(kp, st);
+        case 1: return launch_gd<1>(kp, st);
+        case 2: return launch_gd<2>(kp, st);
+        case 3: return launch_gd<3>(kp, st);
+        // [r4] four to six obstacles (CRX_MAX_OBS = 6: the reference admits any number, control.py:524-562): ONE generic instantiation
+        // per horizon class -- exponent and horizon read at run time, the Riccati update in two passes, the sigma columns of T in
+        // three; the slow path: correct first
+        case 4: case 5: case 6: return kp.N <= 12 ? launch_t<6, 12, 0, 0>(kp, st) : launch_t<6, CRX_MAX_N, 0, 0>(kp, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+#elif defined(CRX_TU_OBSTACLES)
 hipError_t crx_launch_solve_obs(const crx_kparams& kp, int nobs_template, hipStream_t st) {
     switch (nobs_template) {
         case 1: return launch_n<1>(kp, st);
         case 2: return launch_n<2>(kp, st);
         case 3: return launch_n<3>(kp, st);
-        // [r4] four to six obstacles (CRX_MAX_OBS = 6: the reference admits any number, control.py:524-562): ONE generic instantiation
-        // per horizon class -- exponent and horizon read at run time, the Riccati update in two passes, the sigma columns of T in
-        // three; far beyond the register file (the slow path: correct first)
-        case 4: case 5: case 6: return kp.N <= 12 ? launch_t<6, 12, 0, 0>(kp, st) : launch_t<6, CRX_MAX_N, 0, 0>(kp, st);
+        case 4: case 5: case 6: return crx_launch_solve_general(kp, nobs_template, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -2375,7 +2417,7 @@ size_t crx_solve_lds_bytes(int N, int nobs_template) {
     }
 }
 
-#endif  // CRX_TU_OBSTACLES
+#endif  // translation unit
 
 // resident single-wave workgroups per CU of the instantiation that WOULD RUN (N, nobs_template) with the reference's exponent: the
 // runtime's answer, i.e. min over the LDS and the register file, for the same (DEG, NFIX) selection as launch_d / launch_h -- the
@@ -2393,8 +2435,27 @@ static int occ_t() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, WAVE, bytes) != hipSuccess) return -1;
     return n;
 }
+#if CRX_TU_GENERAL
+template <int NOBS>
+static int occ_g(int N) {
+    if (N <= 12) return occ_t<NOBS, 12, 0>();
+    if constexpr (NOBS == 3) {
+        if (N <= 20) return occ_t<3, 20, 0>();
+    }
+    return occ_t<NOBS, CRX_MAX_N, 0>();
+}
+int crx_solve_resident_per_cu_general(int N, int nobs_template) {
+    switch (nobs_template) {
+        case 0: return occ_g<0>(N);
+        case 1: return occ_g<1>(N);
+        case 2: return occ_g<2>(N);
+        case 3: return occ_g<3>(N);
+        default: return N <= 12 ? occ_t<6, 12, 0>() : occ_t<6, CRX_MAX_N, 0>();
+    }
+}
+#else
 template <int NOBS, int NMAX>
-static int occ_h(int N) {
+static int occ_h(int N, int nobs_template) {
 #if CRX_NFIX
     if constexpr (NMAX == 12) {
         if (N == 12) return occ_t<NOBS, 12, 12>();
@@ -2404,23 +2465,25 @@ static int occ_h(int N) {
         if (N == 20) return occ_t<NOBS, 20, 20>();
     }
 #endif
-    return occ_t<NOBS, NMAX, 0>();
+    return crx_solve_resident_per_cu_general(N, nobs_template);
 }
 template <int NOBS>
 static int occ_n(int N) {
-    if (N <= 12) return occ_h<NOBS, 12>(N);
+    if (N <= 12) return occ_h<NOBS, 12>(N, NOBS);
     if constexpr (NOBS == 3) {
-        if (N <= 20) return occ_h<3, 20>(N);
+        if (N <= 20) return occ_h<3, 20>(N, NOBS);
     }
-    return occ_h<NOBS, CRX_MAX_N>(N);
+    return crx_solve_resident_per_cu_general(N, NOBS);
 }
-#ifdef CRX_TU_OBSTACLES
+#endif
+#if CRX_TU_GENERAL
+#elif defined(CRX_TU_OBSTACLES)
 int crx_solve_resident_per_cu_obs(int N, int nobs_template) {
     switch (nobs_template) {
         case 1: return occ_n<1>(N);
         case 2: return occ_n<2>(N);
         case 3: return occ_n<3>(N);
-        default: return N <= 12 ? occ_t<6, 12, 0>() : occ_t<6, CRX_MAX_N, 0>();
+        default: return crx_solve_resident_per_cu_general(N, nobs_template);
     }
 }
 #else

@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
         first_attempt |= out ? 1 : 0;   // uniform: every lane holds the same reduced values
     }
     int status = first_attempt ? CRX_INFEASIBLE : CRX_MAX_ITER, total_it = 0;
+    int proved = first_attempt | bad0;   // CRX_INFEASIBLE is only ever a PROOF (include/crx.h): the screen / a bound the fixed x_0 violates, or the certificate below
     double E0 = HUGE_VAL, f = 0.0;
     for (int attempt = first_attempt; attempt < 2; attempt++) {
         x.el = attempt;
@@ -868,12 +869,15 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
                 tr[14] = mu;
                 tr[15] = al;
             }
-            if (numax > 1e12 && theta > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+            if (numax > 1e12 && theta > 1e-6) { status = CRX_STALLED; it++; break; }   // IPOPT's divergence heuristic: not a proof
         }
         total_it += it;
         SYNC();
         if (attempt == 0 && status == CRX_CONVERGED && !bad0) break;
-        if (attempt == 1 && status == CRX_CONVERGED) status = CRX_INFEASIBLE;   // the reference's (pinned) QP was not solved
+        if (attempt == 0 && status == CRX_INFEASIBLE) proved = 1;
+        // the reference's (pinned) QP was not solved; without a proof of its infeasibility (divergence heuristic, iteration cap, stagnation) the
+        // relaxed plan is reported CRX_STALLED: same plan, no claim about the pinned QP
+        if (attempt == 1 && status == CRX_CONVERGED) status = proved ? CRX_INFEASIBLE : CRX_STALLED;
     }
     // ---- write back: the plan by a roll-out of the model from x_0 (+ w in the second attempt) with the optimal inputs;
     // A, B, C come back from HBM into the K region, the states go through the scratch TB ----

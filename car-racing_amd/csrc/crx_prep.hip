@@ -622,20 +622,27 @@ __global__ void __launch_bounds__(256) crx_game_log_kernel(const crx_game_kparam
 #define CRX_ORDER_KEYS 257
 #define CRX_ORDER_LDS_KEYS 65536
 
+__device__ __forceinline__ bool vx0_finite(const crx_order_kparams& op, int b) {
+    return isfinite(op.x0[(size_t)b * 6]) && isfinite(op.x0[(size_t)b * 6 + 4]) && isfinite(op.x0[(size_t)b * 6 + 5]);
+}
 __device__ __forceinline__ int crx_order_key(const crx_order_kparams& op, int b) {
     if (op.active && op.active[b] == 0) return CRX_ORDER_KEYS - 1;
     if (op.mode == 0) return 255 - min(max(op.iters[b], 0), 255);
-    const int V = op.V, n = min(max(op.n_obs[b], 0), V);
+    const int V = op.V, n = (V > 0 && op.n_obs) ? min(max(op.n_obs[b], 0), V) : 0;   // n_obs may be NULL for an obstacle-free batch (crx_cbf_order_dev)
     const double s = op.x0[(size_t)b * 6 + 4], ey = op.x0[(size_t)b * 6 + 5];
     double hmin = 1e30;
     for (int o = 0; o < n; o++) {
         const size_t r = (size_t)b * V + o;
-        const double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+        double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+        // same fall-back as the solver kernel (crx_kernels.hip set-up): a non-positive or non-finite device-resident entry -> the descriptor's pair
+        if (!(ls > 0.0) || !isfinite(ls)) ls = op.l_sum;
+        if (!(ws > 0.0) || !isfinite(ws)) ws = op.w_sum;
         const double ds = (op.obs_s[r * op.stride] + op.lap_off[r] - s) / ls, de = (op.obs_ey[r * op.stride] - ey) / ws;
         double ps = ds * ds, pe = de * de;
         for (int k = 2; k < op.degree; k += 2) { ps *= ds * ds; pe *= de * de; }
         hmin = fmin(hmin, ps + pe - 1.0 - op.margin);
     }
+    if (!(hmin == hmin) || !(vx0_finite(op, b))) return 0;   // NaN inputs (device-resident data cannot be validated on the host): first, like the deepest crash state
     if (hmin < 0.0) return min(max((int)((hmin + 1.0 + op.margin) * (128.0 / (1.0 + op.margin))), 0), 127);
     const double vx = op.x0[(size_t)b * 6];
     double hp = 1e30;
@@ -644,13 +651,16 @@ __device__ __forceinline__ int crx_order_key(const crx_order_kparams& op, int b)
         const double eyj = op.per_stage_target ? op.xt[((size_t)b * op.stride + j) * 6 + 5] : op.xt[(size_t)b * 6 + 5];
         for (int o = 0; o < n; o++) {
             const size_t r = (size_t)b * V + o;
-            const double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+            double ls = op.obs_dims ? op.obs_dims[r * 2] : op.l_sum, ws = op.obs_dims ? op.obs_dims[r * 2 + 1] : op.w_sum;
+            if (!(ls > 0.0) || !isfinite(ls)) ls = op.l_sum;
+            if (!(ws > 0.0) || !isfinite(ws)) ws = op.w_sum;
             const double ds = (op.obs_s[r * op.stride + j] + op.lap_off[r] - sj) / ls, de = (op.obs_ey[r * op.stride + j] - eyj) / ws;
             double ps = ds * ds, pe = de * de;
             for (int k = 2; k < op.degree; k += 2) { ps *= ds * ds; pe *= de * de; }
             hp = fmin(hp, ps + pe - 1.0 - op.margin);
         }
     }
+    if (!(hp == hp)) return 128;
     if (hp < 0.0) return 128 + min(max((int)((hp + 1.0 + op.margin) * (64.0 / (1.0 + op.margin))), 0), 63);
     const double t = 192.0 + 2.1 * log2(1.0 + hp);         // 255 at hP = 1e9: an obstacle ~30 ellipse lengths off the path
     return t < 255.0 ? (int)t : 255;

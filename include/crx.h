@@ -44,7 +44,10 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 201 /* 0.2.1: same ABI as 0.2.0; the crash path of the MPC-CBF NLPs (crx_ipm_opts.slack_start = 2) takes the crash start's barrier
+#define CRX_VERSION 300 /* 0.3.0: crx_allgather_winners_dev takes the winners' status and the winner record is SURVEY 8e's {int32 flag; int32
+                          status; double X[N+1][6]} (same 632 B at N = 12; 0.2.x: the flag as a double, no status) -- the only signature that
+                          changed; every other entry point and every struct layout is 0.2.x's.
+                          0.2.1: same ABI as 0.2.0; the crash path of the MPC-CBF NLPs (crx_ipm_opts.slack_start = 2) takes the crash start's barrier
                           parameter from its complementarity and keeps the convexified inertia retry between probes -- other iterates, same end
                           points or other KKT points on crash states; every problem off the crash path is bit-identical to 0.2.0.
                           0.2.0: NOT layout-compatible with 0.1.x -- crx_ipm_opts grew by `reach_screen` and `slack_start` (every descriptor
@@ -475,7 +478,10 @@ int crx_track_prep_dev(int N, int V, double lap_length, double safety_time, doub
  *   full-space problem.  On the recorded infeasible instances the cheapest such violation is a ~1e-2
  *   shift of the initial-state equality (:650).  libcrx therefore repeats a failed problem with that
  *   equality relaxed, x_0 = xcurv + w, cost += w_x0 * w'w, terminal constraint kept; X is the plan from
- *   xcurv + w, U its inputs, status CRX_INFEASIBLE.
+ *   xcurv + w, U its inputs, status CRX_INFEASIBLE when the first attempt ended by a PROOF (a bound the fixed x_0 violates,
+ *   the terminal-set reachability screen, the Farkas certificate over input box x unit simplex) and CRX_STALLED when it ended
+ *   without one (multiplier divergence, iteration cap, stagnation on the noise floor, no acceptable step) [0.3.0; <= 0.2.1
+ *   reported both as CRX_INFEASIBLE].  A relaxed attempt that does not converge either keeps its own status (1 / 5).
  */
 int crx_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
                    const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
@@ -662,16 +668,20 @@ int crx_game_log_dev(int batch, int n_points, double lap_length, const double* x
 
 /*
  * Multi-GPU: problems are independent and a planner sweep is sharded by scenario, so the path has
- * exactly ONE exchange step -- an all-gather of the fixed-size winner records {flag, X[N+1][6]} (1 + 6(N+1) doubles =
+ * exactly ONE exchange step -- an all-gather of the fixed-size winner records {int32 flag; int32 status; double X[N+1][6]} (8 + 48 (N + 1) bytes =
  * 632 B at N = 12) -- issued on RCCL (ncclAllGather over xGMI).  One process per GPU.  The caller owns the rendezvous:
  * rank 0 calls crx_comm_get_unique_id and carries the CRX_COMM_ID_BYTES bytes to the other ranks by whatever it has (MPI,
  * a file, torch.distributed's store); every rank then calls crx_comm_init_rank on the device it gave crx_init (collective:
  * returns when all ranks arrived).  RCCL is resolved at run time (a copy the process already holds, e.g. PyTorch's, else
  * /opt/rocm's); libcrx does not link it.
  *   crx_allgather_winners_dev  packs this rank's n_local winners (flag [n_local] int32, best_X [n_local][N+1][6] -- the
- *       outputs of crx_select / crx_planner_plan) into send [n_max][rec] (rows past n_local zero: ragged shards are
- *       padded to the largest, n_max, which every rank derives from (n_total, world) alone) and gathers every rank's
- *       block into recv [world][n_max][rec], in rank order, on `stream`.  rec = 1 + 6 (N + 1), record = [flag, X].
+ *       outputs of crx_select / crx_planner_plan -- and status [n_local] int32, the crx_status of the WINNING region's QP, i.e.
+ *       status[s * n_regions + flag[s]] of crx_planner_solve: a consumer on another rank can tell a fall-back winner,
+ *       overtake_traj_planner.py:365-374, from a solved one; NULL: the field is 0) into send [n_max][rec] (rows past n_local zero:
+ *       ragged shards are padded to the largest, n_max, which every rank derives from (n_total, world) alone) and gathers every
+ *       rank's block into recv [world][n_max][rec], in rank order, on `stream`.  rec = 1 + 6 (N + 1) 8-byte words; word 0 of a record
+ *       holds the two int32 {flag, status} (little endian: flag in the low half), words 1.. the trajectory.  (libcrx <= 0.2.1 carried
+ *       the flag as a double in word 0 and no status; 0.3.0 changed the signature.)
  */
 #define CRX_COMM_ID_BYTES 128
 int crx_comm_get_unique_id(void* id /* [CRX_COMM_ID_BYTES] */);
@@ -679,8 +689,8 @@ int crx_comm_init_rank(const void* id, int world, int rank);
 int crx_comm_world(void);   /* 0 without a communicator */
 int crx_comm_rank(void);    /* -1 without a communicator */
 int crx_comm_destroy(void);
-int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const double* best_X, double* send,
-                              double* recv, void* stream);
+int crx_allgather_winners_dev(int n_local, int n_max, int N, const int32_t* flag, const int32_t* status, const double* best_X,
+                              double* send, double* recv, void* stream);
 
 /* Streams for device-resident loops that overlap independent launches (the two branches of a racing-game step, concurrent
  * sub-batches of races: crx.montecarlo).  Streams only overlap when they sit on different HARDWARE queues; the HIP runtime hands

@@ -579,7 +579,7 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
             w->nu[j] = nn;
             numax = fmax(numax, nn);
         }
-        if (numax > 1e12 && theta > 1e-6) { status = CRX_INFEASIBLE; it++; break; }
+        if (numax > 1e12 && theta > 1e-6) { status = CRX_STALLED; it++; break; }   /* IPOPT's divergence heuristic: not a proof */
     }
     res->status = status;
     res->iters = it;
@@ -630,10 +630,14 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
             else lmpc_ipm(w, &r);
             total = r.iters;
             if (r.status != CRX_CONVERGED || bad0) {
+                /* CRX_INFEASIBLE is only ever a PROOF (include/crx.h): a bound the fixed x_0 violates, the screen, or the certificate inside
+                 * lmpc_ipm.  A first attempt that ended without one (multiplier divergence, iteration cap, stagnation, no acceptable step)
+                 * reports CRX_STALLED after a converged relaxed attempt: same plan, no claim about the pinned QP. */
+                const int proved = screened || bad0 || r.status == CRX_INFEASIBLE;
                 lmpc_setup(w, 1);
                 lmpc_ipm(w, &r);
                 total += r.iters;
-                if (r.status == CRX_CONVERGED) r.status = CRX_INFEASIBLE;   /* the reference's (pinned) QP was not solved */
+                if (r.status == CRX_CONVERGED) r.status = proved ? CRX_INFEASIBLE : CRX_STALLED;   /* the reference's (pinned) QP was not solved */
             }
             double* Xb = X + (size_t)(N + 1) * 6 * b;
             double* Ub = U + (size_t)N * 2 * b;

@@ -70,7 +70,7 @@ bench.init_backend = init_backend
 bench.shutdown_backend = lambda cx, args: None
 bench.SWEEP_BACKEND = sweep_backend
 bench.headline_workload = headline
-bench.kernel_ms_samples = lambda cx, w, reps: [float("nan")]    # no kernel, no time
+bench.kernel_ms_samples = lambda cx, w, reps: (float("nan"), float("nan"))    # no kernel, no time
 bench.occupancy = lambda w: (1, 0)
 bench.sub_configs = lambda cx, args: [("cfg5_weak", lambda: bench.make_sweep(cx, args, "weak"), 2, 1, False),
                                       ("cfg5_strong", lambda: bench.make_sweep(cx, args, "strong"), 2, 1, False)]

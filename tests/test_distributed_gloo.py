@@ -46,6 +46,8 @@ class StubBackend:
         B = x0.shape[0]
         reg = (torch.arange(B) % 4).to(torch.float64)
         ws.X.copy_(x0[:, None, :] + bez_s[:, :, None] / 64.0 + reg[:, None, None])
+        # a per-problem "solver status" (0 converged / 2 proved infeasible = fall-back winner) that depends on the scenario's own data
+        ws.status.copy_((torch.floor(bez_s[:, 0] * 7.0).to(torch.int64) % 3 == 0).to(torch.int32) * 2)
         self.calls.append("solve")
 
     def select_dev(self, desc, n_veh, X, obs_s, obs_ey, old_flag, ws=None):
@@ -80,8 +82,8 @@ def _worker(rank, world, port, n_total, out_dir):
     from crx import synth
 
     A, B = synth.load_AB()
-    fa, Xa = _sweep(synth.cfg3_raw(n_total, N=12, seed=5), A, B, rank, world)
-    torch.save((fa.clone(), Xa.clone()), os.path.join(out_dir, "rank%d.pt" % rank))
+    fa, Xa, sa = _sweep(synth.cfg3_raw(n_total, N=12, seed=5), A, B, rank, world)
+    torch.save((fa.clone(), Xa.clone(), sa.clone()), os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -93,12 +95,31 @@ def test_two_rank_planner_sweep(tmp_path, n_total):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
     A, B = synth.load_AB()
-    f_ref, X_ref = _sweep(synth.cfg3_raw(n_total, N=12, seed=5), A, B, 0, 1)   # single process, no process group
-    assert f_ref.shape == (n_total,) and X_ref.shape == (n_total, 13, 6)
+    f_ref, X_ref, s_ref = _sweep(synth.cfg3_raw(n_total, N=12, seed=5), A, B, 0, 1)   # single process, no process group
+    assert f_ref.shape == (n_total,) and X_ref.shape == (n_total, 13, 6) and s_ref.shape == (n_total,)
+    assert s_ref.dtype == torch.int32 and set(s_ref.tolist()) <= {0, 2} and len(set(s_ref.tolist())) == 2   # both verdicts occur among the winners
     for r in range(world):
-        fa, Xa = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        fa, Xa, sa = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         assert torch.equal(fa, f_ref)
         assert torch.equal(Xa, X_ref)
+        assert torch.equal(sa, s_ref)            # the record carries the winner's status
+
+
+def test_winner_record_is_survey_8e_layout():
+    """{int32 flag; int32 status; double X[N+1][6]}: 632 B at N = 12, word 0 = the two int32 bit for bit."""
+    from crx import dist as cd
+
+    ex = cd.WinnerExchange(5, 12, torch.device("cpu"))
+    assert ex.rec * 8 == 632
+    flag = torch.tensor([3, 0, 1, 2, 3], dtype=torch.int32)
+    st = torch.tensor([0, 2, 0, 5, 3], dtype=torch.int32)
+    X = torch.randn((5, 13, 6), dtype=torch.float64)
+    f2, X2, s2 = ex(flag, X, st)
+    assert torch.equal(f2, flag) and torch.equal(X2, X) and torch.equal(s2, st)
+    raw = ex.send.numpy().view(np.int32).reshape(5, -1)
+    assert np.array_equal(raw[:, 0], flag.numpy()) and np.array_equal(raw[:, 1], st.numpy())
+    f3, _, s3 = ex(flag, X)                      # no status given: the field is 0
+    assert torch.equal(f3, flag) and not s3.any()
 
 
 def test_shard_bounds_cover_everything():

@@ -688,6 +688,60 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
 
 
+@pytest.mark.parametrize("N", [7, 16, 24])
+def test_general_horizons_against_oracle(gpu, orc, AB, N):
+    """The GENERAL instantiations (run-time horizon: every N other than 10 / 12 / 20; csrc/crx_kernels_gen.hip, the conservative
+    translation unit) at batch 256 for 0 .. 3 obstacle slots and the generic 4..6-obstacle instantiation: kernel vs oracle on status,
+    iteration count, X, U AND sigma (the A/B builds that computed wrong numbers in round 4 were general instantiations,
+    and one of them returned a scrambled X with every other output intact).  restore_iters = -1 first (exact status / iteration
+    parity is defined without the restoration phase), then the product defaults (crash path on): same verdict classes."""
+    from crx import abi, synth
+
+    A, B = AB
+    Bn = 256
+    total = 0
+    for V in (0, 1, 2, 3, 5):
+        if V == 0:
+            p = synth.cfg2_mpccbf(Bn, N=N, seed=500 + N, n_obs=1)
+            d = abi.cbf_desc(N, 0, A, B)
+            args = (p["x0"], p["xt"], np.zeros((Bn, 0, N + 1)), np.zeros((Bn, 0, N + 1)), np.zeros((Bn, 0)), np.zeros(Bn, np.int32))
+        else:
+            per_stage = V >= 2
+            p = synth.cfg4_tracking_cbf(Bn, N=N, seed=500 + N + V, n_obs=V) if per_stage else synth.cfg2_mpccbf(Bn, N=N, seed=500 + N + V, n_obs=V)
+            d = abi.cbf_desc(N, V, A, B, alpha=p.get("alpha", 0.6) if not per_stage else 0.6, margin=p.get("margin", 0.15) if not per_stage else 0.15,
+                             per_stage_target=per_stage, **({"Q": (10.0, 0, 0, 5.0, 0, 50.0)} if per_stage else {}))
+            n = np.random.default_rng(N * 10 + V).integers(0, V + 1, Bn).astype(np.int32)
+            n[: Bn // 2] = V                                   # half the batch with every slot in use
+            args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], n)
+        for restore in (-1, None):
+            if restore is not None:
+                d.opts.restore_iters = restore
+            else:
+                d.opts.restore_iters = abi.cbf_desc(N, max(V, 0), A, B).opts.restore_iters
+            rg, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+            tag = "general N=%d V=%d restore_iters=%d" % (N, V, d.opts.restore_iters)
+            if restore == -1:
+                c = _assert_same_verdicts(tag, rg, ro, max_tol_edge=6, max_other=2)
+            else:
+                # the crash path: only the class of the outcome is comparable on the problems that took it (see _classify)
+                crashy = frozenset(np.nonzero((rg["status"] != ro["status"]) | (rg["iters"] != ro["iters"]))[0].tolist())
+                c = _assert_same_verdicts(tag, rg, ro, restored=crashy, max_restored_verdict=max(2, Bn // 50))
+                assert len(crashy) <= Bn // 8, (tag, len(crashy))
+            both = (rg["status"] == 0) & (ro["status"] == 0)
+            same_it = both & (np.abs(rg["iters"] - ro["iters"]) <= 2)
+            assert same_it.sum() >= (0.6 if V else 0.5) * Bn, (tag, int(both.sum()), int(same_it.sum()))
+            dX = np.abs(rg["X"][same_it] - ro["X"][same_it])
+            assert dX[..., [0, 4, 5]].max() <= XW and dX.max() <= XALL, (tag, dX.max())
+            assert np.abs(rg["U"][same_it] - ro["U"][same_it]).max() <= UALL, tag
+            if V:
+                sg, so = rg["sigma"][same_it], ro["sigma"][same_it]
+                assert np.abs(sg - so).max() <= 1e-5 * max(1.0, np.abs(so).max()), (tag, np.abs(sg - so).max())
+            rel = np.abs(rg["cost"][same_it] - ro["cost"][same_it]) / np.maximum(1.0, np.abs(ro["cost"][same_it]))
+            assert rel.max() <= FREL, (tag, rel.max())
+            total += int(same_it.sum())
+    assert total >= 1500
+
+
 def test_path_planner_qps(gpu, orc):
     """crx_path_solve (overtake PATH planner, overtake_path_planner.py:199-318) vs the oracle: random references and
     boxes incl. one-sided / missing bounds, active side rows, infeasible boxes and end points, every horizon."""
@@ -784,7 +838,7 @@ def test_cfg5_shard_full_size(gpu, orc, AB):
     raw = synth.cfg3_raw(S, N=N, seed=5)
     dev = torch.device("cuda", 0)
     sw = pipeline.PlannerSweep(raw, A, B, S, dev)
-    flag, best = sw.step()
+    flag, best, _ = sw.step()
     torch.cuda.synchronize()
     out = {k: getattr(sw.ws, k).cpu().numpy() for k in ("X", "U", "status", "iters", "kkt", "cost")}
     flag, best = flag.cpu().numpy().copy(), best.cpu().numpy().copy()
@@ -802,15 +856,17 @@ def test_cfg5_shard_full_size(gpu, orc, AB):
     Xs = out["X"].reshape(S, R, N + 1, 6)
     np.testing.assert_array_equal(best, Xs[np.arange(S), flag])
     # bit-identical rerun
-    f2, b2 = sw.step()
+    f2, b2, s2 = sw.step()
     torch.cuda.synchronize()
     np.testing.assert_array_equal(f2.cpu().numpy(), flag)
     np.testing.assert_array_equal(b2.cpu().numpy(), best)
+    # the winner record carries the status of the winning region's QP
+    np.testing.assert_array_equal(s2.cpu().numpy(), out["status"].reshape(S, R)[np.arange(S), flag])
     np.testing.assert_array_equal(sw.ws.iters.cpu().numpy(), out["iters"])
     # permutation invariance: scenarios are independent
     perm = np.random.default_rng(1).permutation(S)
     rawp = {k: (v[perm] if isinstance(v, np.ndarray) and v.ndim and v.shape[0] == S else v) for k, v in raw.items()}
-    fp, bp = pipeline.PlannerSweep(rawp, A, B, S, dev).step()
+    fp, bp, _ = pipeline.PlannerSweep(rawp, A, B, S, dev).step()
     torch.cuda.synchronize()
     np.testing.assert_array_equal(fp.cpu().numpy(), flag[perm])
     np.testing.assert_array_equal(bp.cpu().numpy(), best[perm])
@@ -1148,6 +1204,21 @@ def test_dispatch_order_is_bit_identical(gpu, golden_racing_game, AB):
     assert sorted(opb.tolist()) == list(range(3000 * rep))
     small = torch_api.cbf_order_dev(d, *[x[:60000].contiguous() for x in big]).cpu().numpy()      # cached path, same key code
     np.testing.assert_array_equal(small, opb[opb < 60000])
+    # an obstacle-free batch through the C ABI with n_obs == NULL (include/crx.h admits it; ADVICE r4: the key kernel used to read it) and
+    # device-resident dimensions that are garbage (zero / negative / NaN: the key falls back to the descriptor's pair like the solver does)
+    import ctypes as C
+
+    import crx
+    from crx.torch_api import _ptr, _stream
+    d0 = abi.cbf_desc(12, 0, A, B)
+    o0 = torch.full((512,), -1, dtype=torch.int32, device=dev)
+    x00, xt0 = a[0][:512].contiguous(), a[1][:512].contiguous()
+    assert crx.lib().crx_cbf_order_dev(C.byref(d0), C.c_int(512), None, _ptr(x00), _ptr(xt0), None, None, None, None, None, _ptr(o0), _stream()) == 0, crx.lib().crx_last_error()
+    torch.cuda.synchronize()
+    assert sorted(o0.cpu().tolist()) == list(range(512))
+    dims = torch.tensor([0.0, -1.0], dtype=torch.float64, device=dev).repeat(3000, d.n_obs_max, 1).contiguous()
+    dims[::7, :, 0] = float("nan")
+    np.testing.assert_array_equal(torch_api.cbf_order_dev(d, *a, obs_dims=dims).cpu().numpy(), op)
     # learning-MPC QP
     dl, al = helpers.lmpc_inputs(golden_racing_game)
     n = al[0].shape[0]
@@ -1410,17 +1481,23 @@ def test_allgather_winners_c_abi_one_rank(gpu):
     X = torch.randn((n, N + 1, 6), dtype=torch.float64, device=dev)
     send = torch.full((n_max, rec), 7.0, dtype=torch.float64, device=dev)
     recv = torch.full((n_max, rec), -1.0, dtype=torch.float64, device=dev)
-    assert L.crx_allgather_winners_dev(C.c_int(n), C.c_int(n_max), C.c_int(N), _ptr(flag), _ptr(X), _ptr(send), _ptr(recv), _stream()) == 0, L.crx_last_error()
+    status = (torch.arange(n, dtype=torch.int32, device=dev) * 7) % 6                 # every crx_status value
+    assert L.crx_allgather_winners_dev(C.c_int(n), C.c_int(n_max), C.c_int(N), _ptr(flag), _ptr(status), _ptr(X), _ptr(send), _ptr(recv), _stream()) == 0, L.crx_last_error()
     torch.cuda.synchronize()
-    assert torch.equal(recv[:n, 0], flag.to(torch.float64)) and torch.equal(recv[:n, 1:], X.reshape(n, -1))
+    head = recv[:, :1].contiguous().view(torch.int32)                                  # {int32 flag; int32 status; double X[N+1][6]}
+    assert torch.equal(head[:n, 0], flag) and torch.equal(head[:n, 1], status) and torch.equal(recv[:n, 1:], X.reshape(n, -1))
     assert (recv[n:] == 0).all()
+    assert L.crx_allgather_winners_dev(C.c_int(n), C.c_int(n_max), C.c_int(N), _ptr(flag), None, _ptr(X), _ptr(send), _ptr(recv), _stream()) == 0   # NULL status: field 0
+    torch.cuda.synchronize()
+    head = recv[:, :1].contiguous().view(torch.int32)
+    assert torch.equal(head[:n, 0], flag) and not head[:, 1].any()
     # the product path that uses it (crx.dist.WinnerExchange with COLLECTIVE = "crx")
     cdist.COLLECTIVE, cdist.FORCE_COLLECTIVE = "crx", True
     try:
         ex = cdist.WinnerExchange(n, N, dev)
-        f2, X2 = ex(flag, X)
+        f2, X2, s2 = ex(flag, X, status)
         torch.cuda.synchronize()
-        assert torch.equal(f2, flag) and torch.equal(X2, X)
+        assert torch.equal(f2, flag) and torch.equal(X2, X) and torch.equal(s2, status)
     finally:
         cdist.COLLECTIVE, cdist.FORCE_COLLECTIVE = "torch", False
         cdist.CrxComm.destroy()

@@ -1,11 +1,12 @@
 """Registers, scratch and occupancy of the solver kernels, from the compiler's own remarks (no GPU needed):
-    python tools/kernel_resources.py [obs|plan|lmpc]     (recompiles the translation unit with -Rpass-analysis=kernel-resource-usage)"""
+    python tools/kernel_resources.py [obs|plan|gen|lmpc]     (recompiles the translation unit with -Rpass-analysis=kernel-resource-usage)"""
 import os, re, subprocess, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 S = os.path.join(ROOT, "car-racing_amd", "csrc")
 which = sys.argv[1] if len(sys.argv) > 1 else "obs"
 src, sched = {"one": (None, None), "obs": ("crx_kernels_obs.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
               "plan": ("crx_kernels.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+              "gen": ("crx_kernels_gen.hip", ["-mllvm", "-disable-machine-licm"]),
               "lmpc": ("crx_lmpc.hip", [])}[which]
 extra = sys.argv[2:]
 if which == "one":   # python tools/kernel_resources.py one NOBS NMAX DEG NFIX [flags]
