@@ -25,13 +25,23 @@ __device__ __forceinline__ double wrap_below(double s, double L) {   // `while (
 }
 // Every kernel that uses SYNC() runs ONE wavefront per workgroup.  Lanes of a wave execute in lockstep and the LDS
 // unit serves a wave's operations in issue order, so cross-lane exchange through LDS needs no s_barrier and no
-// s_waitcnt -- only that the compiler keeps the program order of the LDS accesses.  A wavefront-scope fence is
-// exactly that (LLVM's AMDGPU memory model emits no instruction for it); measured against __syncthreads():
-// identical results, fewer stall cycles.  CRX_SYNC_BARRIER restores the barrier for A/B runs.
-#ifdef CRX_SYNC_BARRIER
+// s_waitcnt in the HARDWARE -- only that the COMPILER keeps the program order of the LDS accesses around the exchange point.
+// SYNC() = wavefront-scope fence + llvm.amdgcn.wave.barrier: neither emits an instruction; the fence orders the accesses for the IR
+// optimisers, the wave barrier is the scheduling barrier that the machine scheduler may move NOTHING across.
+// [r5] Up to libcrx 0.2.1 SYNC() was the fence alone, and that is not enough: to the compiler the lanes are independent threads, so
+// two LDS accesses of "one thread" to provably different addresses (store ga[lane], load Jc[(lane / 12) ...]) are reorderable, and
+// with alias analysis in codegen the machine scheduler did reorder across a fence in one A/B build of round 4 (DESIGN.md section 8,
+// observation (1): run-time-horizon instantiation <2,24,6,0>, iterative-ilp strategy -- the first 64 entries of the Lagrangian
+// gradient reached the adjoint sweep stale; -amdgpu-use-aa-in-codegen=0, -enable-misched=0, the default strategy and this wave barrier
+// each make that build pass, tools/bughunt_*.sh).  Measured: the barrier costs nothing (cfg2 0.471 -> 0.473 ms, cfg4 11.38 -> 11.41 ms,
+// cfg3 0.275 -> 0.276 ms; the phases are LDS round trips the scheduler could not overlap anyway).
+// CRX_SYNC_FENCE_ONLY restores the old definition for A/B runs, CRX_SYNC_BARRIER a real s_barrier.
+#if defined(CRX_SYNC_BARRIER)
 #define SYNC() __syncthreads()
-#else
+#elif defined(CRX_SYNC_FENCE_ONLY)
 #define SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#else
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ ILP="-mllvm -amdgpu-sched-strategy=iterative-ilp"
 one() {  # name srcdir flags...
   n=$1; d=$2; shift 2
   /opt/rocm/bin/hipcc $FL "$@" -c $d/crx_kernels_obs.hip -o $B/obs_$n.o &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ab/libcrx_bug_$n.so $S/crx_kernels.o $B/obs_$n.o $S/crx_lmpc.o $S/crx_prep.o $S/crx_lmpcprep.o $S/crx_api.o && echo built bug_$n
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ab/libcrx_bug_$n.so $S/crx_kernels.o $B/obs_$n.o $B/gen_stub.o $S/crx_lmpc.o $S/crx_prep.o $S/crx_lmpcprep.o $S/crx_api.o && echo built bug_$n
 }
 one base $B $ILP &
 one nossc $B $ILP -mllvm -disable-ssc &

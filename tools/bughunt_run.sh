@@ -3,7 +3,7 @@
 # a variant FAILS when its iteration counts / statuses leave the oracle's.  Output: gpurun_out/TAG/bughunt.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=$R/gpurun_out/${1:-bughunt}; mkdir -p $O
 make -C oracle -s
-for so in tools/ab/libcrx_bug_*.so; do
+for so in tools/ab/libcrx_bug_${2:-*}.so; do
   n=$(basename $so .so); n=${n#libcrx_bug_}
   CRX_LIB=$R/$so timeout 120 python tools/fuzz_ab.py 9 bug_$n > /dev/null 2>&1
   python - "$n" <<'PY'

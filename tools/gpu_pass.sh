@@ -12,6 +12,7 @@
 #   lines     one line per workload (bench.py --workload ...), for A/B-ing; CRX_LIB selects another build
 #   ab:NAME   the `lines` step with CRX_LIB=tools/ab/libcrx_NAME.so (tools/build_variant.sh NAME "FLAGS" beforehand, in the build container)
 #   suite:NAME the GPU parity suite on tools/ab/libcrx_NAME.so
+#   gen:NAME   the tests that run the GENERAL instantiations (descriptor fuzz, non-tuned horizons, 4..6 obstacles) on tools/ab/libcrx_NAME.so
 #   bits:NAME  bit-for-bit comparison of the in-tree library with tools/ab/libcrx_NAME.so on the solver draws and closed loops (tools/cbf_ab.py)
 #   quick, quick:NAME  the four solver workloads of `lines` only (in-tree library / tools/ab/libcrx_NAME.so)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -60,6 +61,10 @@ suite:*)
   n=${step#suite:}
   ( CRX_LIB=$R/tools/ab/libcrx_$n.so timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -v "^  File\|^Extension\|^$" | tail -30 ) > $O/pytest_$n.log
   echo "$n: $(grep -h 'passed\|failed' $O/pytest_$n.log | tail -1)" ;;
+gen:*)   # the general-instantiation tests (descriptor fuzz, non-tuned horizons at batch 256, 4..6 obstacles) on tools/ab/libcrx_NAME.so
+  n=${step#gen:}
+  ( CRX_LIB=$R/tools/ab/libcrx_$n.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "fuzz_descriptors or general_horizons or many_obstacles or no_stale_lds" 2>&1 | grep -v "^  File\|^Extension\|^$" | tail -30 ) > $O/pytest_gen_$n.log
+  echo "$n: $(grep -h 'passed\|failed' $O/pytest_gen_$n.log | tail -1)" ;;
 bench)
   python bench.py --full-out $O/bench_full.json > $O/bench.json 2> $O/bench.err
   wc -c $O/bench.json; cat $O/bench.json ;;

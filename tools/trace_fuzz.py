@@ -32,7 +32,11 @@ L.crx_trace_enable(0, 64)
 r = gpu.cbf_solve(d, *one)
 buf = np.zeros((64, 16)); L.crx_trace_read(buf.ctypes.data_as(C.c_void_p), 64)
 L.crx_trace_enable(0, 0)
+if os.environ.get("CRX_TRACE_DUMP"):   # rows 32..63: whatever an instrumented build left there (tools/ab/bugsrc/dump)
+    np.save(os.environ["CRX_TRACE_DUMP"], buf)
 print("trial %d problem %d N %d V %d n_obs %d: iters %d status %d kkt %.3e" % (T, I, N, V, int(one[5][0]), int(r["iters"][0]), int(r["status"][0]), float(r["kkt"][0])))
 print("  X", np.array2string(np.asarray(r["X"])[0].ravel()[:24], precision=17), "\n  U", np.array2string(np.asarray(r["U"])[0].ravel()[:8], precision=17), "\n  sumX %.17e sumU %.17e" % (np.asarray(r["X"]).sum(), np.asarray(r["U"]).sum()))
 for i in range(min(int(r["iters"][0]) + 1, 64)):
     print("  %2d e_d %.17e e_p %.17e e_c %.6e mu %.3e al %.17e a_d %.6e dw %.1e acc %d" % ((i,) + tuple(buf[i, :7]) + (int(buf[i, 7]),)))
+    if os.environ.get("CRX_TRACE_COLS"):   # columns 8..15: phase clocks of a -DCRX_PHASE_CLOCKS build, or whatever an instrumented build put there
+        print("       " + " ".join("%.17e" % v for v in buf[i, 8:16]))

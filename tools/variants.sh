@@ -1,28 +1,24 @@
 #!/bin/bash
-# The A/B builds of the solver kernels whose code generation differs most (a semantically neutral barrier once produced a
-# faulting kernel; DESIGN.md section 8: a build of an intermediate source state computed one wrong number): every variant must pass the
-# parity suite.  Run in the build container, then on the GPU box
-#     gpurun -- 'bash tools/gpu_pass.sh TAG suite:slim0 suite:nfix0 suite:deg0 suite:opaque0 suite:opaqueall suite:opaqueall_slim0 \
-#                suite:nodpp suite:nomask suite:local3 suite:local0 bits:olddiet'
-# [r4b] olddiet = every step of the instruction diet off (dynamic LDS, looped sweeps, v_readlane broadcasts, unmasked sweeps): the pre-diet
-# kernel from today's source, the reference of the bit-for-bit comparison; nodpp / nomask / local3 / local0 = one step off, or the lane
-# barrier in both / in neither sweep.  (olddiet itself is NOT a suite target any more: built from the final source its general
-# instantiation <1,24,6,0> writes a scrambled X while status, iterations, cost and U equal the shipped build's bit for bit -- the second
-# of the two observations in DESIGN.md section 8; -DCRX_STATIC_LDS=0, -DCRX_ROWDPP=0 -DCRX_SWEEP_MASK=0 and any two of the three pass.)
+# A/B builds of the solver kernels whose code generation differs most; every variant must pass the parity tests on the GPU
+# (ADVICE r3 / VERDICT r4 item 1: two A/B builds of round 4 computed wrong numbers -- DESIGN.md section 8).  Run in the build container, then
+#     gpurun -- 'bash tools/gpu_pass.sh TAG gen:g000 gen:g001 ... gen:g111 suite:fenceonly suite:slim0 suite:nfix0 suite:opaqueall suite:nodpp'
+# [r5] The GENERAL instantiations (csrc/crx_kernels_gen.hip: run-time horizon / exponent, 4..6 obstacles) over the full 2^3 matrix of the
+# three flags whose combination failed in round 4: gSDM with S = static LDS (+ no register floor: the AGPR-parking build), D = inline-assembly
+# DPP dot products, M = masked sweeps (the shipped unit is g001: dynamic LDS + 256 registers, v_readlane, masked sweeps).
+# Tuned units: fenceonly = SYNC() as up to 0.2.1 (fence without the wave barrier), slim0 / nfix0 / opaqueall / nodpp as in round 4.
 cd "$(dirname "$0")/.."
-rm -rf tools/ab/*/ tools/ab/*.so
-bash tools/build_variant.sh slim0 "-DCRX_SLIM=0" crx_kernels_obs.hip &
-bash tools/build_variant.sh nfix0 "-DCRX_NFIX=0" &
-bash tools/build_variant.sh deg0 "-DCRX_DEG6=0" crx_kernels_obs.hip &
-bash tools/build_variant.sh olddiet "-DCRX_STATIC_LDS=0 -DCRX_RIC_UNROLL=1 -DCRX_SWEEP_UNROLL=0 -DCRX_ROWDPP=0 -DCRX_SWEEP_MASK=0" crx_kernels.hip crx_kernels_obs.hip crx_lmpc.hip &
+rm -rf tools/ab/g[01][01][01] tools/ab/libcrx_g[01][01][01].so
+for S in 0 1; do for D in 0 1; do
+  for M in 0 1; do
+    W=2; [ $S = 1 ] && W=0
+    bash tools/build_variant.sh g$S$D$M "-DCRX_STATIC_LDS=$S -DCRX_GEN_WAVES=$W -DCRX_ROWDPP=$D -DCRX_SWEEP_MASK=$M" crx_kernels_gen.hip > /dev/null &
+  done; wait
+done; done
+bash tools/build_variant.sh fenceonly "-DCRX_SYNC_FENCE_ONLY" crx_kernels.hip crx_kernels_obs.hip crx_kernels_gen.hip crx_lmpc.hip crx_prep.hip crx_lmpcprep.hip > /dev/null &
+bash tools/build_variant.sh slim0 "-DCRX_SLIM=0" crx_kernels_obs.hip > /dev/null &
 wait
-bash tools/build_variant.sh opaque0 "-DCRX_OPAQUE_LANE=0" crx_kernels.hip &
-bash tools/build_variant.sh opaqueall "-DCRX_OPAQUE_LANE=2" crx_kernels_obs.hip &
-bash tools/build_variant.sh opaqueall_slim0 "-DCRX_OPAQUE_LANE=2 -DCRX_SLIM=0" crx_kernels_obs.hip &
-bash tools/build_variant.sh nodpp "-DCRX_ROWDPP=0" &
-wait
-bash tools/build_variant.sh nomask "-DCRX_SWEEP_MASK=0" &
-bash tools/build_variant.sh local3 "-DCRX_SWEEP_LOCAL_LANE=3" crx_kernels_obs.hip &
-bash tools/build_variant.sh local0 "-DCRX_SWEEP_LOCAL_LANE=0" crx_kernels_obs.hip &
+bash tools/build_variant.sh nfix0 "-DCRX_NFIX=0" crx_kernels.hip crx_kernels_obs.hip > /dev/null &
+bash tools/build_variant.sh opaqueall "-DCRX_OPAQUE_LANE=2" crx_kernels_obs.hip > /dev/null &
+bash tools/build_variant.sh nodpp "-DCRX_ROWDPP=0" crx_kernels.hip crx_kernels_obs.hip > /dev/null &
 wait
 ls -la tools/ab/*.so
