@@ -577,8 +577,91 @@ def _planner_case_with_probes(x0, cars, **kw):
 
 mg.planner_case = _planner_case_with_probes
 
+def gen_game(states_npz=os.path.join(REPO, "gpurun_out", "game_states.npz")):
+    """the learning-MPC QPs of the BENCHED closed loop (bench.py `game`: LmpcLaps from the reference's recorded safe set,
+    perturbed starts) as the REFERENCE builds them.  tools/game_states.py dumped the loop's state in front of control steps 0 / 20 / 40 / 60 / 80
+    of 32 races (GPU box); here every such state goes through the reference's own, unmodified LMPCRacingGame.estimate_ABC (utils/base.py:585-622
+    -> control/lmpc_helper.py regression) and control.lmpc (control/control.py:610-730: safe-set selection + the QP) under the recording CasADi
+    stand-in, and HiGHS decides whether the recorded QP has a feasible point (make_golden.golden_solver: linprog on the reference's own rows).
+    Fixture tests/golden/game_draw.npz: per instance the reference-built problem data (x, u_old, A, B, C, selected safe-set points, cost-to-go),
+    HiGHS's verdict, the certified solution where there is one, and what the device had made of the same state (status; deviation of its stage
+    models / safe-set selection from the reference's)."""
+    from control import lmpc_helper
+
+    st = np.load(states_npz)
+    phases = [int(p) for p in st["phases"]]
+    track = mg.make_track(1.0)
+    timestep, laps, N = 0.1, 4, 12
+    ego = offboard.DynamicBicycleModel(name="ego", param=base.CarParam(edgecolor="black"), system_param=base.SystemParam())
+    ego.set_timestep(timestep); ego.set_track(track)
+    lmpc_param = base.LMPCRacingParam(timestep=timestep, lap_number=laps, time_lmpc=10000 * timestep)
+    game_param = base.RacingGameParam(timestep=timestep, alpha=0.8, num_horizon_planner=10)
+    ctrl = offboard.LMPCRacingGame(lmpc_param, racing_game_param=game_param, system_param=ego.system_param)
+    ctrl.set_track(track); ctrl.set_timestep(timestep)
+    ctrl.openloop_prediction = lmpc_helper.LMPCPrediction(lap_number=laps)
+    P = ctrl.ss_xcurv.shape[0]
+    rows = []
+    mg.ELASTIC_ON_INFEASIBLE[0] = 0.0
+    for ph in phases:
+        g = {k.split("/", 1)[1]: st[k] for k in st.files if k.startswith("p%d/" % ph)}
+        Bn = g["x"].shape[0]
+        for b in range(Bn):
+            Pd = g["ss"].shape[2]
+            ctrl.ss_xcurv = 10000 * np.ones((P, 6, laps)); ctrl.u_ss = 10000 * np.ones((P, 2, laps)); ctrl.Qfun = np.zeros((P, laps))
+            ctrl.ss_xcurv[:Pd] = g["ss"][b].transpose(1, 2, 0); ctrl.u_ss[:Pd] = g["us"][b].transpose(1, 2, 0); ctrl.Qfun[:Pd] = g["qf"][b].T
+            ctrl.time_ss = g["time_ss"][b].astype(int).copy(); ctrl.iter = int(g["it"][b])
+            ctrl.lin_points, ctrl.lin_input = g["lin_points"][b].copy(), g["lin_input"][b].copy()
+            x = g["x"][b].copy()
+            ctrl.x = x.copy()
+            Atv, Btv, Ctv, _ = ctrl.estimate_ABC()                      # the reference's regression + linearisation
+            while x[4] > track.lap_length:
+                x[4] -= track.lap_length
+            u_old = g["u_old"][b].copy() if ph > 0 else np.zeros((1, 2))
+            del mg.RECORDS[:]
+            out = control.lmpc(x, lmpc_param, Atv, Btv, Ctv, ctrl.ss_xcurv, ctrl.Qfun, ctrl.iter, track.lap_length, track.width, u_old, ego.system_param)
+            opti, z, info = mg.RECORDS[-1]
+            lp, lp_how, viol = int(info.get("lp_status", -1)), "highs", np.nan
+            if lp not in (0, 2):
+                # HiGHS gave no verdict (status 4: numerical difficulties -- the regression's stage models span eight orders of magnitude):
+                # decide by the PHASE-1 problem on the same rows, min sum(s+ + s-) s.t. Je z + ce = s+ - s-, Ji z + ci >= 0, with the dual
+                # simplex and with the interior-point method; infeasible iff the least equality violation is positive (> 1e-7 of the row scale)
+                from scipy.optimize import linprog
+                n = opti.nvar
+                f0, g0, ce0, Je0, ci0, Ji0 = opti.eval_all(np.zeros(n))
+                me = Je0.shape[0]
+                rs = np.maximum(1.0, np.abs(Je0).max(axis=1))
+                Aeq = np.hstack([Je0 / rs[:, None], -np.eye(me), np.eye(me)])
+                cost = np.concatenate([np.zeros(n), np.ones(2 * me)])
+                Aub = np.hstack([-Ji0, np.zeros((Ji0.shape[0], 2 * me))])
+                res = []
+                for meth in ("highs-ds", "highs-ipm"):
+                    r1 = linprog(cost, A_ub=Aub, b_ub=ci0, A_eq=Aeq, b_eq=-ce0 / rs, bounds=[(None, None)] * n + [(0, None)] * (2 * me), method=meth)
+                    if r1.status == 0:
+                        res.append(float(r1.fun))
+                if res:
+                    viol = min(res)
+                    lp, lp_how = (2 if viol > 1e-7 else 0), "phase-1 (dual simplex / ipm), least violation %.2e" % viol
+            A, Bm, C = np.array(Atv, float), np.array(Btv, float), np.array(Ctv, float).reshape(N, 6)
+            dA = max(np.abs(A.reshape(N, 36) - g["A"][b]).max(), np.abs(Bm.reshape(N, 12) - g["B"][b]).max(), np.abs(C - g["C"][b]).max())
+            rows.append(dict(phase=ph, race=b, x=x, u_old=np.array(u_old, float).reshape(2), A=A, B=Bm, C=C, ss=np.array(out[2], float),
+                             qfun=np.array(out[3], float), lp_status=lp, lp_status_highs=int(info.get("lp_status", -1)), lp_violation=float(viol), success=bool(info["success"]),
+                             U=np.array(out[0], float), X=np.array(out[1], float), dev_status=int(g["status"][b]), dev_iters=int(g["iters"][b]),
+                             dev_model_dev=float(dA), dev_ss_equal=bool(np.array_equal(np.array(out[2], float), g["ss_sel"][b])),
+                             dev_q_equal=bool(np.array_equal(np.array(out[3], float), g["q_sel"][b]))))
+        r_ph = [r for r in rows if r["phase"] == ph]
+        hi = np.array([r["lp_status"] == 2 for r in r_ph]); dv = np.array([r["dev_status"] != 0 for r in r_ph])
+        print("phase %3d: HiGHS infeasible %2d / %d, device non-converged %2d, verdicts equal %2d, stage models within %.1e, safe-set selection equal %d / %d" % (
+            ph, hi.sum(), len(r_ph), dv.sum(), (hi == dv).sum(), max(r["dev_model_dev"] for r in r_ph), sum(r["dev_ss_equal"] for r in r_ph), len(r_ph)), flush=True)
+    out = {k: np.array([r[k] for r in rows]) for k in rows[0]}
+    np.savez_compressed(os.path.join(mg.OUT, "game_draw.npz"), **out)
+    print("game_draw.npz: %d instances, %d infeasible by HiGHS, %d certified solutions" % (len(rows), int((out["lp_status"] == 2).sum()), int(out["success"].sum())))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    if which[0] == "game":
+        gen_game(*which[1:2])
+        sys.exit(0)
     if which[0] == "dims":
         gen_dims()
         sys.exit(0)

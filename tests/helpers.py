@@ -53,6 +53,36 @@ def lmpc_inputs(g, idx=None):
                g["lmpc/ss"][sl], g["lmpc/qfun"][sl])
 
 
+def game_draw_inputs():
+    """tests/golden/game_draw.npz (tests/golden/tools/make_draws.py game): the learning-MPC QPs the REFERENCE builds -- its own regression,
+    safe-set selection and control.lmpc under the recording stand-in -- at the states the benched closed loop (bench.py `game`) visits in
+    front of control steps 0 / 20 / 40 / 60 / 80 of 32 races, with HiGHS's verdict on each recorded QP."""
+    import os
+
+    import conftest
+    g = np.load(os.path.join(conftest.ROOT, "tests", "golden", "game_draw.npz"))
+    d = abi.lmpc_desc(N=g["A"].shape[1], n_ss_max=g["ss"].shape[2], ey_max=1.0)
+    n = g["x"].shape[0]
+    return g, d, (g["x"], g["u_old"], g["A"].reshape(n, -1, 36), g["B"].reshape(n, -1, 12), g["C"], g["ss"], g["qfun"])
+
+
+def check_game_draw(r, g):
+    """One solver's answers on the game draw: converged exactly where HiGHS finds the reference's QP feasible, PROVED infeasible (status 2:
+    the relaxed-x0 plan is what comes back) where HiGHS says infeasible; the unique solution where the third solver certified one."""
+    feas = g["lp_status"] != 2
+    assert (g["lp_status"][feas] == 0).all()
+    st = np.asarray(r["status"])
+    assert ((st == 0) == feas).all(), np.nonzero((st == 0) != feas)[0]
+    assert (st[~feas] == 2).all(), np.bincount(st[~feas], minlength=6)          # every one by a proof (screen / Farkas certificate), none by a heuristic
+    ok = g["success"] & feas
+    assert ok.sum() >= 70
+    assert np.abs(np.asarray(r["X"])[ok] - g["X"][ok]).max() <= 5e-6 and np.abs(np.asarray(r["U"])[ok] - g["U"][ok]).max() <= 5e-6
+    # the fixture also records what the DEVICE loop had made of the same states, from raw state through its own regression: the same verdicts,
+    # the same 44 safe-set points, stage models within 1e-3 (cond 3e11 normal matrices; DESIGN.md section 5.4)
+    assert ((g["dev_status"] != 0) == ~feas).all() and g["dev_ss_equal"].all() and g["dev_q_equal"].all() and g["dev_model_dev"].max() <= 2e-3
+    return int(feas.sum()), int((~feas).sum())
+
+
 def path_inputs(c):
     """crx_path_solve inputs of a recorded OvertakePathPlanner scenario (tests/golden/path_planner.npz), through the
     PRODUCT's host prep (planning/overtake_path_planner.path_qp_inputs)."""

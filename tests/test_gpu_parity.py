@@ -688,6 +688,17 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
 
 
+def test_game_loop_lmpc_verdicts_equal_highs(gpu, orc):
+    """The kernel on the learning-MPC QPs the REFERENCE builds at the states of the benched `game` loop (tests/golden/game_draw.npz; see
+    tests/test_draw_fixtures.py::test_game_loop_lmpc_infeasibility_is_the_references): converged exactly where HiGHS finds the recorded QP
+    feasible, proved infeasible exactly where it does not, the certified solutions reproduced; and kernel = oracle on every instance."""
+    g, d, args = helpers.game_draw_inputs()
+    rg, ro = gpu.lmpc_solve(d, *args), orc.lmpc_solve(d, *args)
+    helpers.check_game_draw(rg, g)
+    assert (rg["status"] == ro["status"]).all()
+    assert np.abs(rg["X"] - ro["X"]).max() <= 1e-5 and np.abs(rg["U"] - ro["U"]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("N", [7, 16, 24])
 def test_general_horizons_against_oracle(gpu, orc, AB, N):
     """The GENERAL instantiations (run-time horizon: every N other than 10 / 12 / 20; csrc/crx_kernels_gen.hip, the conservative
