@@ -659,6 +659,7 @@ static void ipm_solve(work_t* w, result_t* res) {
      * optimal -- instead of crawling to max_iter */
     if (crash_at_start) { n_restore = 1; it_limit = 1 + 3 * o->restore_iters; }
     int crawl = 0, cvx_run = 0;
+    double ep_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     enum { CVX_PROBE = 4 };
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
     if (g_knob[6] >= 0.0 && o->restore_iters >= 0) {   /* experiment: slacks first -- restore before the first iteration when a
@@ -866,16 +867,30 @@ static void ipm_solve(work_t* w, result_t* res) {
         /* stall: STALL_ITERS iterations without a restoration and still infeasible -- the same crawl with steps just above
          * JAM_ALPHA; healthy problems are done (p99 16 iterations, max 30 on the BASELINE draws) or at least feasible by then */
         if (acc && jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
+        /* theta stagnation (experiment knobs 13 = window W, 14 = ratio R; 0 = off): a zero start that may restart and whose constraint
+         * violation fell by less than (1 - R) over the last W iterations */
+        ep_hist[it & 7] = e_p;
+        if (g_knob[13] > 0 && acc && jam_on && n_restore == 0 && crash_path && may_restart && !crash && it >= (int)g_knob[13] && e_p > 1e-6 &&
+            e_p > g_knob[14] * ep_hist[(it - (int)g_knob[13]) & 7]) jam = JAM_COUNT;
         if (!acc || jam >= JAM_COUNT) {
             if (crash_path && may_restart && n_restore < 1 && !crash && crash_point(w, 0)) {
                 /* crash path (ii): the solve started at the reference's zero point and stalls on violated CBF rows -- restart ONCE from
                  * the feasible interior point: the candidate's inputs, then the closed-form cascade and the re-initialisation the
                  * restoration uses (all rows) */
-                restore_slacks(w, o->mu_init, 1);
+                if (g_knob[12] != 0.0) {   /* experiment: the restart as a crash START -- the candidate's cascade, the start's slacks and multipliers, mu from its complementarity */
+                    crash_point(w, 1);
+                    init_rows(w);
+                    double sc = 0.0;
+                    for (int j = 0; j < w->m; j++) sc += w->t[j] * w->nu[j];
+                    mu = fmin(fmax(CRASH_MU_FRAC * sc / (w->m > 0 ? w->m : 1), o->mu_init), 1e6);
+                } else {
+                    restore_slacks(w, o->mu_init, 1);
+                    mu = o->mu_init;
+                }
                 if (g_verbose) fprintf(stderr, "      RESTART from the crash point (acc %d jam %d)\n", acc, jam);
                 crash = 1;
-                n_restore++; it_limit = it + 1 + o->restore_iters;
-                mu = o->mu_init; nf = 0; first = 1; dw_last = 0.0; jam = 0;
+                n_restore++; it_limit = it + 1 + (g_knob[12] > 1.0 ? 3 : 1) * o->restore_iters;
+                nf = 0; first = 1; dw_last = 0.0; jam = 0;
                 continue;
             }
             if (o->restore_iters >= 0 && n_restore < (int)g_knob[5] && restore_slacks(w, o->mu_init, 0)) {

@@ -23,7 +23,7 @@ def classes(seg):
     g = lambda f: sum(v for k, v in c.items() if f(k))
     return (sum(c.values()), g(lambda k: "f64" in k and k.startswith("v_")), g(lambda k: k.startswith("ds_read")), g(lambda k: k.startswith("ds_write")), c.get("v_readlane_b32", 0),
             g(lambda k: "cndmask" in k), g(lambda k: k.startswith("v_mov")), g(lambda k: k.startswith("v_") and ("_u32" in k or "_i32" in k or "_b32" in k) and "cndmask" not in k and "mov" not in k and "readlane" not in k),
-            c.get("s_waitcnt", 0), g(lambda k: k.startswith("s_") and k != "s_waitcnt"))
+            c.get("s_waitcnt", 0), g(lambda k: k.startswith("s_") and k != "s_waitcnt"), g(lambda k: k.startswith("v_accvgpr")))
 prod = build([])
 tot = classes(prod)
 print("crx_solve_kernel<%s>  production build: %d instructions (static), %s" % (tpl, tot[0], " ".join(l.strip() for l in prod if "vgpr_count" in l or "group_segment_fixed_size:" in l)))
@@ -31,7 +31,7 @@ tr = build(["-DCRX_PHASE_CLOCKS"])
 marks = [i for i, l in enumerate(tr) if "s_memtime" in l]
 names = ["(loop top)", "adjoint (KKT error)", "barrier update", "assemble", "ric: terminal + lane maps", "ric: stage-invariant operands", "ric: set-up tail", "ric: T = P M   [per stage]", "ric: H = M'T + ..   [per stage]",
          "ric: factor + update  [per stage]", "ric: sigma_0 / retry logic", "forward sweep (loop body once)", "row steps", "line search (one trial)", "accept + first order"]
-print("%-36s %6s %5s %5s %5s %5s %5s %5s %5s %5s %5s" % ("phase (between clock reads)", "instr", "f64", "ds_r", "ds_w", "rdln", "cndm", "vmov", "vint", "wait", "salu"))
+print("%-36s %6s %5s %5s %5s %5s %5s %5s %5s %5s %5s %5s" % ("phase (between clock reads)", "instr", "f64", "ds_r", "ds_w", "rdln", "cndm", "vmov", "vint", "wait", "salu", "agpr"))
 def loops(a, b):   # bodies of the loops that lie inside [a, b): (label, instructions), innermost first
     lab = {m.group(1): i for i, l in enumerate(tr[a:b], a) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
     out = {}
@@ -42,4 +42,4 @@ def loops(a, b):   # bodies of the loops that lie inside [a, b): (label, instruc
     return sorted(out.items(), key=lambda kv: kv[1])
 for n, (a, b) in enumerate(zip(marks[:-1], marks[1:])):
     lp = loops(a, b)
-    print("%-36s %6d %5d %5d %5d %5d %5d %5d %5d %5d %5d" % (((names[n] if n < len(names) else "?"),) + classes(tr[a + 1:b])), ("  loops: " + ", ".join("%d" % v for _, v in lp)) if lp else "")
+    print("%-36s %6d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d" % (((names[n] if n < len(names) else "?"),) + classes(tr[a + 1:b])), ("  loops: " + ", ".join("%d" % v for _, v in lp)) if lp else "")
