@@ -190,6 +190,45 @@ def make_cbf(cx, key, args, batch=None, filtered=False):
     return w
 
 
+def make_cbf_streams(cx, args, k=4):
+    """configs[1] once more, as a Monte-Carlo sweep would issue it: K INDEPENDENT batches of 256 NLPs (other seeds), one launch each per step on K
+    HIP streams that sit on different hardware queues (crx_streams_create).  A 256-problem launch occupies 256 of the chip's 1024 SIMDs and ends with
+    its slowest problem (36 iterations against a median of 11); independent batches fill the idle SIMDs.  NOT the headline: a receding-horizon loop
+    cannot overlap its own consecutive steps.  units = K x 256 per step."""
+    from crx import abi, synth, torch_api
+    A, B = synth.load_AB()
+    w = Workload()
+    streams, n_conc = torch_api.new_streams(k, cx.dev)
+    parts = []
+    for i in range(k):
+        p = synth.cfg2_mpccbf(256, N=12, seed=2 + 17 * i + 1000 * cx.rank, safe_start=False)
+        d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+        t_in = [cx.to_dev(p[q]) for q in ("x0", "xt", "obs_s", "obs_ey", "lap_off")] + [cx.to_dev(p["n_obs"], torch.int32)]
+        parts.append((d, t_in, torch_api.CbfWorkspace(d, 256, cx.dev)))
+    cur = torch.cuda.current_stream(cx.dev)
+    for st in streams:
+        st.wait_stream(cur)
+
+    def step():
+        for (d, t_in, ws), st in zip(parts, streams):
+            with torch.cuda.stream(st):
+                torch_api.cbf_solve_dev(d, *t_in, ws=ws)
+
+    class Cat:
+        status = property(lambda self: torch.cat([q[2].status for q in parts]))
+        iters = property(lambda self: torch.cat([q[2].iters for q in parts]))
+        kkt = property(lambda self: torch.cat([q[2].kkt for q in parts]))
+
+    w.key, w.kind, w.baseline_config, w.N, w.n_obs, w.desc, w.ws = "cfg2_x%d_streams" % k, "cbf", 1, 12, 1, parts[0][0], Cat()
+    w.batch, w.units = 256, 256 * k
+    w.kernel = "crx_solve_kernel<1>"
+    w.step = step
+    w.solve_parts = [(lambda q=q: torch_api.cbf_solve_dev(q[0], *q[1], ws=q[2])) for q in parts]
+    w.name = "MPC-CBF NLP as configs[1], %d independent batches of 256 in flight on %d HIP streams (%d on distinct hardware queues): what a Monte-Carlo sweep gets from the chip at batch 256" % (k, k, n_conc)
+    w.extra = {"batches_in_flight": k, "streams_on_distinct_queues": int(n_conc), "kernel_ms_is": "sum of the K launches of one step, each timed alone (in the step they overlap)"}
+    return w
+
+
 def make_planner(cx, args, n_scen=None):
     import crx
     from crx import abi, synth, torch_api
@@ -513,6 +552,22 @@ def measure(cx, w, steps, warmup, with_latency=True):
     cx.dsync()
     st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
     k_ms, k_ms_single = kernel_ms_samples(cx, w, min(50, max(5, steps)))
+    kkt_unscaled = None
+    if w.kind in ("cbf", "cbf_tracking", "planner") and not getattr(w, "solve_parts", None):
+        # the UNSCALED KKT error of the converged problems (libcrx diagnostics, crx_debug_kkt_unscaled: the same launch once more with kkt[] = max(reduced
+        # Lagrangian gradient, constraint violation in the reference's row units, complementarity) -- no s_d, no row scaling); outside every timed region
+        import crx
+        L = crx.lib()
+        L.crx_debug_kkt_unscaled(1)
+        try:
+            w.solve()
+            cx.dsync()
+            ku, su = w.ws.kkt.cpu().numpy(), w.ws.status.cpu().numpy()
+            kkt_unscaled = float(ku[su == 0].max()) if (su == 0).any() else None
+        finally:
+            L.crx_debug_kkt_unscaled(0)
+            w.solve()
+            cx.dsync()
     conv = st == 0
     opt = st == 0               # converged at tol (a proved-infeasible planner QP is ANSWERED, not converged: its kkt is +inf by definition)
     if w.kind == "planner":     # a region QP PROVED infeasible (screen / certificate) is an answered problem: the planner consumes the verdict
@@ -552,7 +607,7 @@ def measure(cx, w, steps, warmup, with_latency=True):
                            "infeasible": float((st == 2).mean()), "restored": float((st == 3).mean()),
                            "skipped_masked": float((st == 4).mean()), "stalled": float((st == 5).mean())},
            "converged_frac": float(conv.mean()), "converged_frac_of_launched": conv_of_launched if ran.any() else None,
-           "kkt_max_converged": float(kkt[opt].max()) if opt.any() else None,
+           "kkt_max_converged": float(kkt[opt].max()) if opt.any() else None, "kkt_unscaled_max": kkt_unscaled,
            "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
            "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
     if with_latency:
@@ -603,7 +658,7 @@ def stdout_line(full):
     c, r = full["config"], full["roofline"]
     line = {k: (r4(full[k]) if k in ("value", "value_launched", "ms_per_step") else full[k]) for k in
             ("metric", "value", "value_launched", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    ck = ("workload", "baseline_config", "batch_per_gpu", "problems_launched", "horizon", "n_obs", "tol", "converged_frac", "kkt_max_converged",
+    ck = ("workload", "baseline_config", "batch_per_gpu", "problems_launched", "horizon", "n_obs", "tol", "converged_frac", "kkt_max_converged", "kkt_unscaled_max",
           "iters_p50", "iters_p90", "iters_max", "p50_step_latency_ms", "p99_step_latency_ms", "p50_host_call_one_control_step_ms", "dispatch")
     line["config"] = {k: r4(c[k]) for k in ck if c.get(k) is not None}
     line["config"]["workload"] = str(c["workload"])[:160]
@@ -734,6 +789,7 @@ def sub_configs(cx, args):
     if args.workload is not None or args.no_sub_configs:
         return []
     return [("cfg2_filtered", lambda: make_cbf(cx, "cfg2_filtered", args, None, filtered=True), args.steps, args.warmup, False),
+            ("cfg2_x4_streams", lambda: make_cbf_streams(cx, args, 4), args.steps, args.warmup, False),
             ("cfg3", lambda: make_planner(cx, args), args.steps, args.warmup, True),
             ("cfg4", lambda: make_cbf(cx, "cfg4", args), min(args.steps, 30), min(args.warmup, 3), True),
             ("lmpc", lambda: make_lmpc(cx, args), min(args.steps, 100), min(args.warmup, 5), True),
@@ -762,7 +818,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game", "overtake"],
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg2_filtered", "cfg2_streams", "cfg3", "cfg4", "cfg5", "lmpc", "races", "game", "overtake"],
                     help="measure only this workload (default: headline cfg2 + every other single-GPU config in `summary`)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="cfg5 only")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU problems (cfg2/cfg4/lmpc/races) or scenarios (cfg3); 0 = BASELINE size")
@@ -806,7 +862,7 @@ def main():
     if args.force_collective:
         cdist.FORCE_COLLECTIVE = True
     b = args.batch or None
-    make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
+    make = {"cfg2": lambda: make_cbf(cx, "cfg2", args, b), "cfg2_streams": lambda: make_cbf_streams(cx, args, 4), "cfg2_filtered": lambda: make_cbf(cx, "cfg2_filtered", args, b, filtered=True),
             "cfg3": lambda: make_planner(cx, args, b), "cfg4": lambda: make_cbf(cx, "cfg4", args, b),
             "cfg5": lambda: make_sweep(cx, args, args.scaling), "lmpc": lambda: make_lmpc(cx, args, b), "races": lambda: make_races(cx, args, b),
             "game": lambda: make_game(cx, args, b), "overtake": lambda: make_overtake(cx, args, b)}

@@ -101,6 +101,7 @@ struct PinBuf {
 PinBuf g_hin, g_hout;
 DevBuf g_trace;
 int g_poison = 0;
+int g_kkt_unscaled = 0;
 int g_trace_rows = 0, g_trace_problem = 0;
 
 int ensure_init() {
@@ -247,6 +248,7 @@ int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
     crx_kparams kq = kp;
     if (g_trace_rows != 0) { kq.trace = (double*)g_trace.p; kq.trace_problem = g_trace_problem; kq.trace_rows = g_trace_rows; }
     kq.poison = g_poison;
+    kq.kkt_unscaled = g_kkt_unscaled;
     size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
     if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
     hipError_t e = crx_launch_solve(kq, tmpl, st);
@@ -326,6 +328,13 @@ int crx_trace_read(double* host, int rows) {
 // diagnostics (not in crx.h): make the solver kernels fill their LDS slice with NaN before set-up, so that a read
 // of LDS the kernel did not write shows up as a changed result (tests/test_gpu_parity.py::test_no_stale_lds_reads)
 void crx_debug_poison_lds(int enable) { g_poison = enable != 0; }
+
+// diagnostics (not in crx.h): the solver kernel reports, for every CONVERGED problem of the following planner / CBF solves, the UNSCALED KKT error in
+// kkt[] -- max(reduced Lagrangian gradient, constraint violation of the rows in the reference's units, complementarity), i.e. without IPOPT's s_d
+// = max(100, ||nu||_1 / m) / 100 and without the gradient-based row scaling -- instead of the scaled error the convergence test uses.  IPOPT
+// itself stops on the scaled error <= tol AND unscaled dual_inf <= 1, constr_viol <= 1e-4, compl_inf <= 1e-4 (its defaults); north_star states
+// its tolerance on "the KKT residual": bench.py reports both (kkt_max_converged, kkt_unscaled_max).
+void crx_debug_kkt_unscaled(int enable) { g_kkt_unscaled = enable != 0; }
 
 // diagnostics (not in crx.h): the packed wave reductions and the DPP dot products of crx_wave.h on host data, in [4][64] -> out [16 + 3 * 64]
 // (tests/test_gpu_parity.py::test_packed_wave_reductions)

@@ -33,6 +33,9 @@
 #include "crx_kparams.h"
 #include "crx_wave.h"
 
+#ifndef CRX_KKT_DIAG
+#define CRX_KKT_DIAG 1   /* 0: without the unscaled-KKT diagnostics block of the write-back (A/B builds) */
+#endif
 #ifndef CRX_TU_GENERAL
 #define CRX_TU_GENERAL 0   /* 1: crx_kernels_gen.hip -- the general instantiations, built conservatively (section (7)) */
 #endif
@@ -1277,6 +1280,7 @@ __device__ __forceinline__ int crash_search(double* sm, const Ctx& c, const crx_
     // 16 otherwise [r4b: the search costs a straggler of the headline batch ~2 iterations' worth, and every problem whose zero start
     // violates a row carries it]
     constexpr int NX = L::NX, NZ = L::NZ, G1 = 5;
+    (void)NX; (void)NZ;
     constexpr int SPAN = (L::SLIM ? 5 : 7) * L::MR;
     constexpr int CH = 32 * 2 * (NMAX + 1) <= SPAN ? 32 : 16;
     static_assert(L::rnu == L::rt + L::MR && L::rtt == L::rt + 4 * L::MR && (L::SLIM || L::rw == L::rt + 6 * L::MR), "rt, rnu, rc, rdt, rtt, rsig, rw are contiguous");
@@ -2235,7 +2239,19 @@ crx_solve_kernel(const crx_kparams kp) {
             kp.sigma[(size_t)b * kp.n_obs_max * (N + 1) + e] = (NOBS && ob < c.nobs) ? LD(L::Z + k * NZ + 6 + ob) : 0.0;
         }
     }
-    if (lane == 0) { kp.status[b] = status; kp.kkt[b] = E0; kp.iters[b] = it; }
+    double Eout = E0;
+    if (CRX_KKT_DIAG && kp.kkt_unscaled && status == 0) {
+        // diagnostics (crx_debug_kkt_unscaled): the converged exit is taken right after dual_infeasibility(), so ga holds the reduced Lagrangian gradient
+        // of the returned iterate; the row arrays hold its slacks, multipliers and (scaled) row values.  Outside every loop: no register is carried for it.
+        double eu = 0.0;
+        for (int e = lane; e < N * NZ + NX; e += WAVE) eu = fmax(eu, fabs(LD(L::ga + e)));
+        for (int j = lane; j < m; j += WAVE) {
+            const double sc = row_scale<L>(sm, si, j, N);
+            if (sc != 0.0) eu = fmax(eu, fmax(fabs(LD(L::rc + j) - LD(L::rt + j)) / sc, LD(L::rt + j) * LD(L::rnu + j)));
+        }
+        Eout = wave_max(eu);
+    }
+    if (lane == 0) { kp.status[b] = status; kp.kkt[b] = Eout; kp.iters[b] = it; }
     }
 }
 

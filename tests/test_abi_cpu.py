@@ -119,3 +119,25 @@ def test_product_never_imports_oracle():
                         or re.search(r"crx_oracle_[a-z_]+\s*\(", txt):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_no_spill_store_in_front_of_an_exec_restore():
+    """Round 5, DESIGN.md section 8: ROCm 7.2's LLVM can place a VGPR spill store at the top of a loop-exit block, IN FRONT of the `s_or_b64
+    exec` that re-enables the lanes -- the store runs with EXEC = 0, stores nothing, and every reload returns whatever the scratch slot held
+    (seen in crx_solve_kernel<3,24,6,0> of a scratch-spilling build: wrong trajectories for 78 of 256 problems).  No source construct causes
+    or prevents it; the library's defence is this check of the COMPILER'S OUTPUT: every translation unit is compiled to assembly with the
+    Makefile's flags and must be free of the pattern (tools/exec_prologue_check.py; no GPU needed)."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    tool = os.path.join(conftest.ROOT, "tools", "exec_prologue_check.py")
+
+    def run(unit):
+        r = subprocess.run([sys.executable, tool, unit], capture_output=True, text=True, timeout=1500)
+        return unit, r.returncode, r.stdout[-1500:] + r.stderr[-500:]
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(run, ["gen", "obs", "plan", "lmpc", "prep", "lmpcprep"]))
+    bad = [(u, out) for u, rc, out in res if rc != 0]
+    assert not bad, bad

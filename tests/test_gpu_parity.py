@@ -688,6 +688,37 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
 
 
+def test_unscaled_kkt_diagnostics(gpu, AB):
+    """crx_debug_kkt_unscaled (diagnostics; bench.py's kkt_unscaled_max): kkt[] of a converged solve becomes the UNSCALED KKT error -- without
+    IPOPT's s_d = max(100, ||nu||_1 / m) / 100 and without the row scaling -- and nothing else changes.  On the headline batch it equals the
+    scaled error wherever s_d = 1 (multipliers below 100 on average) and shows the crash states with multipliers of 1e9."""
+    import crx
+    from crx import abi, synth
+
+    A, B = AB
+    p = synth.cfg2_mpccbf(256, safe_start=False)
+    d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+    args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
+    r0 = gpu.cbf_solve(d, *args)
+    crx.lib().crx_debug_kkt_unscaled(1)
+    try:
+        r1 = gpu.cbf_solve(d, *args)
+    finally:
+        crx.lib().crx_debug_kkt_unscaled(0)
+    for k in ("X", "U", "sigma", "cost", "status", "iters"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    ok = r0["status"] == 0
+    assert ok.all()
+    ks, ku = r0["kkt"], r1["kkt"]
+    assert (ku >= ks * (1 - 1e-9)).all()                       # every unscaled term dominates its scaled counterpart
+    assert np.median(ku) <= 1e-8 and (ku <= 1e-6).mean() >= 0.9
+    # the largest belong to the crash states (costs of 1e8, multipliers of 1e9: s_d ~ 1e5): 2.5e-4 on #165 -- inside IPOPT's own unscaled
+    # acceptance thresholds (dual_inf_tol 1, constr_viol_tol = compl_inf_tol = 1e-4 apply to the violation and complementarity parts)
+    assert 1e-6 <= ku.max() <= 1e-3, ku.max()
+    r2 = gpu.cbf_solve(d, *args)
+    np.testing.assert_array_equal(r2["kkt"], ks)               # the switch is off again
+
+
 def test_game_loop_lmpc_verdicts_equal_highs(gpu, orc):
     """The kernel on the learning-MPC QPs the REFERENCE builds at the states of the benched `game` loop (tests/golden/game_draw.npz; see
     tests/test_draw_fixtures.py::test_game_loop_lmpc_infeasibility_is_the_references): converged exactly where HiGHS finds the recorded QP

@@ -110,6 +110,9 @@ issue)
   pmc cfg4_default_3 cfg4 16384 2 "--dispatch index" $B
   pmc cfg2_1 cfg2 16384 3 "--dispatch index" $A
   pmc cfg2_3 cfg2 16384 3 "--dispatch index" $B
+  Cc="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES"    # [r5] the sweeps are unrolled 12x / 20x since round 4: does the loop body still sit in the 64 KB instruction cache two CUs share?
+  pmc cfg4_default_5 cfg4 16384 2 "--dispatch index" $Cc
+  pmc cfg2_5 cfg2 16384 3 "--dispatch index" $Cc
   pmc cfg3_1 cfg3 16384 3 "" $A
   pmc cfg3_3 cfg3 16384 3 "" $B )
   ls $O | grep pmc_ ;;   # summarise locally: python3 profiles/summarize_issue.py $TAG it4,it2,it3 > profiles/rNN_pmc_issue.txt
