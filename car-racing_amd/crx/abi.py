@@ -10,7 +10,7 @@ import numpy as np
 
 CRX_MAX_N = 24
 CRX_MAX_OBS = 6     # obstacles per MPC-CBF NLP
-CRX_MAX_VEH = 3     # vehicles of interest per planner scenario
+CRX_MAX_VEH = 6     # vehicles of interest per planner scenario (= CRX_MAX_OBS)
 
 CRX_CONVERGED, CRX_MAX_ITER, CRX_INFEASIBLE, CRX_RESTORED, CRX_SKIPPED, CRX_STALLED = 0, 1, 2, 3, 4, 5
 

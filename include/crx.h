@@ -64,7 +64,10 @@ extern "C" {
                               loops over every vehicle in the window); its scenarios race 3 cars (overtake_planner_test.py).  Up to 3 run on
                               the tuned instantiations, 4..6 on ONE generic instantiation per horizon class (correct, slow: twice the
                               register file).  A caller with more keeps the nearest (crx.hostprep.pack_obstacles warns). */
-#define CRX_MAX_VEH 3      /* vehicles of interest per planner scenario (n_veh_max of the scene / prep / select descriptors); regions = + 1 */
+#define CRX_MAX_VEH 6      /* vehicles of interest per planner scenario (n_veh_max of the scene / prep / select descriptors); regions = + 1.  The
+                              reference plans around every vehicle get_overtake_flag returns (overtake_traj_planner.py:62-92); its scenarios race
+                              3 cars.  [0.3.0: 3 -> 6, = CRX_MAX_OBS: the tracking NLP behind the planner takes the same vehicles as obstacles.]
+                              A scene with more keeps the nearest (crx_scene reports `overflow`). */
 #define CRX_MAX_REGIONS (CRX_MAX_VEH + 1)
 #define CRX_LMPC_MAX_N 16 /* horizon limit of crx_lmpc_solve (its dense factors share one LDS slice) */
 #define CRX_MAX_SS 60      /* safe-set points per learning-MPC QP (reference: 44) */

@@ -244,9 +244,11 @@ def gen_cfg4(n=64, n_lapped=16, procs=int(os.environ.get("CRX_DRAW_PROCS", "5"))
 
 
 # -------------------------------------------------------------------------------------------------
-def gen_cfg3(n=64):
-    w = synth.cfg3_raw(1024, N=12, seed=3, V=3)
-    N, V = 12, 3
+def gen_cfg3(n=64, V=3, seed=3, name="cfg3_draw.npz"):
+    """V = 3, seed 3: the BASELINE draw.  V = 5 (`cfg3many`, seed 35 -> cfg3_many.npz): five vehicles of interest per scenario = six regions, the
+    planner side of CRX_MAX_VEH = 6 [r5] (the reference plans around every vehicle get_overtake_flag returns: overtake_traj_planner.py:62-92)."""
+    w = synth.cfg3_raw(1024, N=12, seed=seed, V=V)
+    N = 12
     rows = []
     for b in range(n):
         x = w["x"][b]
@@ -271,8 +273,8 @@ def gen_cfg3(n=64):
         print("cfg3 %3d/%d interest %d flag %s region_success %s mma %s" % (
             b + 1, n, row["n_interest"], row.get("direction_flag"), row.get("region_success"), row.get("mma_success")), flush=True)
     out = {"draw/" + k: v for k, v in _stack(rows).items()}
-    out["meta"] = np.array([1024, 12, 3, 3])
-    np.savez_compressed(os.path.join(mg.OUT, "cfg3_draw.npz"), **out)
+    out["meta"] = np.array([1024, 12, V, seed])
+    np.savez_compressed(os.path.join(mg.OUT, name), **out)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -659,6 +661,9 @@ def gen_game(states_npz=os.path.join(REPO, "gpurun_out", "game_states.npz")):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    if which[0] == "cfg3many":
+        gen_cfg3(int(os.environ.get("CRX_DRAW_N3M", "24")), V=5, seed=35, name="cfg3_many.npz")
+        sys.exit(0)
     if which[0] == "game":
         gen_game(*which[1:2])
         sys.exit(0)

@@ -214,20 +214,28 @@ def test_headline_non_converged_are_classified(orc, AB):
 # ---------------------------------------------------------------------------------------------------------------------
 # cfg3: the overtake planner
 # ---------------------------------------------------------------------------------------------------------------------
-def planner_batch():
+# the BASELINE draw (three cars, seed 3) and [r5] five vehicles of interest per scenario = six regions (CRX_MAX_VEH = 6; the reference plans around
+# every vehicle get_overtake_flag returns, overtake_traj_planner.py:62-92): (fixture, V, seed, scenarios at least)
+PLANNER_DRAWS = [("cfg3_draw.npz", 3, 3, 48), ("cfg3_many.npz", 5, 35, 20)]
+PLANNER_IDS = ["three_cars", "five_cars"]
+
+
+def planner_batch(V=3, seed=3):
     from crx import synth
-    return synth.cfg3_planner(1024, N=12, seed=3)
+    return synth.cfg3_planner(1024, N=12, seed=seed, V=V)
 
 
-def test_planner_prep_and_rows_match_reference(orc, AB):
+@pytest.mark.parametrize("draw", PLANNER_DRAWS, ids=PLANNER_IDS)
+def test_planner_prep_and_rows_match_reference(orc, AB, draw):
     from crx import abi
     A, B = AB
-    g = _group(_load("cfg3_draw.npz"), "draw")
-    p = planner_batch()
-    N, V, R = 12, 3, 4
+    fixture, V, seed, n_min = draw
+    g = _group(_load(fixture), "draw")
+    p = planner_batch(V, seed)
+    N, R = 12, V + 1
     d = abi.planner_desc(N, A, B)
     n = len(g["index"])
-    assert n >= 48 or os.environ.get("CRX_DRAW_PARTIAL")
+    assert n >= n_min or os.environ.get("CRX_DRAW_PARTIAL")
     assert g["overtake_flag"].all() and (g["n_interest"] == V).all() and (g["n_veh_ref"] == V).all()   # synth's cars are all of interest
     for r, b in enumerate(g["index"].astype(int)):
         tag = "cfg3 #%d" % b
@@ -257,12 +265,13 @@ def test_planner_prep_and_rows_match_reference(orc, AB):
             assert _rel(pr["cost"], g["region_probe_f"][r][reg]) <= 1e-11, (tag, reg, pr["cost"], g["region_probe_f"][r][reg])
 
 
-def _planner_compare(binding, orc, AB, T):
+def _planner_compare(binding, orc, AB, T, draw=PLANNER_DRAWS[0]):
     from crx import abi
     A, B = AB
-    g = _group(_load("cfg3_draw.npz"), "draw")
-    p = planner_batch()
-    N, V, R = 12, 3, 4
+    fixture, V, seed, _ = draw
+    g = _group(_load(fixture), "draw")
+    p = planner_batch(V, seed)
+    N, R = 12, V + 1
     idx = g["index"].astype(int)
     rows = np.concatenate([np.arange(b * R, (b + 1) * R) for b in idx])
     d = abi.planner_desc(N, A, B)
@@ -285,15 +294,23 @@ def _planner_compare(binding, orc, AB, T):
     sd = abi.select_desc(N, V, LAP)
     n = len(idx)
     sel = orc.select(sd, p["n_veh"][idx], res["X"].reshape(n, R, N + 1, 6), p["obs_s"][idx], p["obs_ey"][idx], p["old_flag"][idx])
-    np.testing.assert_array_equal(sel["flag"], g["direction_flag"])
-    np.testing.assert_allclose(sel["best_X"], g["traj_xcurv"], rtol=0, atol=px)
-    np.testing.assert_allclose(sel["best_X"][:, :, [0, 4, 5]], g["traj_xcurv"][:, :, [0, 4, 5]], rtol=0, atol=pxw)
+    # (two regions whose bounds are not active are the SAME QP: their selection costs tie to 1e-12 in the reference's own numbers and the
+    # arg-min is decided by rounding -- seen with five cars, scenario 16: 82.20997584068166 vs ...279.  A flag may differ only inside such a tie.)
+    diff = np.nonzero(sel["flag"] != g["direction_flag"])[0]
+    for i in diff:
+        c = sel["sel_cost"][i]
+        assert abs(c[sel["flag"][i]] - c[int(g["direction_flag"][i])]) <= 1e-6 * max(1.0, abs(c[sel["flag"][i]])), (i, c)
+    assert len(diff) <= max(1, n // 20), diff
+    same = sel["flag"] == g["direction_flag"]
+    np.testing.assert_allclose(sel["best_X"][same], g["traj_xcurv"][same], rtol=0, atol=px)
+    np.testing.assert_allclose(sel["best_X"][same][:, :, [0, 4, 5]], g["traj_xcurv"][same][:, :, [0, 4, 5]], rtol=0, atol=pxw)
     return res, g
 
 
+@pytest.mark.parametrize("draw", PLANNER_DRAWS, ids=PLANNER_IDS)
 @pytest.mark.parametrize("T", [DEFAULT, TIGHT], ids=["tol1e-8", "tol1e-11"])
-def test_oracle_planner_on_reference_built_draw(orc, AB, T):
-    res, g = _planner_compare(orc, orc, AB, T)
+def test_oracle_planner_on_reference_built_draw(orc, AB, T, draw):
+    res, g = _planner_compare(orc, orc, AB, T, draw)
     ok = g["region_success"].reshape(-1)
     assert ok.sum() >= 0.3 * len(ok) and (~ok).sum() >= 0.2 * len(ok)        # the BASELINE draw: ~41 % infeasible regions
 
