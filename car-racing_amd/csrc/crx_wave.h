@@ -40,9 +40,6 @@ __device__ __forceinline__ double wrap_below(double s, double L) {   // `while (
 #define SYNC() __syncthreads()
 #elif defined(CRX_SYNC_FENCE_ONLY)
 #define SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
-#elif defined(CRX_SYNC_SCHED_DS)
-// A/B: the fence + a scheduling barrier that only LDS instructions may not cross (mask = every class but "all DS" / "DS read" / "DS write")
-#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_sched_barrier(0x047F); } while (0)
 #else
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
