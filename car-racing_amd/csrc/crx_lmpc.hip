@@ -216,6 +216,7 @@ __device__ __forceinline__ void l_lagr(double* sm, const LCtx& x, const crx_lmpc
 // has the note): lmpc launch 1.526 -> 1.489 ms, game step 2.76 -> 2.69 ms.  The general instantiations stay on dynamic LDS: static, the
 // compiler also sees how many waves the LDS admits per CU, rounds five or six per CU down to ONE per SIMD and takes > 256 registers (four per
 // CU); and an amdgpu_waves_per_eu(2) floor against that costs the tuned instantiation 8 % (1.654 ms) -- both measured, tools/gpu_pass.sh game:NAME.
+// [r5] The unit is built with MachineLICM off + max-ilp scheduling (Makefile has the numbers): 216 / 222 VGPRs, two waves per SIMD everywhere.
 template <int NFIX> struct LmpcStaticLds { static constexpr bool v = CRX_STATIC_LDS && NFIX != 0; };
 template <int NMAX, bool DENSE, int MSS, int NFIX = 0>
 __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams kp) {

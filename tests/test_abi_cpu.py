@@ -132,6 +132,12 @@ def test_no_spill_store_in_front_of_an_exec_restore():
     from concurrent.futures import ThreadPoolExecutor
 
     tool = os.path.join(conftest.ROOT, "tools", "exec_prologue_check.py")
+    # the tool mirrors the Makefile's per-unit flags: keep the two in step
+    mk = open(os.path.join(conftest.PKG, "csrc", "Makefile")).read()
+    for frag in ("PLAN_SCHED ?= -mllvm -amdgpu-sched-strategy=max-ilp", "OBS_SCHED ?= -mllvm -amdgpu-sched-strategy=iterative-ilp",
+                 "LMPC_SCHED ?= -mllvm -amdgpu-sched-strategy=max-ilp", "-mllvm -disable-machine-licm $(LMPC_SCHED) -c crx_lmpc.hip",
+                 "-mllvm -disable-machine-licm $(GEN_FLAGS) -c crx_kernels_gen.hip", "FLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH)"):
+        assert frag in mk, frag
 
     def run(unit):
         r = subprocess.run([sys.executable, tool, unit], capture_output=True, text=True, timeout=1500)

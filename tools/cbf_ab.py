@@ -40,13 +40,13 @@ r = gpu.planner_solve(abi.planner_desc(10, A, B), *[p[k] for k in ("x0", "bez_s"
 for k, v in r.items():
     out["plan10/" + k] = np.asarray(v)
 cx = bench.Ctx()
-wo = bench.make_overtake(cx, argparse.Namespace(race_streams=1, dispatch="index"), 1024)
+wo = bench.make_overtake(cx, argparse.Namespace(race_streams=1, dispatch="index", lap_phase=0), 1024)
 po = wo.step.__self__.parts[0]
 for _ in range(30):
     wo.step()
 torch.cuda.synchronize()
 out["overtake/xc"] = po.lm.xc.cpu().numpy(); out["overtake/tU"] = po.tws.U.cpu().numpy(); out["overtake/titers"] = po.tws.iters.cpu().numpy()
-w = bench.make_races(cx, argparse.Namespace(race_streams=1, dispatch="index"), 4096)
+w = bench.make_races(cx, argparse.Namespace(race_streams=1, dispatch="index", lap_phase=0), 4096)
 pr = w.step.__self__.parts[0]
 for _ in range(40):
     w.step()

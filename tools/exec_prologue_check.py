@@ -11,7 +11,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "gen"
 src, fl = {"plan": ("crx_kernels.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
            "obs": ("crx_kernels_obs.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
            "gen": ("crx_kernels_gen.hip", ["-mllvm", "-disable-machine-licm"]),
-           "lmpc": ("crx_lmpc.hip", []), "prep": ("crx_prep.hip", []), "lmpcprep": ("crx_lmpcprep.hip", [])}[which]
+           "lmpc": ("crx_lmpc.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]), "prep": ("crx_prep.hip", []), "lmpcprep": ("crx_lmpcprep.hip", [])}[which]
 out = tempfile.mktemp(suffix=".s")
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function"] + fl + sys.argv[2:] +
                ["--cuda-device-only", "-S", os.path.join(S, src), "-o", out], check=True, stderr=subprocess.DEVNULL)

@@ -7,7 +7,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "obs"
 src, sched = {"one": (None, None), "obs": ("crx_kernels_obs.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
               "plan": ("crx_kernels.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
               "gen": ("crx_kernels_gen.hip", ["-mllvm", "-disable-machine-licm"]),
-              "lmpc": ("crx_lmpc.hip", [])}[which]
+              "lmpc": ("crx_lmpc.hip", ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"])}[which]
 extra = sys.argv[2:]
 if which == "one":   # python tools/kernel_resources.py one NOBS NMAX DEG NFIX [flags]
     tpl = ",".join(sys.argv[2:6]); extra = sys.argv[6:]

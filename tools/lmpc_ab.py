@@ -35,7 +35,7 @@ r = gpu.lmpc_solve(abi.lmpc_desc(12, 44), *[z[k] for k in ("x0", "u_old", "A", "
 for k, v in r.items():
     out["noise/" + k] = np.asarray(v)
 cx = bench.Ctx()
-w = bench.make_game(cx, argparse.Namespace(race_streams=1, dispatch="index"), 4096)
+w = bench.make_game(cx, argparse.Namespace(race_streams=1, dispatch="index", lap_phase=0), 4096)
 p = w.step.__self__.parts[0]
 its = []
 for _ in range(40):
