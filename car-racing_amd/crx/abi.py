@@ -40,7 +40,7 @@ OPTS_OVERRIDE = {}
 def default_opts(**kw):
     """IPOPT defaults the reference inherits (control.py:593 passes print options only) + libcrx's own two switches
     (include/crx.h crx_ipm_opts: reach_screen = 1, slack_start = 2)."""
-    o = IpmOpts(1e-8, 200, 25, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0, 1, 2)
+    o = IpmOpts(1e-8, 200, 50, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0, 1, 2)
     for k, v in {**OPTS_OVERRIDE, **kw}.items():
         setattr(o, k, v)
     return o

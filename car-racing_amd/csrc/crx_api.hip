@@ -412,7 +412,7 @@ double crx_timer_ms(void* timer) {
 }
 
 void crx_ipm_opts_default(crx_ipm_opts* o) {
-    o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 25; o->mu_init = 0.1; o->kappa_eps = 10.0;
+    o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 50; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2; o->grad_scale_max = 100.0;
     o->reach_screen = 1; o->slack_start = 2;
 }

@@ -102,7 +102,7 @@ typedef enum crx_status {
 typedef struct crx_ipm_opts {
     double tol;            /* 1e-8  convergence tolerance on the scaled KKT error */
     int32_t max_iter;      /* 200   (IPOPT: 3000; capped, status CRX_MAX_ITER beyond) */
-    int32_t restore_iters; /* 25    iterations allowed after the first restoration (CRX_RESTORED beyond); < 0: no restoration
+    int32_t restore_iters; /* 50    ([r5]; 25 before: DESIGN 4.2) iterations allowed after the first restoration (CRX_RESTORED beyond); < 0: no restoration
                               phase at all (a failed line search then ends the solve, as in libcrx 0.1.0) */
     double mu_init;        /* 0.1   */
     double kappa_eps;      /* 10    barrier sub-problem tolerance factor */
@@ -130,7 +130,7 @@ typedef struct crx_ipm_opts {
                                  input pairs by f(u) + w sum sigma(u), sigma(u) = the minimal slack cascade for that u, with that
                                  cascade pushed strictly inside -- a feasible interior point; its barrier parameter starts at a tenth of
                                  the point's mean complementarity (not below mu_init), not at mu_init.  (ii) A solve that started at zero and
-                                 stalls on violated CBF rows (no acceptable step, jam, 50 iterations still infeasible) restarts ONCE
+                                 stalls on violated CBF rows (no acceptable step, jam, 100 iterations still infeasible) restarts ONCE
                                  from such a point instead of being abandoned.  (iii) On the crash path a reduced Hessian of the wrong
                                  inertia is first retried WITHOUT the reverse-convex part of the CBF curvature (positive definite by
                                  construction) before IPOPT's delta_w schedule; after an iteration that needed that, the next ones start

@@ -243,6 +243,32 @@ def gen_cfg4(n=64, n_lapped=16, procs=int(os.environ.get("CRX_DRAW_PROCS", "5"))
     np.savez_compressed(os.path.join(mg.OUT, "cfg4_draw.npz"), **out)
 
 
+def _cfg4_stopped_chunk(idx):
+    p = synth.cfg4_tracking_cbf(16384, N=20, seed=4, safe_start=False)
+    return cfg4_rows(p, idx, "cfg4-stopped")
+
+
+def gen_cfg4_stopped(idx_file="/tmp/cfg4_stopped_idx.npy", procs=int(os.environ.get("CRX_DRAW_PROCS", "7"))):
+    """the problems of the BENCHED configs[3] batch (16 384 tracking NLPs, seed 4) that do NOT converge at default options --
+    the oracle finds them (135: 111 restored, 18 stalled, 6 at the iteration cap; idx_file) -- replayed through the reference's own
+    control.mpc_multi_agents and classified by the third solver: is there a certified KKT point of the reference's NLP (zero start, 1000-iteration
+    retry, random starts)?  Every stalled / capped problem and a third of the restored ones -> tests/golden/cfg4_stopped.npz."""
+    import multiprocessing as mp
+
+    idx = np.load(idx_file)
+    st = np.load(idx_file.replace("_idx", "_status"))
+    pick = sorted(set(idx[st != 3].tolist()) | set(idx[st == 3][::3].tolist()))
+    jobs = [pick[i::procs] for i in range(procs)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_cfg4_stopped_chunk, jobs, chunksize=1)
+    rows = sorted([r for rr in res for r in rr], key=lambda r: r["index"])
+    out = {"draw/" + k: v for k, v in _stack(rows).items()}
+    out["meta"] = np.array([16384, 20, 4, 0.0])
+    np.savez_compressed(os.path.join(mg.OUT, "cfg4_stopped.npz"), **out)
+    print("cfg4_stopped.npz: %d problems, certified from the zero start %d, by the retry %d" % (
+        len(rows), int(out["draw/success"].sum()), int(out["draw/retry_certified"].sum())))
+
+
 # -------------------------------------------------------------------------------------------------
 def gen_cfg3(n=64, V=3, seed=3, name="cfg3_draw.npz"):
     """V = 3, seed 3: the BASELINE draw.  V = 5 (`cfg3many`, seed 35 -> cfg3_many.npz): five vehicles of interest per scenario = six regions, the
@@ -661,6 +687,9 @@ def gen_game(states_npz=os.path.join(REPO, "gpurun_out", "game_states.npz")):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    if which[0] == "cfg4stopped":
+        gen_cfg4_stopped(*which[1:2])
+        sys.exit(0)
     if which[0] == "cfg3many":
         gen_cfg3(int(os.environ.get("CRX_DRAW_N3M", "24")), V=5, seed=35, name="cfg3_many.npz")
         sys.exit(0)

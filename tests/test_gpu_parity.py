@@ -256,7 +256,8 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
     # (without any restoration the crash states of the unfiltered draws crawl for 60..200 iterations; over such a run the last bits of
     # two different factorisations add up to a few iterations: ONE such problem per batch is tolerated, same point required)
     _assert_same_verdicts(cfg + " no restoration", g0, o0, tol=T["tol"], max_other=1 if "unfiltered" in cfg else 0)
-    g1, o1 = both_sides(25)
+    RI = abi.default_opts().restore_iters    # 50 [r5]
+    g1, o1 = both_sides(RI)
     touched = set()
     for r0, r1 in ((g0, g1), (o0, o1)):
         dx = np.abs(r0["X"] - r1["X"]).reshape(len(r0["status"]), -1).max(axis=1) > 0
@@ -271,9 +272,9 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
     c = _assert_same_verdicts(cfg, g1, o1, tol=T["tol"], restored=frozenset(touched), max_restored_verdict=max(2, len(touched) // 5))
     # restoration turns failed line searches into defined ends: no problem is left at the iteration cap
     assert (g1["status"] == 1).sum() <= (0 if T["tol"] >= 1e-9 else 2), np.bincount(g1["status"], minlength=4)   # (1e-11 is below the noise floor of a crash state of cost 1e8: its line search ends at a feasible point)
-    assert g1["iters"].max() <= 50 + 1 + 25 + 25, g1["iters"].max()      # stall trigger + restoration budget (+ a second restoration)
+    assert g1["iters"].max() <= min(100 + 1 + RI + RI, 200), g1["iters"].max()      # stall trigger + restoration budget (+ a second restoration), max_iter
     # bounded effort has a price: a crash state that would have crawled to a KKT point in 50..200 iterations now ends as
-    # CRX_RESTORED after at most 76 (raise opts.restore_iters / max_iter to trade latency back for convergence)
+    # CRX_RESTORED after at most 76 ([r5] 151 at the defaults: raise opts.restore_iters / max_iter to trade latency back for convergence)
     assert (g1["status"] == 0).sum() >= 0.95 * (g0["status"] == 0).sum()
     # crash states that do converge carry slacks of 1e2..1e6 (cost 1e6..1e10): their trajectories agree to the default set only
     both = _cmp(cfg, g0, o0, need_same_status=False, T=DEFAULT if "unfiltered" in cfg else T)
@@ -686,6 +687,32 @@ def test_fuzz_descriptors(gpu, orc, AB, golden_racing_game):
         assert both.sum() >= (12 if N <= 12 else 4), (N, ro["status"])
         assert np.abs(rg["X"][both] - ro["X"][both]).max() <= 1e-5, N
         assert np.abs(rg["U"][both] - ro["U"][both]).max() <= 1e-5, N
+
+
+def test_cfg4_non_converged_on_the_gpu(gpu, orc, AB):
+    """The configs[3] problems that did not converge at round 4's budgets (tests/golden/cfg4_stopped.npz: taken from the benched batch, replayed
+    through the reference, classified by the third solver -- tests/test_draw_fixtures.py::test_cfg4_non_converged_are_classified has the story): at
+    round 5's defaults (stall rule at 100 iterations, restore_iters = 50) the kernel converges on the ones the oracle converges on, to the same
+    points, but for a handful of crash states whose outcome class is decided by rounding (profiles/r04_stress_cbf.txt: 99.97 % same status over
+    16 384)."""
+    import test_draw_fixtures as tdf
+
+    A, B = AB
+    g, p = tdf.cfg4_stopped_batch()
+    d = tdf.cbf_desc("cfg4", A, B, tdf.DEFAULT["tol"])
+    assert d.opts.restore_iters == 50
+    rg, ro = gpu.cbf_solve(d, *[p[k] for k in tdf.KEYS]), orc.cbf_solve(d, *[p[k] for k in tdf.KEYS])
+    same = rg["status"] == ro["status"]
+    assert same.mean() >= 0.9, (np.nonzero(~same)[0], rg["status"][~same], ro["status"][~same])
+    lines, counts = tdf.classify_cfg4_stopped(rg, g)
+    print("\n" + str(counts) + "\n  " + "\n  ".join(lines))
+    assert counts["converged"] >= 50, counts
+    both = (rg["status"] == 0) & (ro["status"] == 0)
+    close = np.abs(rg["cost"][both] - ro["cost"][both]) <= 1e-6 * np.maximum(1.0, np.abs(ro["cost"][both]))
+    assert close.mean() >= 0.9, (g["index"][both][~close], rg["cost"][both][~close], ro["cost"][both][~close])
+    # (crash states crawl for 50..110 iterations: over such a run the last bits of two different factorisations add up to a few iterations)
+    di = np.abs(rg["iters"][both][close] - ro["iters"][both][close])
+    assert np.median(di) == 0 and (di <= 1).mean() >= 0.85 and di.max() <= 10, di
 
 
 def test_unscaled_kkt_diagnostics(gpu, AB):
@@ -1589,7 +1616,7 @@ def test_unequal_obstacle_sizes(gpu, orc, AB, T):
     touched = frozenset(np.nonzero((g0["status"] != rg["status"]) | (g0["iters"] != rg["iters"]) | (o0["status"] != ro["status"]) | (o0["iters"] != ro["iters"]))[0].tolist())
     _assert_same_verdicts("unequal cars", rg, ro, tol=Tt["tol"], restored=touched, max_restored_verdict=2, max_tight_stall=2)
     # device entry point
-    d.opts.restore_iters = 25
+    d.opts.restore_iters = abi.default_opts().restore_iters
     dev = torch.device("cuda", 0)
     t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)   # noqa: E731
     ws = torch_api.cbf_solve_dev(d, t(p["x0"]), t(p["xt"]), t(p["obs_s"]), t(p["obs_ey"]), t(p["lap_off"]), t(p["n_obs"], torch.int32), obs_dims=t(p["obs_dims"]))

@@ -13,7 +13,7 @@ p2 = synth.cfg2_mpccbf(2048, safe_start=False)
 d2 = abi.cbf_desc(12, 1, A, B, alpha=0.8, margin=0.2)
 p4 = synth.cfg4_tracking_cbf(1024, safe_start=False)
 d4 = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
-DEF = {0: 1e-3, 1: 5, 2: 50, 3: 0.0, 4: 0, 5: 2, 6: -1}
+DEF = {0: 1e-3, 1: 5, 2: 100, 3: 0.0, 4: 0, 5: 2, 6: -1}
 
 
 def run(knobs, base=None, slack_start=2):
