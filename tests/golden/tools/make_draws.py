@@ -255,6 +255,23 @@ def gen_cfg4_stopped(idx_file="/tmp/cfg4_stopped_idx.npy", procs=int(os.environ.
     retry, random starts)?  Every stalled / capped problem and a third of the restored ones -> tests/golden/cfg4_stopped.npz."""
     import multiprocessing as mp
 
+    if not os.path.exists(idx_file):
+        # which problems: the oracle on the whole batch at ROUND 4's budgets (stall rule at 50 iterations = knob 2, restore_iters = 25; the
+        # defaults have been 100 / 50 since this fixture exists -- DESIGN.md section 4.2)
+        import ctypes
+        import oracle                                   # test infrastructure; used here to pick the problems only
+        from crx import abi
+        orc = oracle.load()
+        p = synth.cfg4_tracking_cbf(16384, N=20, seed=4, safe_start=False)
+        A, B = synth.load_AB()
+        d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+        d.opts.restore_iters = 25
+        orc.lib.crx_oracle_set_knob(2, ctypes.c_double(50.0))
+        r = orc.cbf_solve(d, *[p[k] for k in ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")])
+        orc.lib.crx_oracle_set_knob(2, ctypes.c_double(100.0))
+        bad = np.nonzero(r["status"] != 0)[0]
+        np.save(idx_file, bad)
+        np.save(idx_file.replace("_idx", "_status"), r["status"][bad])
     idx = np.load(idx_file)
     st = np.load(idx_file.replace("_idx", "_status"))
     pick = sorted(set(idx[st != 3].tolist()) | set(idx[st == 3][::3].tolist()))
