@@ -893,7 +893,7 @@ def main():
     for k in ("allgather_ms", "world_size"):
         if k in rec:
             full[k] = rec[k]
-    if cx.rank == 0 and not args.no_cpu_baseline and head.cpu is not None:
+    if cx.rank == 0 and cx.world == 1 and not args.no_cpu_baseline and head.cpu is not None:   # N = 1 only: the other ranks would wait for it
         full["cpu_baseline"] = cpu_baseline(head)
     full["configs"] = []
     for key, mk, st, wu, wl in sub_configs(cx, args):
