@@ -29,6 +29,11 @@ class IpmOpts(C.Structure):
         ("grad_scale_max", C.c_double),
         ("reach_screen", C.c_int32),
         ("slack_start", C.c_int32),
+        ("dual_inf_tol", C.c_double),      # [0.4.0] IPOPT's complete termination test: the three UNSCALED tolerances
+        ("constr_viol_tol", C.c_double),
+        ("compl_inf_tol", C.c_double),
+        ("stall_iters", C.c_int32),        # [0.4.0] the stall rule's budget (a kernel constant until 0.3.x)
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -40,10 +45,16 @@ OPTS_OVERRIDE = {}
 def default_opts(**kw):
     """IPOPT defaults the reference inherits (control.py:593 passes print options only) + libcrx's own two switches
     (include/crx.h crx_ipm_opts: reach_screen = 1, slack_start = 2)."""
-    o = IpmOpts(1e-8, 200, 50, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0, 1, 2)
+    o = IpmOpts(1e-8, 200, 50, 0.1, 10.0, 0.2, 1.5, 0.99, 1e-2, 100.0, 1, 2, 1.0, 1e-4, 1e-4, 100, 0)
     for k, v in {**OPTS_OVERRIDE, **kw}.items():
         setattr(o, k, v)
     return o
+
+
+def cbf_class_budgets(N, n_obs_max):
+    """(stall_iters, restore_iters) crx_cbf_desc_default picks for a problem class; explicit OPTS_OVERRIDE entries win."""
+    kw = {"stall_iters": 50, "restore_iters": 25} if (int(N) <= 12 and int(n_obs_max) <= 1) else {"stall_iters": 100, "restore_iters": 50}
+    return {k: v for k, v in kw.items() if k not in OPTS_OVERRIDE}
 
 
 class PlannerDesc(C.Structure):
@@ -191,7 +202,10 @@ def cbf_desc(N, n_obs_max, A, B, Q=(10.0, 0.0, 0.0, 4.0, 0.0, 40.0), R=(0.1, 0.1
              margin=0.2, ey_max=1.0, per_stage_target=False, delta_max=0.5, a_max=1.0, v_min=0.0,
              v_max=10.0, l_sum=0.4, w_sum=0.2, w_slack=1e4, degree=6, opts=None):
     """Defaults = MPCCBFRacingParam / SystemParam / CarParam (utils/base.py:272-291,708-713,699-705)
-    and the literals in control.mpccbf (control.py:527-528,560)."""
+    and the literals in control.mpccbf (control.py:527-528,560).  Without `opts` the budgets follow the problem class like
+    crx_cbf_desc_default (include/crx.h crx_ipm_opts.stall_iters): (50, 25) for N <= 12 with at most one obstacle slot, (100, 50) otherwise."""
+    if opts is None:
+        opts = default_opts(**cbf_class_budgets(N, n_obs_max))
     return CbfDesc(
         int(N), int(n_obs_max), int(bool(per_stage_target)), int(degree),
         _arr(C.c_double, 36, A), _arr(C.c_double, 12, B), _arr(C.c_double, 6, Q),

@@ -171,8 +171,8 @@ struct Carver {
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
         !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0) ||
-        o.slack_start < 0 || o.slack_start > 3)
-        return fail(CRX_ERR_ARG, "invalid crx_ipm_opts (a descriptor built for libcrx 0.1.x? crx_ipm_opts grew in 0.2: include/crx.h)");
+        o.slack_start < 0 || o.slack_start > 3 || !(o.dual_inf_tol > 0) || !(o.constr_viol_tol > 0) || !(o.compl_inf_tol > 0) || o.stall_iters < 1)
+        return fail(CRX_ERR_ARG, "invalid crx_ipm_opts (a descriptor built for libcrx <= 0.3.x? crx_ipm_opts grew in 0.2 and in 0.4: include/crx.h)");
     return 0;
 }
 
@@ -329,12 +329,12 @@ int crx_trace_read(double* host, int rows) {
 // of LDS the kernel did not write shows up as a changed result (tests/test_gpu_parity.py::test_no_stale_lds_reads)
 void crx_debug_poison_lds(int enable) { g_poison = enable != 0; }
 
-// diagnostics (not in crx.h): the solver kernel reports, for every CONVERGED problem of the following planner / CBF solves, the UNSCALED KKT error in
-// kkt[] -- max(reduced Lagrangian gradient, constraint violation of the rows in the reference's units, complementarity), i.e. without IPOPT's s_d
-// = max(100, ||nu||_1 / m) / 100 and without the gradient-based row scaling -- instead of the scaled error the convergence test uses.  IPOPT
-// itself stops on the scaled error <= tol AND unscaled dual_inf <= 1, constr_viol <= 1e-4, compl_inf <= 1e-4 (its defaults); north_star states
-// its tolerance on "the KKT residual": bench.py reports both (kkt_max_converged, kkt_unscaled_max).
-void crx_debug_kkt_unscaled(int enable) { g_kkt_unscaled = enable != 0; }
+// diagnostics (not in crx.h): the solver kernel reports, for every CONVERGED problem of the following planner / CBF solves, an UNSCALED KKT
+// quantity of the returned iterate in kkt[] instead of the scaled error -- without IPOPT's s_d = max(100, ||nu||_1 / m) / 100 and with the
+// gradient-based row scaling undone (rows in the reference's units).  mode 1: the max of the three; 2: the reduced Lagrangian gradient (IPOPT
+// dual_inf); 3: the constraint violation (constr_viol); 4: the complementarity (compl_inf); 0: off.  Since 0.4.0 these are the quantities the
+// termination test itself bounds (crx_ipm_opts.dual_inf_tol / constr_viol_tol / compl_inf_tol); bench.py reports each (kkt_unscaled_*_max).
+void crx_debug_kkt_unscaled(int mode) { g_kkt_unscaled = (mode >= 0 && mode <= 4) ? mode : 0; }
 
 // diagnostics (not in crx.h): the packed wave reductions and the DPP dot products of crx_wave.h on host data, in [4][64] -> out [16 + 3 * 64]
 // (tests/test_gpu_parity.py::test_packed_wave_reductions)
@@ -415,6 +415,8 @@ void crx_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 50; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2; o->grad_scale_max = 100.0;
     o->reach_screen = 1; o->slack_start = 2;
+    o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4;   // IPOPT's defaults (the reference sets none: control.py:593)
+    o->stall_iters = 100; o->reserved1 = 0;
 }
 
 void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B) {
@@ -435,6 +437,9 @@ void crx_cbf_desc_default(crx_cbf_desc* d, int N, int n_obs_max, const double* A
     d->delta_max = 0.5; d->a_max = 1.0; d->v_min = 0.0; d->v_max = 10.0; d->ey_max = 1.0;
     d->alpha = 0.8; d->margin = 0.2; d->l_sum = 0.4; d->w_sum = 0.2; d->w_slack = 1e4;
     crx_ipm_opts_default(&d->opts);
+    // budgets by problem class (include/crx.h crx_ipm_opts.stall_iters): the short one-obstacle class is done after 30 iterations when
+    // healthy, the three-obstacle N = 20 class needs 53..86
+    if (N <= 12 && n_obs_max <= 1) { d->opts.stall_iters = 50; d->opts.restore_iters = 25; }
 }
 
 void crx_select_desc_default(crx_select_desc* d, int N, int n_veh_max, double lap_length) {

@@ -1783,7 +1783,8 @@ crx_solve_kernel(const crx_kparams kp) {
     // ls_failed: 1 = no acceptable step, 2 = jam (JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the
     // constraints are still violated: the slacks of violated CBF rows are collapsing and every step is cut to nothing --
     // IPOPT's alpha < alpha_min test sends it to restoration from the same situation)
-    constexpr int JAM_COUNT = 5, STALL_ITERS = 100;   // [r5] 100, was 50: see the stall rule below
+    constexpr int JAM_COUNT = 5;
+    const int STALL_ITERS = o.stall_iters;   // [r6] crx_ipm_opts.stall_iters, by problem class (crx_cbf_desc_default): 50 for N <= 12 with one obstacle slot, 100 otherwise
     const double JAM_ALPHA = 1e-3;
     int n_restore = 0, ls_failed = 0, jam = 0, jam_on = (NOBS > 0 && o.restore_iters >= 0), it_limit = 0, cvx_run = 0;
     constexpr int CVX_PROBE = 4;
@@ -1911,11 +1912,28 @@ crx_solve_kernel(const crx_kparams kp) {
         double e_c = cmax;
         const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
         long long tc1 = CLK();
-        const double e_d = dual_infeasibility<NOBS, NMAX, (SweepUnroll<NFIX>::v > 2 ? SweepUnroll<NFIX>::v : 1)>(sm, c) / sd;
+        const double e_du = dual_infeasibility<NOBS, NMAX, (SweepUnroll<NFIX>::v > 2 ? SweepUnroll<NFIX>::v : 1)>(sm, c);
+        const double e_d = e_du / sd;
         long long tc2 = CLK();
         e_c /= sd;
         E0 = fmax(e_d, fmax(e_p, e_c));
-        if (E0 <= o.tol) { status = 0; break; }
+        if (E0 <= o.tol) {
+            // [r6] IPOPT's COMPLETE termination test (OptimalityErrorConvergenceCheck; the reference runs IPOPT on its defaults): the scaled
+            // error <= tol AND the unscaled dual infeasibility <= dual_inf_tol (1), constraint violation <= constr_viol_tol (1e-4),
+            // complementarity <= compl_inf_tol (1e-4).  Unscaled = no s_d, CBF rows in the reference's units (the simple rows are unscaled; t nu is
+            // invariant under the row scaling).  The second half binds on crash states: multipliers of 1e7..1e9 make s_d 1e4..1e7 and the scaled
+            // complementarity passes at mu = 1e-4 already.  Same test in oracle/crx_oracle.c.  The row pass runs on this (once-per-solve) path only.
+            double vu = e_p;
+            if (NOBS) {
+                for (int e = lane; e < N * NOBS; e += WAVE) {
+                    const int k = e / L::NO, ob = e - k * L::NO, j = k * NR + 8 + NOBS + ob;
+                    const double sc = cbf_scale<L>(sm, k, ob);
+                    if (sc != 0.0) vu = fmax(vu, fabs(LD(L::rc + j) - LD(L::rt + j)) / sc);
+                }
+                vu = wave_max(vu);
+            }
+            if (e_du <= o.dual_inf_tol && vu <= o.constr_viol_tol && cmax <= o.compl_inf_tol) { status = 0; break; }
+        }
         if (it >= o.max_iter) break;
         if (NOBS && n_restore > 0 && it >= it_limit) { status = 3; break; }   // restoration budget used up (CRX_RESTORED)
         // ---- barrier update ------------------------------------------------------------------------
@@ -2245,13 +2263,15 @@ crx_solve_kernel(const crx_kparams kp) {
     if (CRX_KKT_DIAG && kp.kkt_unscaled && status == 0) {
         // diagnostics (crx_debug_kkt_unscaled): the converged exit is taken right after dual_infeasibility(), so ga holds the reduced Lagrangian gradient
         // of the returned iterate; the row arrays hold its slacks, multipliers and (scaled) row values.  Outside every loop: no register is carried for it.
-        double eu = 0.0;
-        for (int e = lane; e < N * NZ + NX; e += WAVE) eu = fmax(eu, fabs(LD(L::ga + e)));
+        // kkt_unscaled = 1: the max of the three, 2: dual infeasibility, 3: constraint violation, 4: complementarity
+        double ed = 0.0, ev = 0.0, ec = 0.0;
+        for (int e = lane; e < N * NZ + NX; e += WAVE) ed = fmax(ed, fabs(LD(L::ga + e)));
         for (int j = lane; j < m; j += WAVE) {
             const double sc = row_scale<L>(sm, si, j, N);
-            if (sc != 0.0) eu = fmax(eu, fmax(fabs(LD(L::rc + j) - LD(L::rt + j)) / sc, LD(L::rt + j) * LD(L::rnu + j)));
+            if (sc != 0.0) { ev = fmax(ev, fabs(LD(L::rc + j) - LD(L::rt + j)) / sc); ec = fmax(ec, LD(L::rt + j) * LD(L::rnu + j)); }
         }
-        Eout = wave_max(eu);
+        const int km = kp.kkt_unscaled;
+        Eout = wave_max(km == 2 ? ed : km == 3 ? ev : km == 4 ? ec : fmax(ed, fmax(ev, ec)));
     }
     if (lane == 0) { kp.status[b] = status; kp.kkt[b] = Eout; kp.iters[b] = it; }
     }

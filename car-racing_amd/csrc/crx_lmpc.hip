@@ -498,7 +498,9 @@ __global__ void __launch_bounds__(WAVE) crx_lmpc_kernel(const crx_lmpc_kparams k
             e_d /= sd;
             e_c /= sc;
             E0 = fmax(e_d, fmax(e_p, e_c));
-            if (E0 <= o.tol) { status = CRX_CONVERGED; break; }
+            // [r6] IPOPT's complete test (crx_kernels.hip has the note): scaled error <= tol AND unscaled dual infeasibility / complementarity within
+            // dual_inf_tol / compl_inf_tol (rows are unscaled here: the violation test is implied by e_p <= tol)
+            if (E0 <= o.tol && e_d * sd <= o.dual_inf_tol && e_p <= o.constr_viol_tol && e_c * sc <= o.compl_inf_tol) { status = CRX_CONVERGED; break; }
             if (it >= o.max_iter) break;
             if (mu < 1e-6 && ++late >= CRX_LMPC_LATE) break;
             // Still violated: look for the proof that it must be (first attempt only; oracle/crx_oracle_lmpc.c

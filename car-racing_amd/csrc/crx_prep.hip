@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(WAVE) crx_path_kernel(const crx_path_kparams p
         const double e_c = wave_max(fmax(hasL ? tL * nL : 0.0, hasU ? tU * nU : 0.0)) / sd;
         const double theta = wave_sum(fabs(rpL) + fabs(rpU));
         E0 = fmax(e_d, fmax(e_p, e_c));
-        if (E0 <= o.tol) { st = CRX_CONVERGED; break; }
+        if (E0 <= o.tol && e_d * sd <= o.dual_inf_tol && e_p <= o.constr_viol_tol && e_c * sd <= o.compl_inf_tol) { st = CRX_CONVERGED; break; }   // [r6] IPOPT's complete test
         if (it >= o.max_iter) break;
         for (;;) {
             const double e_cm = wave_max(fmax(hasL ? fabs(tL * nL - mu) : 0.0, hasU ? fabs(tU * nU - mu) : 0.0)) / sd;

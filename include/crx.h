@@ -44,7 +44,11 @@
 extern "C" {
 #endif
 
-#define CRX_VERSION 300 /* 0.3.0: crx_allgather_winners_dev takes the winners' status and the winner record is SURVEY 8e's {int32 flag; int32
+#define CRX_VERSION 400 /* 0.4.0: NOT layout-compatible with 0.3.x -- crx_ipm_opts grew by IPOPT's three UNSCALED termination tolerances
+                          (`dual_inf_tol`, `constr_viol_tol`, `compl_inf_tol`: "converged" now means IPOPT's complete test, not the scaled error
+                          alone) and by `stall_iters` (the stall rule's budget, a kernel constant until 0.3.x; crx_cbf_desc_default picks it and
+                          `restore_iters` by problem class).
+                          0.3.0: crx_allgather_winners_dev takes the winners' status and the winner record is SURVEY 8e's {int32 flag; int32
                           status; double X[N+1][6]} (same 632 B at N = 12; 0.2.x: the flag as a double, no status) -- the only signature that
                           changed; every other entry point and every struct layout is 0.2.x's.
                           0.2.1: same ABI as 0.2.0; the crash path of the MPC-CBF NLPs (crx_ipm_opts.slack_start = 2) takes the crash start's barrier
@@ -100,9 +104,10 @@ typedef enum crx_status {
 /* Interior-point options.  Defaults (crx_ipm_opts_default) restate IPOPT 3.x defaults that the
  * reference inherits by passing only print options (control.py:593, overtake_traj_planner.py:335). */
 typedef struct crx_ipm_opts {
-    double tol;            /* 1e-8  convergence tolerance on the scaled KKT error */
+    double tol;            /* 1e-8  convergence tolerance on the scaled KKT error (IPOPT `tol`); since 0.4.0 necessary, not sufficient: see
+                              dual_inf_tol / constr_viol_tol / compl_inf_tol at the end of this struct */
     int32_t max_iter;      /* 200   (IPOPT: 3000; capped, status CRX_MAX_ITER beyond) */
-    int32_t restore_iters; /* 50    ([r5]; 25 before: DESIGN 4.2) iterations allowed after the first restoration (CRX_RESTORED beyond); < 0: no restoration
+    int32_t restore_iters; /* 50 / 25  (by problem class: see stall_iters below) iterations allowed after the first restoration (CRX_RESTORED beyond); < 0: no restoration
                               phase at all (a failed line search then ends the solve, as in libcrx 0.1.0) */
     double mu_init;        /* 0.1   */
     double kappa_eps;      /* 10    barrier sub-problem tolerance factor */
@@ -143,6 +148,24 @@ typedef struct crx_ipm_opts {
                                  reference: a near-miss that the zero start solves ends at the local minimum IPOPT reaches from zero, and at
                                  another one from the candidate point; the reference's recorded closed loop is reproduced step by step with 2,
                                  not with 3. */
+    /* [0.4.0] IPOPT's complete termination test.  IPOPT accepts a point only if the scaled error is <= tol AND three UNSCALED
+     * quantities are below their own tolerances (IpOptErrorConvCheck.cpp; the reference runs IPOPT on defaults, control.py:593,
+     * overtake_traj_planner.py:335).  "Unscaled" = without the s_d / s_c normalisation of the error measure and with the
+     * gradient-based row scaling of the CBF rows undone (rows in the reference's units).  Until 0.3.x libcrx stopped on the scaled
+     * error alone: a crash state with multipliers of 1e7..1e9 (s_d of 1e4..1e7) was reported converged with a complementarity of
+     * 2.5e-4 (configs[1]) / 5.5e-4 (configs[3]) -- beyond the 1e-4 IPOPT (and north_star) allow. */
+    double dual_inf_tol;    /* 1     max |reduced Lagrangian gradient|, unscaled                (IPOPT dual_inf_tol) */
+    double constr_viol_tol; /* 1e-4  max |c_j - t_j| with the row scaling undone               (IPOPT constr_viol_tol) */
+    double compl_inf_tol;   /* 1e-4  max t_j nu_j                                              (IPOPT compl_inf_tol) */
+    int32_t stall_iters;    /* 100 / 50  MPC-CBF NLPs: a solve that started at the reference's zero point and is still infeasible (by 1e-6)
+                              after this many iterations is sent to the crash restart / the closed-form restoration.  A
+                              kernel constant until 0.3.x (50 in 0.1..0.2, 100 in 0.3).  crx_ipm_opts_default: 100; crx_cbf_desc_default
+                              chooses (stall_iters, restore_iters) by problem class: (50, 25) for N <= 12 with at most one obstacle slot --
+                              the class of BASELINE configs[1], where a healthy solve is done after 30 iterations --, (100, 50) for every
+                              longer horizon or more obstacles (configs[3]: healthy solves of 53..86 iterations).  With the defaults a
+                              solve ends after at most stall_iters + 1 + restore_iters (76 / 151) iterations when it went through a
+                              restoration, 1 + 3 restore_iters (76 / 151) when it started on the crash path: below max_iter in both. */
+    int32_t reserved1;
 } crx_ipm_opts;
 
 /* ---- planner region QP (overtake_traj_planner.py:263-334) ------------------------------------ */

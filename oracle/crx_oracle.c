@@ -374,6 +374,7 @@ static void scale_rows(work_t* w) {
 typedef struct {
     int status, iters;
     double kkt, cost;
+    double kkt3[3];   /* UNSCALED dual infeasibility / constraint violation / complementarity of the returned iterate (IPOPT's second test) */
 } result_t;
 
 /* One workspace per thread, allocated on first use and kept for the life of the thread (OpenMP keeps its
@@ -392,13 +393,17 @@ static int thread_ws(work_t** w, ocp_t** p) {
 #include <stdio.h>
 static int g_verbose = 0;
 void crx_oracle_set_verbose(int v) { g_verbose = v; }
+/* diagnostics, mirror of libcrx's crx_debug_kkt_unscaled: kkt[] of a CONVERGED solve becomes 1: the max of / 2: the dual infeasibility /
+ * 3: the constraint violation / 4: the complementarity of the returned iterate, UNSCALED (no s_d; CBF rows in the reference's units) */
+static int g_kkt_unscaled = 0;
+void crx_oracle_debug_kkt_unscaled(int mode) { g_kkt_unscaled = (mode >= 0 && mode <= 4) ? mode : 0; }
 /* experiment knobs (tools/tail_knobs.py): 0 JAM_ALPHA, 1 JAM_COUNT, 2 STALL_ITERS, 3 CRAWL_ALPHA, 4 CRAWL_COUNT (0 = off),
  * 5 max restorations, 6 restore at the start when a CBF row of stage <= knob is violated (-1 = off), 7 slack start of a
  * violated row: 0 = |c| (shipped), x > 0 = max(c, x * slack_push) (IPOPT's own start is x = 1), 9 do not charge the knob-6
  * restoration to the budget, 11 probe period of the sticky convexification (0 = CVX_PROBE, < 0 = every iteration probes: not sticky).
  * Defaults = the shipped algorithm; the kernel has no such knobs.  (What used to be knobs 8 and 14 are
  * crx_ipm_opts.reach_screen / .slack_start since ABI 0.2.) */
-static double g_knob[16] = {1e-3, 5, 100, 0.0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static double g_knob[16] = {1e-3, 5, 0, 0.0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 void crx_oracle_set_knob(int i, double v) { if (i >= 0 && i < 16) g_knob[i] = v; }
 
 /* Restoration for the CBF NLP, entered when the filter line search finds no acceptable step (where IPOPT switches to
@@ -651,7 +656,7 @@ static void ipm_solve(work_t* w, result_t* res) {
     enum { MAXF = 32 };
     double Fth[MAXF], Fph[MAXF];
     int nf = 0;
-    const int JAM_COUNT = (int)g_knob[1], STALL_ITERS = (int)g_knob[2];
+    const int JAM_COUNT = (int)g_knob[1], STALL_ITERS = g_knob[2] > 0 ? (int)g_knob[2] : o->stall_iters;   /* knob 2: experiments only (0 = the descriptor's) */
     const double JAM_ALPHA = g_knob[0];
     int status = CRX_MAX_ITER, it = 0, n_restore = 0, first = 1, jam = 0, jam_on = 1, it_limit = 0;
     /* a solve that STARTS on the crash path has a budget too (three times the restoration budget + 1: it has the whole way to go; 2x
@@ -693,7 +698,14 @@ static void ipm_solve(work_t* w, result_t* res) {
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (g_verbose)
             fprintf(stderr, "it %3d f %.8e ed %.6e ep %.6e ec %.6e mu %.1e dw %.1e nf %d\n", it, w->f, e_d, e_p, e_c, mu, dw_last, nf);
-        if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
+        /* IPOPT's termination test (IpOptErrorConvCheck.cpp, OptimalityErrorConvergenceCheck::CurrentIsConverged; the reference runs it on
+         * default options, control.py:593 / overtake_traj_planner.py:335): the scaled error <= tol AND the UNSCALED dual infeasibility <=
+         * dual_inf_tol (1), constraint violation <= constr_viol_tol (1e-4), complementarity <= compl_inf_tol (1e-4).  Unscaled: no s_d, and the
+         * gradient-based row scaling d_j of the CBF rows undone (t nu is invariant under it).  The second half binds on crash states:
+         * multipliers of 1e7..1e9 make s_d 1e4..1e7 and the scaled complementarity passes at mu = 1e-4 already. */
+        res->kkt3[0] = e_d * sd; res->kkt3[2] = e_c * sd; res->kkt3[1] = 0.0;
+        for (int j = 0; j < m; j++) res->kkt3[1] = fmax(res->kkt3[1], fabs(rp[j]) / w->d[j]);
+        if (E0 <= o->tol && res->kkt3[0] <= o->dual_inf_tol && res->kkt3[1] <= o->constr_viol_tol && res->kkt3[2] <= o->compl_inf_tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
         if (n_restore > 0 && it >= it_limit) { status = CRX_RESTORED; break; }   /* restoration budget used up */
         /* barrier update */
@@ -928,6 +940,8 @@ static void ipm_solve(work_t* w, result_t* res) {
     res->status = status;
     res->iters = it;
     res->kkt = E0;
+    if (g_kkt_unscaled && status == CRX_CONVERGED)
+        res->kkt = g_kkt_unscaled == 1 ? fmax(res->kkt3[0], fmax(res->kkt3[1], res->kkt3[2])) : res->kkt3[g_kkt_unscaled - 2];
     res->cost = w->f;
 }
 
@@ -951,6 +965,7 @@ void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 50; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2;
     o->grad_scale_max = 100.0; o->reach_screen = 1; o->slack_start = 2;
+    o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4; o->stall_iters = 100; o->reserved1 = 0;
 }
 
 /* The region QP of generate_traj_per_region as the canonical stage-structured problem (line numbers into

@@ -412,7 +412,9 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
         e_c /= sc;
         E0 = fmax(e_d, fmax(e_p, e_c));
         if (lv) fprintf(stderr, "it %3d f %.10e ed %.2e ep %.2e ec %.2e mu %.1e theta %.2e nf %d sd %.1f\n", it, f, e_d, e_p, e_c, mu, theta, nf, sd);
-        if (E0 <= o->tol) { status = CRX_CONVERGED; break; }
+        /* IPOPT's complete test (crx_oracle.c has the note): scaled error <= tol AND unscaled dual infeasibility / complementarity within
+         * dual_inf_tol / compl_inf_tol (rows are unscaled here: the violation test is implied by e_p <= tol) */
+        if (E0 <= o->tol && e_d * sd <= o->dual_inf_tol && e_p <= o->constr_viol_tol && e_c * sc <= o->compl_inf_tol) { status = CRX_CONVERGED; break; }
         if (it >= o->max_iter) break;
         if (mu < 1e-6 && ++late >= LATE_ITERS) break;
         /* still violated: look for the proof that it must be (first attempt only; scale = sum of all multipliers) */
@@ -743,7 +745,7 @@ int crx_oracle_path_solve(const crx_path_desc* d, int batch, const double* opt, 
             const double sd = m ? fmax(smax, nus / m) / smax : 1.0;
             e_d /= sd; e_c /= sd;
             E0 = fmax(e_d, fmax(e_p, e_c));
-            if (E0 <= o->tol) { st = CRX_CONVERGED; break; }
+            if (E0 <= o->tol && e_d * sd <= o->dual_inf_tol && e_p <= o->constr_viol_tol && e_c * sd <= o->compl_inf_tol) { st = CRX_CONVERGED; break; }   /* IPOPT's complete test */
             if (it >= o->max_iter) break;
             for (;;) {
                 double e_cm = 0.0;

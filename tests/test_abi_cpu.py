@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.crx_version() == 300   # include/crx.h CRX_VERSION
+    assert lib.crx_version() == 400   # include/crx.h CRX_VERSION
 
 
 def test_struct_layouts_match_header(lib):
