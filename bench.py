@@ -50,14 +50,22 @@ METRIC = "NLP solves/sec (N=12, 6-state bicycle); p50 per-step solve latency"
 
 
 def kernel_source_hash():
-    """sha256 over the sources the SOLVER kernel is built from (crx_kernels.hip, crx_wave.h, the Makefile's flags): guards the
-    rocprofv3 numbers kept under profiles/ (HBM traffic of crx_solve_kernel) against a kernel that changed since."""
+    """sha256 over everything the solver kernels are built from -- every kernel source and header, the Makefile's flags, and the COMPILER's version
+    string: guards the rocprofv3 numbers kept under profiles/ (HBM traffic per launch) against a kernel or a toolchain that changed since."""
     import hashlib
+    import subprocess
     h = hashlib.sha256()
     d = os.path.join(ROOT, "car-racing_amd", "csrc")
-    for f in ("crx_kernels.hip", "crx_kernels_obs.hip", "crx_kernels_gen.hip", "crx_wave.h", "Makefile"):
+    for f in ("crx_kernels.hip", "crx_kernels_obs.hip", "crx_kernels_gen.hip", "crx_lmpc.hip", "crx_prep.hip", "crx_lmpcprep.hip", "crx_kparams.h", "crx_wave.h",
+              "Makefile"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
+    try:    # a toolchain bump re-schedules the kernels without touching a source line
+        ver = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True, timeout=60).stdout
+        ver = "\n".join(ln for ln in ver.splitlines() if "InstalledDir" not in ln)
+    except Exception:
+        ver = "hipcc: unavailable"
+    h.update(ver.encode())
     return h.hexdigest()[:16]
 
 
@@ -568,23 +576,36 @@ def measure(cx, w, steps, warmup, with_latency=True):
     k_ms_train = k_ms
     if region_ms is not None:
         k_ms = region_ms
-    kkt_unscaled = None
+    kkt_unscaled, kkt_parts, n_beyond = None, {}, None
     if w.kind in ("cbf", "cbf_tracking", "planner") and not getattr(w, "solve_parts", None):
-        # the UNSCALED KKT error of the converged problems (libcrx diagnostics, crx_debug_kkt_unscaled: the same launch once more with kkt[] = max(reduced
-        # Lagrangian gradient, constraint violation in the reference's row units, complementarity) -- no s_d, no row scaling); outside every timed region
+        # the UNSCALED KKT quantities of the converged problems (libcrx diagnostics, crx_debug_kkt_unscaled(mode): the same launch once more with kkt[] = 2: the
+        # reduced Lagrangian gradient, 3: the constraint violation in the reference's row units, 4: the complementarity -- no s_d, no row scaling); outside
+        # every timed region.  Since libcrx 0.4.0 these are what the termination test itself bounds (IPOPT's dual_inf_tol 1, constr_viol_tol 1e-4,
+        # compl_inf_tol 1e-4): `value` counts a problem only if its status is 0 AND its violation and complementarity are <= 1e-4 (north_star's figure).
         import crx
         L = crx.lib()
-        L.crx_debug_kkt_unscaled(1)
+        beyond = np.zeros(len(st), dtype=bool)
         try:
-            w.solve()
-            cx.dsync()
-            ku, su = w.ws.kkt.cpu().numpy(), w.ws.status.cpu().numpy()
-            kkt_unscaled = float(ku[su == 0].max()) if (su == 0).any() else None
+            for mode, name in ((2, "dual"), (3, "viol"), (4, "compl")):
+                L.crx_debug_kkt_unscaled(mode)
+                w.solve()
+                cx.dsync()
+                ku, su = w.ws.kkt.cpu().numpy(), w.ws.status.cpu().numpy()
+                kkt_parts[name] = float(ku[su == 0].max()) if (su == 0).any() else None
+                if name != "dual":
+                    beyond |= (su == 0) & ~(ku <= 1e-4)
+                else:
+                    kkt_parts["dual_above_1e-4"] = int(((su == 0) & ~(ku <= 1e-4)).sum())
         finally:
             L.crx_debug_kkt_unscaled(0)
             w.solve()
             cx.dsync()
+        n_beyond = int(beyond.sum())
+        vals = [v for k, v in kkt_parts.items() if k in ("dual", "viol", "compl") and v is not None]
+        kkt_unscaled = max(vals) if vals else None
     conv = st == 0
+    if n_beyond:                # status 0 with an unscaled violation / complementarity beyond 1e-4: not counted (cannot happen at default options)
+        conv = conv & ~beyond
     opt = st == 0               # converged at tol (a proved-infeasible planner QP is ANSWERED, not converged: its kkt is +inf by definition)
     if w.kind == "planner":     # a region QP PROVED infeasible (screen / certificate) is an answered problem: the planner consumes the verdict
         conv = conv | (st == 2)
@@ -624,6 +645,8 @@ def measure(cx, w, steps, warmup, with_latency=True):
                            "skipped_masked": float((st == 4).mean()), "stalled": float((st == 5).mean())},
            "converged_frac": float(conv.mean()), "converged_frac_of_launched": conv_of_launched if ran.any() else None,
            "kkt_max_converged": float(kkt[opt].max()) if opt.any() else None, "kkt_unscaled_max": kkt_unscaled,
+           "kkt_unscaled_dual_max": kkt_parts.get("dual"), "kkt_unscaled_viol_max": kkt_parts.get("viol"), "kkt_unscaled_compl_max": kkt_parts.get("compl"),
+           "converged_beyond_1e-4_viol_or_compl": n_beyond, "converged_with_dual_above_1e-4": kkt_parts.get("dual_above_1e-4"),
            "iters_p50": float(np.median(it[st != 4])) if (st != 4).any() else 0.0,
            "iters_p90": float(np.percentile(it[st != 4], 90)) if (st != 4).any() else 0.0, "iters_max": int(it.max())}
     if with_latency:
@@ -677,6 +700,7 @@ def stdout_line(full):
     line = {k: (r4(full[k]) if k in ("value", "value_launched", "ms_per_step") else full[k]) for k in
             ("metric", "value", "value_launched", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     ck = ("workload", "baseline_config", "batch_per_gpu", "problems_launched", "horizon", "n_obs", "tol", "converged_frac", "kkt_max_converged", "kkt_unscaled_max",
+          "kkt_unscaled_dual_max", "kkt_unscaled_viol_max", "kkt_unscaled_compl_max", "converged_beyond_1e-4_viol_or_compl", "converged_with_dual_above_1e-4",
           "iters_p50", "iters_p90", "iters_max", "p50_step_latency_ms", "p99_step_latency_ms", "p50_host_call_one_control_step_ms", "dispatch")
     line["config"] = {k: r4(c[k]) for k in ck if c.get(k) is not None}
     line["config"]["workload"] = str(c["workload"])[:160]

@@ -83,6 +83,43 @@ def kkt_certificate(opti, z, nu=None, act_tol=1e-7):
     )
 
 
+def kkt_certificate_ipopt(opti, z, compl_tol=1e-4):
+    """[r6] The same question with the multiplier recovery an INTERIOR-POINT answer needs: find lam (free) and nu >= 0 with
+    nu_j c_j <= compl_tol (IPOPT's compl_inf_tol; rows at their bound: unbounded above) that minimise ||grad f - Je' lam - Ji' nu||_inf --
+    a linear program over ALL rows (HiGHS), no activity threshold.  Why: IPOPT accepts a complementarity of 1e-4, so a returned point may hold a
+    row with a slack of 1e-5 and a multiplier of 1; `kkt_certificate` drops that row as inactive (c > act_tol = 1e-7), fits nu = 0 and reports
+    the row's whole gradient as a stationarity defect -- cfg2 #99: 0.86 with rows active to 1e-7, 0.26 to 1e-5, 8.6e-6 to 1e-3, and 4.5e-7 from
+    this program (three rows with slacks 2.9e-7 / 2.2e-6 / 4.1e-5 carry multipliers of 0.17..0.29).  Rows are equilibrated by their largest
+    gradient entry (a CBF row's is 1e2..1e9) and the program is solved on the scale of ||grad f||_inf; HiGHS's own tolerances (1e-7 on that
+    scale) bound the accuracy from below: a clean KKT point reads ~1e-8 x ||grad f||, where the active-set fit reads 1e-11."""
+    f, gf, ce, Je, ci, Ji = opti.eval_all(z)
+    me, m, n = len(ce), len(ci), len(z)
+    s = np.maximum(1.0, np.abs(Ji).max(axis=1)) if m else np.zeros(0)
+    se = np.maximum(1.0, np.abs(Je).max(axis=1)) if me else np.zeros(0)
+    Js, cs, Jes = (Ji / s[:, None], ci / s, Je / se[:, None])
+    gs = max(1.0, float(np.abs(gf).max()))
+    bounds = [(None, None)] * me + [(0.0, None if cs[j] <= 0.0 else compl_tol / cs[j] / gs) for j in range(m)] + [(0.0, None)]
+    M = np.hstack([Jes.T, Js.T])
+    one = np.ones((n, 1))
+    res = linprog(np.concatenate([np.zeros(me + m), [1.0]]), A_ub=np.block([[-M, -one], [M, -one]]), b_ub=np.concatenate([-gf / gs, gf / gs]),
+                  bounds=bounds, method="highs")
+    if res.status != 0:
+        return None
+    x = res.x[: me + m] * gs
+    nu = x[me:] / s
+    return dict(
+        f=float(f),
+        stationarity=float(np.abs(gf - M @ x).max()),
+        eq_violation=float(np.abs(ce).max()) if me else 0.0,
+        ineq_violation=float(max(0.0, -ci.min())) if m else 0.0,
+        min_multiplier=float(nu.min()) if m else 0.0,
+        complementarity=float(np.abs(nu * np.maximum(ci, 0.0)).max()) if m else 0.0,
+        n_active=int((ci <= 1e-7).sum()),
+        lam_eq=x[:me] / se,
+        nu=nu,
+    )
+
+
 def _polish_qp(H, g, Ae, be, Ai, bi, z, iters=50):
     """Primal active-set clean-up of an (almost converged) convex-QP solution: fix the active set
     found by SLSQP, solve the equality-constrained KKT system exactly, repair sign/feasibility."""

@@ -246,18 +246,23 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
         kw = dict(Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
     args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
 
+    budgets = {}
+
     def both_sides(restore_iters):
         d = abi.cbf_desc(p["N"], p["obs_s"].shape[1], A, B, alpha=p["alpha"], margin=p["margin"], **kw)
         _with_tol(d, T["tol"])
-        d.opts.restore_iters = restore_iters
+        if restore_iters is not None:
+            d.opts.restore_iters = restore_iters
+        budgets.update(stall=d.opts.stall_iters, restore=d.opts.restore_iters)
         return gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
 
     g0, o0 = both_sides(-1)
     # (without any restoration the crash states of the unfiltered draws crawl for 60..200 iterations; over such a run the last bits of
     # two different factorisations add up to a few iterations: ONE such problem per batch is tolerated, same point required)
     _assert_same_verdicts(cfg + " no restoration", g0, o0, tol=T["tol"], max_other=1 if "unfiltered" in cfg else 0)
-    RI = abi.default_opts().restore_iters    # 50 [r5]
-    g1, o1 = both_sides(RI)
+    g1, o1 = both_sides(None)                # the budgets of the problem class [r6]: (stall_iters, restore_iters) = (50, 25) for N = 12 with one obstacle slot, (100, 50) otherwise
+    RI, SI = budgets["restore"], budgets["stall"]
+    assert (SI, RI) == ((50, 25) if cfg.startswith("cfg2") else (100, 50))
     touched = set()
     for r0, r1 in ((g0, g1), (o0, o1)):
         dx = np.abs(r0["X"] - r1["X"]).reshape(len(r0["status"]), -1).max(axis=1) > 0
@@ -272,9 +277,9 @@ def test_synthetic_cbf_batches(gpu, orc, AB, cfg, T):
     c = _assert_same_verdicts(cfg, g1, o1, tol=T["tol"], restored=frozenset(touched), max_restored_verdict=max(2, len(touched) // 5))
     # restoration turns failed line searches into defined ends: no problem is left at the iteration cap
     assert (g1["status"] == 1).sum() <= (0 if T["tol"] >= 1e-9 else 2), np.bincount(g1["status"], minlength=4)   # (1e-11 is below the noise floor of a crash state of cost 1e8: its line search ends at a feasible point)
-    assert g1["iters"].max() <= min(100 + 1 + RI + RI, 200), g1["iters"].max()      # stall trigger + restoration budget (+ a second restoration), max_iter
+    assert g1["iters"].max() <= max(SI + 1 + RI, 1 + 3 * RI), g1["iters"].max()      # stall trigger + restoration budget (a second restoration shares it) | a crash start's budget: < max_iter
     # bounded effort has a price: a crash state that would have crawled to a KKT point in 50..200 iterations now ends as
-    # CRX_RESTORED after at most 76 ([r5] 151 at the defaults: raise opts.restore_iters / max_iter to trade latency back for convergence)
+    # CRX_RESTORED after at most 76 (one-obstacle class) / 151 (the others) iterations: raise opts.stall_iters / restore_iters to trade latency back for convergence
     assert (g1["status"] == 0).sum() >= 0.95 * (g0["status"] == 0).sum()
     # crash states that do converge carry slacks of 1e2..1e6 (cost 1e6..1e10): their trajectories agree to the default set only
     both = _cmp(cfg, g0, o0, need_same_status=False, T=DEFAULT if "unfiltered" in cfg else T)
@@ -703,7 +708,7 @@ def test_cfg4_non_converged_on_the_gpu(gpu, orc, AB):
     assert d.opts.restore_iters == 50
     rg, ro = gpu.cbf_solve(d, *[p[k] for k in tdf.KEYS]), orc.cbf_solve(d, *[p[k] for k in tdf.KEYS])
     same = rg["status"] == ro["status"]
-    assert same.mean() >= 0.9, (np.nonzero(~same)[0], rg["status"][~same], ro["status"][~same])
+    assert same.mean() >= 0.95, (np.nonzero(~same)[0], rg["status"][~same], ro["status"][~same])
     lines, counts = tdf.classify_cfg4_stopped(rg, g)
     print("\n" + str(counts) + "\n  " + "\n  ".join(lines))
     assert counts["converged"] >= 50, counts
@@ -715,35 +720,101 @@ def test_cfg4_non_converged_on_the_gpu(gpu, orc, AB):
     assert np.median(di) == 0 and (di <= 1).mean() >= 0.85 and di.max() <= 10, di
 
 
-def test_unscaled_kkt_diagnostics(gpu, AB):
-    """crx_debug_kkt_unscaled (diagnostics; bench.py's kkt_unscaled_max): kkt[] of a converged solve becomes the UNSCALED KKT error -- without
-    IPOPT's s_d = max(100, ||nu||_1 / m) / 100 and without the row scaling -- and nothing else changes.  On the headline batch it equals the
-    scaled error wherever s_d = 1 (multipliers below 100 on average) and shows the crash states with multipliers of 1e9."""
+@pytest.mark.parametrize("kind,n,seed", [("cfg2", 4096, 1), ("cfg4", 2048, 11)])
+def test_stress_kernel_vs_oracle_at_scale(gpu, orc, AB, kind, n, seed):
+    """[r6] tools/stress_cbf.py as a test: kernel vs oracle on draws 16x larger than the parity tests hold, other seeds than the benched
+    ones.  Same status on >= 99.9 % of the problems; every pair BOTH sides report converged whose trajectories differ by more than 1e-5 is CLASSIFIED by
+    the oracle-free certificate of tests/kkt_check.py (a linear program over all rows at IPOPT's complementarity tolerance): both points must be KKT
+    points of the reference's NLP -- two local solutions of a non-convex problem, the cheaper side recorded -- and such pairs stay below 0.5 %."""
+    import kkt_check
+    from crx import abi, synth
+
+    A, B = AB
+    if kind == "cfg2":
+        p = synth.cfg2_mpccbf(n, seed=seed, safe_start=False)
+        d = abi.cbf_desc(12, 1, A, B, alpha=0.8, margin=0.2)
+    else:
+        p = synth.cfg4_tracking_cbf(n, seed=seed, safe_start=False)
+        d = abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True)
+    args = [p[k] for k in kkt_check.KEYS]
+    rg, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+    sg, so = rg["status"], ro["status"]
+    same = sg == so
+    print("\n%s x %d (seed %d): converged gpu %d oracle %d; status differs on %s" % (kind, n, seed, (sg == 0).sum(), (so == 0).sum(),
+          [(int(b), int(sg[b]), int(rg["iters"][b]), int(so[b]), int(ro["iters"][b])) for b in np.nonzero(~same)[0]]))
+    assert same.mean() >= 0.999, same.mean()
+    assert (sg == 0).mean() >= (0.9995 if kind == "cfg2" else 0.997)
+    lines, table = kkt_check.classify_pairs(d, p, rg, ro)
+    print("pairs with |dX| > 1e-5: %s\n  " % table + "\n  ".join(lines))
+    assert table["uncertified"] == 0, table
+    assert table["pairs"] <= 0.005 * n, table
+    both = (sg == 0) & (so == 0)
+    dx = np.abs(rg["X"] - ro["X"]).reshape(n, -1).max(axis=1)
+    near = both & (dx <= 1e-5)
+    rel = np.abs(rg["cost"] - ro["cost"]) / np.maximum(1.0, np.abs(ro["cost"]))
+    assert rel[near].max() <= 1e-6, rel[near].max()
+    assert (rg["iters"][near] == ro["iters"][near]).mean() >= 0.97
+
+
+@pytest.mark.parametrize("kind", ["cfg2", "cfg4"])
+def test_converged_means_ipopts_complete_test(gpu, orc, AB, kind):
+    """[r6] "Converged" = IPOPT's COMPLETE termination test (the reference runs IPOPT on default options: control.py:593): the scaled error <= tol AND the
+    unscaled dual infeasibility <= 1, constraint violation <= 1e-4, complementarity <= 1e-4 (crx_ipm_opts.dual_inf_tol / constr_viol_tol /
+    compl_inf_tol).  Every converged problem of the headline batch (configs[1], SURVEY 8d draw, crash states included) and of a configs[3] batch meets
+    north_star's 1e-4 on violation and complementarity -- read back through the diagnostics switch crx_debug_kkt_unscaled(mode), which changes nothing
+    else --, the oracle reports the same components, and with the three tolerances opened the solver is libcrx 0.3's: scaled error only, complementarity
+    of a crash state beyond 1e-4."""
     import crx
     from crx import abi, synth
 
     A, B = AB
-    p = synth.cfg2_mpccbf(256, safe_start=False)
-    d = abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+    if kind == "cfg2":
+        p = synth.cfg2_mpccbf(256, safe_start=False)
+        mk = lambda **kw: abi.cbf_desc(12, 1, A, B, alpha=p["alpha"], margin=p["margin"], opts=abi.default_opts(**{**abi.cbf_class_budgets(12, 1), **kw}))   # noqa: E731
+    else:
+        p = synth.cfg4_tracking_cbf(2048, N=20, seed=4, safe_start=False)
+        mk = lambda **kw: abi.cbf_desc(20, 3, A, B, alpha=0.6, margin=0.15, Q=(10.0, 0, 0, 5.0, 0, 50.0), per_stage_target=True,   # noqa: E731
+                                       opts=abi.default_opts(**{**abi.cbf_class_budgets(20, 3), **kw}))
+    d = mk()
+    assert (d.opts.dual_inf_tol, d.opts.constr_viol_tol, d.opts.compl_inf_tol) == (1.0, 1e-4, 1e-4)
     args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
     r0 = gpu.cbf_solve(d, *args)
-    crx.lib().crx_debug_kkt_unscaled(1)
+    ok = r0["status"] == 0
+    assert ok.mean() >= (1.0 if kind == "cfg2" else 0.995)
+    parts = {}
     try:
-        r1 = gpu.cbf_solve(d, *args)
+        for mode, name in ((2, "dual"), (3, "viol"), (4, "compl"), (1, "max")):
+            crx.lib().crx_debug_kkt_unscaled(mode)
+            orc.lib.crx_oracle_debug_kkt_unscaled(mode)
+            r1, ro = gpu.cbf_solve(d, *args), orc.cbf_solve(d, *args)
+            for k in ("X", "U", "sigma", "cost", "status", "iters"):
+                np.testing.assert_array_equal(r0[k], r1[k])                # the switch changes kkt[] of the converged problems and nothing else
+            np.testing.assert_array_equal(r1["kkt"][~ok], r0["kkt"][~ok])
+            parts[name] = r1["kkt"][ok]
+            both = ok & (ro["status"] == 0) & (ro["iters"] == r0["iters"])
+            assert both.mean() >= 0.97
+            # same quantity on both sides (different linear algebra: the last digits of a 1e-9 residual differ)
+            assert (np.abs(r1["kkt"][both] - ro["kkt"][both]) <= 1e-6 + 0.5 * np.maximum(r1["kkt"][both], ro["kkt"][both])).mean() >= 0.95, name
     finally:
         crx.lib().crx_debug_kkt_unscaled(0)
-    for k in ("X", "U", "sigma", "cost", "status", "iters"):
-        np.testing.assert_array_equal(r0[k], r1[k])
-    ok = r0["status"] == 0
-    assert ok.all()
-    ks, ku = r0["kkt"], r1["kkt"]
-    assert (ku >= ks * (1 - 1e-9)).all()                       # every unscaled term dominates its scaled counterpart
-    assert np.median(ku) <= 1e-8 and (ku <= 1e-6).mean() >= 0.9
-    # the largest belong to the crash states (costs of 1e8, multipliers of 1e9: s_d ~ 1e5): 2.5e-4 on #165 -- inside IPOPT's own unscaled
-    # acceptance thresholds (dual_inf_tol 1, constr_viol_tol = compl_inf_tol = 1e-4 apply to the violation and complementarity parts)
-    assert 1e-6 <= ku.max() <= 1e-3, ku.max()
+        orc.lib.crx_oracle_debug_kkt_unscaled(0)
+    print("\n%s: unscaled dual %.2e  violation %.2e  complementarity %.2e (max over %d converged)" % (kind, parts["dual"].max(), parts["viol"].max(), parts["compl"].max(), ok.sum()))
+    assert parts["viol"].max() <= 1e-4 and parts["compl"].max() <= 1e-4 and parts["dual"].max() <= 1.0
+    np.testing.assert_array_equal(parts["max"], np.maximum(parts["dual"], np.maximum(parts["viol"], parts["compl"])))
+    assert (parts["max"] >= r0["kkt"][ok] * (1 - 1e-9)).all()              # every unscaled term dominates its scaled counterpart
+    assert np.median(parts["max"]) <= 1e-8
     r2 = gpu.cbf_solve(d, *args)
-    np.testing.assert_array_equal(r2["kkt"], ks)               # the switch is off again
+    np.testing.assert_array_equal(r2["kkt"], r0["kkt"])                    # the switch is off again
+    # libcrx 0.3's test (scaled error alone) = the three tolerances opened: same solver, and what it used to accept
+    d3 = mk(dual_inf_tol=1e30, constr_viol_tol=1e30, compl_inf_tol=1e30)
+    r3 = gpu.cbf_solve(d3, *args)
+    assert (r3["iters"] <= r0["iters"]).all() and (r3["iters"] < r0["iters"]).sum() >= 1
+    crx.lib().crx_debug_kkt_unscaled(4)
+    try:
+        c3 = gpu.cbf_solve(d3, *args)
+    finally:
+        crx.lib().crx_debug_kkt_unscaled(0)
+    assert c3["kkt"][c3["status"] == 0].max() > 1e-4
 
 
 def test_game_loop_lmpc_verdicts_equal_highs(gpu, orc):
@@ -975,7 +1046,7 @@ def test_cfg4_full_size(gpu, orc, AB):
     args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
     r1 = gpu.cbf_solve(d, *args)
     ok = r1["status"] == 0
-    assert ok.mean() >= 0.90, ok.mean()
+    assert ok.mean() >= 0.999, ok.mean()       # [r6] 99.95 % at the class budgets (stall_iters 100, restore_iters 50); the threshold was 0.90 until round 5
     # SURVEY 8d's draw puts ~7 % of the egos inside or about to enter an obstacle's unsafe set (crash states): those end
     # as CRX_RESTORED / CRX_INFEASIBLE; an undefined end (iteration cap) is practically absent
     assert (r1["status"] == 1).mean() <= 2e-3, np.bincount(r1["status"], minlength=4)

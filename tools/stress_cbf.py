@@ -2,9 +2,9 @@
 16 384 cfg2 and 8 192 cfg4 problems, several seeds.  python tools/stress_cbf.py [n_seeds]"""
 import os, sys, time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path[:0] = [ROOT, ROOT + "/car-racing_amd"]
+sys.path[:0] = [ROOT, ROOT + "/car-racing_amd", ROOT + "/tests"]
 import numpy as np
-import crx, oracle
+import crx, oracle, kkt_check
 from crx import abi, synth
 gpu = crx.init(); orc = oracle.load(); A, B = synth.load_AB()
 KEYS = ("x0", "xt", "obs_s", "obs_ey", "lap_off", "n_obs")
@@ -21,3 +21,11 @@ for seed in range(1, 1 + (int(sys.argv[1]) if len(sys.argv) > 1 else 2)):
         print("seed %d %s: n %d | converged gpu %d oracle %d, one side only %d (gpu only %d, oracle only %d) | same status %.4f same iters %.4f |iters diff| max %d | both converged: cost rel max %.1e (> 1e-6: %d), |dX| max %.1e (> 1e-5: %d) | kkt max gpu %.1e | %.1f s gpu call, %.1f s oracle" % (
             seed, name, len(sg), (sg == 0).sum(), (so == 0).sum(), ((sg == 0) != (so == 0)).sum(), ((sg == 0) & (so != 0)).sum(), ((sg != 0) & (so == 0)).sum(), (sg == so).mean(), (ig == io).mean(), np.abs(ig - io).max(),
             rel.max(), (rel > 1e-6).sum(), dx.max(), (dx > 1e-5).sum(), rg["kkt"][sg == 0].max(), tg, to), flush=True)
+        # every both-converged pair that differs: the oracle-free certificate on both points (tests/kkt_check.py)
+        lines, table = kkt_check.classify_pairs(d, p, rg, ro)
+        print("   pairs with |dX| > 1e-5: %s" % table)
+        for ln in lines:
+            if "two KKT" in ln or "NOT" in ln:
+                print("     " + ln)
+        for b in np.nonzero(sg != so)[0]:
+            print("     status differs #%d: gpu %d after %d, oracle %d after %d" % (b, sg[b], ig[b], so[b], io[b]))
