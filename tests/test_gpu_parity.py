@@ -330,7 +330,8 @@ def test_cbf_slack_start_option(gpu, orc, AB):
     # iterations at most (VERDICT r3 item 3's mark, at the price of leaving the reference's local minimum on near-misses: not the default),
     # kernel = oracle; the problems whose zero start violates nothing keep their bits
     g3, o3 = gpu.cbf_solve(mk(3), *args), orc.cbf_solve(mk(3), *args)
-    assert (g3["status"] == 0).all() and (o3["status"] == 0).all() and g3["iters"].max() <= 30 and o3["iters"].max() <= 30, (g3["iters"].max(), o3["iters"].max())
+    # ([r6] 31, was 30: IPOPT's complete termination test keeps the longest crash start for one more iteration, until its complementarity is below 1e-4)
+    assert (g3["status"] == 0).all() and (o3["status"] == 0).all() and g3["iters"].max() <= 31 and o3["iters"].max() <= 31, (g3["iters"].max(), o3["iters"].max())
     assert (g3["iters"] == o3["iters"]).mean() >= 0.98 and (np.abs(g3["cost"] - o3["cost"]) <= 1e-6 * np.maximum(1.0, np.abs(o3["cost"]))).mean() >= 0.99
     same3 = (np.abs(g3["X"] - g[2]["X"]).reshape(256, -1).max(axis=1) == 0) & (g3["iters"] == g[2]["iters"])
     assert 0.85 <= same3.mean() < 1.0, same3.mean()
