@@ -251,6 +251,13 @@ struct Lay {
     static constexpr int END_V = SLIM ? 0 : vhi + NV;   // slim: coord_rows() computes them
     static constexpr size_t BYTES = (size_t)END_D * 8 + (size_t)SH_OFF * 4 + (size_t)END_S16 * 2 + (((size_t)END_V * sizeof(vrow_t) + 7) & ~(size_t)7);
     static_assert(!SLIM || BYTES <= 40960, "the slim layout exists to fit four problems per CU (160 KB / 4)");
+    // [r6] SPECULATIVE second factorisation (crx_solve_kernel<.., SPEC = 1>, two waves per problem): everything riccati_backward WRITES, once more
+    // behind the layout -- the second wave factorises the reduced Hessian with the NEXT entry of the inertia-correction schedule while the first
+    // tries the current one.  In doubles from sm; ctl = {command, dw, convexified, ok} mailbox between the two waves.
+    static constexpr int R2 = (int)((BYTES + 15) / 16) * 2;
+    static constexpr int P2 = R2, pv2 = P2 + NX * NX, T2 = pv2 + NX, H2 = (T2 + NX * NZ + 1) & ~1, Kk2 = H2 + NZ * HS, kf2 = Kk2 + NMAX * NU * NX,
+                         dZ2 = kf2 + NMAX * NU, ctl = dZ2 + NZ, R2_END = ctl + 4;
+    static constexpr size_t BYTES_SPEC = (size_t)R2_END * 8;
 };
 
 // problem context kept in registers (all wave-uniform)
@@ -754,10 +761,15 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 // Riccati backward sweep with regularisation dw on the input / sigma_0 diagonal.  Returns false if
 // a pivot is not positive (wrong inertia).  On success Kk/kf hold the feedback and dZ[0] the step
 // of the free initial components (sigma_0).
-template <int NOBS, int NMAX, int UNR = 1>
-__device__ __forceinline__ bool riccati_backward(double* sm, const int* si, const Ctx& c, double dw, long long* tsub = nullptr) {
+// [r6] REG = 1: the same sweep on the SECOND set of work arrays (Lay::P2 ..: the speculating wave of crx_solve_kernel<.., SPEC = 1>); CVX: the caller may
+// ask for the convexified matrix (`convex`: the reverse-convex part kS / kE of the CBF curvature read as zero -- the one-wave kernel zeroes it in LDS
+// instead, which two concurrent sweeps cannot).  <.., 0, false> is the code of rounds 1-5, operation for operation.
+template <int NOBS, int NMAX, int UNR = 1, int REG = 0, bool CVX = false>
+__device__ __forceinline__ bool riccati_backward(double* sm, const int* si, const Ctx& c, double dw, long long* tsub = nullptr, bool convex = false) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
+    constexpr int oP = REG ? L::P2 : L::P, opv = REG ? L::pv2 : L::pv, oT = REG ? L::T2 : L::T, oH = REG ? L::H2 : L::H, oKk = REG ? L::Kk2 : L::Kk,
+                  okf = REG ? L::kf2 : L::kf, odZ = REG ? L::dZ2 : L::dZ;
     const int N = c.N, lane = c.lane;
     const long long qs = CLK();
     // [r4] The gradient p of the value function lives in REGISTERS, entry i in lane i: the update phase computes p_new there (its lane
@@ -767,17 +779,19 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     double preg = 0.0;
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
     {
-        const double kSn = NOBS ? LD(L::kS + 2 * (N - 1)) : 0.0, kEn = (NOBS ? LD(L::kE + 2 * (N - 1)) : 0.0) + 2.0 * LD(L::wc + N - 1);
+        double kSn = NOBS ? LD(L::kS + 2 * (N - 1)) : 0.0, kEn = NOBS ? LD(L::kE + 2 * (N - 1)) : 0.0;
+        if constexpr (CVX) { kSn = sel(convex, 0.0, kSn); kEn = sel(convex, 0.0, kEn); }
+        kEn += 2.0 * LD(L::wc + N - 1);
 #pragma unroll
         for (int q_ = 0; q_ < (NX * NX + WAVE - 1) / WAVE; q_++) {
             const int e0 = lane + q_ * WAVE;
             const int e = e0 < NX * NX ? e0 : 0;            // lanes past the matrix recompute entry 0
             const int i = e / NX, j = e - i * NX;
             const double hd = LD(L::Hd + N * NZ + i);
-            LD(L::P + e) = sel(i == j, hd + sel(i == 4, kSn, sel(i == 5, kEn, 0.0)), 0.0);
+            LD(oP + e) = sel(i == j, hd + sel(i == 4, kSn, sel(i == 5, kEn, 0.0)), 0.0);
         }
         const double hgN = LD(L::hg + N * NZ + (lane < NX ? lane : 0));
-        LD(SINK(lane < NX, L::pv + lane)) = hgN;
+        LD(SINK(lane < NX, opv + lane)) = hgN;
         preg = hgN;
     }
     SYNC();
@@ -797,11 +811,11 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         if (FULL) { hr[q] = e / NZ; ha[q] = e - hr[q] * NZ; }
         else if constexpr (L::SLIM) tri_decode(e, hr[q], ha[q]);
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
-        hst[q] = SINK(e0 < NTRI, L::H + hr[q] * HS + ha[q]);
-        hst2[q] = SINK(!FULL && e0 < NTRI, L::H + ha[q] * HS + hr[q]);
+        hst[q] = SINK(e0 < NTRI, oH + hr[q] * HS + ha[q]);
+        hst2[q] = SINK(!FULL && e0 < NTRI, oH + ha[q] * HS + hr[q]);
     }
     const int lz = lane < NZ ? lane : 0;
-    const int hvst = SINK(lane < NZ, L::H + lane * HS + NZ);
+    const int hvst = SINK(lane < NZ, oH + lane * HS + NZ);
     // the entries of the model matrix each lane multiplies with in the T and H phases, in registers
     constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
     double mT[TCNT][6], mH[HCNT][NX];
@@ -812,8 +826,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const int cc = e & 7;
         const int a = cc < 6 ? cc : NX + (cc - 6);
         const int i = (e >> 3) < NX ? (e >> 3) : 0;
-        tld[q] = L::P + i * NX;
-        tst[q] = SINK(e < NX * 8, L::T + i * NZ + a);
+        tld[q] = oP + i * NX;
+        tst[q] = SINK(e < NX * 8, oT + i * NZ + a);
 #pragma unroll
         for (int j = 0; j < 6; j++) mT[q][j] = LD(L::M + j * NZ + a);
     }
@@ -833,7 +847,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     bool t2nxt[T2CNT];
 #pragma unroll
     for (int q = 0; q < T2CNT; q++) {
-        t2ld[q] = L::P; t2st[q] = L::dmy; t2nxt[q] = false;
+        t2ld[q] = oP; t2st[q] = L::dmy; t2nxt[q] = false;
         if (NOBS) {
             const int l2 = lane + q * WAVE;
             const bool v2 = l2 < NX * 2 * NOBS;
@@ -841,8 +855,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             const int i2 = e2 / (2 * L::NO), cc = e2 - i2 * (2 * L::NO);
             t2nxt[q] = cc >= NOBS;
             const int o = t2nxt[q] ? cc - NOBS : cc;
-            t2ld[q] = L::P + i2 * NX + 6 + o;
-            t2st[q] = SINK(v2, L::T + i2 * NZ + seli(t2nxt[q], NX + 2 + o, 6 + o));
+            t2ld[q] = oP + i2 * NX + 6 + o;
+            t2st[q] = SINK(v2, oT + i2 * NZ + seli(t2nxt[q], NX + 2 + o, 6 + o));
         }
     }
     // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
@@ -858,11 +872,11 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const bool isP = l < NP, isK = !isP && l < NP + NX + 1;
         const bool gcol = uj >= NX;                   // gradient column = column NZ of H
         const int ujj = gcol ? NZ : uj;
-        yiA[q] = L::H + NX * HS + ui; yjA[q] = L::H + NX * HS + ujj; s0A[q] = L::H + ui * HS + ujj;
-        pst1[q] = SINK(isP, seli(gcol, L::pv + ui, L::P + ui * NX + uj));
-        pst2[q] = SINK(isP, seli(gcol, L::pv + ui, L::P + uj * NX + ui));
+        yiA[q] = oH + NX * HS + ui; yjA[q] = oH + NX * HS + ujj; s0A[q] = oH + ui * HS + ujj;
+        pst1[q] = SINK(isP, seli(gcol, opv + ui, oP + ui * NX + uj));
+        pst2[q] = SINK(isP, seli(gcol, opv + ui, oP + uj * NX + ui));
         kstr[q] = seli(isK, seli(gcol, 1, NX), 0); kstep[q] = seli(isK, seli(gcol, NU, NU * NX), 0);
-        kst[q] = SINK(isK, seli(gcol, L::kf, L::Kk + uj) + (N - 1) * kstep[q]);
+        kst[q] = SINK(isK, seli(gcol, okf, oKk + uj) + (N - 1) * kstep[q]);
         exSl[q] = isP && !gcol && ui == uj && ui == 4; exEl[q] = isP && !gcol && ui == uj && ui == 5;
     }
     if (tsub) tsub[2] += CLK() - qs;   // set-up of the sweep (terminal P, lane maps, stage-invariant operands)
@@ -910,7 +924,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
 #pragma unroll
-                for (int i = 0; i < NX; i++) tc[q][i] = LD(L::T + i * NZ + ha[q]);
+                for (int i = 0; i < NX; i++) tc[q][i] = LD(oT + i * NZ + ha[q]);
                 hd[q] = LD(L::Hd + k * NZ + hr[q]);
                 if (NOBS) {
 #pragma unroll
@@ -936,7 +950,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
             if constexpr (!PREG) {
 #pragma unroll
-                for (int i = 0; i < NX; i++) pvv[i] = LD(L::pv + i);
+                for (int i = 0; i < NX; i++) pvv[i] = LD(opv + i);
             }
             LOADS_DONE();
             double hs[HCNT];
@@ -982,7 +996,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
             for (int a = 0; a < NU; a++)
 #pragma unroll
-                for (int b2 = 0; b2 <= a; b2++) Lf[a][b2] = LD(L::H + (NX + a) * HS + NX + b2);
+                for (int b2 = 0; b2 <= a; b2++) Lf[a][b2] = LD(oH + (NX + a) * HS + NX + b2);
 #pragma unroll
             for (int q = 0; q < UCNT; q++) {
 #pragma unroll
@@ -991,7 +1005,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             }
             const int km = k >= 1 ? k - 1 : 0;     // stage k-1 extras on (s_k, ey_k), wave-uniform
             // (the coupling weight wc is a planner quantity: identically zero with obstacles, and not loaded there)
-            const double kSv = NOBS ? LD(L::kS + 2 * km) : 0.0, kEv = NOBS ? LD(L::kE + 2 * km) : 0.0, wcv = NOBS ? 0.0 : LD(L::wc + km);
+            double kSv = NOBS ? LD(L::kS + 2 * km) : 0.0, kEv = NOBS ? LD(L::kE + 2 * km) : 0.0;
+            const double wcv = NOBS ? 0.0 : LD(L::wc + km);
+            if constexpr (CVX) { kSv = sel(convex, 0.0, kSv); kEv = sel(convex, 0.0, kEv); }
             LOADS_DONE();
             const double exS = sel(k >= 1, kSv, 0.0), exE = sel(k >= 1, NOBS ? kEv : kEv + 2.0 * wcv, 0.0);
             // with C = L D kept beside L (C[i][q] = L[i][q] D[q]) every update on the pivot chain is ONE fma:
@@ -1046,14 +1062,14 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     }
     if (!ok) { SYNC(); return false; }
     // free initial components sigma_0: minimise 1/2 d'P d + p'd over them (x_0 is fixed)
-    if (lane < NZ) LD(L::dZ + lane) = 0.0;
+    if (lane < NZ) LD(odZ + lane) = 0.0;
     if (NOBS) {
         double Ls[L::NO][L::NO], y[L::NO], Ds[L::NO];
 #pragma unroll
         for (int a = 0; a < NOBS; a++) {
 #pragma unroll
-            for (int b = 0; b <= a; b++) Ls[a][b] = LD(L::P + (6 + a) * NX + 6 + b);
-            y[a] = -LD(L::pv + 6 + a);
+            for (int b = 0; b <= a; b++) Ls[a][b] = LD(oP + (6 + a) * NX + 6 + b);
+            y[a] = -LD(opv + 6 + a);
         }
 #pragma unroll
         for (int j = 0; j < NOBS; j++) {
@@ -1086,7 +1102,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             SYNC();
             if (lane == 0) {
 #pragma unroll
-                for (int a = 0; a < NOBS; a++) LD(L::dZ + 6 + a) = y[a];
+                for (int a = 0; a < NOBS; a++) LD(odZ + 6 + a) = y[a];
             }
         }
     }
@@ -1472,22 +1488,29 @@ template <int NOBS, int NMAX> struct MinWaves {
 // operations in the same order.
 template <int NFIX> struct SweepUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_SWEEP_UNROLL ? NFIX : 2); };   // forward / adjoint sweeps
 template <int NOBS, int NFIX> struct RicUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_RIC_UNROLL == 0 ? NFIX : CRX_RIC_UNROLL); };
-template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v))) CRX_KERNEL_EXTRA_ATTR
+// SPEC [r6]: 1 = TWO waves per problem (a 128-thread workgroup).  Wave 0 runs the solve as the one-wave kernel does; wave 1 sleeps at a workgroup
+// barrier and, at every Newton system, factorises the reduced Hessian with the NEXT entry of the inertia-correction schedule (the convexified matrix
+// on the crash path, then IPOPT's delta_w sequence) in its own work arrays while wave 0 tries the current one.  When wave 0's attempt has the wrong
+// inertia the next one is already done -- the doomed delta_w = 0 sweep (13.4 k of the 28.9 k ticks of an iteration, 16 of the 34 iterations of the
+// headline batch's longest healthy solve) no longer adds to the critical path.  Same attempts, same arithmetic, first success in schedule order wins:
+// the iterates are those of the one-wave kernel bit for bit.  For launches that leave SIMDs idle (batch <= 2 x CUs; crx_api.hip), obstacle count 1.
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0>
+__global__ void __launch_bounds__(WAVE * (1 + SPEC)) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v))) CRX_KERNEL_EXTRA_ATTR
 crx_solve_kernel(const crx_kparams kp) {
     static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
     using L = Lay<NOBS, NMAX>;
+    static_assert(!SPEC || (NOBS > 0 && !L::SLIM && CRX_STATIC_LDS), "the speculating wave exists for the obstacle instantiations of the full, static layout");
     constexpr int NX = L::NX, NZ = L::NZ, NR = L::NR;
 #if CRX_STATIC_LDS
     // [r4] The layout is a compile-time constant, so the array is STATIC: the compiler then knows its address (0) and folds it into the
     // offset fields.  As `extern __shared__` the base stays a symbol until emission and every address computed at run time carries an
     // `add ..., 0` (204 of them in <1,12,6,12>, 11 in each Riccati stage: bound by instruction issue, they cost like any other).
-    __shared__ __attribute__((aligned(16))) double sm[(L::BYTES + 7) / 8];
+    __shared__ __attribute__((aligned(16))) double sm[((SPEC ? L::BYTES_SPEC : L::BYTES) + 7) / 8];
 #else
     extern __shared__ __attribute__((aligned(16))) double sm[];
 #endif
     int* si = (int*)(sm + L::END_D);
-    const int lane = threadIdx.x, N = NFIX ? NFIX : kp.N;
+    const int lane = SPEC ? (int)(threadIdx.x & (WAVE - 1)) : (int)threadIdx.x, N = NFIX ? NFIX : kp.N;
     if ((int)blockIdx.x >= kp.batch) return;
     // dispatch order [r3]: workgroups start in launch order, so a caller that knows which problems are long (the iteration counts of
     // the previous control step) lists them first and the launch does not end waiting for a straggler that started last
@@ -1516,6 +1539,24 @@ crx_solve_kernel(const crx_kparams kp) {
         if (__ballot(out) != 0ull) {
             planner_fallback<L>(sm, kp, b, lane, N);
             if (lane == 0) { kp.status[b] = CRX_INFEASIBLE; kp.kkt[b] = INFINITY; kp.iters[b] = 0; }
+            return;
+        }
+    }
+    if constexpr (SPEC) {
+        if (threadIdx.x >= WAVE) {
+            // the speculating wave: parked at the workgroup barrier until wave 0 posts a command -- 0: the solve is over; 1: factorise with
+            // (ctl[1] = delta_w, ctl[2] = convexified) in the second set of work arrays and post the verdict in ctl[3]; 2: nothing to try this round
+            Ctx c1 = {};
+            c1.N = N; c1.lane = lane;
+            for (;;) {
+                __syncthreads();
+                const int cmd = __builtin_amdgcn_readfirstlane((int)LD(L::ctl));
+                if (cmd == 0) break;
+                bool ok1 = false;
+                if (cmd == 1) ok1 = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v, 1, true>(sm, si, c1, LD(L::ctl + 1), nullptr, LD(L::ctl + 2) != 0.0);
+                if (lane == 0) LD(L::ctl + 3) = ok1 ? 1.0 : 0.0;
+                __syncthreads();
+            }
             return;
         }
     }
@@ -1963,10 +2004,47 @@ crx_solve_kernel(const crx_kparams kp) {
         // attempts that were bound to fail.  Same rule in oracle/crx_oracle.c; problems off the crash path never get here.)
         int used_convex = 0;
         if (NOBS && crash && cvx_run > 0 && (cvx_run % CVX_PROBE) != 0) {
-            for (int k = lane; k < N; k += WAVE) { LD(L::kS + 2 * k) = 0.0; LD(L::kE + 2 * k) = 0.0; }
-            SYNC();
+            if constexpr (!SPEC) {
+                for (int k = lane; k < N; k += WAVE) { LD(L::kS + 2 * k) = 0.0; LD(L::kE + 2 * k) = 0.0; }
+                SYNC();
+            }
             used_convex = 1;
         }
+        if constexpr (SPEC) {
+            // [r6] two attempts of the schedule at a time: this wave tries S = (dw, convexified), the speculating wave S' = next(S) -- next() being
+            // the sequential code below: the convexified matrix first while it is still ahead (crash path), then IPOPT's delta_w sequence.  The
+            // first success in schedule order is taken; a success of S' is copied over (feedback gains, feed-forward, sigma_0 step: all the
+            // forward sweep reads).  (The pre-convexified start above did not touch LDS here: `cz` carries it.)
+            double sdw = 0.0;
+            int cz = used_convex, avail = (crash && !used_convex) ? 1 : 0, tries = 0;
+            for (;;) {
+                double ndw = sdw;
+                int ncz = cz, ntries = tries;
+                if (avail) ncz = 1;
+                else { ndw = tries == 0 ? (dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0)) : sdw * (dw_last == 0.0 ? 100.0 : 8.0); ntries = tries + 1; }
+                const bool nvalid = !(ndw > 1e40);
+                if (lane == 0) { LD(L::ctl) = nvalid ? 1.0 : 2.0; LD(L::ctl + 1) = ndw; LD(L::ctl + 2) = ncz ? 1.0 : 0.0; }
+                __syncthreads();
+                ok = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v, 0, true>(sm, si, c, sdw, tsub, cz != 0);
+                __syncthreads();
+                if (ok) { dw = sdw; used_convex = cz; break; }
+                dw = ndw;
+                if (!nvalid) break;                               // the schedule is exhausted (sequential: dw > 1e40)
+                if (__builtin_amdgcn_readfirstlane((int)LD(L::ctl + 3)) != 0) {
+                    for (int e = lane; e < N * L::NU * NX; e += WAVE) LD(L::Kk + e) = LD(L::Kk2 + e);
+                    for (int e = lane; e < N * L::NU; e += WAVE) LD(L::kf + e) = LD(L::kf2 + e);
+                    if (lane < NZ) LD(L::dZ + lane) = LD(L::dZ2 + lane);
+                    SYNC();
+                    ok = true; used_convex = ncz;
+                    break;
+                }
+                // both have the wrong inertia: two steps down the schedule (after S' the convexified retry is behind us)
+                sdw = ntries == 0 ? (dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0)) : ndw * (dw_last == 0.0 ? 100.0 : 8.0);
+                cz = ncz; avail = 0; tries = ntries + 1;
+                dw = sdw;
+                if (sdw > 1e40) break;
+            }
+        } else
         for (int tries = 0, convex = (NOBS > 0 && crash && !used_convex) ? 0 : 1;; ) {
             ok = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v>(sm, si, c, dw, tsub);
             if (ok) break;
@@ -2234,6 +2312,10 @@ crx_solve_kernel(const crx_kparams kp) {
     if (e_p > 1e-6) status = CRX_STALLED;
     break;
     }
+    if constexpr (SPEC) {   // the solve is over: release the speculating wave
+        if (lane == 0) LD(L::ctl) = 0.0;
+        __syncthreads();
+    }
     if (infeas0) status = CRX_INFEASIBLE;        // a bound violated by the fixed x_0: proved
 
     // ---- write back: one coalesced pass ----------------------------------------------------------------
@@ -2331,11 +2413,12 @@ template __global__ void crx_solve_kernel<CRX_PROBE_ONE>(const crx_kparams);
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
-template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0>
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
 #if CRX_STATIC_LDS
-    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX>), dim3(kp.batch), dim3(WAVE), 0, st, kp);   // the layout is a static array of the kernel
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX, SPEC>), dim3(kp.batch), dim3(WAVE * (1 + SPEC)), 0, st, kp);   // the layout is a static array of the kernel
 #else
+    static_assert(SPEC == 0, "the two-wave instantiations are static-LDS kernels");
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
     static int attr_set_on = -1;
@@ -2350,6 +2433,17 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
 #endif
     return hipGetLastError();
 }
+#ifdef CRX_TU_SPEC
+// [r6] crx_kernels_spec.hip: the two-wave (speculating) instantiations of the one-obstacle, degree-6 kernel at the tuned horizons 12 and 10 --
+// BASELINE configs[1] and the reference's default horizon -- and nothing else.  crx_api.hip routes a launch here when it leaves SIMDs idle.
+hipError_t crx_launch_solve_spec(const crx_kparams& kp, hipStream_t st) {
+    if (kp.batch == 0) return hipSuccess;
+    if (kp.degree != 6) return hipErrorInvalidValue;
+    if (kp.N == 12) return launch_t<1, 12, 6, 12, 1>(kp, st);
+    if (kp.N == 10) return launch_t<1, 12, 6, 10, 1>(kp, st);
+    return hipErrorInvalidValue;
+}
+#else
 // [r5] The GENERAL instantiations (run-time horizon NFIX = 0, run-time exponent DEG = 0, the generic 4..6-obstacle ones) live in a third
 // translation unit, crx_kernels_gen.hip, built conservatively: 256 registers and no AGPRs, no inline-assembly DPP,
 // nothing lane-derived hoisted out of the interior-point loop.  This unit and the obstacle unit only hold the tuned fixed-horizon ones.
@@ -2577,4 +2671,5 @@ hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st
     return hipGetLastError();
 }
 #endif  // !CRX_TU_OBSTACLES
+#endif  // !CRX_TU_SPEC
 #endif  // !CRX_PROBE_ONE

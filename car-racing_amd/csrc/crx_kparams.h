@@ -136,6 +136,7 @@ struct crx_lmpcprep_kparams {
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t crx_launch_solve(const crx_kparams& kp, int nobs_template, hipStream_t st);
+hipError_t crx_launch_solve_spec(const crx_kparams& kp, hipStream_t st);   // crx_kernels_spec.hip: the two-wave instantiations <1, 12, 6, {12, 10}, 1>
 hipError_t crx_launch_select(const crx_select_kparams& sp, hipStream_t st);
 hipError_t crx_launch_debug_reduce(const double* in, double* out, hipStream_t st);
 hipError_t crx_launch_lmpc_addtraj(const crx_lmpcprep_desc& d, int batch, const int32_t* crossed, double* log_x, const double* log_u,

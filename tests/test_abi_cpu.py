@@ -122,28 +122,58 @@ def test_product_never_imports_oracle():
 
 
 def test_no_spill_store_in_front_of_an_exec_restore():
-    """Round 5, DESIGN.md section 8: ROCm 7.2's LLVM can place a VGPR spill store at the top of a loop-exit block, IN FRONT of the `s_or_b64
+    """Round 5, DESIGN.md section 5.7: ROCm 7.2's LLVM can place a VGPR spill store at the top of a loop-exit block, IN FRONT of the `s_or_b64
     exec` that re-enables the lanes -- the store runs with EXEC = 0, stores nothing, and every reload returns whatever the scratch slot held
     (seen in crx_solve_kernel<3,24,6,0> of a scratch-spilling build: wrong trajectories for 78 of 256 problems).  No source construct causes
-    or prevents it; the library's defence is this check of the COMPILER'S OUTPUT: every translation unit is compiled to assembly with the
-    Makefile's flags and must be free of the pattern (tools/exec_prologue_check.py; no GPU needed)."""
+    or prevents it; the library's defence is a check of the COMPILER'S OUTPUT.  [r6] The check runs on the code objects that SHIP
+    (tools/exec_prologue_check.py extracts and disassembles what is embedded in libcrx.so -- whatever flags or ROCm install built it; `make`
+    runs it after linking and fails on a FATAL finding), counts reloads / AGPR reads / plain copies as well as stores, and tells the FATAL form
+    (an edge reaches the block with EXEC = 0) from the narrowing one."""
     import subprocess
     import sys
-    from concurrent.futures import ThreadPoolExecutor
 
-    tool = os.path.join(conftest.ROOT, "tools", "exec_prologue_check.py")
-    # the tool mirrors the Makefile's per-unit flags: keep the two in step
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tools"))
+    import exec_prologue_check as epc
+
+    # the classifier itself, on hand-made disassembly: round 5's pattern, the narrowing form, and a region ENTRY that is not a finding
+    txt = """
+0000000000001000 <_Z16crx_solve_kernelILi3ELi24ELi6ELi0ELi0EEv11crx_kparams>:
+	s_and_saveexec_b64 s[2:3], vcc                             // 000000001000: BE82206A
+0000000000001004 <L0>:
+	v_add_u32_e32 v1, 64, v1                                   // 000000001004: 00000000
+	s_andn2_b64 exec, exec, s[4:5]                             // 000000001008: 00000000
+	s_cbranch_execnz L0                                        // 00000000100C: 00000000
+0000000000001010 <L1>:
+	scratch_store_dwordx2 off, v[36:37], off offset:24         // 000000001010: 00000000
+	s_or_b64 exec, exec, s[2:3]                                // 000000001018: 00000000
+	v_cmp_gt_i32_e32 vcc, 5, v0                                // 00000000101C: 00000000
+	s_and_saveexec_b64 s[6:7], vcc                             // 000000001020: 00000000
+	v_mov_b32_e32 v9, 0                                        // 000000001024: 00000000
+0000000000001028 <L2>:
+	v_accvgpr_read_b32 v7, a3                                  // 000000001028: 00000000
+	s_or_b64 exec, exec, s[6:7]                                // 00000000102C: 00000000
+0000000000001030 <L3>:
+	scratch_store_dword off, v0, off offset:392                // 000000001030: 00000000
+	s_mov_b64 s[2:3], exec                                     // 000000001038: 00000000
+	s_and_b64 s[4:5], s[2:3], s[4:5]                           // 00000000103C: 00000000
+	s_mov_b64 exec, s[4:5]                                     // 000000001040: 00000000
+	s_cbranch_execz L4                                         // 000000001044: 00000000
+0000000000001048 <L4>:
+	v_mov_b32_e32 v8, v6                                       // 000000001048: 00000000
+	s_or_b64 exec, exec, s[2:3]                                // 00000000104C: 00000000
+	s_endpgm                                                   // 000000001050: 00000000
+"""
+    got = [(label, ins.split()[0], fatal) for (_f, label, _a, ins, _r, fatal) in epc.scan_text(txt)]
+    assert got == [("L1", "scratch_store_dwordx2", True), ("L2", "v_accvgpr_read_b32", False), ("L4", "v_mov_b32_e32", True)], got
+
+    if not os.path.exists(epc.OBJDUMP):
+        pytest.skip("ROCm binutils (%s) not installed: the shipped code objects cannot be disassembled here" % epc.OBJDUMP)
+    lib = os.path.join(conftest.PKG, "crx", "libcrx.so")
+    r = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "tools", "exec_prologue_check.py"), lib], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
+    m = __import__("re").search(r"(\d+) code object\(s\)", r.stdout)
+    assert m and int(m.group(1)) >= 8, r.stdout[-300:]       # every translation unit of the library was looked at
+    # the Makefile runs the same check on every build
     mk = open(os.path.join(conftest.PKG, "csrc", "Makefile")).read()
-    for frag in ("PLAN_SCHED ?= -mllvm -amdgpu-sched-strategy=max-ilp", "OBS_SCHED ?= -mllvm -amdgpu-sched-strategy=iterative-ilp",
-                 "LMPC_SCHED ?= -mllvm -amdgpu-sched-strategy=max-ilp", "-mllvm -disable-machine-licm $(LMPC_SCHED) -c crx_lmpc.hip",
-                 "-mllvm -disable-machine-licm $(GEN_FLAGS) -c crx_kernels_gen.hip", "FLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH)"):
-        assert frag in mk, frag
-
-    def run(unit):
-        r = subprocess.run([sys.executable, tool, unit], capture_output=True, text=True, timeout=1500)
-        return unit, r.returncode, r.stdout[-1500:] + r.stderr[-500:]
-
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        res = list(ex.map(run, ["gen", "obs", "plan", "lmpc", "prep", "lmpcprep"]))
-    bad = [(u, out) for u, rc, out in res if rc != 0]
-    assert not bad, bad
+    assert "exec_prologue_check.py $(OUT)" in mk and "all: $(OUT) check" in mk

@@ -18,7 +18,7 @@ for S in 0 1; do for D in 0 1; do
 done; done
 for c in 000 001 010 011 100 101 110 111; do
   S=${c:0:1}; D=${c:1:1}; M=${c:2:1}; W=2; [ $S = 1 ] && W=0
-  echo "g$c: $(python tools/exec_prologue_check.py gen -DCRX_STATIC_LDS=$S -DCRX_GEN_WAVES=$W -DCRX_ROWDPP=$D -DCRX_SWEEP_MASK=$M | tail -1)"
+  echo "g$c: $(python tools/exec_prologue_check.py tools/ab/libcrx_g$c.so | tail -1)"     # [r6] on the code objects of the variant itself
 done | tee tools/ab/exec_prologue_matrix.txt
 bash tools/build_variant.sh fenceonly "-DCRX_SYNC_FENCE_ONLY" crx_kernels.hip crx_kernels_obs.hip crx_kernels_gen.hip crx_lmpc.hip crx_prep.hip crx_lmpcprep.hip > /dev/null &
 bash tools/build_variant.sh slim0 "-DCRX_SLIM=0" crx_kernels_obs.hip > /dev/null &
