@@ -102,7 +102,7 @@ PinBuf g_hin, g_hout;
 DevBuf g_trace;
 int g_poison = 0;
 int g_kkt_unscaled = 0;
-int g_spec = -1;   // diagnostics (crx_debug_speculation): -1 = by the launch's size, 0 = never, 1 = wherever the two-wave instantiation exists
+int g_spec = 0;    // diagnostics (crx_debug_speculation): 0 = never (default), 1 = wherever the two-wave instantiation exists, 2 = that kernel with its second wave idle
 int g_trace_rows = 0, g_trace_problem = 0;
 
 int ensure_init() {
@@ -252,19 +252,13 @@ int launch_solve(const crx_kparams& kp, int tmpl, hipStream_t st) {
     kq.kkt_unscaled = g_kkt_unscaled;
     size_t lds = crx_solve_lds_bytes(kp.N, tmpl);
     if (lds > 160 * 1024) return fail(CRX_ERR_ARG, "N=%d with %d obstacles needs %zu B of LDS (> 160 KiB)", kp.N, tmpl, lds);
-    // [r6] launches that leave SIMDs idle take the TWO-WAVE instantiation where it exists (one obstacle slot, the reference's exponent, N = 12 / 10):
-    // a second wave per problem factorises with the next entry of the inertia-correction schedule while the first tries the current one
-    // (crx_kernels.hip, SPEC).  Identical results; worth it only while a CU holds fewer problems than it has SIMD pairs.
-    bool spec = tmpl == 1 && kq.mode == 1 && kq.degree == 6 && (kq.N == 12 || kq.N == 10) && kq.trace == nullptr && g_spec != 0;
-    if (spec && g_spec < 0) {
-        static int cus_of[64] = {0};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) spec = false;
-        else {
-            if (cus_of[dev] == 0 && hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus_of[dev] = -1;
-            spec = cus_of[dev] > 0 && kq.batch <= 2 * cus_of[dev];
-        }
-    }
+    // [r6] The TWO-WAVE instantiation (one obstacle slot, the reference's exponent, N = 12 / 10; crx_kernels.hip SPEC): a second wave per problem factorises
+    // with the next entry of the inertia-correction schedule while the first tries the current one.  OPT-IN (crx_debug_speculation), not the default:
+    // measured on the headline batch (profiles/r06_speculation.txt) a doomed attempt costs 1.7 us, not a sweep's 5.8 -- the recursion stops at the
+    // first non-positive pivot -- so the longest healthy solve (34 iterations, 24 doomed attempts) gains 2.5 % alone and the 256-problem launch, which
+    // pays two workgroup barriers per iteration in every problem, loses 1 % (0.4759 -> 0.4805 ms).
+    const bool spec = tmpl == 1 && kq.mode == 1 && kq.degree == 6 && (kq.N == 12 || kq.N == 10) && g_spec > 0;
+    kq.spec_idle = g_spec == 2;
     hipError_t e = spec ? crx_launch_solve_spec(kq, st) : crx_launch_solve(kq, tmpl, st);
     if (e != hipSuccess) return fail(CRX_ERR_HIP, "solver launch: %s", hipGetErrorString(e));
     return 0;
@@ -348,9 +342,10 @@ void crx_debug_poison_lds(int enable) { g_poison = enable != 0; }
 // gradient-based row scaling undone (rows in the reference's units).  mode 1: the max of the three; 2: the reduced Lagrangian gradient (IPOPT
 // dual_inf); 3: the constraint violation (constr_viol); 4: the complementarity (compl_inf); 0: off.  Since 0.4.0 these are the quantities the
 // termination test itself bounds (crx_ipm_opts.dual_inf_tol / constr_viol_tol / compl_inf_tol); bench.py reports each (kkt_unscaled_*_max).
-// diagnostics (not in crx.h): the two-wave (speculating) instantiation of the one-obstacle solver kernel -- -1: chosen by the launch's size (default:
-// batch <= 2 x the device's CUs), 0: never, 1: whenever it exists (A/B runs; tests/test_gpu_parity.py::test_speculating_wave_is_bit_identical)
-void crx_debug_speculation(int mode) { g_spec = mode < 0 ? -1 : (mode ? 1 : 0); }
+// diagnostics (not in crx.h): the two-wave (speculating) instantiation of the one-obstacle solver kernel -- 0: never (default), 1: whenever it exists
+// (A/B runs; tests/test_gpu_parity.py::test_speculating_wave_follows_the_sequential_schedule), 2: that kernel with its second wave left idle (separates
+// "another kernel" from "another wave's result" when two runs disagree)
+void crx_debug_speculation(int mode) { g_spec = mode < 0 ? 0 : (mode > 2 ? 1 : mode); }
 
 void crx_debug_kkt_unscaled(int mode) { g_kkt_unscaled = (mode >= 0 && mode <= 4) ? mode : 0; }
 

@@ -1490,10 +1490,11 @@ template <int NFIX> struct SweepUnroll { static constexpr int v = NFIX == 0 ? 1 
 template <int NOBS, int NFIX> struct RicUnroll { static constexpr int v = NFIX == 0 ? 1 : (CRX_RIC_UNROLL == 0 ? NFIX : CRX_RIC_UNROLL); };
 // SPEC [r6]: 1 = TWO waves per problem (a 128-thread workgroup).  Wave 0 runs the solve as the one-wave kernel does; wave 1 sleeps at a workgroup
 // barrier and, at every Newton system, factorises the reduced Hessian with the NEXT entry of the inertia-correction schedule (the convexified matrix
-// on the crash path, then IPOPT's delta_w sequence) in its own work arrays while wave 0 tries the current one.  When wave 0's attempt has the wrong
-// inertia the next one is already done -- the doomed delta_w = 0 sweep (13.4 k of the 28.9 k ticks of an iteration, 16 of the 34 iterations of the
-// headline batch's longest healthy solve) no longer adds to the critical path.  Same attempts, same arithmetic, first success in schedule order wins:
-// the iterates are those of the one-wave kernel bit for bit.  For launches that leave SIMDs idle (batch <= 2 x CUs; crx_api.hip), obstacle count 1.
+// on the crash path, then IPOPT's delta_w sequence) in its own work arrays while wave 0 tries the current one; the first success in schedule order
+// is taken, so the iterates are those of the same kernel running the schedule one attempt at a time, bit for bit (the test compares exactly that).
+// An EXPERIMENT, opt-in (crx_debug_speculation), built because VERDICT r5 asked what the idle SIMDs of a 256-problem launch could do: measured, a
+// doomed attempt is cheap (the recursion stops at the first non-positive pivot: 1.7 us against 5.8 for a sweep), the longest healthy solve of the
+// headline batch gains 2.5 % alone and the launch loses 1 % to the two barriers per iteration (profiles/r06_speculation.txt).
 template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0>
 __global__ void __launch_bounds__(WAVE * (1 + SPEC)) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v))) CRX_KERNEL_EXTRA_ATTR
 crx_solve_kernel(const crx_kparams kp) {
@@ -2023,13 +2024,15 @@ crx_solve_kernel(const crx_kparams kp) {
                 if (avail) ncz = 1;
                 else { ndw = tries == 0 ? (dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0)) : sdw * (dw_last == 0.0 ? 100.0 : 8.0); ntries = tries + 1; }
                 const bool nvalid = !(ndw > 1e40);
-                if (lane == 0) { LD(L::ctl) = nvalid ? 1.0 : 2.0; LD(L::ctl + 1) = ndw; LD(L::ctl + 2) = ncz ? 1.0 : 0.0; }
+                const bool post = nvalid && kp.spec_idle == 0;      // (spec_idle: diagnostics -- the second wave is never asked: the schedule runs one attempt at a time)
+                if (lane == 0) { LD(L::ctl) = post ? 1.0 : 2.0; LD(L::ctl + 1) = ndw; LD(L::ctl + 2) = ncz ? 1.0 : 0.0; }
                 __syncthreads();
                 ok = riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v, 0, true>(sm, si, c, sdw, tsub, cz != 0);
                 __syncthreads();
                 if (ok) { dw = sdw; used_convex = cz; break; }
                 dw = ndw;
                 if (!nvalid) break;                               // the schedule is exhausted (sequential: dw > 1e40)
+                if (!post) { sdw = ndw; cz = ncz; avail = 0; tries = ntries; continue; }
                 if (__builtin_amdgcn_readfirstlane((int)LD(L::ctl + 3)) != 0) {
                     for (int e = lane; e < N * L::NU * NX; e += WAVE) LD(L::Kk + e) = LD(L::Kk2 + e);
                     for (int e = lane; e < N * L::NU; e += WAVE) LD(L::kf + e) = LD(L::kf2 + e);

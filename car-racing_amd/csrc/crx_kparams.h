@@ -29,6 +29,7 @@ struct crx_kparams {
     int trace_problem, trace_rows;
     int poison;   // diagnostics: fill the LDS slice with NaN before set-up (catches reads of stale LDS)
     int kkt_unscaled;   // diagnostics (crx_debug_kkt_unscaled): kkt[b] of a CONVERGED solve = an UNSCALED KKT quantity (no s_d, CBF rows in the reference's units): 1 max, 2 dual, 3 violation, 4 complementarity
+    int spec_idle;      // diagnostics (crx_debug_speculation(2)): the two-wave kernel with its second wave never asked
     const int32_t* active;   // optional [batch / active_div]: 0 = leave this problem alone (status CRX_SKIPPED, outputs untouched)
     int active_div;          // problems per mask entry (planner: the regions of a scenario share one entry); 0 or 1: one each
     const int32_t* order;    // optional [batch]: workgroup i solves problem order[i] (longest-first dispatch); NULL: i

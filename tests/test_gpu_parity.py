@@ -721,6 +721,44 @@ def test_cfg4_non_converged_on_the_gpu(gpu, orc, AB):
     assert np.median(di) == 0 and (di <= 1).mean() >= 0.85 and di.max() <= 10, di
 
 
+@pytest.mark.parametrize("N", [12, 10])
+def test_speculating_wave_follows_the_sequential_schedule(gpu, AB, N):
+    """[r6] The two-wave instantiation crx_solve_kernel<1, 12, 6, N, SPEC = 1> (opt-in experiment, crx_debug_speculation: a second wave factorises the
+    reduced Hessian with the NEXT entry of the inertia-correction schedule while the first tries the current one).  (a) With the second wave working
+    (mode 1) every output of every problem equals, bit for bit, what the same kernel computes with that wave left idle (mode 2: the schedule one
+    attempt at a time) -- the headline draw with its crash states (convexified retries, delta_w sequences, restarts, restorations), the filtered
+    draw, lapped cars, both tolerance sets.  (b) Against the shipped one-wave kernel (another compilation of the same source: last-bit differences in
+    how the compiler fuses multiply-adds) statuses and iteration counts are identical and the trajectories agree to 1e-6."""
+    import crx
+    from crx import abi, synth
+
+    A, B = AB
+    L = crx.lib()
+    n_ic = 0
+    for safe, lapped, tol in ((False, 0.0, 1e-8), (True, 0.0, 1e-8), (False, 0.25, 1e-11)):
+        p = synth.cfg2_mpccbf(256, N=N, seed=2 if N == 12 else 7, safe_start=safe, lapped_frac=lapped)
+        d = abi.cbf_desc(N, 1, A, B, alpha=p["alpha"], margin=p["margin"])
+        d.opts.tol = tol
+        args = (p["x0"], p["xt"], p["obs_s"], p["obs_ey"], p["lap_off"], p["n_obs"])
+        try:
+            r0 = gpu.cbf_solve(d, *args)          # the default: the one-wave kernel
+            L.crx_debug_speculation(2)
+            r2 = gpu.cbf_solve(d, *args)
+            L.crx_debug_speculation(1)
+            r1 = gpu.cbf_solve(d, *args)
+            r1b = gpu.cbf_solve(d, *args)
+        finally:
+            L.crx_debug_speculation(0)
+        for k in ("X", "U", "sigma", "cost", "status", "iters", "kkt"):
+            np.testing.assert_array_equal(r1[k], r2[k], err_msg=k)
+            np.testing.assert_array_equal(r1[k], r1b[k], err_msg=k)
+        same = (r0["status"] == r1["status"]) & (r0["iters"] == r1["iters"])
+        assert same.mean() >= (1.0 if tol >= 1e-9 else 0.98), np.nonzero(~same)[0]
+        assert np.abs(r0["X"][same] - r1["X"][same]).max() <= 1e-6 * max(1.0, tol / 1e-11 * 1e-3 if tol < 1e-9 else 1.0)
+        n_ic += int((r0["iters"] > 25).sum())
+    assert n_ic >= 3           # the draws hold the long solves the speculation exists for
+
+
 @pytest.mark.parametrize("kind,n,seed", [("cfg2", 4096, 1), ("cfg4", 2048, 11)])
 def test_stress_kernel_vs_oracle_at_scale(gpu, orc, AB, kind, n, seed):
     """[r6] tools/stress_cbf.py as a test: kernel vs oracle on draws 16x larger than the parity tests hold, other seeds than the benched
