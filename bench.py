@@ -815,6 +815,8 @@ def init_backend(cx, args):
         abi.OPTS_OVERRIDE["reach_screen"] = 0
     if args.slack_start is not None:
         abi.OPTS_OVERRIDE["slack_start"] = int(args.slack_start)
+    if args.qp_method is not None:
+        abi.OPTS_OVERRIDE["qp_method"] = int(args.qp_method)
 
 
 def shutdown_backend(cx, args):
@@ -884,6 +886,9 @@ def main():
                     help="closed-loop workloads game / overtake: untimed control steps before the measurement; the timed steps start there whatever --warmup is")
     ap.add_argument("--no-reach-screen", action="store_true",
                     help="planner QPs: reachability screen off (crx_ipm_opts.reach_screen = 0): every region goes through the interior-point iteration")
+    ap.add_argument("--qp-method", type=int, default=None, choices=[0, 1],
+                    help="the convex rows (planner / path / learning-MPC QPs), crx_ipm_opts.qp_method: 0 = Mehrotra's predictor-corrector (default), "
+                         "1 = IPOPT's monotone barrier + filter line search (libcrx <= 0.3)")
     ap.add_argument("--slack-start", type=int, default=None, choices=[0, 1, 2, 3],
                     help="CBF NLPs, crx_ipm_opts.slack_start: 0 = IPOPT's sigma = 0 start only, 1 = start the slacks at their provable lower bounds, "
                          "2 (default) = the crash path (provable crash states start from a feasible interior point, a stalled solve restarts from it), "

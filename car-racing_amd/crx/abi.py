@@ -33,7 +33,7 @@ class IpmOpts(C.Structure):
         ("constr_viol_tol", C.c_double),
         ("compl_inf_tol", C.c_double),
         ("stall_iters", C.c_int32),        # [0.4.0] the stall rule's budget (a kernel constant until 0.3.x)
-        ("reserved1", C.c_int32),
+        ("qp_method", C.c_int32),          # [0.4.0] 0 = Mehrotra predictor-corrector for the all-linear problems, 1 = IPOPT-style filter line search
     ]
 
 

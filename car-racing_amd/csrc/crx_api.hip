@@ -172,7 +172,7 @@ struct Carver {
 int check_opts(const crx_ipm_opts& o) {
     if (!(o.tol > 0) || o.max_iter < 1 || !(o.mu_init > 0) || !(o.tau_min > 0 && o.tau_min < 1) ||
         !(o.slack_push > 0) || !(o.kappa_mu > 0 && o.kappa_mu < 1) || !(o.theta_mu > 1) || !(o.grad_scale_max > 0) ||
-        o.slack_start < 0 || o.slack_start > 3 || !(o.dual_inf_tol > 0) || !(o.constr_viol_tol > 0) || !(o.compl_inf_tol > 0) || o.stall_iters < 1)
+        o.slack_start < 0 || o.slack_start > 3 || !(o.dual_inf_tol > 0) || !(o.constr_viol_tol > 0) || !(o.compl_inf_tol > 0) || o.stall_iters < 1 || o.qp_method < 0 || o.qp_method > 1)
         return fail(CRX_ERR_ARG, "invalid crx_ipm_opts (a descriptor built for libcrx <= 0.3.x? crx_ipm_opts grew in 0.2 and in 0.4: include/crx.h)");
     return 0;
 }
@@ -429,7 +429,7 @@ void crx_ipm_opts_default(crx_ipm_opts* o) {
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2; o->grad_scale_max = 100.0;
     o->reach_screen = 1; o->slack_start = 2;
     o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4;   // IPOPT's defaults (the reference sets none: control.py:593)
-    o->stall_iters = 100; o->reserved1 = 0;
+    o->stall_iters = 100; o->qp_method = 0;
 }
 
 void crx_planner_desc_default(crx_planner_desc* d, int N, const double* A, const double* B) {

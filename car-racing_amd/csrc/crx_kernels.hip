@@ -764,7 +764,9 @@ __device__ __forceinline__ void assemble_newton(double* sm, const int* si, const
 // [r6] REG = 1: the same sweep on the SECOND set of work arrays (Lay::P2 ..: the speculating wave of crx_solve_kernel<.., SPEC = 1>); CVX: the caller may
 // ask for the convexified matrix (`convex`: the reverse-convex part kS / kE of the CBF curvature read as zero -- the one-wave kernel zeroes it in LDS
 // instead, which two concurrent sweeps cannot).  <.., 0, false> is the code of rounds 1-5, operation for operation.
-template <int NOBS, int NMAX, int UNR = 1, int REG = 0, bool CVX = false>
+// KEEPF [r6]: the factor of every stage's Huu (unit-lower L, reciprocal pivots) is left behind in the stage's slice of Hd -- consumed by this stage's H
+// phase, rewritten by the next assemble_newton -- for riccati_backward_vec, the second solve of the predictor-corrector iteration.
+template <int NOBS, int NMAX, int UNR = 1, int REG = 0, bool CVX = false, bool KEEPF = false>
 __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, const Ctx& c, double dw, long long* tsub = nullptr, bool convex = false) {
     using L = Lay<NOBS, NMAX>;
     constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ, HS = L::HS;
@@ -1030,6 +1032,16 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                     Lf[i][j] = u * rD[j];
                 }
             }
+            if constexpr (KEEPF) {
+                static_assert(NU * (NU + 1) / 2 <= NZ, "the factor fits the stage's slice of Hd");
+                int f_ = 0;
+#pragma unroll
+                for (int a = 0; a < NU; a++) {
+                    LD(SINK(lane == 0, L::Hd + k * NZ + f_)) = rD[a]; f_++;
+#pragma unroll
+                    for (int b2 = 0; b2 < a; b2++) { LD(SINK(lane == 0, L::Hd + k * NZ + f_)) = Lf[a][b2]; f_++; }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < UCNT; q++) {
 #pragma unroll
@@ -1108,6 +1120,55 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     }
     SYNC();
     return ok;
+}
+
+// [r6] Second solve with the factorisation riccati_backward<.., KEEPF> left behind: the VECTOR recursion alone, for another Newton gradient hg
+// (the corrector of the predictor-corrector iteration).  Per stage, lanes 0 .. NZ-1:  hv = M'p + hg_k  (one broadcast-FMA dot product, p in lanes
+// 0 .. NX-1),  kff = -Huu^{-1} hu  from the stored factor (L, 1 / D: Hd[k][0 .. 2]),  p <- hx + K'hu  with the stored feedback K (= -Huu^{-1} Hux).
+// ~30 instructions per stage against ~135 of the full stage.  Writes kf; the matrices P are not needed again.
+template <int NOBS, int NMAX, int UNR = 1>
+__device__ __forceinline__ void riccati_backward_vec(double* sm, const Ctx& c) {
+    using L = Lay<NOBS, NMAX>;
+    static_assert(NOBS == 0 && L::NU == 2, "the second solve exists for the all-linear problems (two inputs per stage)");
+    constexpr int NX = L::NX, NU = L::NU, NZ = L::NZ;
+    const int N = c.N, lane = c.lane;
+    if (!CRX_SWEEP_MASK || lane < NZ) {
+        const bool in = CRX_SWEEP_MASK || lane < NZ;
+        const int la = in ? lane : 0, lx = la < NX ? la : 0;
+        double mcol[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) mcol[i] = LD(L::M + i * NZ + la);
+        double p = LD(L::hg + N * NZ + la);             // lanes < NX: p_N = the terminal gradient
+        double gk = LD(L::hg + (N - 1) * NZ + la);
+        auto stage = [&](int k) {
+            const double gn = LD(L::hg + (k >= 1 ? k - 1 : 0) * NZ + la);
+            const double rD0 = LD(L::Hd + k * NZ + 0), rD1 = LD(L::Hd + k * NZ + 1), L10 = LD(L::Hd + k * NZ + 2);
+            const double k0 = LD(L::Kk + (k * NU + 0) * NX + lx), k1 = LD(L::Kk + (k * NU + 1) * NX + lx);
+            double hv = gk;
+            if constexpr (ROWDPP<L>) {
+                hv = row_dot<NX, 0>(p, mcol, hv);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; i++) hv += mcol[i] * lane_f64(p, i);
+            }
+            const double hu0 = lane_f64(hv, NX), hu1 = lane_f64(hv, NX + 1);
+            const double y1 = hu1 - L10 * hu0;
+            const double z1 = y1 * rD1;
+            const double z0 = hu0 * rD0 - L10 * z1;
+            LD(SINK(in && lane < NU, L::kf + k * NU + lane)) = sel(lane == 0, -z0, -z1);
+            p = hv + k0 * hu0 + k1 * hu1;               // lanes < NX: p_k (the other lanes carry numbers nobody reads)
+            gk = gn;
+            STAGE_FENCE();
+        };
+        if constexpr (UNR > 1) {
+#pragma unroll UNR
+            for (int k = N - 1; k >= 0; k--) stage(k);
+        } else {
+            for (int k = N - 1; k >= 0; k--) stage(k);
+        }
+        LD(SINK(in, L::dZ + lane)) = 0.0;               // dx_0 = 0 (x_0 is fixed; no free sigma_0 without obstacles)
+    }
+    SYNC();
 }
 
 // forward sweep: du = K dx + kff, dx_{k+1} = M [dx; du]; fills dZ for every stage.  The recursion lives in registers:
@@ -1495,7 +1556,9 @@ template <int NOBS, int NFIX> struct RicUnroll { static constexpr int v = NFIX =
 // An EXPERIMENT, opt-in (crx_debug_speculation), built because VERDICT r5 asked what the idle SIMDs of a 256-problem launch could do: measured, a
 // doomed attempt is cheap (the recursion stops at the first non-positive pivot: 1.7 us against 5.8 for a sweep), the longest healthy solve of the
 // headline batch gains 2.5 % alone and the launch loses 1 % to the two barriers per iteration (profiles/r06_speculation.txt).
-template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0>
+// QPM [r6]: the method of the all-linear problems (NOBS == 0; crx_ipm_opts.qp_method): 0 = Mehrotra's predictor-corrector, 1 = IPOPT's monotone
+// barrier + filter line search (what every problem ran up to libcrx 0.3; instantiations with obstacles ignore it).
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0, int QPM = 0>
 __global__ void __launch_bounds__(WAVE * (1 + SPEC)) __attribute__((amdgpu_waves_per_eu(MinWaves<NOBS, NMAX>::v))) CRX_KERNEL_EXTRA_ATTR
 crx_solve_kernel(const crx_kparams kp) {
     static_assert(NFIX <= NMAX, "fixed horizon inside the layout");
@@ -1911,6 +1974,153 @@ crx_solve_kernel(const crx_kparams kp) {
         if ((crash_state || kp.slack_start == 3) && crash_cand >= 0) { crash_write<NOBS, NMAX, true>(sm, c, kp, crash_cand); crash = 1; n_restore = 1; it_limit = 1 + 3 * o.restore_iters; }
     }
     init_point();
+    if constexpr (NOBS == 0 && QPM == 0) {
+    // ---- [r6] Mehrotra's predictor-corrector for the all-linear problems (planner region QPs, MPC-CBF NLPs without an obstacle slot): a convex QP has
+    // ONE solution, so the path to it is free (oracle/crx_oracle.c qp_pc_solve has the algorithm note and runs the same arithmetic
+    // on a dense Cholesky).  Per iteration ONE factorisation -- the Riccati sweep, with the factors kept (KEEPF) -- and two solves: the affine-scaling
+    // predictor (mu = 0), sigma = (mu_aff / mu)^3, and the corrector for t nu = sigma mu - dt_aff dnu_aff through riccati_backward_vec; separate primal
+    // and dual step lengths, no merit function, no filter, no line search.  Start, error measure, termination test, infeasibility proofs: as below.
+    (void)theta_min; (void)theta_max; (void)nf; (void)dw_last; (void)logsum_t; (void)cmin; (void)mu; (void)crash; (void)crash_path;
+    double gap = 0.0;
+    for (int j = lane; j < m; j += WAVE) gap += (row_scale<L>(sm, si, j, N) != 0.0) ? LD(L::rt + j) * LD(L::rnu + j) : 0.0;
+    gap = wave_sum(gap);
+    constexpr int RP = (L::MR + WAVE - 1) / WAVE;
+    for (;; it++) {
+#if CRX_OPAQUE_LANE
+        asm volatile("" : "+v"(c.lane));
+        const int lane = c.lane;   // shadows the kernel's `lane` inside the loop body (see the loop below)
+#endif
+        const double sd = fmax(smax, nus / fmax(mact, 1.0)) / smax;
+        const double e_du = dual_infeasibility<NOBS, NMAX, (SweepUnroll<NFIX>::v > 2 ? SweepUnroll<NFIX>::v : 1)>(sm, c);
+        E0 = fmax(e_du / sd, fmax(e_p, cmax / sd));
+        if (E0 <= o.tol && e_du <= o.dual_inf_tol && e_p <= o.constr_viol_tol && cmax <= o.compl_inf_tol) { status = 0; break; }   // IPOPT's complete test
+        if (it >= o.max_iter) break;
+        const double mu_k = gap / fmax(mact, 1.0);
+        // ---- predictor: the affine-scaling direction ---------------------------------------------------
+        assemble_newton<NOBS, NMAX>(sm, si, c, 0.0);
+        if (!riccati_backward<NOBS, NMAX, RicUnroll<NOBS, NFIX>::v, 0, false, true>(sm, si, c, 0.0)) break;   // (a convex QP: cannot happen short of overflow)
+        riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
+        double dta[RP], dna[RP], rpm = 0.0, rdm = 0.0;
+#pragma unroll
+        for (int q_ = 0; q_ < RP; q_++) {
+            const bool jv = lane + q_ * WAVE < m;
+            const int j = jv ? lane + q_ * WAVE : 0;
+            const int pk = RIVT(si, j);
+            const bool on = jv && LD(L::rsc + j) != 0.0;
+            const double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
+            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j), rsj = LD(L::rsig + j), rwj = LD(L::rw + j);
+            const double rp = rcj - t;
+            dta[q_] = sel(on, jd + rp, 0.0);
+            dna[q_] = sel(on, -rwj + rsj * (rp - dta[q_]), 0.0);
+            rpm = fmax(rpm, -dta[q_] * rti);                  // (absent rows: dt = 0)
+            rdm = fmax(rdm, sel(on, -dna[q_] * frcp(nu), 0.0));
+        }
+        wave_max2(rpm, rdm);
+        const double apa = rpm > 1.0 ? 1.0 / rpm : 1.0, ada = rdm > 1.0 ? 1.0 / rdm : 1.0;      // to the boundary
+        double ga_ = 0.0;
+#pragma unroll
+        for (int q_ = 0; q_ < RP; q_++) {
+            const bool jv = lane + q_ * WAVE < m;
+            const int j = jv ? lane + q_ * WAVE : 0;
+            ga_ += sel(jv && LD(L::rsc + j) != 0.0, (LD(L::rt + j) + apa * dta[q_]) * (LD(L::rnu + j) + ada * dna[q_]), 0.0);
+        }
+        const double mu_aff = wave_sum(ga_) / fmax(mact, 1.0);
+        double sigma = mu_aff / mu_k;
+        sigma = sigma * sigma * sigma;
+        // (the centering target never goes below IPOPT's smallest barrier parameter: with sigma -> 1e-9 the products t nu fall to 1e-30 in two steps and
+        // the reduced gradient sits on a rounding floor above tol for ever -- oracle note)
+        const double smu = fmax(sigma * mu_k, o.tol / 10.0);
+        // ---- corrector: w <- w_aff - (sigma mu - dt_aff dnu_aff) / t, hg <- hg + J'(w - w_aff); same factor -----------
+        SYNC();                                               // every lane has read its dZ entries: dZ is scratch from here to the forward sweep
+#pragma unroll
+        for (int q_ = 0; q_ < RP; q_++) {
+            const bool jv = lane + q_ * WAVE < m;
+            const int j = jv ? lane + q_ * WAVE : 0;
+            const bool on = jv && LD(L::rsc + j) != 0.0;
+            const double dwj = sel(on, -(smu - dta[q_] * dna[q_]) * LD(L::rtt + j), 0.0);
+            const double rwj = LD(L::rw + j);
+            LD(SINK(jv, L::rw + j)) = rwj + dwj;
+            LD(SINK(jv, L::dZ + j)) = dwj;                    // (MR <= NV without obstacles: the rows fit)
+        }
+        static_assert(L::MR <= L::NV, "row scratch inside dZ");
+        SYNC();
+        COORDS(e, ev, lane, N * NZ + NX) {
+            const int k = e / NZ, a = e - k * NZ;
+            int rl, rh;
+            coord_rows<L>(si, c, e, k, a, rl, rh);
+            const double dl = LD(L::dZ + (rl >= 0 ? rl : 0)), dh = LD(L::dZ + (rh >= 0 ? rh : 0)), g0 = LD(L::hg + e);
+            LD(SINK(ev && !(k == N && a >= NX), L::hg + e)) = g0 + sel(rl >= 0, dl, 0.0) - sel(rh >= 0, dh, 0.0);
+        }
+        SYNC();
+        riccati_backward_vec<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
+        riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
+        const double tau = fmax(o.tau_min, 1.0 - mu_k);
+        rpm = 0.0; rdm = 0.0;
+#pragma unroll
+        for (int q_ = 0; q_ < RP; q_++) {
+            const bool jv = lane + q_ * WAVE < m;
+            const int j = jv ? lane + q_ * WAVE : 0;
+            const int pk = RIVT(si, j);
+            const bool on = jv && LD(L::rsc + j) != 0.0;
+            const double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
+            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j), rsj = LD(L::rsig + j), rwj = LD(L::rw + j);
+            const double rp = rcj - t;
+            dta[q_] = sel(on, jd + rp, 0.0);                  // the corrected step of the row's slack / multiplier
+            dna[q_] = sel(on, -rwj + rsj * (rp - dta[q_]), 0.0);
+            rpm = fmax(rpm, -dta[q_] * rti);
+            rdm = fmax(rdm, sel(on, -dna[q_] * frcp(nu), 0.0));
+        }
+        wave_max2(rpm, rdm);
+        const double a_p = rpm > tau ? tau / rpm : 1.0, a_d = rdm > tau ? tau / rdm : 1.0;
+        if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0) {
+            double* tr = kp.trace + (size_t)it * 16;
+            tr[0] = e_du / sd; tr[1] = e_p; tr[2] = cmax / sd; tr[3] = mu_k; tr[4] = a_p; tr[5] = a_d; tr[6] = sigma; tr[7] = 1.0;
+        }
+        // ---- accept: no merit function, no filter (linear rows: the primal residual shrinks by 1 - a_p) ---------------
+        SYNC();
+        COORDS(e, ev, lane, N * NZ + NX) {
+            const double zn = LD(L::Z + e) + a_p * LD(L::dZ + e);
+            LD(SINK(ev, L::Z + e)) = zn;
+        }
+        SYNC();
+        double numax = 0.0, th = 0.0, gs = 0.0;
+        nus = 0.0; cmax = 0.0;
+#pragma unroll
+        for (int q_ = 0; q_ < RP; q_++) {
+            const bool jv = lane + q_ * WAVE < m;
+            const int j = jv ? lane + q_ * WAVE : 0;
+            const int pk = RIVT(si, j);
+            const bool on = jv && LD(L::rsc + j) != 0.0;
+            const double v = RIV_SGN(pk) * (LD(L::Z + RIV_IDX(pk)) - LD(L::rb + j));
+            double tn = LD(L::rt + j) + a_p * dta[q_];
+            tn = sel(v > tn, v, tn);                          // the slack never lags behind its row (a full primal step makes them equal)
+            const double nn = LD(L::rnu + j) + a_d * dna[q_];
+            LD(SINK(on, L::rt + j)) = tn;
+            LD(SINK(on, L::rnu + j)) = nn;
+            LD(SINK(jv, L::rc + j)) = sel(on, v, 1.0);
+            numax = fmax(numax, sel(on, nn, 0.0));
+            th = fmax(th, sel(on, fabs(v - tn), 0.0));
+            nus += sel(on, nn, 0.0);
+            gs += sel(on, tn * nn, 0.0);
+            cmax = fmax(cmax, sel(on, tn * nn, 0.0));
+        }
+        SYNC();
+        {
+            double z0 = 0.0;
+            wave_max4(numax, th, cmax, z0);
+            double z1 = 0.0, z2 = 0.0;
+            wave_sum4(nus, gs, z1, z2);
+        }
+        gap = gs;
+        e_p = th;
+        first_order<NOBS, NMAX>(sm, si, c);
+        if (numax > 1e12 && th > 1e-6) { status = CRX_STALLED; it++; break; }   // IPOPT's divergence heuristic: not a proof
+        if (th > 1e-6) {   // still violated after the step: look for the proof that it must be
+            if (box_certificate<NOBS, NMAX>(sm, si, c, kp.delta_max, kp.a_max) < -1e-8 * numax) { status = 2; it++; break; }
+        }
+    }
+    f = cost_value<NOBS, NMAX>(sm, c, 0.0);
+    } else {
     if (NOBS && crash) {
         // [r4] the crash start's barrier parameter comes from its own complementarity (oracle/crx_oracle.c has the note): slacks of 1e2 .. 1e5 with
         // multipliers of 1 are nowhere near the central path of mu = 0.1, and the iteration crawled for 25 steps before mu moved at all.
@@ -2315,6 +2525,7 @@ crx_solve_kernel(const crx_kparams kp) {
     if (e_p > 1e-6) status = CRX_STALLED;
     break;
     }
+    }   // QPM
     if constexpr (SPEC) {   // the solve is over: release the speculating wave
         if (lane == 0) LD(L::ctl) = 0.0;
         __syncthreads();
@@ -2416,12 +2627,15 @@ template __global__ void crx_solve_kernel<CRX_PROBE_ONE>(const crx_kparams);
 // ------------------------------------------------------------------------------------------------
 // (7) launchers (plain C++ linkage inside the library; the C ABI lives in crx_api.hip)
 // ------------------------------------------------------------------------------------------------
-template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0>
+template <int NOBS, int NMAX, int DEG = 0, int NFIX = 0, int SPEC = 0, int QPM = 0>
 static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
+    if constexpr (NOBS == 0 && QPM == 0) {   // the all-linear problems: crx_ipm_opts.qp_method picks the instantiation (0 = predictor-corrector, 1 = filter line search)
+        if (kp.opts.qp_method != 0) return launch_t<NOBS, NMAX, DEG, NFIX, SPEC, 1>(kp, st);
+    }
 #if CRX_STATIC_LDS
-    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX, SPEC>), dim3(kp.batch), dim3(WAVE * (1 + SPEC)), 0, st, kp);   // the layout is a static array of the kernel
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX, SPEC, QPM>), dim3(kp.batch), dim3(WAVE * (1 + SPEC)), 0, st, kp);   // the layout is a static array of the kernel
 #else
-    static_assert(SPEC == 0, "the two-wave instantiations are static-LDS kernels");
+    static_assert(SPEC == 0 && QPM == 0, "the two-wave and the A/B instantiations are static-LDS kernels");
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
     static int attr_set_on = -1;

@@ -946,6 +946,136 @@ static void ipm_solve(work_t* w, result_t* res) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * [r6] Convex rows: Mehrotra's predictor-corrector (Mehrotra, SIAM J. Optim. 2, 1992; the form of Nocedal & Wright, Alg. 16.4) for the
+ * problems whose rows are all LINEAR and whose cost is a strictly convex quadratic -- the planner's region QPs
+ * (planning/overtake_traj_planner.py:263-334) and MPC-CBF NLPs with no obstacle slot.  Such a problem has ONE solution: parity with the
+ * reference does not depend on the path an interior-point method takes to it, only on the tolerance it is solved to (VERDICT r5
+ * item 2), so these rows no longer run IPOPT's monotone barrier + filter line search (kept as crx_ipm_opts.qp_method = 1):
+ *   per iteration ONE factorisation of  H + J' Sigma J,  Sigma = nu / t,  and two solves with it:
+ *   predictor   the affine-scaling step (mu = 0);  step lengths to the boundary;  mu_aff = (t + a_p dt)'(nu + a_d dnu) / m;  sigma = (mu_aff / mu)^3
+ *   corrector   the step for  t nu = sigma mu - dt_aff dnu_aff;  fraction-to-the-boundary rule, SEPARATE primal and dual step lengths;
+ *   no merit function, no filter, no line search: the rows are linear, so the primal residual shrinks by (1 - a_p) and t stays c(z) once a
+ *   full primal step was taken.
+ * Unchanged around it: the starting point, the error measure and IPOPT's complete termination test (so "converged" means the same thing), the
+ * infeasibility proofs (fixed-x0 rows, reachability screen, Farkas certificate over the input box after a step that leaves rows violated), the
+ * multiplier-divergence heuristic (CRX_STALLED).  Same arithmetic in crx_kernels.hip (qp_predictor_corrector): the kernel's Riccati recursion
+ * is the block Cholesky of the same matrix; it reuses the feedback gains for the second solve.
+ * ---------------------------------------------------------------------------------------------- */
+static void qp_pc_solve(work_t* w, result_t* res) {
+    const crx_ipm_opts* o = w->o;
+    const int n = w->nred, m = w->m;
+    const double smax = 100.0;
+    memset(w->v, 0, sizeof(double) * n);
+    unpack(w, w->v);
+    scale_rows(w);          /* (no CBF rows here: every d_j stays 1) */
+    init_rows(w);
+    static _Thread_local double rp[MAXM], dta[MAXM], dna[MAXM], rhs2[MAXRED], tmp[MAXRED];
+    int status = CRX_MAX_ITER, it = 0;
+    double E0 = HUGE_VAL;
+    for (it = 0;; it++) {
+        double nus = 0.0;
+        for (int j = 0; j < m; j++) nus += fabs(w->nu[j]);
+        const double sd = fmax(smax, nus / (m > 0 ? m : 1)) / smax;
+        double e_d = 0.0, e_p = 0.0, e_c = 0.0, gap = 0.0;
+        for (int a = 0; a < n; a++) {
+            double s = w->g[a];
+            for (int j = 0; j < m; j++) s -= w->J[j][a] * w->nu[j];
+            e_d = fmax(e_d, fabs(s));
+        }
+        for (int j = 0; j < m; j++) {
+            rp[j] = w->c[j] - w->t[j];
+            e_p = fmax(e_p, fabs(rp[j]));
+            e_c = fmax(e_c, w->t[j] * w->nu[j]);
+            gap += w->t[j] * w->nu[j];
+        }
+        res->kkt3[0] = e_d; res->kkt3[1] = e_p; res->kkt3[2] = e_c;
+        E0 = fmax(e_d / sd, fmax(e_p, e_c / sd));
+        if (g_verbose) fprintf(stderr, "pc it %3d f %.8e ed %.3e ep %.3e ec %.3e gap/m %.2e\n", it, w->f, e_d / sd, e_p, e_c / sd, gap / (m > 0 ? m : 1));
+        if (E0 <= o->tol && e_d <= o->dual_inf_tol && e_p <= o->constr_viol_tol && e_c <= o->compl_inf_tol) { status = CRX_CONVERGED; break; }
+        if (it >= o->max_iter) break;
+#pragma omp atomic
+        g_niter++;
+        const double mu = gap / (m > 0 ? m : 1);
+        /* H + J' Sigma J (lower triangle), factorised once */
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b <= a; b++) w->H[a][b] = w->Hf[a][b];
+        for (int j = 0; j < m; j++) {
+            const double sg = w->nu[j] / w->t[j];
+            const double* Jr = w->J[j];
+            for (int a = 0; a < n; a++) {
+                if (Jr[a] == 0.0) continue;
+                const double sa = sg * Jr[a];
+                for (int b = 0; b <= a; b++) w->H[a][b] += sa * Jr[b];
+            }
+        }
+        if (!chol(n, w->H)) break;        /* cannot happen for a convex QP short of overflow: the last iterate is returned, CRX_MAX_ITER */
+        /* predictor: affine-scaling direction (mu = 0) */
+        for (int a = 0; a < n; a++) {
+            double s = -w->g[a];
+            for (int j = 0; j < m; j++) s += w->J[j][a] * (-w->nu[j] / w->t[j] * rp[j]);
+            w->rhs[a] = s;
+        }
+        memcpy(w->dv, w->rhs, sizeof(double) * n);
+        chol_solve(n, w->H, w->dv);
+        double ap = 1.0, ad = 1.0;
+        for (int j = 0; j < m; j++) {
+            double s = rp[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * w->dv[a];
+            dta[j] = s;
+            dna[j] = -w->nu[j] - w->nu[j] / w->t[j] * s;
+            if (s < 0.0) ap = fmin(ap, -w->t[j] / s);
+            if (dna[j] < 0.0) ad = fmin(ad, -w->nu[j] / dna[j]);
+        }
+        double gap_aff = 0.0;
+        for (int j = 0; j < m; j++) gap_aff += (w->t[j] + ap * dta[j]) * (w->nu[j] + ad * dna[j]);
+        const double mu_aff = gap_aff / (m > 0 ? m : 1);
+        double sigma = mu_aff / mu;
+        sigma = sigma * sigma * sigma;
+        /* the centering target never goes below IPOPT's smallest barrier parameter (tol / 10): with sigma -> 1e-9 the products t nu fall to 1e-30 in two
+         * steps, Sigma = nu / t of the active rows reaches 1e30 and the reduced gradient sits on a rounding floor of 1e-7 -- above tol -- for ever */
+        const double smu = fmax(sigma * mu, o->tol / 10.0);
+        /* corrector: t nu = sigma mu - dt_aff dnu_aff; same factor */
+        for (int a = 0; a < n; a++) {
+            double s = w->rhs[a];
+            for (int j = 0; j < m; j++) s += w->J[j][a] * ((smu - dta[j] * dna[j]) / w->t[j]);
+            rhs2[a] = s;
+        }
+        memcpy(w->dv, rhs2, sizeof(double) * n);
+        chol_solve(n, w->H, w->dv);
+        const double tau = fmax(o->tau_min, 1.0 - mu);       /* IPOPT's fraction-to-the-boundary parameter, on the duality measure */
+        ap = 1.0; ad = 1.0;
+        for (int j = 0; j < m; j++) {
+            double s = rp[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * w->dv[a];
+            w->dt[j] = s;
+            w->dnu[j] = (smu - dta[j] * dna[j]) / w->t[j] - w->nu[j] - w->nu[j] / w->t[j] * s;
+            if (s < 0.0) ap = fmin(ap, -tau * w->t[j] / s);
+            if (w->dnu[j] < 0.0) ad = fmin(ad, -tau * w->nu[j] / w->dnu[j]);
+        }
+        if (g_verbose) fprintf(stderr, "      mu %.2e mu_aff %.2e sigma %.2e a_p %.4f a_d %.4f\n", mu, mu_aff, sigma, ap, ad);
+        for (int a = 0; a < n; a++) w->v[a] += ap * w->dv[a];
+        eval_full(w);
+        double numax = 0.0, th = 0.0;
+        for (int j = 0; j < m; j++) {
+            double tn = w->t[j] + ap * w->dt[j];
+            if (w->c[j] > tn) tn = w->c[j];          /* the slack never lags behind its row (a full primal step makes them equal) */
+            w->t[j] = tn;
+            w->nu[j] += ad * w->dnu[j];
+            numax = fmax(numax, w->nu[j]);
+            th = fmax(th, fabs(w->c[j] - tn));
+        }
+        if (numax > 1e12 && th > 1e-6) { status = CRX_STALLED; it++; break; }   /* IPOPT's divergence heuristic: not a proof */
+        if (th > 1e-6 && box_certificate(w, tmp) < -1e-8 * numax) { status = CRX_INFEASIBLE; it++; break; }
+    }
+    res->status = status;
+    res->iters = it;
+    res->kkt = E0;
+    if (g_kkt_unscaled && status == CRX_CONVERGED)
+        res->kkt = g_kkt_unscaled == 1 ? fmax(res->kkt3[0], fmax(res->kkt3[1], res->kkt3[2])) : res->kkt3[g_kkt_unscaled - 2];
+    res->cost = w->f;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * scipy.interpolate.interp1d(kind="linear") restated (scipy/interpolate/_interpolate.py
  * _call_linear): searchsorted on x, clip index to [1, n-1], slope form.
  * ---------------------------------------------------------------------------------------------- */
@@ -965,7 +1095,7 @@ void crx_oracle_ipm_opts_default(crx_ipm_opts* o) {
     o->tol = 1e-8; o->max_iter = 200; o->restore_iters = 50; o->mu_init = 0.1; o->kappa_eps = 10.0;
     o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->slack_push = 1e-2;
     o->grad_scale_max = 100.0; o->reach_screen = 1; o->slack_start = 2;
-    o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4; o->stall_iters = 100; o->reserved1 = 0;
+    o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4; o->stall_iters = 100; o->qp_method = 0;
 }
 
 /* The region QP of generate_traj_per_region as the canonical stage-structured problem (line numbers into
@@ -1039,7 +1169,7 @@ int crx_oracle_planner_solve(const crx_planner_desc* d, int batch, const double*
         if (screened) { r.status = CRX_INFEASIBLE; r.iters = 0; r.kkt = INFINITY; r.cost = INFINITY; }
         else {
         setup(w, p, &d->opts);
-        ipm_solve(w, &r);
+        if (d->opts.qp_method == 0) qp_pc_solve(w, &r); else ipm_solve(w, &r);
         }
         if (infeas0) r.status = CRX_INFEASIBLE;
         double* Xb = X + (size_t)(N + 1) * 6 * b;
@@ -1137,7 +1267,7 @@ int crx_oracle_cbf_solve_dims(const crx_cbf_desc* d, int batch, const double* x0
                        xb[5] < -d->ey_max - d->opts.tol || xb[5] > d->ey_max + d->opts.tol); /* Q9 */
         result_t r;
         setup(w, p, &d->opts);
-        ipm_solve(w, &r);
+        if (p->linear_rows && d->opts.qp_method == 0) qp_pc_solve(w, &r); else ipm_solve(w, &r);
         if (infeas0) r.status = CRX_INFEASIBLE;
         unpack(w, w->v);
         memcpy(X + (size_t)(N + 1) * 6 * b, w->x, sizeof(double) * 6 * (N + 1));
