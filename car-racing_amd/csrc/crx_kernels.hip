@@ -2031,47 +2031,58 @@ crx_solve_kernel(const crx_kparams kp) {
         // the reduced gradient sits on a rounding floor above tol for ever -- oracle note)
         const double smu = fmax(sigma * mu_k, o.tol / 10.0);
         // ---- corrector: w <- w_aff - (sigma mu - dt_aff dnu_aff) / t, hg <- hg + J'(w - w_aff); same factor -----------
-        SYNC();                                               // every lane has read its dZ entries: dZ is scratch from here to the forward sweep
+        // (second pass, rare: a corrected step shorter than PC_SHORT_STEP is redone as a plain centring step t nu = mu -- the second-order term was
+        // computed for a full affine step that cannot be taken; oracle note.  The row / gradient updates are written as differences to what is applied.)
+        constexpr double PC_SHORT_STEP = 0.2;
+        double cr[RP], s_new = smu, s_old = 0.0, c_old = 0.0, a_p = 1.0, a_d = 1.0;
 #pragma unroll
-        for (int q_ = 0; q_ < RP; q_++) {
-            const bool jv = lane + q_ * WAVE < m;
-            const int j = jv ? lane + q_ * WAVE : 0;
-            const bool on = jv && LD(L::rsc + j) != 0.0;
-            const double dwj = sel(on, -(smu - dta[q_] * dna[q_]) * LD(L::rtt + j), 0.0);
-            const double rwj = LD(L::rw + j);
-            LD(SINK(jv, L::rw + j)) = rwj + dwj;
-            LD(SINK(jv, L::dZ + j)) = dwj;                    // (MR <= NV without obstacles: the rows fit)
+        for (int q_ = 0; q_ < RP; q_++) cr[q_] = dta[q_] * dna[q_];
+        const double tau = fmax(o.tau_min, 1.0 - mu_k);
+        for (int pass = 0;; pass++) {
+            const double c_new = pass == 0 ? 1.0 : 0.0;       // weight of the second-order term
+            SYNC();                                           // every lane has read its dZ entries: dZ is scratch from here to the forward sweep
+#pragma unroll
+            for (int q_ = 0; q_ < RP; q_++) {
+                const bool jv = lane + q_ * WAVE < m;
+                const int j = jv ? lane + q_ * WAVE : 0;
+                const bool on = jv && LD(L::rsc + j) != 0.0;
+                const double dwj = sel(on, -((s_new - c_new * cr[q_]) - (s_old - c_old * cr[q_])) * LD(L::rtt + j), 0.0);
+                const double rwj = LD(L::rw + j);
+                LD(SINK(jv, L::rw + j)) = rwj + dwj;
+                LD(SINK(jv, L::dZ + j)) = dwj;                // (MR <= NV without obstacles: the rows fit)
+            }
+            SYNC();
+            COORDS(e, ev, lane, N * NZ + NX) {
+                const int k = e / NZ, a = e - k * NZ;
+                int rl, rh;
+                coord_rows<L>(si, c, e, k, a, rl, rh);
+                const double dl = LD(L::dZ + (rl >= 0 ? rl : 0)), dh = LD(L::dZ + (rh >= 0 ? rh : 0)), g0 = LD(L::hg + e);
+                LD(SINK(ev && !(k == N && a >= NX), L::hg + e)) = g0 + sel(rl >= 0, dl, 0.0) - sel(rh >= 0, dh, 0.0);
+            }
+            SYNC();
+            riccati_backward_vec<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
+            riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
+            rpm = 0.0; rdm = 0.0;
+#pragma unroll
+            for (int q_ = 0; q_ < RP; q_++) {
+                const bool jv = lane + q_ * WAVE < m;
+                const int j = jv ? lane + q_ * WAVE : 0;
+                const int pk = RIVT(si, j);
+                const bool on = jv && LD(L::rsc + j) != 0.0;
+                const double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
+                const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j), rsj = LD(L::rsig + j), rwj = LD(L::rw + j);
+                const double rp = rcj - t;
+                dta[q_] = sel(on, jd + rp, 0.0);              // the corrected step of the row's slack / multiplier
+                dna[q_] = sel(on, -rwj + rsj * (rp - dta[q_]), 0.0);
+                rpm = fmax(rpm, -dta[q_] * rti);
+                rdm = fmax(rdm, sel(on, -dna[q_] * frcp(nu), 0.0));
+            }
+            wave_max2(rpm, rdm);
+            a_p = rpm > tau ? tau / rpm : 1.0; a_d = rdm > tau ? tau / rdm : 1.0;
+            if (pass == 0 && fmin(a_p, a_d) < PC_SHORT_STEP) { s_old = s_new; c_old = 1.0; s_new = fmax(mu_k, o.tol / 10.0); continue; }
+            break;
         }
         static_assert(L::MR <= L::NV, "row scratch inside dZ");
-        SYNC();
-        COORDS(e, ev, lane, N * NZ + NX) {
-            const int k = e / NZ, a = e - k * NZ;
-            int rl, rh;
-            coord_rows<L>(si, c, e, k, a, rl, rh);
-            const double dl = LD(L::dZ + (rl >= 0 ? rl : 0)), dh = LD(L::dZ + (rh >= 0 ? rh : 0)), g0 = LD(L::hg + e);
-            LD(SINK(ev && !(k == N && a >= NX), L::hg + e)) = g0 + sel(rl >= 0, dl, 0.0) - sel(rh >= 0, dh, 0.0);
-        }
-        SYNC();
-        riccati_backward_vec<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
-        riccati_forward<NOBS, NMAX, SweepUnroll<NFIX>::v>(sm, c);
-        const double tau = fmax(o.tau_min, 1.0 - mu_k);
-        rpm = 0.0; rdm = 0.0;
-#pragma unroll
-        for (int q_ = 0; q_ < RP; q_++) {
-            const bool jv = lane + q_ * WAVE < m;
-            const int j = jv ? lane + q_ * WAVE : 0;
-            const int pk = RIVT(si, j);
-            const bool on = jv && LD(L::rsc + j) != 0.0;
-            const double jd = RIV_SGN(pk) * LD(L::dZ + RIV_IDX(pk));
-            const double t = LD(L::rt + j), nu = LD(L::rnu + j), rti = LD(L::rtt + j), rcj = LD(L::rc + j), rsj = LD(L::rsig + j), rwj = LD(L::rw + j);
-            const double rp = rcj - t;
-            dta[q_] = sel(on, jd + rp, 0.0);                  // the corrected step of the row's slack / multiplier
-            dna[q_] = sel(on, -rwj + rsj * (rp - dta[q_]), 0.0);
-            rpm = fmax(rpm, -dta[q_] * rti);
-            rdm = fmax(rdm, sel(on, -dna[q_] * frcp(nu), 0.0));
-        }
-        wave_max2(rpm, rdm);
-        const double a_p = rpm > tau ? tau / rpm : 1.0, a_d = rdm > tau ? tau / rdm : 1.0;
         if (kp.trace && b == kp.trace_problem && it < (kp.trace_rows < 0 ? -kp.trace_rows : kp.trace_rows) && lane == 0) {
             double* tr = kp.trace + (size_t)it * 16;
             tr[0] = e_du / sd; tr[1] = e_p; tr[2] = cmax / sd; tr[3] = mu_k; tr[4] = a_p; tr[5] = a_d; tr[6] = sigma; tr[7] = 1.0;

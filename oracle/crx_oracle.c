@@ -883,9 +883,12 @@ static void ipm_solve(work_t* w, result_t* res) {
         if (acc && jam_on && n_restore == 0 && it >= STALL_ITERS && e_p > 1e-6) jam = JAM_COUNT;
         /* theta stagnation (experiment knobs 13 = window W, 14 = ratio R; 0 = off): a zero start that may restart and whose constraint
          * violation fell by less than (1 - R) over the last W iterations */
-        ep_hist[it & 7] = e_p;
-        if (g_knob[13] > 0 && acc && jam_on && n_restore == 0 && crash_path && may_restart && !crash && it >= (int)g_knob[13] && e_p > 1e-6 &&
-            e_p > g_knob[14] * ep_hist[(it - (int)g_knob[13]) & 7]) jam = JAM_COUNT;
+        {   /* (the window is clamped to the ring's 7 usable slots and the old value is read BEFORE this iteration's is stored: ADVICE r5) */
+            const int W = g_knob[13] > 7.0 ? 7 : (int)g_knob[13];
+            const double ep_old = ep_hist[(it - W) & 7];
+            ep_hist[it & 7] = e_p;
+            if (W > 0 && acc && jam_on && n_restore == 0 && crash_path && may_restart && !crash && it >= W && e_p > 1e-6 && e_p > g_knob[14] * ep_old) jam = JAM_COUNT;
+        }
         if (!acc || jam >= JAM_COUNT) {
             if (crash_path && may_restart && n_restore < 1 && !crash && crash_point(w, 0)) {
                 /* crash path (ii): the solve started at the reference's zero point and stalls on violated CBF rows -- restart ONCE from
@@ -954,6 +957,7 @@ static void ipm_solve(work_t* w, result_t* res) {
  *   per iteration ONE factorisation of  H + J' Sigma J,  Sigma = nu / t,  and two solves with it:
  *   predictor   the affine-scaling step (mu = 0);  step lengths to the boundary;  mu_aff = (t + a_p dt)'(nu + a_d dnu) / m;  sigma = (mu_aff / mu)^3
  *   corrector   the step for  t nu = sigma mu - dt_aff dnu_aff;  fraction-to-the-boundary rule, SEPARATE primal and dual step lengths;
+ *               if either comes out below 0.2 the solve is redone (same factor) as a plain centring step  t nu = mu;
  *   no merit function, no filter, no line search: the rows are linear, so the primal residual shrinks by (1 - a_p) and t stays c(z) once a
  *   full primal step was taken.
  * Unchanged around it: the starting point, the error measure and IPOPT's complete termination test (so "converged" means the same thing), the
@@ -961,6 +965,7 @@ static void ipm_solve(work_t* w, result_t* res) {
  * multiplier-divergence heuristic (CRX_STALLED).  Same arithmetic in crx_kernels.hip (qp_predictor_corrector): the kernel's Riccati recursion
  * is the block Cholesky of the same matrix; it reuses the feedback gains for the second solve.
  * ---------------------------------------------------------------------------------------------- */
+#define PC_SHORT_STEP 0.2
 static void qp_pc_solve(work_t* w, result_t* res) {
     const crx_ipm_opts* o = w->o;
     const int n = w->nred, m = w->m;
@@ -1033,8 +1038,9 @@ static void qp_pc_solve(work_t* w, result_t* res) {
         sigma = sigma * sigma * sigma;
         /* the centering target never goes below IPOPT's smallest barrier parameter (tol / 10): with sigma -> 1e-9 the products t nu fall to 1e-30 in two
          * steps, Sigma = nu / t of the active rows reaches 1e30 and the reduced gradient sits on a rounding floor of 1e-7 -- above tol -- for ever */
-        const double smu = fmax(sigma * mu, o->tol / 10.0);
+        double smu = fmax(sigma * mu, o->tol / 10.0);
         /* corrector: t nu = sigma mu - dt_aff dnu_aff; same factor */
+        for (int pass = 0; pass < 2; pass++) {
         for (int a = 0; a < n; a++) {
             double s = w->rhs[a];
             for (int j = 0; j < m; j++) s += w->J[j][a] * ((smu - dta[j] * dna[j]) / w->t[j]);
@@ -1051,6 +1057,16 @@ static void qp_pc_solve(work_t* w, result_t* res) {
             w->dnu[j] = (smu - dta[j] * dna[j]) / w->t[j] - w->nu[j] - w->nu[j] / w->t[j] * s;
             if (s < 0.0) ap = fmin(ap, -tau * w->t[j] / s);
             if (w->dnu[j] < 0.0) ad = fmin(ad, -tau * w->nu[j] / w->dnu[j]);
+        }
+        if (pass == 0 && fmin(ap, ad) < PC_SHORT_STEP) {
+            /* a short step: the second-order term dt_aff dnu_aff was computed for a full affine step that cannot be taken, and a corrector that leans on
+             * it walks the iterate off the central path (1 of 65 536 region QPs of the configs[4] shard cycled for 60 iterations, steps of 0.03..0.1 at
+             * sigma 0.5..0.9) -- redo the solve, same factor, as a plain centring step: t nu = mu */
+            smu = fmax(mu, o->tol / 10.0);
+            for (int j = 0; j < m; j++) dta[j] = 0.0;
+            continue;
+        }
+        break;
         }
         if (g_verbose) fprintf(stderr, "      mu %.2e mu_aff %.2e sigma %.2e a_p %.4f a_d %.4f\n", mu, mu_aff, sigma, ap, ad);
         for (int a = 0; a < n; a++) w->v[a] += ap * w->dv[a];
