@@ -165,11 +165,14 @@ typedef struct crx_ipm_opts {
                               longer horizon or more obstacles (configs[3]: healthy solves of 53..86 iterations).  With the defaults a
                               solve ends after at most stall_iters + 1 + restore_iters (76 / 151) iterations when it went through a
                               restoration, 1 + 3 restore_iters (76 / 151) when it started on the crash path: below max_iter in both. */
-    int32_t qp_method;      /* 0     [0.4.0] problems whose rows are all linear and whose cost is a convex quadratic (planner region QPs, MPC-CBF NLPs without an
-                              obstacle slot, the learning-MPC QP, the path planner's QPs) -- ONE solution, so the path to it is free:
-                              0: Mehrotra's predictor-corrector (one factorisation and two solves per iteration, no line search);
-                              1: IPOPT's monotone barrier + filter line search, as libcrx <= 0.3 ran them (A/B runs).  Same starting point,
-                              same termination test, same infeasibility proofs either way.  Problems with CBF rows ignore it. */
+    int32_t qp_method;      /* 0     [0.4.0] the solver-kernel problems whose rows are all linear and whose cost is a convex quadratic -- planner region QPs, MPC-CBF
+                              NLPs without an obstacle slot -- have ONE solution, so the path to it is free:
+                              0: Mehrotra's predictor-corrector (one factorisation and two solves per iteration, no line search): 6.5 iterations
+                                 per region QP instead of 10.3, BASELINE configs[2] 0.285 -> 0.247 ms per 4096 QPs;
+                              1: IPOPT's monotone barrier + filter line search, as libcrx <= 0.3 ran them (A/B runs).
+                              Same starting point, same termination test, same infeasibility proofs either way.  Problems with CBF rows ignore it; so do
+                              the learning-MPC QP and the path planner's QPs (measured on the oracle: 15.5 -> 11.5 iterations against a second solve of
+                              a third of an iteration -- no gain). */
 } crx_ipm_opts;
 
 /* ---- planner region QP (overtake_traj_planner.py:263-334) ------------------------------------ */

@@ -589,6 +589,222 @@ static void lmpc_ipm(lw_t* w, lres_t* res) {
     res->cost = f;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * [r6] EXPERIMENT, not the shipped algorithm: Mehrotra's predictor-corrector for the learning-MPC QP (crx_oracle.c qp_pc_solve has the algorithm
+ * note) -- a convex QP with the 7 equalities  x_N = SS lambd, 1'lambd = 1:  ONE factorisation of the reduced KKT matrix [K E'; E 0] per iteration
+ * (LU with partial pivoting on the symmetrically equilibrated matrix, as lmpc_ipm), two solves with it, the corrected step redone as a plain centring
+ * step when it comes out short; the equality multipliers move with the primal step length (as lmpc_ipm).  Same start, error measure, termination
+ * test, stagnation rule and infeasibility certificate.  MEASURED (profiles/r06_mehrotra.txt): 15.5 -> 11.5 iterations per QP on the recorded lap and
+ * on the 160 QPs of the benched game loop (same verdicts, same solutions to 1e-5) -- a quarter fewer, where the planner's region QPs lose 36 %; the
+ * second solve of the kernel's block elimination (forward substitution with L_u, the product-form solves, back substitution, one more row pass) is
+ * ~19 k of an iteration's 52 k ticks: 11.5 x 71 k against 15.5 x 52 k = 3 % -- not built into crx_lmpc.hip; crx_ipm_opts.qp_method does not reach
+ * the learning-MPC QP.  Kept behind crx_oracle_lmpc_set_pc for the record.
+ * ---------------------------------------------------------------------------------------------- */
+enum { PC_NK = LNV + LNE };
+static _Thread_local double pc_Mx[PC_NK][PC_NK], pc_Mo[PC_NK][PC_NK], pc_sc[PC_NK];
+static _Thread_local int pc_piv[PC_NK];
+static int pc_factor(lw_t* w) {
+    const int n = w->n, nk = n + LNE;
+    for (int a = 0; a < n; a++) {
+        for (int b = 0; b <= a; b++) { pc_Mo[a][b] = w->K[a][b]; pc_Mo[b][a] = w->K[a][b]; }
+        for (int r = 0; r < LNE; r++) { pc_Mo[a][n + r] = w->E[r][a]; pc_Mo[n + r][a] = w->E[r][a]; }
+    }
+    for (int r = 0; r < LNE; r++)
+        for (int q = 0; q < LNE; q++) pc_Mo[n + r][n + q] = 0.0;
+    for (int a = 0; a < nk; a++) {
+        double mx = 0.0;
+        for (int b = 0; b < nk; b++) mx = fmax(mx, fabs(pc_Mo[a][b]));
+        pc_sc[a] = mx > 0.0 ? 1.0 / sqrt(mx) : 1.0;
+    }
+    for (int a = 0; a < nk; a++)
+        for (int b = 0; b < nk; b++) pc_Mx[a][b] = pc_Mo[a][b] * pc_sc[a] * pc_sc[b];
+    for (int k = 0; k < nk; k++) {
+        int pk = k;
+        double mx = fabs(pc_Mx[k][k]);
+        for (int i = k + 1; i < nk; i++)
+            if (fabs(pc_Mx[i][k]) > mx) { mx = fabs(pc_Mx[i][k]); pk = i; }
+        pc_piv[k] = pk;
+        if (mx == 0.0) return 0;
+        if (pk != k)
+            for (int b = 0; b < nk; b++) { double tsw = pc_Mx[k][b]; pc_Mx[k][b] = pc_Mx[pk][b]; pc_Mx[pk][b] = tsw; }
+        for (int i = k + 1; i < nk; i++) {
+            double l = pc_Mx[i][k] / pc_Mx[k][k];
+            pc_Mx[i][k] = l;
+            if (l != 0.0)
+                for (int b = k + 1; b < nk; b++) pc_Mx[i][b] -= l * pc_Mx[k][b];
+        }
+    }
+    return 1;
+}
+static void pc_solve(const lw_t* w, const double* rhs, const double* e, double* dv, double* dy) {
+    static _Thread_local double bb[PC_NK], xx[PC_NK], rr[PC_NK];
+    const int n = w->n, nk = n + LNE;
+    for (int a = 0; a < n; a++) bb[a] = rhs[a];
+    for (int r = 0; r < LNE; r++) bb[n + r] = -e[r];
+    memset(xx, 0, sizeof(double) * nk);
+    for (int pass = 0; pass < 2; pass++) {      /* one step of iterative refinement */
+        for (int a = 0; a < nk; a++) {
+            double s = bb[a];
+            if (pass)
+                for (int b = 0; b < nk; b++) s -= pc_Mo[a][b] * xx[b];
+            rr[a] = s * pc_sc[a];
+        }
+        for (int k = 0; k < nk; k++)
+            if (pc_piv[k] != k) { double tsw = rr[k]; rr[k] = rr[pc_piv[k]]; rr[pc_piv[k]] = tsw; }
+        for (int k = 0; k < nk; k++)
+            for (int i = k + 1; i < nk; i++) rr[i] -= pc_Mx[i][k] * rr[k];
+        for (int i = nk - 1; i >= 0; i--) {
+            double s = rr[i];
+            for (int b = i + 1; b < nk; b++) s -= pc_Mx[i][b] * rr[b];
+            rr[i] = s / pc_Mx[i][i];
+        }
+        for (int a = 0; a < nk; a++) xx[a] += rr[a] * pc_sc[a];
+    }
+    for (int a = 0; a < n; a++) dv[a] = xx[a];
+    for (int r = 0; r < LNE; r++) dy[r] = xx[n + r];
+}
+#define LPC_SHORT_STEP 0.2
+/* EXPERIMENT switches (tools only; libcrx's learning-MPC kernel runs lmpc_ipm's algorithm): g_lmpc_pc = 1 routes crx_oracle_lmpc_solve through lmpc_pc;
+ * g_pcv = 1: one step length for primal and dual, 2: the equality multipliers move with the dual step length */
+static int g_lmpc_pc = 0, g_pcv = 0;
+void crx_oracle_lmpc_set_pc(int on, int variant) { g_lmpc_pc = on != 0; g_pcv = variant; }
+static void lmpc_pc(lw_t* w, lres_t* res) {
+    const crx_ipm_opts* o = &w->d->opts;
+    const int n = w->n, m = w->m;
+    const double smax = 100.0;
+    static _Thread_local double c[LMR], g[LNV], rp[LMR], dt[LMR], dnu[LMR], dta[LMR], dna[LMR], rhs[LNV], rhs2[LNV], dv[LNV], e[LNE], dy[LNE];
+    memset(w->v, 0, sizeof(double) * n);
+    memset(w->y, 0, sizeof(w->y));
+    for (int j = 0; j < m; j++) {
+        w->t[j] = fmax(fabs(w->jb[j]), o->slack_push);
+        w->nu[j] = 1.0;
+    }
+    {
+        int j0 = 4 * w->N + 3 * (w->N - 1);
+        for (int j = j0; j < m; j++) {
+            double gg = w->g0[w->nu2 + (j - j0)];
+            if (gg > 1.0) w->nu[j] = gg;
+        }
+    }
+    int status = CRX_MAX_ITER, it = 0, late = 0;
+    enum { LATE_ITERS = 25 };
+    double E0 = HUGE_VAL;
+    for (it = 0;; it++) {
+        for (int j = 0; j < m; j++) {
+            double s = w->jb[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * w->v[a];
+            c[j] = s;
+        }
+        for (int r = 0; r < LNE; r++) {
+            double s = w->eb[r];
+            for (int a = 0; a < n; a++) s += w->E[r][a] * w->v[a];
+            e[r] = s;
+        }
+        for (int a = 0; a < n; a++) {
+            double s = w->g0[a];
+            for (int b = 0; b < n; b++) s += w->H[a][b] * w->v[b];
+            g[a] = s;
+        }
+        double nus = 0.0, ys = 0.0, gap = 0.0;
+        for (int j = 0; j < m; j++) { nus += fabs(w->nu[j]); gap += w->t[j] * w->nu[j]; }
+        for (int r = 0; r < LNE; r++) ys += fabs(w->y[r]);
+        const double sd = fmax(smax, (nus + ys) / (m + LNE)) / smax, sc = fmax(smax, nus / m) / smax;
+        double e_d = 0.0, e_p = 0.0, e_c = 0.0, theta = 0.0;
+        for (int a = 0; a < n; a++) {
+            double s = g[a];
+            for (int j = 0; j < m; j++) s -= w->J[j][a] * w->nu[j];
+            for (int r = 0; r < LNE; r++) s += w->E[r][a] * w->y[r];
+            e_d = fmax(e_d, fabs(s));
+        }
+        for (int j = 0; j < m; j++) {
+            rp[j] = c[j] - w->t[j];
+            e_p = fmax(e_p, fabs(rp[j]));
+            theta += fabs(rp[j]);
+            e_c = fmax(e_c, w->t[j] * w->nu[j]);
+        }
+        for (int r = 0; r < LNE; r++) { e_p = fmax(e_p, fabs(e[r])); theta += fabs(e[r]); }
+        E0 = fmax(e_d / sd, fmax(e_p, e_c / sc));
+        const double mu = gap / m;
+        if (lv) fprintf(stderr, "pc it %3d ed %.2e ep %.2e ec %.2e mu %.1e theta %.2e\n", it, e_d / sd, e_p, e_c / sc, mu, theta);
+        if (E0 <= o->tol && e_d <= o->dual_inf_tol && e_p <= o->constr_viol_tol && e_c <= o->compl_inf_tol) { status = CRX_CONVERGED; break; }
+        if (it >= o->max_iter) break;
+        if (mu < 1e-6 && ++late >= LATE_ITERS) break;      /* the noise floor of an unstable local model: see lmpc_ipm */
+        if (!w->elastic && it > 0 && theta > 1e-6 && lmpc_certificate(w, c, e) < -1e-8 * (nus + ys)) { status = CRX_INFEASIBLE; break; }
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b <= a; b++) w->K[a][b] = w->H[a][b];
+        for (int j = 0; j < m; j++) {
+            const double sg = w->nu[j] / w->t[j];
+            const double* Jr = w->J[j];
+            for (int a = 0; a < n; a++) {
+                if (Jr[a] == 0.0) continue;
+                const double sa = sg * Jr[a];
+                for (int b = 0; b <= a; b++) w->K[a][b] += sa * Jr[b];
+            }
+        }
+        if (!pc_factor(w)) break;
+        for (int a = 0; a < n; a++) {
+            double s = -g[a];
+            for (int r = 0; r < LNE; r++) s -= w->E[r][a] * w->y[r];
+            for (int j = 0; j < m; j++) s += w->J[j][a] * (-w->nu[j] / w->t[j] * rp[j]);
+            rhs[a] = s;
+        }
+        pc_solve(w, rhs, e, dv, dy);
+        double ap = 1.0, ad = 1.0;
+        for (int j = 0; j < m; j++) {
+            double s = rp[j];
+            for (int a = 0; a < n; a++) s += w->J[j][a] * dv[a];
+            dta[j] = s;
+            dna[j] = -w->nu[j] - w->nu[j] / w->t[j] * s;
+            if (s < 0.0) ap = fmin(ap, -w->t[j] / s);
+            if (dna[j] < 0.0) ad = fmin(ad, -w->nu[j] / dna[j]);
+        }
+        double gap_aff = 0.0;
+        for (int j = 0; j < m; j++) gap_aff += (w->t[j] + ap * dta[j]) * (w->nu[j] + ad * dna[j]);
+        double sigma = gap_aff / m / mu;
+        sigma = sigma * sigma * sigma;
+        double smu = fmax(sigma * mu, o->tol / 10.0), cw = 1.0;
+        const double tau = fmax(o->tau_min, 1.0 - mu);
+        for (int pass = 0; pass < 2; pass++) {
+            for (int a = 0; a < n; a++) {
+                double s = rhs[a];
+                for (int j = 0; j < m; j++) s += w->J[j][a] * ((smu - cw * dta[j] * dna[j]) / w->t[j]);
+                rhs2[a] = s;
+            }
+            pc_solve(w, rhs2, e, dv, dy);
+            ap = 1.0; ad = 1.0;
+            for (int j = 0; j < m; j++) {
+                double s = rp[j];
+                for (int a = 0; a < n; a++) s += w->J[j][a] * dv[a];
+                dt[j] = s;
+                dnu[j] = (smu - cw * dta[j] * dna[j]) / w->t[j] - w->nu[j] - w->nu[j] / w->t[j] * s;
+                if (s < 0.0) ap = fmin(ap, -tau * w->t[j] / s);
+                if (dnu[j] < 0.0) ad = fmin(ad, -tau * w->nu[j] / dnu[j]);
+            }
+            if (pass == 0 && fmin(ap, ad) < LPC_SHORT_STEP) { smu = fmax(mu, o->tol / 10.0); cw = 0.0; continue; }
+            break;
+        }
+        if (g_pcv == 1) { ap = fmin(ap, ad); ad = ap; }
+        if (lv) fprintf(stderr, "      sigma %.2e a_p %.4f a_d %.4f\n", sigma, ap, ad);
+        for (int a = 0; a < n; a++) w->v[a] += ap * dv[a];
+        for (int r = 0; r < LNE; r++) w->y[r] += (g_pcv == 2 ? ad : ap) * dy[r];
+        double numax = 0.0;
+        for (int j = 0; j < m; j++) {
+            double cj = w->jb[j];
+            for (int a = 0; a < n; a++) cj += w->J[j][a] * w->v[a];
+            double tn = w->t[j] + ap * dt[j];
+            if (cj > tn) tn = cj;
+            w->t[j] = tn;
+            w->nu[j] += ad * dnu[j];
+            numax = fmax(numax, w->nu[j]);
+        }
+        if (numax > 1e12 && theta > 1e-6) { status = CRX_STALLED; it++; break; }
+    }
+    res->status = status;
+    res->iters = it;
+    res->kkt = E0;
+    res->cost = lmpc_f(w, w->v);
+}
+
 int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, const double* u_old, const double* A,
                           const double* B, const double* C, const double* ss, const double* qfun, const int32_t* n_ss,
                           double* X, double* U, double* lambda, double* cost, int32_t* status, double* kkt,
@@ -629,7 +845,7 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
                 }
             }
             if (screened) { r.status = CRX_INFEASIBLE; r.iters = 0; r.kkt = HUGE_VAL; r.cost = 0.0; }
-            else lmpc_ipm(w, &r);
+            else if (g_lmpc_pc) lmpc_pc(w, &r); else lmpc_ipm(w, &r);
             total = r.iters;
             if (r.status != CRX_CONVERGED || bad0) {
                 /* CRX_INFEASIBLE is only ever a PROOF (include/crx.h): a bound the fixed x_0 violates, the screen, or the certificate inside
@@ -637,7 +853,7 @@ int crx_oracle_lmpc_solve(const crx_lmpc_desc* d, int batch, const double* x0, c
                  * reports CRX_STALLED after a converged relaxed attempt: same plan, no claim about the pinned QP. */
                 const int proved = screened || bad0 || r.status == CRX_INFEASIBLE;
                 lmpc_setup(w, 1);
-                lmpc_ipm(w, &r);
+                if (g_lmpc_pc) lmpc_pc(w, &r); else lmpc_ipm(w, &r);
                 total += r.iters;
                 if (r.status == CRX_CONVERGED) r.status = proved ? CRX_INFEASIBLE : CRX_STALLED;   /* the reference's (pinned) QP was not solved */
             }
