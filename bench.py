@@ -333,6 +333,9 @@ def make_lmpc(cx, args, batch=None):
     return w
 
 
+LAP_WINDOW = 60
+
+
 def to_lap_phase(cx, w, conc, phase, what):
     """Closed-loop workloads: `phase` untimed control steps after construction, a snapshot there, and a rewind hook that measure()
     calls after its warm-up -- the timed steps always cover control steps [phase, phase + steps) of the lap, so the record does not
@@ -350,7 +353,12 @@ def to_lap_phase(cx, w, conc, phase, what):
         cx.dsync()
 
     w.rewind = rewind
-    w.extra["lap_phase"] = "timed steps = control steps [%d, %d + steps) of %s; the status / iteration fields describe step %d + steps" % (phase, phase, what, phase)
+    # [r6] a FIXED window of the lap, whatever --steps is: the timed steps are control steps phase .. phase + WINDOW - 1, all of them when --steps ==
+    # WINDOW, every (WINDOW / steps)-th when fewer (the steps in between run untimed), cyclically (rewind) when more; the status / iteration fields
+    # are taken over one untimed pass through the whole window.  The driver's 20-step line and a 60-step record describe the same 60 control steps.
+    w.window = LAP_WINDOW
+    w.extra["lap_phase"] = ("timed steps sample control steps [%d, %d) of %s (all of them at --steps %d; every (%d / steps)-th below, the rest untimed; cyclic above); "
+                            "the status / iteration fields are taken over all %d steps of the window") % (phase, phase + LAP_WINDOW, what, LAP_WINDOW, LAP_WINDOW, LAP_WINDOW)
 
 
 def make_races(cx, args, batch=None):
@@ -523,15 +531,35 @@ def measure(cx, w, steps, warmup, with_latency=True):
     if getattr(w, "step_is_one_launch", False):
         from crx import torch_api
         region_tm = torch_api.Timer()
-    t0 = time.perf_counter()
-    if region_tm is not None:
-        region_tm.begin()
-    for _ in range(steps):
-        w.step()
-    if region_tm is not None:
-        region_tm.end()
-    cx.sync_all()
-    elapsed = time.perf_counter() - t0
+    window = getattr(w, "window", 0)
+    if window:
+        # closed loops: exactly `steps` timed steps, each bracketed by barrier + synchronize, sampled over the fixed window (to_lap_phase)
+        stride = max(1, window // steps) if steps <= window else 1
+        elapsed, timed, pos = 0.0, 0, 0
+        while timed < steps:
+            if pos == window:
+                w.rewind()
+                pos = 0
+            if pos % stride == 0:
+                cx.sync_all()
+                t0 = time.perf_counter()
+                w.step()
+                cx.sync_all()
+                elapsed += time.perf_counter() - t0
+                timed += 1
+            else:
+                w.step()
+            pos += 1
+    else:
+        t0 = time.perf_counter()
+        if region_tm is not None:
+            region_tm.begin()
+        for _ in range(steps):
+            w.step()
+        if region_tm is not None:
+            region_tm.end()
+        cx.sync_all()
+        elapsed = time.perf_counter() - t0
     region_ms = region_tm.ms() / steps if region_tm is not None else None
     if cx.world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cx.dev)
@@ -569,8 +597,18 @@ def measure(cx, w, steps, warmup, with_latency=True):
                 w.host_call()
                 hlat.append((time.perf_counter() - t1) * 1e3)
     # ---- status / iteration fields: read after one more step(), i.e. they describe a launch the workload really issues
-    w.step()
-    cx.dsync()
+    win = None
+    if window:     # closed loops: one untimed pass through the whole window, every step's status / iteration counts kept
+        w.rewind()
+        acc = []
+        for _ in range(window):
+            w.step()
+            cx.dsync()
+            acc.append((w.ws.status.cpu().numpy().copy(), w.ws.iters.cpu().numpy().copy()))
+        win = (np.concatenate([a[0] for a in acc]), np.concatenate([a[1] for a in acc]))
+    else:
+        w.step()
+        cx.dsync()
     st, it, kkt = w.ws.status.cpu().numpy(), w.ws.iters.cpu().numpy(), w.ws.kkt.cpu().numpy()
     k_ms, k_ms_single = kernel_ms_samples(cx, w, min(50, max(5, steps)))
     k_ms_train = k_ms
@@ -637,6 +675,11 @@ def measure(cx, w, steps, warmup, with_latency=True):
                 tsrc = "stale"                                   # the kept summary was measured on other kernel sources
     except Exception:
         traffic = None
+    if win is not None:      # fractions and iteration statistics over the window (the roofline figures above stay per launch: the window's last step)
+        st, it = win
+        conv = st == 0
+        ran = st != 4
+        conv_of_launched = float(conv[ran].mean()) if ran.any() else 0.0
     cfg = {"workload": w.name, "baseline_config": w.baseline_config, "batch_per_gpu": int(w.batch), "problems_launched": launched,
            "horizon": int(N), "n_obs": 0 if w.kind == "lmpc" else int(n_obs), "n_ss": int(n_obs) if w.kind == "lmpc" else 0,
            "tol": w.desc.opts.tol,

@@ -47,29 +47,44 @@ def _order(obj, iters, active=None):
 class Snapshot:
     """The state of a closed-loop object (MpccbfRaces / LmpcLaps / GameLaps, or a Concurrent of them) at this moment: every tensor
     and every plain number reachable through its attributes (workspaces and nested loops included) is copied; restore() puts the
-    values AND the attribute bindings back (step() swaps xc / xc_next).  bench.py uses it to start the timed steps of the closed-loop
+    values AND the attribute bindings back (step() swaps xc / xc_next); tensors held in lists, tuples and dicts and the state of torch.Generator
+    objects (the plant-noise stream) are captured too [r6]; objects without a __dict__ hold nothing that is captured.  bench.py uses it to start the timed steps of the closed-loop
     workloads at a stated lap phase whatever --steps / --warmup are.  The caller synchronises the device around both calls."""
 
     def __init__(self, obj):
         import ctypes
-        self.tensors, self.scalars = [], []
+        self.tensors, self.scalars, self.items, self.gens = [], [], [], []
         seen = set()
+        skip = (ctypes.Structure, torch.cuda.Stream, type)
+
+        def visit(holder, key, v, is_item):
+            """one value reachable from `obj`: holder.key (attribute) or holder[key] (list / dict item)"""
+            if torch.is_tensor(v):
+                (self.items if is_item else self.tensors).append((holder, key, v, v.clone()))
+            elif isinstance(v, torch.Generator):
+                self.gens.append((v, v.get_state()))          # the plant-noise stream restarts where it was
+            elif isinstance(v, (bool, int, float)):
+                if not is_item:
+                    self.scalars.append((holder, key, v))
+            elif isinstance(v, (list, tuple)):
+                if id(v) not in seen:
+                    seen.add(id(v))
+                    for i, e in enumerate(v):
+                        visit(v, i, e, True)
+            elif isinstance(v, dict):
+                if id(v) not in seen:
+                    seen.add(id(v))
+                    for k2, e in list(v.items()):
+                        visit(v, k2, e, True)
+            elif hasattr(v, "__dict__") and not isinstance(v, skip):
+                walk(v)
 
         def walk(o):
-            if id(o) in seen:
+            if id(o) in seen or not hasattr(o, "__dict__"):      # (objects with __slots__ only: nothing to capture)
                 return
             seen.add(id(o))
             for k, v in list(vars(o).items()):
-                if torch.is_tensor(v):
-                    self.tensors.append((o, k, v, v.clone()))
-                elif isinstance(v, (bool, int, float)):
-                    self.scalars.append((o, k, v))
-                elif isinstance(v, (list, tuple)):
-                    for e in v:
-                        if hasattr(e, "__dict__") and not isinstance(e, (ctypes.Structure, torch.cuda.Stream, torch.Generator)):
-                            walk(e)
-                elif hasattr(v, "__dict__") and not isinstance(v, (ctypes.Structure, torch.cuda.Stream, torch.Generator, type)):
-                    walk(v)
+                visit(o, k, v, False)
 
         walk(obj)
 
@@ -77,8 +92,14 @@ class Snapshot:
         for o, k, t, c in self.tensors:
             t.copy_(c)
             setattr(o, k, t)
+        for holder, k, t, c in self.items:             # tensors held in lists / dicts: values back; a mutable holder also gets its binding back
+            t.copy_(c)
+            if not isinstance(holder, tuple):
+                holder[k] = t
         for o, k, v in self.scalars:
             setattr(o, k, v)
+        for gen, state in self.gens:
+            gen.set_state(state)
 
 
 class Concurrent:

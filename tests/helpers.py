@@ -81,6 +81,14 @@ def check_game_draw(r, g):
     # the fixture also records what the DEVICE loop had made of the same states, from raw state through its own regression: the same verdicts,
     # the same 44 safe-set points, stage models within 1e-3 (cond 3e11 normal matrices)
     assert ((g["dev_status"] != 0) == ~feas).all() and g["dev_ss_equal"].all() and g["dev_q_equal"].all() and g["dev_model_dev"].max() <= 2e-3
+    # [r6] the RELAXED plan of the infeasible ones (libcrx's own semantics: x_0 = xcurv + w, cost += 1e4 w'w, no rows on stage 0 -- a strictly convex QP)
+    # against the third solver's certified solution of that QP, written down explicitly from the reference's problem data
+    # (tests/golden/tools/lmpc_relaxed.py; the same explicit form reproduces the reference-built feasible QPs to 6e-7)
+    rel = g["relaxed_ok"]
+    assert rel.sum() == (~feas).sum() >= 60 and (rel == ~feas).all()
+    X, U = np.asarray(r["X"])[rel], np.asarray(r["U"])[rel]
+    assert np.abs(X - g["relaxed_X"][rel]).max() <= 5e-5 and np.abs(U - g["relaxed_U"][rel]).max() <= 5e-5
+    assert np.abs((X[:, 0] - g["x"][rel]) - g["relaxed_w"][rel]).max() <= 1e-6          # the plan starts at xcurv + w
     return int(feas.sum()), int((~feas).sum())
 
 

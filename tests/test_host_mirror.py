@@ -246,3 +246,24 @@ def test_scene_oracle_vs_mirror_and_reference(orc, golden_planner):
                 np.testing.assert_array_equal(r["obs_s"][s, k], ps[s, v])
                 np.testing.assert_array_equal(r["obs_ey"][s, k], pe[s, v])
     assert seen_over >= 3 and seen_empty >= 3
+
+
+def test_snapshot_restores_containers_and_generators():
+    """crx.montecarlo.Snapshot (bench.py's rewind of the closed-loop workloads): tensors held directly, in lists / tuples / dicts and in nested
+    objects come back with their values AND bindings, plain numbers too, and a torch.Generator restarts where it was."""
+    import torch
+    from crx import montecarlo
+
+    class Obj:
+        pass
+
+    a, b = Obj(), Obj()
+    a.x = torch.zeros(3); a.lst = [torch.ones(2), 5]; a.dct = {"k": torch.ones(1)}; a.gen = torch.Generator().manual_seed(3); a.n = 1
+    b.y = torch.ones(2); a.b = b; a.tup = (torch.zeros(1),)
+    snap = montecarlo.Snapshot(a)
+    r0 = torch.rand(2, generator=a.gen)
+    a.x += 1; a.lst[0] += 1; a.dct["k"] += 5; a.n = 7; b.y *= 3; a.tup[0].add_(2)
+    a.x, b.y = b.y, a.x                      # step() swaps bindings like this
+    snap.restore()
+    assert a.x.sum() == 0 and a.lst[0].sum() == 2 and a.dct["k"].item() == 1 and a.n == 1 and b.y.sum() == 2 and a.tup[0].item() == 0
+    assert torch.equal(torch.rand(2, generator=a.gen), r0)
