@@ -2678,39 +2678,33 @@ hipError_t crx_launch_solve_spec(const crx_kparams& kp, hipStream_t st) {
 hipError_t crx_launch_solve_general(const crx_kparams& kp, int nobs_template, hipStream_t st);
 int crx_solve_resident_per_cu_general(int N, int nobs_template);
 #if !CRX_TU_GENERAL
-// fixed-horizon instantiations: N = 10 (the reference's defaults: utils/base.py:281, :390), 12 (BASELINE configs[1], [2], [4]), 20 (configs[3])
-template <int NOBS, int NMAX, int DEG>
-static hipError_t launch_h(const crx_kparams& kp, hipStream_t st) {
-#if CRX_NFIX
-    if constexpr (NMAX == 12) {
-        if (kp.N == 12) return launch_t<NOBS, 12, DEG, 12>(kp, st);
-        if (kp.N == 10) return launch_t<NOBS, 12, DEG, 10>(kp, st);
-    }
-    if constexpr (NMAX == 20) {
-        if (kp.N == 20) return launch_t<NOBS, 20, DEG, 20>(kp, st);
-    }
+// fixed-horizon (tuned) instantiations [r6: a BUILD PARAMETER].  CRX_NFIX_LIST -- `make NFIX_LIST=10,12,16,20` -- names the horizons that get an
+// instantiation with the horizon as a compile-time constant (straight-line sweeps, immediates for every stage address: 1.5 .. 2x the general unit's
+// speed, profiles/r06_variants.txt) for every obstacle count 0 .. 3; any other horizon runs on the general unit.  Default: 10 (the reference's
+// defaults: utils/base.py:281, :390), 12 (BASELINE configs[1], [2], [4]), 20 (configs[3]).  Layout class of a horizon: <= 12 -> 12; <= 20 with three
+// obstacle slots -> 20 (the slim layout, four problems per CU); otherwise CRX_MAX_N.  Budget per entry: one kernel per obstacle count (two for the
+// planner: crx_ipm_opts.qp_method), ~100 KB of code and 15 .. 40 s of build time each; registers / LDS as its layout class.
+#ifndef CRX_NFIX_LIST
+#define CRX_NFIX_LIST 10, 12, 20
 #endif
-    return crx_launch_solve_general(kp, NOBS, st);
+template <int NOBS, int NF> struct NfixLayout { static constexpr int v = NF <= 12 ? 12 : ((NOBS == 3 && NF <= 20) ? 20 : CRX_MAX_N); };
+template <int NOBS, int DEG, int... NFS>
+static bool launch_fixed(const crx_kparams& kp, hipStream_t st, hipError_t& e) {
+    bool hit = false;
+    (void)((kp.N == NFS ? (e = launch_t<NOBS, NfixLayout<NOBS, NFS>::v, DEG, NFS>(kp, st), hit = true) : false) || ...);
+    return hit;
 }
 // obstacle instantiations: the degree-6 one for the reference's exponent; other exponents (2 / 4 / 8) take the general unit
-template <int NOBS, int NMAX>
-static hipError_t launch_d(const crx_kparams& kp, hipStream_t st) {
-    if constexpr (NOBS > 0 && CRX_DEG6) {
-        if (kp.degree == 6) return launch_h<NOBS, NMAX, 6>(kp, st);
-        return crx_launch_solve_general(kp, NOBS, st);
-    } else {
-        return launch_h<NOBS, NMAX, 0>(kp, st);
-    }
-}
-
-// horizon classes: 12 and CRX_MAX_N for every obstacle count, plus 20 for the 3-obstacle instantiation
-// (BASELINE config 4: N = 20)
 template <int NOBS>
 static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
-    if (kp.N <= 12) return launch_d<NOBS, 12>(kp, st);
-    if constexpr (NOBS == 3) {       // (if constexpr: <3,20> must exist in ONE translation unit only, the obstacle one)
-        if (kp.N <= 20) return launch_d<3, 20>(kp, st);
+    hipError_t e = hipSuccess;
+#if CRX_NFIX
+    if constexpr (NOBS > 0 && CRX_DEG6) {
+        if (kp.degree == 6 && launch_fixed<NOBS, 6, CRX_NFIX_LIST>(kp, st, e)) return e;
+    } else {
+        if (launch_fixed<NOBS, 0, CRX_NFIX_LIST>(kp, st, e)) return e;
     }
+#endif
     return crx_launch_solve_general(kp, NOBS, st);
 }
 #endif  // !CRX_TU_GENERAL
@@ -2814,25 +2808,18 @@ int crx_solve_resident_per_cu_general(int N, int nobs_template) {
     }
 }
 #else
-template <int NOBS, int NMAX>
-static int occ_h(int N, int nobs_template) {
-#if CRX_NFIX
-    if constexpr (NMAX == 12) {
-        if (N == 12) return occ_t<NOBS, 12, 12>();
-        if (N == 10) return occ_t<NOBS, 12, 10>();
-    }
-    if constexpr (NMAX == 20) {
-        if (N == 20) return occ_t<NOBS, 20, 20>();
-    }
-#endif
-    return crx_solve_resident_per_cu_general(N, nobs_template);
+template <int NOBS, int... NFS>
+static bool occ_fixed(int N, int& n) {
+    bool hit = false;
+    (void)((N == NFS ? (n = occ_t<NOBS, NfixLayout<NOBS, NFS>::v, NFS>(), hit = true) : false) || ...);
+    return hit;
 }
 template <int NOBS>
 static int occ_n(int N) {
-    if (N <= 12) return occ_h<NOBS, 12>(N, NOBS);
-    if constexpr (NOBS == 3) {
-        if (N <= 20) return occ_h<3, 20>(N, NOBS);
-    }
+#if CRX_NFIX
+    int n = 0;
+    if (occ_fixed<NOBS, CRX_NFIX_LIST>(N, n)) return n;
+#endif
     return crx_solve_resident_per_cu_general(N, NOBS);
 }
 #endif

@@ -16,10 +16,10 @@ D=$R/tools/ab/$NAME
 mkdir -p $D
 make -C $S -s
 OBJS=""
-for f in crx_kernels crx_kernels_obs crx_kernels_gen crx_lmpc crx_prep crx_lmpcprep crx_api; do
+for f in crx_kernels crx_kernels_obs crx_kernels_spec crx_kernels_gen crx_lmpc crx_prep crx_lmpcprep crx_api; do
   if echo " $FILES " | grep -q " $f.hip "; then
     NOLICM=${NOLICM--mllvm -disable-machine-licm}                         # NOLICM= (empty): MachineLICM left on
-    LICM=""; [ $f = crx_kernels ] && LICM="$NOLICM $PLAN_SCHED"; [ $f = crx_kernels_obs ] && LICM="$NOLICM $OBS_SCHED"; [ $f = crx_kernels_gen ] && LICM="$NOLICM"; [ $f = crx_lmpc ] && LICM="$NOLICM ${LMPC_SCHED--mllvm -amdgpu-sched-strategy=max-ilp}"
+    LICM=""; [ $f = crx_kernels ] && LICM="$NOLICM $PLAN_SCHED"; [ $f = crx_kernels_obs ] && LICM="$NOLICM $OBS_SCHED"; [ $f = crx_kernels_spec ] && LICM="$NOLICM $OBS_SCHED"; [ $f = crx_kernels_gen ] && LICM="$NOLICM"; [ $f = crx_lmpc ] && LICM="$NOLICM ${LMPC_SCHED--mllvm -amdgpu-sched-strategy=max-ilp}"
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $LICM $EXTRA -I$S -c $S/$f.hip -o $D/$f.o
     OBJS="$OBJS $D/$f.o"
   else

@@ -10,7 +10,7 @@ import crx
 from crx import abi, synth, torch_api
 crx.init(0); A, B = synth.load_AB(); dev = torch.device("cuda", 0)
 t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)   # noqa: E731
-for kind, Ns in (("cfg2", (11, 12, 13)), ("cfg4", (19, 20, 21))):
+for kind, Ns in (("cfg2", (11, 12, 13, 15, 16, 17, 20)), ("cfg4", (15, 16, 17, 19, 20, 21))):
     for N in Ns:
         Bn = 4096
         if kind == "cfg2":
