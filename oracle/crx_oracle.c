@@ -251,8 +251,8 @@ static void eval_fc(work_t* w, const double* v, double* f, double* c) {
     for (int j = 0; j < w->m; j++) c[j] = w->d[j] * row_value(w, j);
 }
 
-static long g_nchol = 0, g_niter = 0;
-long crx_oracle_stat(int i) { long v = i ? g_niter : g_nchol; if (i < 0) { g_nchol = g_niter = 0; } return v; }
+static long g_nchol = 0, g_niter = 0, g_nsoc = 0;
+long crx_oracle_stat(int i) { long v = i == 2 ? g_nsoc : (i ? g_niter : g_nchol); if (i < 0) { g_nchol = g_niter = g_nsoc = 0; } return v; }
 static int chol(int n, double H[][MAXRED]) {
 #pragma omp atomic
     g_nchol++;
@@ -856,6 +856,67 @@ static void ipm_solve(work_t* w, result_t* res) {
                 }
             }
             if (acc) break;
+            /* EXPERIMENT (knob 10 = number of corrections, IPOPT: max_soc = 4; 0 = off, the shipped algorithm): IPOPT's second-order correction
+             * (Waechter & Biegler 2006, sec. 2.4).  When the FIRST trial step is rejected and does not reduce the constraint violation, the step is
+             * re-solved -- same matrix -- with the primal residual replaced by  c_soc = al * (c - t)_k + (c - t)(trial),  up to max_soc times while
+             * theta shrinks by kappa_soc = 0.99; a corrected trial point goes through the same filter tests.  Measures what the restatement leaves out. */
+            if (ls == 0 && g_knob[10] > 0.0 && thn >= theta) {
+                static _Thread_local double csoc[MAXM], dvs[MAXRED], dts[MAXM], vs[MAXRED], cs2[MAXM], ts2[MAXM];
+                for (int j = 0; j < m; j++) csoc[j] = al * rp[j] + (ctrial[j] - ttrial[j]);
+                double th_old = thn, als = al;
+                for (int p_ = 0; p_ < (int)g_knob[10] && !acc; p_++) {
+                    for (int a = 0; a < n; a++) {
+                        double s_ = -w->g[a];
+                        for (int j = 0; j < m; j++) s_ += w->J[j][a] * (mu / w->t[j] - w->nu[j] / w->t[j] * csoc[j]);
+                        dvs[a] = s_;
+                    }
+                    chol_solve(n, w->H, dvs);
+                    als = 1.0;
+                    for (int j = 0; j < m; j++) {
+                        double s_ = csoc[j];
+                        for (int a = 0; a < n; a++) s_ += w->J[j][a] * dvs[a];
+                        dts[j] = s_;
+                        if (s_ < 0.0 && -tau * w->t[j] / s_ < als) als = -tau * w->t[j] / s_;
+                    }
+                    for (int a = 0; a < n; a++) vs[a] = w->v[a] + als * dvs[a];
+                    double fs;
+                    eval_fc(w, vs, &fs, cs2);
+                    double phs = fs, ths = 0.0;
+                    for (int j = 0; j < m; j++) {
+                        double tn = w->t[j] + als * dts[j];
+                        if (cs2[j] > tn) tn = cs2[j];
+                        ts2[j] = tn;
+                        phs -= mu * log(tn);
+                        ths += fabs(cs2[j] - tn);
+                    }
+                    int okf2 = (ths <= theta_max) && (phs == phs);
+                    for (int i = 0; i < nf && okf2; i++)
+                        if (!(ths < Fth[i] || phs < Fph[i])) okf2 = 0;
+                    if (okf2) {
+                        int sw2 = (Dphi < 0.0) && (al * pow(-Dphi, 2.3) > pow(theta, 1.1));
+                        if (theta <= theta_min && sw2) {
+                            if (phs <= phi0 + eta * al * Dphi + 10.0 * 2.2e-16 * fabs(phi0)) { acc = 1; ftype = 1; }
+                        } else if (ths <= (1.0 - 1e-5) * theta || phs <= phi0 - 1e-8 * theta) {
+                            acc = 1;
+                        }
+                    }
+                    if (acc) {
+                        memcpy(vtrial, vs, sizeof(double) * n); memcpy(ttrial, ts2, sizeof(double) * m);
+                        /* the multiplier step below uses w->dt: the corrected slack step */
+                        for (int j = 0; j < m; j++) { w->dt[j] = dts[j]; w->dnu[j] = (mu - w->t[j] * w->nu[j] - w->nu[j] * dts[j]) / w->t[j]; }
+                        a_d = 1.0;
+                        for (int j = 0; j < m; j++) if (w->dnu[j] < 0.0) a_d = fmin(a_d, -tau * w->nu[j] / w->dnu[j]);
+                        al = als;
+#pragma omp atomic
+                        g_nsoc++;
+                        break;
+                    }
+                    if (ths > 0.99 * th_old) break;
+                    th_old = ths;
+                    for (int j = 0; j < m; j++) csoc[j] = als * csoc[j] + (cs2[j] - ts2[j]);
+                }
+                if (acc) break;
+            }
             al *= 0.5;
         }
         if (g_verbose > 1 && jblock >= 0)
