@@ -400,6 +400,48 @@ def test_reach_screen_changes_no_verdict(gpu, orc, AB):
     np.testing.assert_array_equal((ro["status"] == abi.CRX_INFEASIBLE) & (ro["iters"] == 0), screened)
 
 
+@pytest.mark.parametrize("N,zero_obs", [(12, False), (20, False), (10, True)])
+def test_convex_rows_two_methods_one_solution(gpu, orc, AB, N, zero_obs):
+    """[r6] crx_ipm_opts.qp_method (include/crx.h): the all-linear problems -- planner region QPs, MPC-CBF NLPs without an obstacle slot -- are strictly
+    convex QPs with ONE solution, so Mehrotra's predictor-corrector (0, shipped) and IPOPT's filter line search (1, libcrx <= 0.3) must agree on
+    every verdict and on the solution to the tolerance both are solved to; the predictor-corrector takes fewer iterations (the point of it), kernel
+    and oracle run the same arithmetic (same statuses, iteration counts equal on nearly all), and the infeasibility proofs are untouched."""
+    from crx import abi, synth
+
+    A, B = AB
+    if zero_obs:      # the tracking problems of test_zero_obstacle_nlps_incl_infeasible: a narrow track, a third of them infeasible
+        Bn = 512
+        rng = np.random.default_rng(78)
+        x0 = np.zeros((Bn, 6))
+        x0[:, 0] = rng.uniform(0.8, 2.0, Bn); x0[:, 1] = rng.uniform(-0.2, 0.2, Bn); x0[:, 3] = rng.uniform(-1.2, 1.2, Bn)
+        x0[:, 4] = rng.uniform(0, 5, Bn); x0[:, 5] = rng.uniform(-0.14, 0.14, Bn)
+        xt = np.zeros((Bn, 6)); xt[:, 0] = 1.5
+        z = np.zeros((Bn, 0, N + 1))
+        mk = lambda qm: abi.cbf_desc(N, 0, A, B, ey_max=0.15, v_min=0.5, v_max=2.2, opts=abi.default_opts(qp_method=qm))   # noqa: E731
+        args = [x0, xt, z, z, np.zeros((Bn, 0)), np.zeros(Bn, dtype=np.int32)]
+        solve_g, solve_o = gpu.cbf_solve, orc.cbf_solve
+    else:
+        p = synth.cfg3_planner(512, N=N, seed=7)
+        mk = lambda qm: abi.planner_desc(N, A, B, opts=abi.default_opts(qp_method=qm))   # noqa: E731
+        args = [p[k] for k in ("x0", "bez_s", "bez_ey", "ey_lb", "ey_ub")]
+        solve_g, solve_o = gpu.planner_solve, orc.planner_solve
+    g0, g1, o0 = solve_g(mk(0), *args), solve_g(mk(1), *args), solve_o(mk(0), *args)
+    np.testing.assert_array_equal(g0["status"], g1["status"])
+    np.testing.assert_array_equal(g0["status"], o0["status"])
+    ok = g0["status"] == 0
+    assert ok.sum() >= 0.4 * len(ok)
+    # one solution: both methods at tol 1e-8 sit within the conditioning of the QP (lambda_min 1e-6: the uncosted states are only as sharp as 3e-4)
+    assert np.abs(g0["X"][ok] - g1["X"][ok])[..., [0, 4, 5]].max() <= 1e-4            # (the cost-weighted states; measured 4e-6)
+    assert (np.abs(g0["cost"][ok] - g1["cost"][ok]) / np.maximum(1.0, np.abs(g1["cost"][ok]))).max() <= 1e-8
+    assert np.abs(g0["X"][ok] - o0["X"][ok])[..., [0, 4, 5]].max() <= 1e-5            # kernel = oracle, same algorithm
+    assert (g0["iters"][ok] == o0["iters"][ok]).mean() >= 0.97
+    assert g0["iters"][ok].mean() <= 0.8 * g1["iters"][ok].mean(), (g0["iters"][ok].mean(), g1["iters"][ok].mean())
+    assert g0["kkt"][ok].max() <= 1e-8 and g1["kkt"][ok].max() <= 1e-8
+    # proofs: the same regions are screened out / certified infeasible, after no more iterations than before
+    bad = g0["status"] == abi.CRX_INFEASIBLE
+    assert (g0["iters"][bad] <= g1["iters"][bad]).mean() >= 0.95
+
+
 def test_golden_lmpc(gpu, orc, golden_racing_game):
     """Learning-MPC QPs recorded from the reference's LMPC lap: kernel (block Cholesky in LDS) vs the
     oracle (full KKT LU) vs the certified goldens."""
