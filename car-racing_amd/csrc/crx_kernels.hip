@@ -78,6 +78,9 @@
 #ifndef CRX_DEG6
 #define CRX_DEG6 1   // 0: every CBF launch takes the general-exponent instantiation (A/B builds)
 #endif
+#ifndef CRX_T_PAD
+#define CRX_T_PAD 0
+#endif
 #ifndef CRX_SLIM
 #define CRX_SLIM 1 /* make EXTRA=-DCRX_SLIM=0: the full LDS layout for every instantiation (A/B builds, tools/ab_slim.sh) */
 #endif
@@ -211,12 +214,15 @@ struct Lay {
     // 28 412 -> 27 164 B; its residency stays at four per CU, the register file's limit: 296 registers, and a floor of two
     // waves per SIMD would park 92 of them).
     static constexpr int HS = NZ + 1;                // row stride of H: column NZ is the gradient hv (odd strides for NZ = 8, 10, 12, 14)
-    static constexpr bool PT_ALIAS = NX * NX + NX + NX * NZ <= MR, H_ALIAS = NZ * HS <= NV;
+    // row stride of T (A/B builds, VERDICT r5 item 6: -DCRX_T_PAD=1 pads the even strides of the obstacle layouts to odd ones against LDS bank conflicts of
+    // the T stores; measured round 6: profiles/r06_pmc_issue.txt)
+    static constexpr int TS = NZ + ((CRX_T_PAD && NOBS > 0 && (NZ % 2 == 0)) ? 1 : 0);
+    static constexpr bool PT_ALIAS = NX * NX + NX + NX * TS <= MR, H_ALIAS = NZ * HS <= NV;
     static constexpr int WORK = kS + (NOBS ? 2 * NMAX : 0);
     static constexpr int P = PT_ALIAS ? rdt : WORK;
     static constexpr int pv = P + NX * NX;
     static constexpr int T = pv + NX;
-    static constexpr int WORK2 = PT_ALIAS ? WORK : T + NX * NZ;
+    static constexpr int WORK2 = PT_ALIAS ? WORK : T + NX * TS;
     static constexpr int H = H_ALIAS ? dZ : WORK2;           // [NZ][HS]  (over dZ from its start: stage 0 of dZ is written only after the sweep)
     static constexpr int Kk = H_ALIAS ? WORK2 : H + NZ * HS; // [NMAX][NU][NX]
     static constexpr int G = SLIM ? Kk : Gpos;
@@ -255,7 +261,7 @@ struct Lay {
     // behind the layout -- the second wave factorises the reduced Hessian with the NEXT entry of the inertia-correction schedule while the first
     // tries the current one.  In doubles from sm; ctl = {command, dw, convexified, ok} mailbox between the two waves.
     static constexpr int R2 = (int)((BYTES + 15) / 16) * 2;
-    static constexpr int P2 = R2, pv2 = P2 + NX * NX, T2 = pv2 + NX, H2 = (T2 + NX * NZ + 1) & ~1, Kk2 = H2 + NZ * HS, kf2 = Kk2 + NMAX * NU * NX,
+    static constexpr int P2 = R2, pv2 = P2 + NX * NX, T2 = pv2 + NX, H2 = (T2 + NX * TS + 1) & ~1, Kk2 = H2 + NZ * HS, kf2 = Kk2 + NMAX * NU * NX,
                          dZ2 = kf2 + NMAX * NU, ctl = dZ2 + NZ, R2_END = ctl + 4;
     static constexpr size_t BYTES_SPEC = (size_t)R2_END * 8;
 };
@@ -829,7 +835,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         const int a = cc < 6 ? cc : NX + (cc - 6);
         const int i = (e >> 3) < NX ? (e >> 3) : 0;
         tld[q] = oP + i * NX;
-        tst[q] = SINK(e < NX * 8, oT + i * NZ + a);
+        tst[q] = SINK(e < NX * 8, oT + i * L::TS + a);
 #pragma unroll
         for (int j = 0; j < 6; j++) mT[q][j] = LD(L::M + j * NZ + a);
     }
@@ -858,7 +864,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             t2nxt[q] = cc >= NOBS;
             const int o = t2nxt[q] ? cc - NOBS : cc;
             t2ld[q] = oP + i2 * NX + 6 + o;
-            t2st[q] = SINK(v2, oT + i2 * NZ + seli(t2nxt[q], NX + 2 + o, 6 + o));
+            t2st[q] = SINK(v2, oT + i2 * L::TS + seli(t2nxt[q], NX + 2 + o, 6 + o));
         }
     }
     // update phase: lane map [0, NP) the upper triangle of P_new incl. the gradient column (i <= j <= NX),
@@ -926,7 +932,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
 #pragma unroll
-                for (int i = 0; i < NX; i++) tc[q][i] = LD(oT + i * NZ + ha[q]);
+                for (int i = 0; i < NX; i++) tc[q][i] = LD(oT + i * L::TS + ha[q]);
                 hd[q] = LD(L::Hd + k * NZ + hr[q]);
                 if (NOBS) {
 #pragma unroll
