@@ -353,12 +353,12 @@ def to_lap_phase(cx, w, conc, phase, what):
         cx.dsync()
 
     w.rewind = rewind
-    # [r6] a FIXED window of the lap, whatever --steps is: the timed steps are control steps phase .. phase + WINDOW - 1, all of them when --steps ==
-    # WINDOW, every (WINDOW / steps)-th when fewer (the steps in between run untimed), cyclically (rewind) when more; the status / iteration fields
-    # are taken over one untimed pass through the whole window.  The driver's 20-step line and a 60-step record describe the same 60 control steps.
+    # [r6] a FIXED window of the lap, whatever --steps is: the timed steps are control steps phase .. phase + WINDOW - 1, whole passes of them (--steps
+    # is rounded up to a multiple of WINDOW and reported as such; rewind between passes, outside the timed region); the status / iteration fields are
+    # taken over one untimed pass through the whole window.  A 20-step request and a 60-step record describe the same 60 control steps.
     w.window = LAP_WINDOW
-    w.extra["lap_phase"] = ("timed steps sample control steps [%d, %d) of %s (all of them at --steps %d; every (%d / steps)-th below, the rest untimed; cyclic above); "
-                            "the status / iteration fields are taken over all %d steps of the window") % (phase, phase + LAP_WINDOW, what, LAP_WINDOW, LAP_WINDOW, LAP_WINDOW)
+    w.extra["lap_phase"] = ("timed steps = whole passes over control steps [%d, %d) of %s (--steps rounded up to a multiple of %d); "
+                            "the status / iteration fields are taken over all %d steps of the window") % (phase, phase + LAP_WINDOW, what, LAP_WINDOW, LAP_WINDOW)
 
 
 def make_races(cx, args, batch=None):
@@ -533,23 +533,20 @@ def measure(cx, w, steps, warmup, with_latency=True):
         region_tm = torch_api.Timer()
     window = getattr(w, "window", 0)
     if window:
-        # closed loops: exactly `steps` timed steps, each bracketed by barrier + synchronize, sampled over the fixed window (to_lap_phase)
-        stride = max(1, window // steps) if steps <= window else 1
-        elapsed, timed, pos = 0.0, 0, 0
-        while timed < steps:
-            if pos == window:
-                w.rewind()
-                pos = 0
-            if pos % stride == 0:
-                cx.sync_all()
-                t0 = time.perf_counter()
+        # closed loops: WHOLE passes over the fixed window (to_lap_phase), one barrier + synchronize bracket per pass -- the sub-batches on their streams
+        # pipeline across consecutive control steps, which a bracket per step would destroy (+25 % on `game`).  `steps` is rounded up to a multiple of
+        # the window and reported as such: a 20-step request and a 60-step request time the same 60 control steps.
+        n_pass = max(1, -(-steps // window))
+        elapsed = 0.0
+        for _ in range(n_pass):
+            w.rewind()
+            cx.sync_all()
+            t0 = time.perf_counter()
+            for _ in range(window):
                 w.step()
-                cx.sync_all()
-                elapsed += time.perf_counter() - t0
-                timed += 1
-            else:
-                w.step()
-            pos += 1
+            cx.sync_all()
+            elapsed += time.perf_counter() - t0
+        steps = n_pass * window
     else:
         t0 = time.perf_counter()
         if region_tm is not None:
