@@ -956,7 +956,7 @@ def main():
     head = headline_workload(cx, args, make)
     rec = measure(cx, head, args.steps, args.warmup, with_latency=head.host_call is not None)
     full = {"metric": METRIC, "value": rec["value"], "value_launched": rec["value_launched"], "unit": "solves/s", "n_gpus": cx.world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
+            "steps": rec["steps"], "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],   # (rec["steps"] == --steps but for the closed loops: whole passes of their lap window)
             "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": rec["config"], "roofline": rec["roofline"], "headline": rec,
             "kernel_source_sha256": kernel_source_hash()}
     for k in ("allgather_ms", "world_size"):
