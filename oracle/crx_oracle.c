@@ -251,8 +251,8 @@ static void eval_fc(work_t* w, const double* v, double* f, double* c) {
     for (int j = 0; j < w->m; j++) c[j] = w->d[j] * row_value(w, j);
 }
 
-static long g_nchol = 0, g_niter = 0, g_nsoc = 0;
-long crx_oracle_stat(int i) { long v = i == 2 ? g_nsoc : (i ? g_niter : g_nchol); if (i < 0) { g_nchol = g_niter = g_nsoc = 0; } return v; }
+static long g_nchol = 0, g_niter = 0, g_nsoc = 0, g_nwatch = 0;
+long crx_oracle_stat(int i) { long v = i == 3 ? g_nwatch : (i == 2 ? g_nsoc : (i ? g_niter : g_nchol)); if (i < 0) { g_nchol = g_niter = g_nsoc = g_nwatch = 0; } return v; }
 static int chol(int n, double H[][MAXRED]) {
 #pragma omp atomic
     g_nchol++;
@@ -663,7 +663,7 @@ static void ipm_solve(work_t* w, result_t* res) {
      * loses 1 % of the three-car draw), after which it ends CRX_RESTORED like a restarted one -- feasible through its slacks, not
      * optimal -- instead of crawling to max_iter */
     if (crash_at_start) { n_restore = 1; it_limit = 1 + 3 * o->restore_iters; }
-    int crawl = 0, cvx_run = 0;
+    int crawl = 0, cvx_run = 0, short_run = 0;
     double ep_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     enum { CVX_PROBE = 4 };
     static _Thread_local double ctrial[MAXM], ttrial[MAXM], vtrial[MAXRED], rd[MAXRED], rp[MAXM], tmp[MAXRED];
@@ -928,6 +928,13 @@ static void ipm_solve(work_t* w, result_t* res) {
             Fph[nf] = phi0 - 1e-8 * theta;
             nf++;
         }
+        /* statistic only (crx_oracle_stat(3)): IPOPT's WATCHDOG would arm itself after watchdog_shortened_iter_trigger = 10 successive iterations whose
+         * step the line search had to shorten below the fraction-to-the-boundary length -- counted once per solve: an upper bound on the solves the
+         * (unrestated) watchdog could influence */
+        if (acc && al < a_p) { if (++short_run == 10) {
+#pragma omp atomic
+            g_nwatch++;
+        } } else short_run = 0;
         /* jam: JAM_COUNT accepted steps in a row shorter than JAM_ALPHA while the constraints are still violated -- the
          * slacks of violated CBF rows are collapsing and every step is cut to nothing (IPOPT's alpha < alpha_min test
          * sends it to restoration from the same situation) */
