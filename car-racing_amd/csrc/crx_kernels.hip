@@ -2652,18 +2652,18 @@ static hipError_t launch_t(const crx_kparams& kp, hipStream_t st) {
 #if CRX_STATIC_LDS
     hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX, SPEC, QPM>), dim3(kp.batch), dim3(WAVE * (1 + SPEC)), 0, st, kp);   // the layout is a static array of the kernel
 #else
-    static_assert(SPEC == 0 && QPM == 0, "the two-wave and the A/B instantiations are static-LDS kernels");
+    static_assert(SPEC == 0, "the two-wave instantiations are static-LDS kernels");
     const size_t bytes = Lay<NOBS, NMAX>::BYTES;
     // the opt-in to > 64 KiB of dynamic LDS is a property of the (function, device) pair: set once per device, not per launch
     static int attr_set_on = -1;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (attr_set_on != dev) {
-        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)crx_solve_kernel<NOBS, NMAX, DEG, NFIX, 0, QPM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_set_on = dev;
     }
-    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
+    hipLaunchKernelGGL((crx_solve_kernel<NOBS, NMAX, DEG, NFIX, 0, QPM>), dim3(kp.batch), dim3(WAVE), bytes, st, kp);
 #endif
     return hipGetLastError();
 }
@@ -2704,6 +2704,7 @@ static bool launch_fixed(const crx_kparams& kp, hipStream_t st, hipError_t& e) {
 template <int NOBS>
 static hipError_t launch_n(const crx_kparams& kp, hipStream_t st) {
     hipError_t e = hipSuccess;
+    (void)e;
 #if CRX_NFIX
     if constexpr (NOBS > 0 && CRX_DEG6) {
         if (kp.degree == 6 && launch_fixed<NOBS, 6, CRX_NFIX_LIST>(kp, st, e)) return e;
