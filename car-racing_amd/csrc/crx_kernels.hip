@@ -81,6 +81,9 @@
 #ifndef CRX_T_PAD
 #define CRX_T_PAD 0
 #endif
+#ifndef CRX_PT_REG
+#define CRX_PT_REG 1   // [r6] Riccati sweep of the 0- / 1-obstacle instantiations: (P | p) in registers, T by half-row broadcast-FMAs (0: P through LDS; A/B builds)
+#endif
 #ifndef CRX_SLIM
 #define CRX_SLIM 1 /* make EXTRA=-DCRX_SLIM=0: the full LDS layout for every instantiation (A/B builds, tools/ab_slim.sh) */
 #endif
@@ -783,24 +786,50 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     // [r4] The gradient p of the value function lives in REGISTERS, entry i in lane i: the update phase computes p_new there (its lane
     // map puts the gradient column first), and the H phase forms hv = M'p + hg with broadcast-FMAs (crx_wave.h row_dot) instead of NX
     // LDS reads per stage.  (pv in LDS is still written: the sigma_0 solve after the sweep reads it.)
-    constexpr bool PREG = ROWDPP<L> && L::UCNT == 1;
-    double preg = 0.0;
+    // [r6] PTR (NX <= 7: no or one obstacle): ALL of (P | p) lives in registers, one entry per lane -- lane 8 i + j holds P[i][j] (i, j < NX), lane
+    // 8 NX + j holds p[j] -- and the T phase reads it with broadcast-FMAs inside the 8-lane halves of the DPP rows (crx_wave.h halfrow_dot6: lane
+    // 8 i + c computes T[i][a(c)], its six operands P[i][0..5] sit in its own half-row).  The update phase computes P_new straight into that map (entry
+    // (i, j) with i > j as its mirror image (j, i) does, operand for operand: symmetric to the bit as before), so the store -> load round trip of P
+    // between the update and the T phase, one of the three of a stage, is gone; the sigma column of P goes from the update phase straight into T.
+    // Same operations on the same operands in the same order as the LDS form: identical bits (tools/cbf_ab.py).  hv = M'p + hg is formed in the
+    // DPP row that holds p (lanes 48 ..).  The NX + 1 feedback columns take the lanes the map leaves free (NX = 7: lanes 8 g + 7; NX = 6: 56 .. 62).
+    constexpr bool PTR = CRX_PT_REG && ROWDPP<L> && L::UCNT == 1 && NX <= 7;
+    constexpr bool PREG = !PTR && ROWDPP<L> && L::UCNT == 1;
+    constexpr int PVF = (NX * 8) & 15;   // position of p[0] inside its DPP row (row 3 for NX = 6 and 7)
+    static_assert(!PTR || (NX * 8) / 16 == 3, "p sits in DPP row 3, where hv is formed");
+    // (the map is derived from an OPAQUE copy of the lane index, per call -- as the table look-up of the LDS form was: pure arithmetic on the lane index
+    // would be hoisted out of the interior-point loop into ~10 registers the one-obstacle instantiation does not have: 36 B of scratch per lane)
+    int lo = lane;
+    if constexpr (PTR) asm volatile("" : "+v"(lo));
+    const int g8 = lo >> 3, c8 = lo & 7;
+    const bool isPm = g8 < NX && c8 < NX, isPv = g8 == NX && c8 < NX;
+    double preg = 0.0, pn = 0.0;
     // terminal: P_N = diag(Hd[N][0..NX)) + stage N-1 extras on (s_N, ey_N);  p_N = hg[N]
     {
         double kSn = NOBS ? LD(L::kS + 2 * (N - 1)) : 0.0, kEn = NOBS ? LD(L::kE + 2 * (N - 1)) : 0.0;
         if constexpr (CVX) { kSn = sel(convex, 0.0, kSn); kEn = sel(convex, 0.0, kEn); }
         kEn += 2.0 * LD(L::wc + N - 1);
+        if constexpr (PTR) {
+            const double hd = LD(L::Hd + N * NZ + seli(isPm, g8, 0));
+            const double hgN = LD(L::hg + N * NZ + seli(c8 < NX, c8, 0));
+            pn = sel(isPv, hgN, sel(isPm && g8 == c8, hd + sel(g8 == 4, kSn, sel(g8 == 5, kEn, 0.0)), 0.0));
+            if (NOBS) {   // sigma columns of T: sigma_k -> 0 (constant over the sweep), sigma_{k+1} -> P[:, 6]
+                LD(SINK(lo < NX, oT + lo * L::TS + 6)) = 0.0;
+                LD(SINK(isPm && c8 == 6, oT + g8 * L::TS + NX + 2)) = pn;
+            }
+        } else {
 #pragma unroll
-        for (int q_ = 0; q_ < (NX * NX + WAVE - 1) / WAVE; q_++) {
-            const int e0 = lane + q_ * WAVE;
-            const int e = e0 < NX * NX ? e0 : 0;            // lanes past the matrix recompute entry 0
-            const int i = e / NX, j = e - i * NX;
-            const double hd = LD(L::Hd + N * NZ + i);
-            LD(oP + e) = sel(i == j, hd + sel(i == 4, kSn, sel(i == 5, kEn, 0.0)), 0.0);
+            for (int q_ = 0; q_ < (NX * NX + WAVE - 1) / WAVE; q_++) {
+                const int e0 = lane + q_ * WAVE;
+                const int e = e0 < NX * NX ? e0 : 0;            // lanes past the matrix recompute entry 0
+                const int i = e / NX, j = e - i * NX;
+                const double hd = LD(L::Hd + N * NZ + i);
+                LD(oP + e) = sel(i == j, hd + sel(i == 4, kSn, sel(i == 5, kEn, 0.0)), 0.0);
+            }
+            const double hgN = LD(L::hg + N * NZ + (lane < NX ? lane : 0));
+            LD(SINK(lane < NX, opv + lane)) = hgN;
+            preg = hgN;
         }
-        const double hgN = LD(L::hg + N * NZ + (lane < NX ? lane : 0));
-        LD(SINK(lane < NX, opv + lane)) = hgN;
-        preg = hgN;
     }
     SYNC();
     bool ok = true;
@@ -822,8 +851,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         hst[q] = SINK(e0 < NTRI, oH + hr[q] * HS + ha[q]);
         hst2[q] = SINK(!FULL && e0 < NTRI, oH + ha[q] * HS + hr[q]);
     }
-    const int lz = lane < NZ ? lane : 0;
-    const int hvst = SINK(lane < NZ, oH + lane * HS + NZ);
+    const bool hvl = PTR ? (lane >= 48 && lane < 48 + NZ) : lane < NZ;   // the lanes that form hv (PTR: in the DPP row of p)
+    const int lz = hvl ? (PTR ? lane - 48 : lane) : 0;
+    const int hvst = SINK(hvl, oH + lz * HS + NZ);
     // the entries of the model matrix each lane multiplies with in the T and H phases, in registers
     constexpr int TCNT = (NX * 8 + WAVE - 1) / WAVE;   // 1 for NX <= 8, 2 for NX = 9
     double mT[TCNT][6], mH[HCNT][NX];
@@ -875,9 +905,17 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
     for (int q = 0; q < UCNT; q++) {
         const int l = lane + q * WAVE;
-        const int upk = UPDP(si, l);
-        const int ui = upk >> 8, uj = upk & 255;     // feedback lanes: column uj, ui = 0 (unused)
-        const bool isP = l < NP, isK = !isP && l < NP + NX + 1;
+        int ui, uj; bool isP, isK;                   // feedback lanes: column uj, ui = 0 (unused)
+        if constexpr (PTR) {
+            isP = isPm || isPv;
+            isK = NX == 7 ? c8 == 7 : (g8 == 7 && c8 <= NX);
+            ui = seli(isPm, g8 < c8 ? g8 : c8, seli(isPv, c8, 0));
+            uj = seli(isPm, g8 < c8 ? c8 : g8, seli(isPv, NX, seli(isK, NX == 7 ? g8 : c8, 0)));
+        } else {
+            const int upk = UPDP(si, l);
+            ui = upk >> 8; uj = upk & 255;
+            isP = l < NP; isK = !isP && l < NP + NX + 1;
+        }
         const bool gcol = uj >= NX;                   // gradient column = column NZ of H
         const int ujj = gcol ? NZ : uj;
         yiA[q] = oH + NX * HS + ui; yjA[q] = oH + NX * HS + ujj; s0A[q] = oH + ui * HS + ujj;
@@ -897,7 +935,10 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         // T = P M, one pass: only the x- and u-columns of M carry numbers (6+2 columns, NX*8 <= 64
         // dot products of length 6); the sigma_k columns of T are zero and the sigma_{k+1} columns
         // are copies of P's sigma columns (M = [A 0 B 0; 0 0 0 I]).
-        {
+        if constexpr (PTR) {
+            __builtin_amdgcn_wave_barrier();   // scheduling region boundary only (the update phase in front needs no exchange with this one)
+            LD(tst[0]) = halfrow_dot6(pn, mT[0], (lane & 8) != 0);
+        } else {
             double pl[TCNT][6];
 #pragma unroll
             for (int q = 0; q < TCNT; q++)
@@ -956,7 +997,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 }
             }
             double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
-            if constexpr (!PREG) {
+            if constexpr (!PREG && !PTR) {
 #pragma unroll
                 for (int i = 0; i < NX; i++) pvv[i] = LD(opv + i);
             }
@@ -979,7 +1020,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 }
                 hs[q] = t;
             }
-            if constexpr (PREG) {
+            if constexpr (PTR) {
+                hvs = row_dot<NX, PVF>(pn, mz, hvs);
+            } else if constexpr (PREG) {
                 hvs = row_dot<NX, 0>(preg, mz, hvs);
             } else {
 #pragma unroll
@@ -1060,13 +1103,22 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 // negation commutes with every rounding below, the bits are those of the negate-at-the-store form [r4])
                 for (int a = 0; a < NU; a++) { yj[q][a] *= -rD[a]; t[q] = fma(yi[q][a], yj[q][a], t[q]); }
                 t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
-                LD(pst1[q]) = t[q];
-                LD(pst2[q]) = t[q];
+                if constexpr (PTR) {
+                    pn = t[0];                     // (P_new | p_new) stays in registers; its sigma column is the next stage's sigma_{k+1} column of T
+                    if (NOBS) LD(SINK(isPm && c8 == 6, oT + g8 * L::TS + NX + 2)) = pn;
+                } else {
+                    LD(pst1[q]) = t[q];
+                    LD(pst2[q]) = t[q];
+                }
                 if constexpr (PREG) preg = t[0];   // lanes 0 .. NX-1: p_new (gradient column of the lane map)
 #pragma unroll
                 for (int a = NU - 2; a >= 0; a--) {
 #pragma unroll
-                    for (int qq = a + 1; qq < NU; qq++) yj[q][a] -= Lf[qq][a] * yj[q][qq];
+                    // (an explicit fma: with P_new in registers the last stage of a problem without obstacles has no use for t, the scaled yj
+                    // above is left with ONE use, and -ffp-contract would fold its multiplication into this line instead -- fma(y, -1/D, -(L yj)) -- another
+                    // rounding of the stage-0 feedback than in every other stage and than in the LDS form: found as last-bit differences in 46 % of
+                    // the planner QPs, profiles/r06_ptreg.txt)
+                    for (int qq = a + 1; qq < NU; qq++) yj[q][a] = fma(-Lf[qq][a], yj[q][qq], yj[q][a]);
                 }
 #pragma unroll
                 for (int a = 0; a < NU; a++) LD(kst[q] + a * kstr[q]) = yj[q][a];
@@ -1079,6 +1131,11 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         if (tsub) { tsub[0] += q1 - q0; tsub[1] += q2 - q1; tsub[3] += q4 - q2; }
     }
     if (!ok) { SYNC(); return false; }
+    if constexpr (PTR && NOBS > 0) {   // (P_0 | p_0) of the sigma_0 solve below: the only reader of P and pv outside the sweep
+        LD(SINK(isPm, oP + g8 * NX + c8)) = pn;
+        LD(SINK(isPv, opv + c8)) = pn;
+        SYNC();
+    }
     // free initial components sigma_0: minimise 1/2 d'P d + p'd over them (x_0 is fixed)
     if (lane < NZ) LD(odZ + lane) = 0.0;
     if (NOBS) {

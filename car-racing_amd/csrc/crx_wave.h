@@ -86,6 +86,22 @@ __device__ __forceinline__ double row_dot(double x, const double* m, double acc)
     return acc;
 }
 
+// [r6] The same inside each 8-LANE HALF of a row: returns, in lane 8 g + c, sum_{j < 6} m[j] * x(lane 8 g + j), j ascending, from 0 -- the T phase
+// of the Riccati sweep with P in registers (lane 8 i + j holds P[i][j]: riccati_backward, PTR).  row_newbcast reaches one lane per 16-lane row, so
+// TWO accumulators run over all lanes -- lane j of the row (right for lanes 0..7 of the row) and lane 8 + j (right for lanes 8..15) -- and the caller's
+// `upper` (lane & 8) selects.  The two chains are independent and interleave: 12 issue slots for what was 6 LDS reads + 6 FMAs behind a
+// store -> load round trip.  (bank_mask does NOT do this with one accumulator: on gfx950 a v_fmac_f64_dpp lane whose bank is masked off comes back
+// ZERO, not unchanged -- tools/ubench/halfrow.hip.)  s_nop 1 and the early-clobber accumulators: as in row_dot.
+__device__ __forceinline__ double halfrow_dot6(double x, const double* m, bool upper) {
+    double lo = 0.0, hi = 0.0;
+#define CRX_HR(i, j, j8) "v_fmac_f64_dpp %0, %2, %" #i " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %" #i " row_newbcast:" #j8 " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" CRX_HR(3, 0, 8) CRX_HR(4, 1, 9) CRX_HR(5, 2, 10) CRX_HR(6, 3, 11) CRX_HR(7, 4, 12) CRX_HR(8, 5, 13)
+        : "+&v"(lo), "+&v"(hi) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]));
+#undef CRX_HR
+    return upper ? hi : lo;
+}
+
 #define ROW_REDUCE(v, OP)                                                         \
     v = OP(v, dpp_f64<0xB1>(v));  /* quad_perm [1,0,3,2] */                       \
     v = OP(v, dpp_f64<0x4E>(v));  /* quad_perm [2,3,0,1] */                       \
