@@ -81,6 +81,15 @@
 #ifndef CRX_T_PAD
 #define CRX_T_PAD 0
 #endif
+#ifndef CRX_MASK_FMA
+#define CRX_MASK_FMA 1   // [r6] Riccati sweep: "add x on the lanes of a set" as fma(mask, x, t) with a 0 / 1 lane mask kept in registers instead of v_cndmask pairs + add (0: selects; A/B builds)
+#endif
+#ifndef CRX_H_MIRROR
+#define CRX_H_MIRROR 0   // 1: the H phase of the Riccati sweep stores the upper triangle of H as well, as up to round 6 (A/B builds)
+#endif
+#ifndef CRX_HUU_FIRST
+#define CRX_HUU_FIRST 1   // [r6] update phase of the Riccati sweep: the loads of Huu are issued before the other operands (0: the scheduler's order; A/B builds)
+#endif
 #ifndef CRX_PT_REG
 #define CRX_PT_REG 1   // [r6] Riccati sweep of the 0- / 1-obstacle instantiations: (P | p) in registers, T by half-row broadcast-FMAs (0: P through LDS; A/B builds)
 #endif
@@ -849,7 +858,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         else if constexpr (L::SLIM) tri_decode(e, hr[q], ha[q]);
         else { const int pk = si[L::triH + e]; hr[q] = pk >> 8; ha[q] = pk & 255; }
         hst[q] = SINK(e0 < NTRI, oH + hr[q] * HS + ha[q]);
-        hst2[q] = SINK(!FULL && e0 < NTRI, oH + ha[q] * HS + hr[q]);
+        hst2[q] = SINK(CRX_H_MIRROR && !FULL && e0 < NTRI, oH + ha[q] * HS + hr[q]);
     }
     const bool hvl = PTR ? (lane >= 48 && lane < 48 + NZ) : lane < NZ;   // the lanes that form hv (PTR: in the DPP row of p)
     const int lz = hvl ? (PTR ? lane - 48 : lane) : 0;
@@ -902,6 +911,11 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
     constexpr int NP = NX * (NX + 1) / 2 + NX, UCNT = L::UCNT;
     int yiA[UCNT], yjA[UCNT], s0A[UCNT], pst1[UCNT], pst2[UCNT], kstr[UCNT], kstep[UCNT], kst[UCNT];
     bool exSl[UCNT], exEl[UCNT];
+    // [r6] 0 / 1 lane masks: t + x on the lanes of a set, t on the others, is fma(mask, x, t) -- one rounding of the same sum (x finite: 0 * x = 0) --
+    // instead of two v_cndmask_b32 and an add per use and stage
+    double mSl[UCNT], mEl[UCNT], mdg[HCNT];
+#pragma unroll
+    for (int q = 0; q < HCNT; q++) mdg[q] = hr[q] == ha[q] ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < UCNT; q++) {
         const int l = lane + q * WAVE;
@@ -918,12 +932,16 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         }
         const bool gcol = uj >= NX;                   // gradient column = column NZ of H
         const int ujj = gcol ? NZ : uj;
-        yiA[q] = oH + NX * HS + ui; yjA[q] = oH + NX * HS + ujj; s0A[q] = oH + ui * HS + ujj;
+        // [r6] H(ui, uj) is read from the LOWER triangle (uj >= ui), like every other operand of the phase: the H phase need not mirror its entries
+        // (one LDS store per pass and stage).  The planner's H is a full matrix, every entry its own sum: its (ui, uj) stays where it was.
+        yiA[q] = oH + NX * HS + ui; yjA[q] = oH + NX * HS + ujj;
+        s0A[q] = (FULL || CRX_H_MIRROR) ? oH + ui * HS + ujj : seli(gcol, oH + ui * HS + ujj, oH + uj * HS + ui);
         pst1[q] = SINK(isP, seli(gcol, opv + ui, oP + ui * NX + uj));
         pst2[q] = SINK(isP, seli(gcol, opv + ui, oP + uj * NX + ui));
         kstr[q] = seli(isK, seli(gcol, 1, NX), 0); kstep[q] = seli(isK, seli(gcol, NU, NU * NX), 0);
         kst[q] = SINK(isK, seli(gcol, okf, oKk + uj) + (N - 1) * kstep[q]);
         exSl[q] = isP && !gcol && ui == uj && ui == 4; exEl[q] = isP && !gcol && ui == uj && ui == 5;
+        mSl[q] = exSl[q] ? 1.0 : 0.0; mEl[q] = exEl[q] ? 1.0 : 0.0;
     }
     if (tsub) tsub[2] += CLK() - qs;   // set-up of the sweep (terminal P, lane maps, stage-invariant operands)
 #pragma unroll UNR
@@ -968,6 +986,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
         {
             // every operand of the phase is loaded first (LOADS_DONE pins that order: left alone, the scheduler trickles
             // the loads out between the FMAs and the two chains pay the LDS latency one after the other)
+            // (PTR: the gradient of the stage FIRST -- hv = M'p + hg needs nothing else from LDS, its broadcast-FMAs run while the other loads are in flight)
+            double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
+            if constexpr (PTR) __builtin_amdgcn_sched_barrier(0);        // (left alone the scheduler issues this load last)
             const double kc = (NOBS == 0) ? 2.0 * LD(L::wc + k) : 0.0;   // coupling cost exists in planner mode only
             double tc[HCNT][NX], hd[HCNT], jr[HCNT][L::NO], ja[HCNT][L::NO], rs[L::NO];
 #pragma unroll
@@ -996,12 +1017,15 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                     }
                 }
             }
-            double hvs = LD(L::hg + k * NZ + lz), pvv[NX];
             if constexpr (!PREG && !PTR) {
 #pragma unroll
                 for (int i = 0; i < NX; i++) pvv[i] = LD(opv + i);
             }
             LOADS_DONE();
+            if constexpr (PTR) {
+                hvs = row_dot<NX, PVF>(pn, mz, hvs);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             double hs[HCNT];
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
@@ -1010,7 +1034,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
                 for (int i = 0; i < NX; i++) t += mH[q][i] * tc[q][i];
                 const double dg = hd[q] + sel(r >= NX || (k == 0 && r >= 6), dw, 0.0);
-                t += sel(r == a, dg, 0.0);
+                if constexpr (CRX_MASK_FMA) t = fma(mdg[q], dg, t);
+                else t += sel(r == a, dg, 0.0);
                 if (NOBS) {
 #pragma unroll
                     for (int o = 0; o < NOBS; o++) t += rs[o] * jr[q][o] * ja[q][o];
@@ -1021,7 +1046,6 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 hs[q] = t;
             }
             if constexpr (PTR) {
-                hvs = row_dot<NX, PVF>(pn, mz, hvs);
             } else if constexpr (PREG) {
                 hvs = row_dot<NX, 0>(preg, mz, hvs);
             } else {
@@ -1031,7 +1055,7 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
 #pragma unroll
             for (int q = 0; q < HCNT; q++) {
                 LD(hst[q]) = hs[q];
-                if (!FULL) LD(hst2[q]) = hs[q];
+                if (!FULL && CRX_H_MIRROR) LD(hst2[q]) = hs[q];
             }
             LD(hvst) = hvs;
         }
@@ -1048,6 +1072,9 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
             for (int a = 0; a < NU; a++)
 #pragma unroll
                 for (int b2 = 0; b2 <= a; b2++) Lf[a][b2] = LD(oH + (NX + a) * HS + NX + b2);
+            // (Huu FIRST: the pivot chain -- the longest of the phase -- starts when these are back, while the other loads are in flight; left alone the
+            // scheduler issues them fourth)
+            if constexpr (CRX_HUU_FIRST) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < UCNT; q++) {
 #pragma unroll
@@ -1102,7 +1129,8 @@ __device__ __forceinline__ bool riccati_backward(double* sm, const int* si, cons
                 // (yj carries MINUS D^{-1} y from here on: the feedback -L^{-T} D^{-1} y is then stored as it comes out of the back substitution --
                 // negation commutes with every rounding below, the bits are those of the negate-at-the-store form [r4])
                 for (int a = 0; a < NU; a++) { yj[q][a] *= -rD[a]; t[q] = fma(yi[q][a], yj[q][a], t[q]); }
-                t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
+                if constexpr (CRX_MASK_FMA) t[q] = fma(mSl[q], exS, fma(mEl[q], exE, t[q]));   // (at most one of the two masks is set)
+                else t[q] += sel(exSl[q], exS, sel(exEl[q], exE, 0.0));
                 if constexpr (PTR) {
                     pn = t[0];                     // (P_new | p_new) stays in registers; its sigma column is the next stage's sigma_{k+1} column of T
                     if (NOBS) LD(SINK(isPm && c8 == 6, oT + g8 * L::TS + NX + 2)) = pn;
