@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B builds of the solver kernels whose code generation differs most; every variant must pass the parity tests on the GPU
 # (ADVICE r3 / VERDICT r4 item 1: two A/B builds of round 4 computed wrong numbers -- DESIGN.md section 8).  Run in the build container, then
-#     gpurun -- 'bash tools/gpu_pass.sh TAG gen:g000 gen:g001 ... gen:g111 suite:fenceonly suite:slim0 suite:nfix0 suite:opaqueall suite:nodpp suite:ptreg0 bits:ptreg0'
+#     gpurun -- 'bash tools/gpu_pass.sh TAG gen:g000 gen:g001 ... gen:g111 suite:fenceonly suite:slim0 suite:nfix0 suite:opaqueall suite:nodpp suite:ptreg0 suite:r5form bits:ptreg0 bits:r5form'
 # [r5] The GENERAL instantiations (csrc/crx_kernels_gen.hip: run-time horizon / exponent, 4..6 obstacles) over the full 2^3 matrix of the
 # three flags whose combination failed in round 4: gSDM with S = static LDS (+ no register floor: the AGPR-parking build), D = inline-assembly
 # DPP dot products, M = masked sweeps (the shipped unit is g101: static LDS + AGPR copies, v_readlane, masked sweeps).  Every cell is first
@@ -29,5 +29,8 @@ bash tools/build_variant.sh nodpp "-DCRX_ROWDPP=0" crx_kernels.hip crx_kernels_o
 wait
 # [r6] ptreg0 = the Riccati sweep with P through LDS (the form of rounds 1-5; the shipped one keeps (P | p) in registers: DESIGN.md 5.1) -- also the
 # reference build of `gpu_pass.sh TAG bits:ptreg0`.  (The gS1M cells and nfix0 run the register form on run-time horizons.)
-bash tools/build_variant.sh ptreg0 "-DCRX_PT_REG=0" > /dev/null
+bash tools/build_variant.sh ptreg0 "-DCRX_PT_REG=0" > /dev/null &
+# r5form = the Riccati sweep as rounds 1-5 had it, every round-6 switch off: P through LDS, mirrored H stores, select + add, the scheduler's load order
+bash tools/build_variant.sh r5form "-DCRX_PT_REG=0 -DCRX_H_MIRROR=1 -DCRX_MASK_FMA=0 -DCRX_HUU_FIRST=0" crx_kernels.hip crx_kernels_obs.hip crx_kernels_gen.hip > /dev/null &
+wait
 ls -la tools/ab/*.so
